@@ -1,0 +1,123 @@
+"""ctypes binding of libdfx.so (the C ABI declared in include/dfx.h).
+
+There is NO CPU fallback: if the shared library is missing or no gfx950 device is usable the calls raise.
+``import torch`` must happen before the library is loaded so that libdfx.so binds to the same
+libamdhip64.so.7 instance PyTorch uses (device pointers and streams are then shared).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdfx.so")
+
+DFX_OK = 0
+DFX_E_INVALID = -1
+DFX_E_HIP = -2
+DFX_E_NOGPU = -3
+
+
+class DfxError(RuntimeError):
+    """Raised for every non-zero status of the C ABI (mirrors vc::CUDAException thrown by
+    CudaCheckLastError in the reference, sources/cuda/launch_utils.h:26-32)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"dfx error {code}: {msg}")
+        self.code = code
+
+
+class Img(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("pitch_bytes", C.c_size_t), ("w", C.c_uint32), ("h", C.c_uint32)]
+
+
+class SE3(C.Structure):
+    _fields_ = [("q", C.c_float * 4), ("t", C.c_float * 3)]
+
+
+class Cam(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("u0", C.c_float), ("v0", C.c_float), ("w", C.c_float), ("h", C.c_float)]
+
+
+class SfmParams(C.Structure):
+    _fields_ = [("huber_delta", C.c_float), ("avg_dpt", C.c_float), ("min_dpt", C.c_float), ("valid_border", C.c_int32)]
+
+
+class CorrItem(C.Structure):
+    _fields_ = [("residual", C.c_float), ("_pad", C.c_uint32), ("inliers", C.c_uint64)]
+
+
+class SfmPair(C.Structure):
+    _fields_ = [("pose0", SE3), ("pose1", SE3), ("cam", Cam), ("img0", Img), ("img1", Img), ("dpt0", Img),
+                ("valid0", Img), ("prx0_jac", Img), ("grad1", Img)]
+
+
+def item_jtj_len(np_):
+    return np_ * (np_ + 1) // 2
+
+
+def item_inliers_offset(np_):
+    return ((item_jtj_len(np_) + np_ + 1) * 4 + 7) & ~7
+
+
+def item_size(np_):
+    return item_inliers_offset(np_) + 8
+
+
+_lib = None
+
+_PROTOS = {
+    "dfx_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "dfx_ctx_destroy": (None, [C.c_void_p]),
+    "dfx_last_error": (C.c_char_p, []),
+    "dfx_version": (C.c_char_p, []),
+    "dfx_sync": (C.c_int, [C.c_void_p]),
+    "dfx_sfm_set_step_blocks": (C.c_int, [C.c_void_p, C.c_int]),
+    "dfx_device_cu_count": (C.c_int, [C.c_void_p]),
+    "dfx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "dfx_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "dfx_se3_step": (C.c_int, [C.c_void_p, C.POINTER(SE3), C.POINTER(Cam), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img),
+                               C.POINTER(Img), C.c_float, C.c_void_p]),
+    "dfx_se3_warp": (C.c_int, [C.c_void_p, C.POINTER(SE3), C.POINTER(Cam), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img),
+                               C.POINTER(Img), C.POINTER(CorrItem)]),
+    "dfx_sfm_step": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SE3), C.POINTER(SE3), C.POINTER(Cam), C.POINTER(SfmParams),
+                               C.POINTER(Img), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img),
+                               C.POINTER(Img), C.c_void_p]),
+    "dfx_sfm_error": (C.c_int, [C.c_void_p, C.POINTER(SE3), C.POINTER(SE3), C.POINTER(Cam), C.POINTER(SfmParams),
+                                C.POINTER(Img), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img),
+                                C.POINTER(CorrItem)]),
+    "dfx_sfm_step_batch_async": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SfmParams), C.POINTER(SfmPair), C.c_int, C.c_void_p]),
+    "dfx_sfm_step_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SfmParams), C.POINTER(SfmPair), C.c_int, C.c_void_p]),
+    "dfx_update_depth": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(Img), C.POINTER(Img), C.c_float,
+                                   C.POINTER(Img)]),
+    "dfx_sobel_gradients": (C.c_int, [C.c_void_p, C.POINTER(Img), C.POINTER(Img)]),
+    "dfx_gaussian_blur_down": (C.c_int, [C.c_void_p, C.POINTER(Img), C.POINTER(Img)]),
+    "dfx_squared_error": (C.c_int, [C.c_void_p, C.POINTER(Img), C.POINTER(Img), C.POINTER(C.c_float)]),
+    "dfx_depth_aligner_step": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(Img), C.POINTER(Img),
+                                         C.POINTER(Img), C.c_float, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
+
+
+def lib():
+    """Loads libdfx.so (once).  Raises if it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DfxError(DFX_E_NOGPU, f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                        "or `make -C deepfactors_amd/csrc`")
+        try:
+            import torch  # noqa: F401  (binds libamdhip64.so.7 first, see module docstring)
+        except Exception:  # pragma: no cover - torch is only plumbing
+            pass
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != DFX_OK:
+        raise DfxError(rc, lib().dfx_last_error().decode("utf-8", "replace"))

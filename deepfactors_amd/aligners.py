@@ -1,0 +1,349 @@
+"""Python host-side mirror of the reference's operator interface for the alignment hot path.
+
+Same names, argument order and error behaviour as the reference's C++ classes
+(``df::SfmAligner<float,CS>`` cu_sfmaligner.h:50-97, ``df::SE3Aligner<float>`` cu_se3aligner.h:40-88,
+``df::DepthAligner`` cu_depthaligner.h, free functions of cu_image_proc.h:27-46); every call goes through the C ABI
+of libdfx.so.  PyTorch is plumbing only: it owns the device memory (``torch.Tensor`` on ``cuda``) and the stream.
+
+Poses are 7-vectors ``(qx, qy, qz, qw, tx, ty, tz)`` (``Sophus::SE3f``), cameras 6-vectors ``(fx, fy, u0, v0, w, h)``
+(``df::PinholeCamera<float>``).  Images are float32 CUDA tensors: ``[H, W]``, gradients ``[H, W, 2]``,
+code Jacobians ``[H, W*CS]`` (or ``[H, W, CS]``); rows may be pitched (``stride(0)`` free, inner dims contiguous).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Cam, CorrItem, DfxError, Img, SE3, SfmPair, SfmParams, check, item_inliers_offset, item_jtj_len, item_size
+
+
+# ------------------------------------------------------------------------------------------------------------
+# result PODs
+# ------------------------------------------------------------------------------------------------------------
+class JTJJrReductionItem:
+    """``df::JTJJrReductionItem<float,NP>`` (reduction_items.h:77-143)."""
+
+    def __init__(self, np_, raw=None):
+        self.NP = np_
+        if raw is None:
+            raw = np.zeros(item_size(np_), np.uint8)
+        self.raw = raw
+        nt = item_jtj_len(np_)
+        f = raw[: (nt + np_ + 1) * 4].view(np.float32)
+        self.JtJ = f[:nt]
+        self.Jtr = f[nt:nt + np_]
+        self.residual = float(f[nt + np_])
+        off = item_inliers_offset(np_)
+        self.inliers = int(raw[off:off + 8].view(np.uint64)[0])
+
+    def toDenseMatrix(self):
+        """``SquareUpperTriangularMatrix::toDenseMatrix()``: mirror the packed upper triangle."""
+        M = np.zeros((self.NP, self.NP), np.float32)
+        M[np.triu_indices(self.NP)] = self.JtJ
+        return M + np.triu(M, 1).T
+
+
+class CorrespondenceReductionItem:
+    """``df::CorrespondenceReductionItem<float>`` (reduction_items.h:35-71)."""
+
+    def __init__(self, residual=0.0, inliers=0):
+        self.residual = float(residual)
+        self.inliers = int(inliers)
+
+
+class DenseSfmParams:
+    """``df::DenseSfmParams`` (dense_sfm.h:36-43)."""
+
+    def __init__(self, huber_delta=0.1, avg_dpt=2.0, min_dpt=0.0, valid_border=2):
+        self.huber_delta, self.avg_dpt, self.min_dpt, self.valid_border = huber_delta, avg_dpt, min_dpt, valid_border
+
+    def _c(self):
+        return SfmParams(self.huber_delta, self.avg_dpt, self.min_dpt, int(self.valid_border))
+
+
+class SfmAlignerParams:
+    """``df::SfmAlignerParams`` (cu_sfmaligner.h:41-48).  Thread counts are accepted for interface parity; the
+    gfx950 kernels use fixed 256-thread workgroups and ``step_blocks`` workgroups per pair (0 = automatic)."""
+
+    def __init__(self, sfmparams=None, step_threads=256, step_blocks=0, eval_threads=256, eval_blocks=0):
+        self.sfmparams = sfmparams or DenseSfmParams()
+        self.step_threads, self.step_blocks = step_threads, step_blocks
+        self.eval_threads, self.eval_blocks = eval_threads, eval_blocks
+
+
+# ------------------------------------------------------------------------------------------------------------
+# argument marshalling
+# ------------------------------------------------------------------------------------------------------------
+def _img(t, name, elems_per_px=1):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise DfxError(_lib.DFX_E_INVALID, f"{name}: tensor must live on a HIP device (got {t.device}); there is no CPU path")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: float32 required, got {t.dtype}")
+    if t.dim() == 3:
+        if t.stride(2) != 1 or t.stride(1) != t.shape[2]:
+            raise ValueError(f"{name}: inner dimensions must be contiguous")
+        h, w = t.shape[0], t.shape[1] * t.shape[2]
+    elif t.dim() == 2:
+        if t.stride(1) != 1:
+            raise ValueError(f"{name}: rows must be contiguous")
+        h, w = t.shape
+    else:
+        raise ValueError(f"{name}: expected a 2-D or 3-D tensor")
+    if w % elems_per_px:
+        raise ValueError(f"{name}: row length {w} not a multiple of {elems_per_px}")
+    return Img(t.data_ptr(), t.stride(0) * 4, w // elems_per_px, h)
+
+
+def _se3(p):
+    a = np.asarray(p, np.float32).reshape(7)
+    return SE3((C.c_float * 4)(*a[:4]), (C.c_float * 3)(*a[4:]))
+
+
+def _cam(c):
+    a = np.asarray(c, np.float32).reshape(6)
+    return Cam(*[float(v) for v in a])
+
+
+class Context:
+    """One dfx_ctx: device + stream + scratch.  By default it enqueues on PyTorch's current stream of `device`, so
+    ``torch.cuda.Event`` timing and tensor lifetime rules apply unchanged."""
+
+    def __init__(self, device=0, stream="torch"):
+        self._h = C.c_void_p()
+        L = _lib.lib()
+        if not torch.cuda.is_available():
+            raise DfxError(_lib.DFX_E_NOGPU, "no HIP device visible to PyTorch; libdfx has no CPU fallback")
+        self.device = int(device)
+        if stream == "torch":
+            sh = torch.cuda.current_stream(self.device).cuda_stream
+        elif stream is None:
+            sh = None
+        else:
+            sh = int(stream)
+        check(L.dfx_ctx_create(self.device, C.c_void_p(sh) if sh else None, C.byref(self._h)))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def sync(self):
+        check(_lib.lib().dfx_sync(self._h))
+
+    def cu_count(self):
+        return int(_lib.lib().dfx_device_cu_count(self._h))
+
+    def set_profiling(self, enable):
+        check(_lib.lib().dfx_set_profiling(self._h, int(bool(enable))))
+
+    def profile_read(self):
+        """(n_launches, total_ms) of the step kernel since the last read (HIP events on the context's stream)."""
+        n, ms = C.c_int(0), C.c_double(0.0)
+        check(_lib.lib().dfx_profile_read(self._h, C.byref(n), C.byref(ms)))
+        return int(n.value), float(ms.value)
+
+    def close(self):
+        if self._h:
+            _lib.lib().dfx_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    key = int(device)
+    if key not in _default_ctx:
+        _default_ctx[key] = Context(key)
+    return _default_ctx[key]
+
+
+# ------------------------------------------------------------------------------------------------------------
+# SfmAligner
+# ------------------------------------------------------------------------------------------------------------
+class SfmAligner:
+    """``df::SfmAligner<float,CS>``."""
+
+    def __init__(self, params=None, code_size=32, ctx=None):
+        self.params_ = params or SfmAlignerParams()
+        self.CS = int(code_size)
+        self.ctx = ctx or default_context()
+        self.SetStepThreadsBlocks(self.params_.step_threads, self.params_.step_blocks)
+
+    # cu_sfmaligner.cpp:187-203: glog CHECK on bad values -> here an exception
+    def SetStepThreadsBlocks(self, threads, blocks):
+        if threads % 64:
+            raise DfxError(_lib.DFX_E_INVALID, "threads must be a multiple of 64 (the CDNA wavefront)")
+        self.params_.step_threads, self.params_.step_blocks = threads, blocks
+        check(_lib.lib().dfx_sfm_set_step_blocks(self.ctx.handle, int(blocks)))
+
+    def SetEvalThreadsBlocks(self, threads, blocks):
+        if threads % 64:
+            raise DfxError(_lib.DFX_E_INVALID, "threads must be a multiple of 64 (the CDNA wavefront)")
+        self.params_.eval_threads, self.params_.eval_blocks = threads, blocks
+
+    def RunStep(self, pose0, pose1, code0, cam, img0, img1, dpt0, std0, valid0, prx0_jac, grad1):
+        """cu_sfmaligner.cpp:149-185.  `code0` is unused by the kernel (depth is already decoded), as in the reference."""
+        del code0
+        np_ = 12 + self.CS
+        raw = np.zeros(item_size(np_), np.uint8)
+        p = self.params_.sfmparams._c()
+        s0, s1, cm = _se3(pose0), _se3(pose1), _cam(cam)
+        i0, i1, d0 = _img(img0, "img0"), _img(img1, "img1"), _img(dpt0, "dpt0")
+        jc, g1 = _img(prx0_jac, "prx0_jac"), _img(grad1, "grad1", 2)
+        sd = _img(std0, "std0") if std0 is not None else None
+        vd = _img(valid0, "valid0") if valid0 is not None else None
+        check(_lib.lib().dfx_sfm_step(self.ctx.handle, self.CS, C.byref(s0), C.byref(s1), C.byref(cm), C.byref(p), C.byref(i0),
+                                      C.byref(i1), C.byref(d0), C.byref(sd) if sd else None, C.byref(vd) if vd else None,
+                                      C.byref(jc), C.byref(g1), raw.ctypes.data_as(C.c_void_p)))
+        return JTJJrReductionItem(np_, raw)
+
+    def EvaluateError(self, pose0, pose1, cam, img0, img1, dpt0, std0, grad1):
+        """cu_sfmaligner.cpp:120-147."""
+        out = CorrItem()
+        p = self.params_.sfmparams._c()
+        s0, s1, cm = _se3(pose0), _se3(pose1), _cam(cam)
+        i0, i1, d0 = _img(img0, "img0"), _img(img1, "img1"), _img(dpt0, "dpt0")
+        sd = _img(std0, "std0") if std0 is not None else None
+        g1 = _img(grad1, "grad1", 2) if grad1 is not None else None
+        check(_lib.lib().dfx_sfm_error(self.ctx.handle, C.byref(s0), C.byref(s1), C.byref(cm), C.byref(p), C.byref(i0), C.byref(i1),
+                                       C.byref(d0), C.byref(sd) if sd else None, C.byref(g1) if g1 else None, C.byref(out)))
+        return CorrespondenceReductionItem(out.residual, out.inliers)
+
+    # ---- batched extension (one launch over n independent pairs) ----
+    def make_pairs(self, pairs):
+        """pairs: iterable of dicts with keys pose0,pose1,cam,img0,img1,dpt0,prx0_jac,grad1[,valid0] -> SfmPair array."""
+        pairs = list(pairs)
+        arr = (SfmPair * len(pairs))()
+        for k, q in enumerate(pairs):
+            arr[k].pose0, arr[k].pose1, arr[k].cam = _se3(q["pose0"]), _se3(q["pose1"]), _cam(q["cam"])
+            arr[k].img0, arr[k].img1, arr[k].dpt0 = _img(q["img0"], "img0"), _img(q["img1"], "img1"), _img(q["dpt0"], "dpt0")
+            arr[k].prx0_jac, arr[k].grad1 = _img(q["prx0_jac"], "prx0_jac"), _img(q["grad1"], "grad1", 2)
+            if q.get("valid0") is not None:
+                arr[k].valid0 = _img(q["valid0"], "valid0")
+        return arr
+
+    def set_poses(self, arr, k, pose0, pose1):
+        arr[k].pose0, arr[k].pose1 = _se3(pose0), _se3(pose1)
+
+    def RunStepBatchAsync(self, pair_array, out_items_dev):
+        """Enqueue one batched launch; results land in `out_items_dev` (uint8 CUDA tensor, n*item_size bytes)."""
+        n = len(pair_array)
+        isz = item_size(12 + self.CS)
+        if out_items_dev.numel() * out_items_dev.element_size() < n * isz:
+            raise ValueError("output buffer too small")
+        p = self.params_.sfmparams._c()
+        check(_lib.lib().dfx_sfm_step_batch_async(self.ctx.handle, self.CS, C.byref(p), pair_array, n,
+                                                  C.c_void_p(out_items_dev.data_ptr())))
+
+    def RunStepBatch(self, pair_array):
+        n = len(pair_array)
+        np_ = 12 + self.CS
+        isz = item_size(np_)
+        raw = np.zeros(n * isz, np.uint8)
+        p = self.params_.sfmparams._c()
+        check(_lib.lib().dfx_sfm_step_batch(self.ctx.handle, self.CS, C.byref(p), pair_array, n, raw.ctypes.data_as(C.c_void_p)))
+        return [JTJJrReductionItem(np_, raw[k * isz:(k + 1) * isz]) for k in range(n)]
+
+    @staticmethod
+    def items_from_bytes(raw, cs):
+        np_ = 12 + cs
+        isz = item_size(np_)
+        raw = np.ascontiguousarray(raw).view(np.uint8)
+        return [JTJJrReductionItem(np_, raw[k * isz:(k + 1) * isz]) for k in range(len(raw) // isz)]
+
+
+# ------------------------------------------------------------------------------------------------------------
+# SE3Aligner
+# ------------------------------------------------------------------------------------------------------------
+class SE3Aligner:
+    """``df::SE3Aligner<float>``."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+        self.huber_delta_ = 0.1
+
+    def SetHuberDelta(self, val):
+        self.huber_delta_ = float(val)
+
+    def RunStep(self, se3, cam, img0, img1, dpt0, grad1):
+        """cu_se3aligner.cpp:153-176."""
+        raw = np.zeros(item_size(6), np.uint8)
+        s, cm = _se3(se3), _cam(cam)
+        i0, i1, d0, g1 = _img(img0, "img0"), _img(img1, "img1"), _img(dpt0, "dpt0"), _img(grad1, "grad1", 2)
+        check(_lib.lib().dfx_se3_step(self.ctx.handle, C.byref(s), C.byref(cm), C.byref(i0), C.byref(i1), C.byref(d0), C.byref(g1),
+                                      self.huber_delta_, raw.ctypes.data_as(C.c_void_p)))
+        return JTJJrReductionItem(6, raw)
+
+    def Warp(self, se3, cam, img0, img1, dpt0, img2):
+        """cu_se3aligner.cpp:125-151: renders img1 into frame 0 (`img2`), returns the signed residual sum + inliers."""
+        out = CorrItem()
+        s, cm = _se3(se3), _cam(cam)
+        i0, i1, d0, i2 = _img(img0, "img0"), _img(img1, "img1"), _img(dpt0, "dpt0"), _img(img2, "img2")
+        check(_lib.lib().dfx_se3_warp(self.ctx.handle, C.byref(s), C.byref(cm), C.byref(i0), C.byref(i1), C.byref(d0), C.byref(i2),
+                                      C.byref(out)))
+        return CorrespondenceReductionItem(out.residual, out.inliers)
+
+
+class DepthAligner:
+    """``df::DepthAligner<float,CS>`` (cu_depthaligner.cpp:78-110)."""
+
+    def __init__(self, code_size=32, ctx=None):
+        self.CS = int(code_size)
+        self.ctx = ctx or default_context()
+
+    def RunStep(self, code, target_dpt, prx_orig, prx_jac, avg_dpt=2.0):
+        jc = _img(prx_jac, "prx_jac")
+        tg, po = _img(target_dpt, "target_dpt"), _img(prx_orig, "prx_orig")
+        if jc.w // tg.w != self.CS:   # CHECK_EQ(codesize, CS) at cu_depthaligner.cpp:90-91
+            raise DfxError(_lib.DFX_E_INVALID, "DepthAligner used with a different code size than it was created for")
+        raw = np.zeros(item_size(self.CS), np.uint8)
+        cd = np.ascontiguousarray(np.asarray(code, np.float32).reshape(self.CS))
+        check(_lib.lib().dfx_depth_aligner_step(self.ctx.handle, self.CS, cd.ctypes.data_as(C.POINTER(C.c_float)), C.byref(tg),
+                                                C.byref(po), C.byref(jc), float(avg_dpt), raw.ctypes.data_as(C.c_void_p)))
+        return JTJJrReductionItem(self.CS, raw)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# cu_image_proc.h free functions
+# ------------------------------------------------------------------------------------------------------------
+def UpdateDepth(code, prx_orig, prx_jac, avg_dpt, dpt_out, ctx=None):
+    """``df::UpdateDepth`` (cu_image_proc.cpp:266-277)."""
+    ctx = ctx or default_context()
+    cd = np.ascontiguousarray(np.asarray(code, np.float32).reshape(-1))
+    po, jc, do = _img(prx_orig, "prx_orig"), _img(prx_jac, "prx_jac"), _img(dpt_out, "dpt_out")
+    if jc.w != po.w * len(cd):
+        raise DfxError(_lib.DFX_E_INVALID, f"prx_jac row length {jc.w} != W*CS = {po.w}*{len(cd)}")
+    check(_lib.lib().dfx_update_depth(ctx.handle, len(cd), cd.ctypes.data_as(C.POINTER(C.c_float)), C.byref(po), C.byref(jc),
+                                      float(avg_dpt), C.byref(do)))
+
+
+def SobelGradients(img, grad, ctx=None):
+    """``df::SobelGradients`` (cu_image_proc.cpp:94-112)."""
+    ctx = ctx or default_context()
+    i, g = _img(img, "img"), _img(grad, "grad", 2)
+    check(_lib.lib().dfx_sobel_gradients(ctx.handle, C.byref(i), C.byref(g)))
+
+
+def GaussianBlurDown(inp, out, ctx=None):
+    """``df::GaussianBlurDown`` (cu_image_proc.cpp:166-186)."""
+    ctx = ctx or default_context()
+    i, o = _img(inp, "in"), _img(out, "out")
+    check(_lib.lib().dfx_gaussian_blur_down(ctx.handle, C.byref(i), C.byref(o)))
+
+
+def SquaredError(buf1, buf2, ctx=None):
+    """``df::SquaredError`` (cu_image_proc.cpp:208-240)."""
+    ctx = ctx or default_context()
+    a, b = _img(buf1, "buf1"), _img(buf2, "buf2")
+    out = C.c_float(0)
+    check(_lib.lib().dfx_squared_error(ctx.handle, C.byref(a), C.byref(b), C.byref(out)))
+    return float(out.value)

@@ -1,0 +1,639 @@
+// dfx_api.cpp -- C-ABI of libdfx.so (include/dfx.h): argument validation, host-side pose algebra
+// (RelativePose + Jacobians, reference common/algorithm/warping.h:98-137, done once per pair in double),
+// scratch management and the launch/copy/sync protocol around the gfx950 kernels.
+//
+// This is HIP-only product code: there is no CPU fallback and nothing here touches oracle/.
+#include "../../include/dfx.h"
+#include "dfx_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define DFX_HIP(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) return fail(DFX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));   \
+  } while (0)
+
+constexpr int kStageSlots = 8;
+
+}  // namespace
+
+struct dfx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int cu_count = 0;
+  int step_blocks = 0;   // 0 = auto
+
+  float* partials = nullptr;   // device scratch for workgroup partials
+  size_t partials_bytes = 0;
+  char* items_dev = nullptr;   // device result items (sync API)
+  size_t items_bytes = 0;
+  dfx::SfmPairDev* pairs_dev = nullptr;
+  size_t pairs_cap = 0;        // per stage slot
+  float* code_dev = nullptr;   // 64 floats per stage slot
+  float* depth_scratch = nullptr;
+  size_t depth_scratch_bytes = 0;
+
+  // pinned host staging ring (descriptors / codes going up) and a result area coming down
+  char* stage_host = nullptr;
+  size_t stage_slot_bytes = 0;
+  hipEvent_t stage_ev[kStageSlots] = {};
+  bool stage_used[kStageSlots] = {};
+  int stage_next = 0;
+  char* result_host = nullptr;
+  size_t result_bytes = 0;
+
+  // measurement hook (dfx_set_profiling): event pairs around the step kernel
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;   // all created pairs
+  size_t prof_used = 0;                                       // pairs recorded since the last read
+};
+
+namespace {
+
+int ensure_device(dfx_ctx* c) {
+  DFX_HIP(hipSetDevice(c->device));
+  return DFX_OK;
+}
+
+int grow_dev(void** p, size_t* cap, size_t need) {
+  if (*cap >= need) return DFX_OK;
+  if (*p) DFX_HIP(hipFree(*p));
+  *p = nullptr;
+  *cap = 0;
+  size_t n = need + need / 2;
+  DFX_HIP(hipMalloc(p, n));
+  DFX_HIP(hipMemset(*p, 0, n));
+  *cap = n;
+  return DFX_OK;
+}
+
+// Pinned staging ring: returns a host slot whose previous upload has completed.
+int stage_acquire(dfx_ctx* c, size_t bytes, int* slot, char** host) {
+  if (bytes > c->stage_slot_bytes) {
+    // drain and regrow
+    DFX_HIP(hipStreamSynchronize(c->stream));
+    if (c->stage_host) DFX_HIP(hipHostFree(c->stage_host));
+    c->stage_host = nullptr;
+    size_t n = bytes * 2;
+    if (n < 4096) n = 4096;
+    DFX_HIP(hipHostMalloc((void**)&c->stage_host, n * kStageSlots, hipHostMallocDefault));
+    c->stage_slot_bytes = n;
+    for (int i = 0; i < kStageSlots; ++i) c->stage_used[i] = false;
+  }
+  const int s = c->stage_next;
+  c->stage_next = (s + 1) % kStageSlots;
+  if (c->stage_used[s]) DFX_HIP(hipEventSynchronize(c->stage_ev[s]));
+  *slot = s;
+  *host = c->stage_host + (size_t)s * c->stage_slot_bytes;
+  return DFX_OK;
+}
+
+int stage_release(dfx_ctx* c, int slot) {
+  DFX_HIP(hipEventRecord(c->stage_ev[slot], c->stream));
+  c->stage_used[slot] = true;
+  return DFX_OK;
+}
+
+int ensure_result_host(dfx_ctx* c, size_t bytes) {
+  if (c->result_bytes >= bytes) return DFX_OK;
+  if (c->result_host) DFX_HIP(hipHostFree(c->result_host));
+  c->result_host = nullptr;
+  size_t n = bytes * 2;
+  if (n < 8192) n = 8192;
+  DFX_HIP(hipHostMalloc((void**)&c->result_host, n, hipHostMallocDefault));
+  c->result_bytes = n;
+  return DFX_OK;
+}
+
+// ---- pose algebra in double ---------------------------------------------------------------------------------
+void quat_to_R(const float* q, double* R) {
+  double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double n = std::sqrt(x * x + y * y + z * z + w * w);
+  if (n > 0) { x /= n; y /= n; z /= n; w /= n; }
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// pose_10 = pose1^-1 * pose0 and the two blocks of its Jacobians (warping.h:105-137, called as
+// RelativePose(pose1, pose0, J1, J0) at cu_sfmaligner.cpp:166):  M = R1^T,  HM = hat(R1^T (t1 - t0)) R1^T
+void relative_pose(const dfx_se3& p0, const dfx_se3& p1, float* R10, float* t10, float* M, float* HM) {
+  double R0[9], R1[9];
+  quat_to_R(p0.q, R0);
+  quat_to_R(p1.q, R1);
+  double Mt[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Mt[i * 3 + j] = R1[j * 3 + i];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    double s = 0;
+    for (int k = 0; k < 3; ++k) s += Mt[i * 3 + k] * R0[k * 3 + j];
+    R10[i * 3 + j] = (float)s;
+  }
+  const double d01[3] = { (double)p0.t[0] - p1.t[0], (double)p0.t[1] - p1.t[1], (double)p0.t[2] - p1.t[2] };
+  double v[3];
+  for (int i = 0; i < 3; ++i) {
+    const double s = Mt[i * 3] * d01[0] + Mt[i * 3 + 1] * d01[1] + Mt[i * 3 + 2] * d01[2];
+    t10[i] = (float)s;
+    v[i] = -s;   // R1^T (t1 - t0)
+  }
+  const double Hh[9] = { 0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0 };
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    double s = 0;
+    for (int k = 0; k < 3; ++k) s += Hh[i * 3 + k] * Mt[k * 3 + j];
+    HM[i * 3 + j] = (float)s;
+    if (M) M[i * 3 + j] = (float)Mt[i * 3 + j];
+  }
+}
+
+bool img_ok(const dfx_img* im) { return im && im->ptr && im->w > 0 && im->h > 0 && im->pitch_bytes > 0; }
+
+int check_img(const dfx_img* im, const char* name, uint32_t w, uint32_t h, size_t elem_bytes) {
+  if (!img_ok(im)) return fail(DFX_E_INVALID, "%s: null or empty image view", name);
+  if (im->w != w || im->h != h) return fail(DFX_E_INVALID, "%s: size %ux%u, expected %ux%u", name, im->w, im->h, w, h);
+  if (im->pitch_bytes < (size_t)w * elem_bytes) return fail(DFX_E_INVALID, "%s: pitch %zu < row bytes %zu", name, im->pitch_bytes, (size_t)w * elem_bytes);
+  if (im->pitch_bytes > 0xffffffffull) return fail(DFX_E_INVALID, "%s: pitch too large", name);
+  if (((uintptr_t)im->ptr | im->pitch_bytes) & 3) return fail(DFX_E_INVALID, "%s: pointer/pitch not 4-byte aligned", name);
+  return DFX_OK;
+}
+
+int fill_sfm_pair(int cs, const dfx_se3* pose0, const dfx_se3* pose1, const dfx_cam* cam, const dfx_img* img0,
+                  const dfx_img* img1, const dfx_img* dpt0, const dfx_img* valid0, const dfx_img* jac, const dfx_img* grad1,
+                  uint32_t W, uint32_t H, dfx::SfmPairDev* d) {
+  int rc;
+  if ((rc = check_img(img0, "img0", W, H, 4))) return rc;
+  if ((rc = check_img(img1, "img1", W, H, 4))) return rc;
+  if ((rc = check_img(dpt0, "dpt0", W, H, 4))) return rc;
+  if ((rc = check_img(grad1, "grad1", W, H, 8))) return rc;
+  if ((rc = check_img(jac, "prx0_jac", W * (uint32_t)cs, H, 4))) return rc;
+  const size_t jalign = (size_t)(cs / 16) * 4;   // one MFMA-layout vector load per lane
+  if (((uintptr_t)jac->ptr | jac->pitch_bytes) & (jalign - 1))
+    return fail(DFX_E_INVALID, "prx0_jac: pointer/pitch must be %zu-byte aligned for cs=%d", jalign, cs);
+  if (((uintptr_t)grad1->ptr | grad1->pitch_bytes) & 7) return fail(DFX_E_INVALID, "grad1: pointer/pitch must be 8-byte aligned");
+  if (valid0 && valid0->ptr) {
+    if ((rc = check_img(valid0, "valid0", W, H, 4))) return rc;
+    d->valid0 = (float*)valid0->ptr;
+    d->pitch_valid0 = (uint32_t)valid0->pitch_bytes;
+  } else {
+    d->valid0 = nullptr;
+    d->pitch_valid0 = 0;
+  }
+  relative_pose(*pose0, *pose1, d->R, d->t, d->M, d->HM);
+  d->fx = cam->fx; d->fy = cam->fy; d->u0 = cam->u0; d->v0 = cam->v0; d->w = cam->w; d->h = cam->h;
+  d->img0 = (const float*)img0->ptr; d->img1 = (const float*)img1->ptr; d->dpt0 = (const float*)dpt0->ptr;
+  d->jac = (const float*)jac->ptr; d->grad1 = (const float*)grad1->ptr;
+  d->pitch_img0 = (uint32_t)img0->pitch_bytes; d->pitch_img1 = (uint32_t)img1->pitch_bytes;
+  d->pitch_dpt0 = (uint32_t)dpt0->pitch_bytes; d->pitch_jac = (uint32_t)jac->pitch_bytes;
+  d->pitch_grad1 = (uint32_t)grad1->pitch_bytes;
+  return DFX_OK;
+}
+
+int auto_step_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int npairs) {
+  const int nchunks = (int)(((size_t)W * H + 63) / 64);
+  int maxb = (nchunks + 3) / 4;   // one chunk per wave at most
+  if (maxb < 1) maxb = 1;
+  int b = c->step_blocks;
+  if (b <= 0) {
+    const int target_total = c->cu_count * 3;   // 3 workgroups (12 waves) per CU
+    b = (target_total + npairs - 1) / npairs;
+    if (b < 1) b = 1;
+  }
+  return b < maxb ? b : maxb;
+}
+
+int simple_blocks(uint32_t W, uint32_t H) {
+  int b = (int)(((size_t)W * H + 255) / 256);
+  if (b > dfx::kMaxSimpleBlocks) b = dfx::kMaxSimpleBlocks;
+  return b < 1 ? 1 : b;
+}
+
+int fill_simple(const dfx_se3* pose_10, const dfx_cam* cam, const dfx_img* img0, const dfx_img* img1, const dfx_img* dpt0,
+                const dfx_img* grad1, const dfx_img* img2, dfx::SimplePairDev* d) {
+  if (!pose_10 || !cam) return fail(DFX_E_INVALID, "null pose/camera");
+  if (!img_ok(img0)) return fail(DFX_E_INVALID, "img0: null or empty image view");
+  const uint32_t W = img0->w, H = img0->h;
+  int rc;
+  if ((rc = check_img(img0, "img0", W, H, 4))) return rc;
+  if ((rc = check_img(img1, "img1", W, H, 4))) return rc;
+  if ((rc = check_img(dpt0, "dpt0", W, H, 4))) return rc;
+  double R[9];
+  quat_to_R(pose_10->q, R);
+  for (int i = 0; i < 9; ++i) d->R[i] = (float)R[i];
+  d->t[0] = pose_10->t[0]; d->t[1] = pose_10->t[1]; d->t[2] = pose_10->t[2];
+  d->fx = cam->fx; d->fy = cam->fy; d->u0 = cam->u0; d->v0 = cam->v0; d->w = cam->w; d->h = cam->h;
+  d->img0 = (const float*)img0->ptr; d->img1 = (const float*)img1->ptr; d->dpt0 = (const float*)dpt0->ptr;
+  d->pitch_img0 = (uint32_t)img0->pitch_bytes; d->pitch_img1 = (uint32_t)img1->pitch_bytes;
+  d->pitch_dpt0 = (uint32_t)dpt0->pitch_bytes;
+  d->grad1 = nullptr; d->pitch_grad1 = 0; d->img2 = nullptr; d->pitch_img2 = 0;
+  if (grad1) {
+    if ((rc = check_img(grad1, "grad1", W, H, 8))) return rc;
+    if (((uintptr_t)grad1->ptr | grad1->pitch_bytes) & 7) return fail(DFX_E_INVALID, "grad1: pointer/pitch must be 8-byte aligned");
+    d->grad1 = (const float*)grad1->ptr; d->pitch_grad1 = (uint32_t)grad1->pitch_bytes;
+  }
+  if (img2) {
+    if ((rc = check_img(img2, "img2", W, H, 4))) return rc;
+    d->img2 = (float*)img2->ptr; d->pitch_img2 = (uint32_t)img2->pitch_bytes;
+  }
+  return DFX_OK;
+}
+
+// copy `bytes` of device results to the host and wait (the reference's blocking copyFrom)
+int fetch_result(dfx_ctx* c, const void* dev, void* host_out, size_t bytes) {
+  int rc;
+  if ((rc = ensure_result_host(c, bytes))) return rc;
+  DFX_HIP(hipMemcpyAsync(c->result_host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+  DFX_HIP(hipStreamSynchronize(c->stream));
+  std::memcpy(host_out, c->result_host, bytes);
+  return DFX_OK;
+}
+
+bool cs_supported(int cs) { return cs == 16 || cs == 32 || cs == 64; }
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+DFX_API const char* dfx_last_error(void) { return g_last_error.c_str(); }
+DFX_API const char* dfx_version(void) { return "dfx 0.1 (gfx950, HIP)"; }
+
+DFX_API int dfx_ctx_create(int device, void* stream, dfx_ctx** out) {
+  if (!out) return fail(DFX_E_INVALID, "dfx_ctx_create: out is null");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) return fail(DFX_E_NOGPU, "no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+  if (device < 0 || device >= ndev) return fail(DFX_E_INVALID, "device %d out of range [0,%d)", device, ndev);
+  DFX_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  DFX_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(DFX_E_NOGPU, "libdfx is built for gfx950 only; device %d is %s", device, prop.gcnArchName);
+  dfx_ctx* c = new dfx_ctx();
+  c->device = device;
+  c->cu_count = prop.multiProcessorCount;
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+  } else {
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(DFX_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    c->own_stream = true;
+  }
+  for (int i = 0; i < kStageSlots; ++i) {
+    e = hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming);
+    if (e != hipSuccess) { delete c; return fail(DFX_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(e)); }
+  }
+  *out = c;
+  return DFX_OK;
+}
+
+DFX_API void dfx_ctx_destroy(dfx_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->partials) (void)hipFree(c->partials);
+  if (c->items_dev) (void)hipFree(c->items_dev);
+  if (c->pairs_dev) (void)hipFree(c->pairs_dev);
+  if (c->code_dev) (void)hipFree(c->code_dev);
+  if (c->depth_scratch) (void)hipFree(c->depth_scratch);
+  if (c->stage_host) (void)hipHostFree(c->stage_host);
+  if (c->result_host) (void)hipHostFree(c->result_host);
+  for (int i = 0; i < kStageSlots; ++i) if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
+  for (auto& pr : c->prof_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+DFX_API int dfx_sync(dfx_ctx* c) {
+  if (!c) return fail(DFX_E_INVALID, "null context");
+  DFX_HIP(hipStreamSynchronize(c->stream));
+  return DFX_OK;
+}
+
+DFX_API int dfx_sfm_set_step_blocks(dfx_ctx* c, int blocks_per_pair) {
+  if (!c) return fail(DFX_E_INVALID, "null context");
+  if (blocks_per_pair < 0 || blocks_per_pair > 65535) return fail(DFX_E_INVALID, "blocks_per_pair out of range");
+  c->step_blocks = blocks_per_pair;
+  return DFX_OK;
+}
+
+DFX_API int dfx_device_cu_count(dfx_ctx* c) { return c ? c->cu_count : 0; }
+
+DFX_API int dfx_set_profiling(dfx_ctx* c, int enable) {
+  if (!c) return fail(DFX_E_INVALID, "null context");
+  DFX_HIP(hipStreamSynchronize(c->stream));
+  c->profiling = enable != 0;
+  c->prof_used = 0;
+  return DFX_OK;
+}
+
+DFX_API int dfx_profile_read(dfx_ctx* c, int* n_launches, double* total_ms) {
+  if (!c || !n_launches || !total_ms) return fail(DFX_E_INVALID, "null argument");
+  DFX_HIP(hipStreamSynchronize(c->stream));
+  double tot = 0;
+  for (size_t i = 0; i < c->prof_used; ++i) {
+    float ms = 0;
+    DFX_HIP(hipEventElapsedTime(&ms, c->prof_pool[i].first, c->prof_pool[i].second));
+    tot += ms;
+  }
+  *n_launches = (int)c->prof_used;
+  *total_ms = tot;
+  c->prof_used = 0;
+  return DFX_OK;
+}
+
+// ---- SfmAligner ------------------------------------------------------------------------------------------------
+DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
+                                     void* out_items_dev) {
+  if (!c || !params || !pairs || !out_items_dev) return fail(DFX_E_INVALID, "dfx_sfm_step_batch: null argument");
+  if (!cs_supported(cs)) return fail(DFX_E_INVALID, "unsupported code size %d (16, 32, 64)", cs);
+  if (n <= 0 || n > 65535) return fail(DFX_E_INVALID, "batch size %d out of range [1,65535]", n);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  if (!img_ok(&pairs[0].img0)) return fail(DFX_E_INVALID, "pair 0: img0 null or empty");
+  const uint32_t W = pairs[0].img0.w, H = pairs[0].img0.h;
+  if ((size_t)W * H >= (1ull << 31)) return fail(DFX_E_INVALID, "image too large");
+
+  int slot;
+  char* host;
+  const size_t desc_bytes = sizeof(dfx::SfmPairDev) * (size_t)n;
+  if ((rc = stage_acquire(c, desc_bytes, &slot, &host))) return rc;
+  dfx::SfmPairDev* hd = reinterpret_cast<dfx::SfmPairDev*>(host);
+  for (int p = 0; p < n; ++p) {
+    const dfx_sfm_pair& q = pairs[p];
+    if ((rc = fill_sfm_pair(cs, &q.pose0, &q.pose1, &q.cam, &q.img0, &q.img1, &q.dpt0, &q.valid0, &q.prx0_jac, &q.grad1, W, H, &hd[p]))) {
+      g_last_error = "pair " + std::to_string(p) + ": " + g_last_error;
+      return rc;
+    }
+  }
+  // device descriptor array: one region per stage slot so that in-flight launches keep their own copy
+  if (c->pairs_cap < (size_t)n) {
+    DFX_HIP(hipStreamSynchronize(c->stream));
+    if (c->pairs_dev) DFX_HIP(hipFree(c->pairs_dev));
+    c->pairs_dev = nullptr;
+    const size_t cap = (size_t)n * 2;
+    DFX_HIP(hipMalloc((void**)&c->pairs_dev, sizeof(dfx::SfmPairDev) * cap * kStageSlots));
+    c->pairs_cap = cap;
+  }
+  dfx::SfmPairDev* dd = c->pairs_dev + (size_t)slot * c->pairs_cap;
+  DFX_HIP(hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, c->stream));
+  if ((rc = stage_release(c, slot))) return rc;
+
+  const int bpp = auto_step_blocks(c, W, H, n);
+  const size_t pbytes = dfx::sfm_step_partials_bytes(cs, n, bpp);
+  if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes))) return rc;
+
+  dfx::SfmParamsDev prm{ params->huber_delta, params->avg_dpt, params->min_dpt, (float)params->valid_border };
+  hipEvent_t eb = nullptr, ee = nullptr;
+  if (c->profiling) {
+    if (c->prof_used == c->prof_pool.size()) {
+      hipEvent_t a, b;
+      DFX_HIP(hipEventCreate(&a));
+      DFX_HIP(hipEventCreate(&b));
+      c->prof_pool.emplace_back(a, b);
+    }
+    eb = c->prof_pool[c->prof_used].first;
+    ee = c->prof_pool[c->prof_used].second;
+    c->prof_used++;
+  }
+  DFX_HIP(dfx::launch_sfm_step(cs, dd, n, (int)W, (int)H, prm, bpp, c->partials, out_items_dev, dfx_item_size(12 + cs), c->stream, eb, ee));
+  return DFX_OK;
+}
+
+DFX_API int dfx_sfm_step_batch(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
+                               void* out_items_host) {
+  if (!c || !out_items_host) return fail(DFX_E_INVALID, "dfx_sfm_step_batch: null argument");
+  if (!cs_supported(cs)) return fail(DFX_E_INVALID, "unsupported code size %d (16, 32, 64)", cs);
+  if (n <= 0) return fail(DFX_E_INVALID, "batch size %d", n);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  const size_t bytes = dfx_item_size(12 + cs) * (size_t)n;
+  if (c->items_bytes < bytes) DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, bytes))) return rc;
+  if ((rc = dfx_sfm_step_batch_async(c, cs, params, pairs, n, c->items_dev))) return rc;
+  return fetch_result(c, c->items_dev, out_items_host, bytes);
+}
+
+DFX_API int dfx_sfm_step(dfx_ctx* c, int cs, const dfx_se3* pose0, const dfx_se3* pose1, const dfx_cam* cam,
+                         const dfx_sfm_params* params, const dfx_img* img0, const dfx_img* img1, const dfx_img* dpt0,
+                         const dfx_img* std0, const dfx_img* valid0, const dfx_img* prx0_jac, const dfx_img* grad1,
+                         void* out_item) {
+  (void)std0;   // dead input in the reference: the uncertainty weight is computed and discarded (dense_sfm.h:58-67)
+  if (!pose0 || !pose1 || !cam || !img0 || !img1 || !dpt0 || !prx0_jac || !grad1) return fail(DFX_E_INVALID, "dfx_sfm_step: null argument");
+  dfx_sfm_pair p;
+  std::memset(&p, 0, sizeof(p));
+  p.pose0 = *pose0; p.pose1 = *pose1; p.cam = *cam;
+  p.img0 = *img0; p.img1 = *img1; p.dpt0 = *dpt0; p.prx0_jac = *prx0_jac; p.grad1 = *grad1;
+  if (valid0) p.valid0 = *valid0;
+  return dfx_sfm_step_batch(c, cs, params, &p, 1, out_item);
+}
+
+DFX_API int dfx_sfm_error(dfx_ctx* c, const dfx_se3* pose0, const dfx_se3* pose1, const dfx_cam* cam,
+                          const dfx_sfm_params* params, const dfx_img* img0, const dfx_img* img1, const dfx_img* dpt0,
+                          const dfx_img* std0, const dfx_img* grad1, dfx_corr_item* out) {
+  (void)std0; (void)grad1;   // both only feed the discarded uncertainty weight (dense_sfm.h:97-104)
+  if (!c || !pose0 || !pose1 || !params || !out) return fail(DFX_E_INVALID, "dfx_sfm_error: null argument");
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  dfx_se3 p10;
+  float R10[9], HM[9];
+  relative_pose(*pose0, *pose1, R10, p10.t, nullptr, HM);
+  dfx::SimplePairDev d;
+  p10.q[0] = p10.q[1] = p10.q[2] = 0; p10.q[3] = 1;
+  if ((rc = fill_simple(&p10, cam, img0, img1, dpt0, nullptr, nullptr, &d))) return rc;
+  for (int i = 0; i < 9; ++i) d.R[i] = R10[i];
+  const int blocks = simple_blocks(img0->w, img0->h);
+  const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
+  if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes))) return rc;
+  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, 256))) return rc;
+  DFX_HIP(dfx::launch_sfm_error(d, (int)img0->w, (int)img0->h, params->huber_delta, blocks, c->partials, c->items_dev, c->stream));
+  return fetch_result(c, c->items_dev, out, sizeof(dfx_corr_item));
+}
+
+// ---- SE3Aligner ------------------------------------------------------------------------------------------------
+DFX_API int dfx_se3_step(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam, const dfx_img* img0, const dfx_img* img1,
+                         const dfx_img* dpt0, const dfx_img* grad1, float huber_delta, void* out_item) {
+  if (!c || !out_item || !grad1) return fail(DFX_E_INVALID, "dfx_se3_step: null argument");
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  dfx::SimplePairDev d;
+  if ((rc = fill_simple(pose_10, cam, img0, img1, dpt0, grad1, nullptr, &d))) return rc;
+  const int blocks = simple_blocks(img0->w, img0->h);
+  const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
+  if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes))) return rc;
+  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, 256))) return rc;
+  DFX_HIP(dfx::launch_se3_step(d, (int)img0->w, (int)img0->h, huber_delta, blocks, c->partials, c->items_dev, c->stream));
+  return fetch_result(c, c->items_dev, out_item, dfx_item_size(6));
+}
+
+DFX_API int dfx_se3_warp(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam, const dfx_img* img0, const dfx_img* img1,
+                         const dfx_img* dpt0, const dfx_img* img2_out, dfx_corr_item* out) {
+  if (!c || !out || !img2_out) return fail(DFX_E_INVALID, "dfx_se3_warp: null argument");
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  dfx::SimplePairDev d;
+  if ((rc = fill_simple(pose_10, cam, img0, img1, dpt0, nullptr, img2_out, &d))) return rc;
+  const int blocks = simple_blocks(img0->w, img0->h);
+  const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
+  if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes))) return rc;
+  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, 256))) return rc;
+  DFX_HIP(dfx::launch_se3_warp(d, (int)img0->w, (int)img0->h, blocks, c->partials, c->items_dev, c->stream));
+  return fetch_result(c, c->items_dev, out, sizeof(dfx_corr_item));
+}
+
+// ---- image-proc ------------------------------------------------------------------------------------------------
+static int upload_code(dfx_ctx* c, int cs, const float* code, float** code_dev_out) {
+  int rc, slot;
+  char* host;
+  if (!c->code_dev) DFX_HIP(hipMalloc((void**)&c->code_dev, sizeof(float) * 64 * kStageSlots));
+  if ((rc = stage_acquire(c, sizeof(float) * 64, &slot, &host))) return rc;
+  std::memcpy(host, code, sizeof(float) * (size_t)cs);
+  float* dst = c->code_dev + (size_t)slot * 64;
+  DFX_HIP(hipMemcpyAsync(dst, host, sizeof(float) * (size_t)cs, hipMemcpyHostToDevice, c->stream));
+  if ((rc = stage_release(c, slot))) return rc;
+  *code_dev_out = dst;
+  return DFX_OK;
+}
+
+DFX_API int dfx_update_depth(dfx_ctx* c, int cs, const float* code, const dfx_img* prx_orig, const dfx_img* prx_jac,
+                             float avg_dpt, const dfx_img* dpt_out) {
+  if (!c || !code) return fail(DFX_E_INVALID, "dfx_update_depth: null argument");
+  if (!cs_supported(cs)) return fail(DFX_E_INVALID, "unsupported code size %d (16, 32, 64)", cs);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  if (!img_ok(prx_orig)) return fail(DFX_E_INVALID, "prx_orig: null or empty image view");
+  const uint32_t W = prx_orig->w, H = prx_orig->h;
+  if ((rc = check_img(prx_orig, "prx_orig", W, H, 4))) return rc;
+  if ((rc = check_img(dpt_out, "dpt_out", W, H, 4))) return rc;
+  if ((rc = check_img(prx_jac, "prx_jac", W * (uint32_t)cs, H, 4))) return rc;
+  if (((uintptr_t)prx_jac->ptr | prx_jac->pitch_bytes) & 15) return fail(DFX_E_INVALID, "prx_jac: pointer/pitch must be 16-byte aligned");
+  float* code_dev;
+  if ((rc = upload_code(c, cs, code, &code_dev))) return rc;
+  DFX_HIP(dfx::launch_update_depth(cs, code_dev, (const float*)prx_orig->ptr, (uint32_t)prx_orig->pitch_bytes,
+                                   (const float*)prx_jac->ptr, (uint32_t)prx_jac->pitch_bytes, avg_dpt, (float*)dpt_out->ptr,
+                                   (uint32_t)dpt_out->pitch_bytes, (int)W, (int)H, c->stream));
+  // the reference's UpdateDepth returns after CudaCheckLastError = cudaDeviceSynchronize (cu_image_proc.cpp:276)
+  DFX_HIP(hipStreamSynchronize(c->stream));
+  return DFX_OK;
+}
+
+DFX_API int dfx_sobel_gradients(dfx_ctx* c, const dfx_img* img, const dfx_img* grad_out) {
+  if (!c) return fail(DFX_E_INVALID, "null context");
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  if (!img_ok(img)) return fail(DFX_E_INVALID, "img: null or empty image view");
+  if ((rc = check_img(img, "img", img->w, img->h, 4))) return rc;
+  if ((rc = check_img(grad_out, "grad", img->w, img->h, 8))) return rc;
+  if (((uintptr_t)grad_out->ptr | grad_out->pitch_bytes) & 7) return fail(DFX_E_INVALID, "grad: pointer/pitch must be 8-byte aligned");
+  DFX_HIP(dfx::launch_sobel((const float*)img->ptr, (uint32_t)img->pitch_bytes, (float*)grad_out->ptr, (uint32_t)grad_out->pitch_bytes,
+                            (int)img->w, (int)img->h, c->stream));
+  DFX_HIP(hipStreamSynchronize(c->stream));
+  return DFX_OK;
+}
+
+DFX_API int dfx_gaussian_blur_down(dfx_ctx* c, const dfx_img* in, const dfx_img* out) {
+  if (!c) return fail(DFX_E_INVALID, "null context");
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  if (!img_ok(in) || !img_ok(out)) return fail(DFX_E_INVALID, "null or empty image view");
+  if ((rc = check_img(in, "in", in->w, in->h, 4))) return rc;
+  if ((rc = check_img(out, "out", out->w, out->h, 4))) return rc;
+  DFX_HIP(dfx::launch_blur_down((const float*)in->ptr, (uint32_t)in->pitch_bytes, (int)in->w, (int)in->h, (float*)out->ptr,
+                                (uint32_t)out->pitch_bytes, (int)out->w, (int)out->h, c->stream));
+  DFX_HIP(hipStreamSynchronize(c->stream));
+  return DFX_OK;
+}
+
+DFX_API int dfx_squared_error(dfx_ctx* c, const dfx_img* a, const dfx_img* b, float* out) {
+  if (!c || !out) return fail(DFX_E_INVALID, "null argument");
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  if (!img_ok(a)) return fail(DFX_E_INVALID, "a: null or empty image view");
+  if ((rc = check_img(a, "a", a->w, a->h, 4))) return rc;
+  if ((rc = check_img(b, "b", a->w, a->h, 4))) return rc;
+  const int blocks = simple_blocks(a->w, a->h);
+  const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
+  if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes))) return rc;
+  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, 256))) return rc;
+  DFX_HIP(dfx::launch_squared_error((const float*)a->ptr, (uint32_t)a->pitch_bytes, (const float*)b->ptr, (uint32_t)b->pitch_bytes,
+                                    (int)a->w, (int)a->h, blocks, c->partials, (float*)c->items_dev, c->stream));
+  return fetch_result(c, c->items_dev, out, sizeof(float));
+}
+
+DFX_API int dfx_depth_aligner_step(dfx_ctx* c, int cs, const float* code, const dfx_img* target_dpt, const dfx_img* prx_orig,
+                                   const dfx_img* prx_jac, float avg_dpt, void* out_item) {
+  if (!c || !code || !out_item) return fail(DFX_E_INVALID, "dfx_depth_aligner_step: null argument");
+  if (!cs_supported(cs)) return fail(DFX_E_INVALID, "unsupported code size %d (16, 32, 64)", cs);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  if (!img_ok(prx_orig)) return fail(DFX_E_INVALID, "prx_orig: null or empty image view");
+  const uint32_t W = prx_orig->w, H = prx_orig->h;
+  if ((rc = check_img(prx_orig, "prx_orig", W, H, 4))) return rc;
+  if ((rc = check_img(target_dpt, "target_dpt", W, H, 4))) return rc;
+  if ((rc = check_img(prx_jac, "prx_jac", W * (uint32_t)cs, H, 4))) return rc;
+  if (((uintptr_t)prx_jac->ptr | prx_jac->pitch_bytes) & 15) return fail(DFX_E_INVALID, "prx_jac: pointer/pitch must be 16-byte aligned");
+  // current depth into scratch (the kernel body of the reference recomputes DepthFromCode per pixel)
+  const size_t dbytes = (size_t)W * H * sizeof(float);
+  if (c->depth_scratch_bytes < dbytes) DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = grow_dev((void**)&c->depth_scratch, &c->depth_scratch_bytes, dbytes))) return rc;
+  float* code_dev;
+  if ((rc = upload_code(c, cs, code, &code_dev))) return rc;
+  DFX_HIP(dfx::launch_update_depth(cs, code_dev, (const float*)prx_orig->ptr, (uint32_t)prx_orig->pitch_bytes,
+                                   (const float*)prx_jac->ptr, (uint32_t)prx_jac->pitch_bytes, avg_dpt, c->depth_scratch, W * 4,
+                                   (int)W, (int)H, c->stream));
+  // pseudo-pair descriptor
+  int slot;
+  char* host;
+  if ((rc = stage_acquire(c, sizeof(dfx::SfmPairDev), &slot, &host))) return rc;
+  dfx::SfmPairDev* hd = reinterpret_cast<dfx::SfmPairDev*>(host);
+  std::memset(hd, 0, sizeof(*hd));
+  hd->fx = hd->fy = 1.f;
+  hd->img0 = (const float*)target_dpt->ptr; hd->pitch_img0 = (uint32_t)target_dpt->pitch_bytes;
+  hd->dpt0 = c->depth_scratch; hd->pitch_dpt0 = W * 4;
+  hd->jac = (const float*)prx_jac->ptr; hd->pitch_jac = (uint32_t)prx_jac->pitch_bytes;
+  if (c->pairs_cap < 1) {
+    DFX_HIP(hipMalloc((void**)&c->pairs_dev, sizeof(dfx::SfmPairDev) * 2 * kStageSlots));
+    c->pairs_cap = 2;
+  }
+  dfx::SfmPairDev* dd = c->pairs_dev + (size_t)slot * c->pairs_cap;
+  DFX_HIP(hipMemcpyAsync(dd, hd, sizeof(*hd), hipMemcpyHostToDevice, c->stream));
+  if ((rc = stage_release(c, slot))) return rc;
+  const int bpp = auto_step_blocks(c, W, H, 1);
+  const size_t pbytes = dfx::sfm_step_partials_bytes(cs, 1, bpp);
+  if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes))) return rc;
+  const size_t ibytes = dfx_item_size(cs);
+  if (c->items_bytes < ibytes) DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, ibytes))) return rc;
+  DFX_HIP(dfx::launch_depth_aligner_step(cs, dd, (int)W, (int)H, avg_dpt, bpp, c->partials, c->items_dev, c->stream));
+  return fetch_result(c, c->items_dev, out_item, ibytes);
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+// dfx_device.hpp -- device-side math shared by the gfx950 kernels.
+//
+// Restates (does not copy) the per-pixel math of the reference's L0 headers for CDNA4:
+//   warping.h:204-291 (correspondence + Jacobians), pinhole_camera_impl.h:41-108,
+//   m_estimators.h:50-56 (Huber), dense_sfm.h:133-201, lucas_kanade_se3.h:41-77.
+// Everything here is wave64 code; nothing assumes a 32-wide warp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dfx {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// 4-byte-aligned views for bilinear taps: (ix, ix+1) pairs start at arbitrary dword addresses.
+// gfx950 global loads only need dword alignment for multi-dword accesses.
+struct __attribute__((packed, aligned(4))) f32x2_u { float x, y; };
+struct __attribute__((packed, aligned(8))) f32x4_u8 { float x, y, z, w; };
+
+// Wave-uniform geometry of one (keyframe -> frame) pair; lives in kernarg/SGPRs.
+struct Geo {
+  float R[9];   // rotation of pose_10 = pose1^-1 * pose0, row-major
+  float t[3];
+  float fx, fy, u0, v0, w, h;
+  float ifx, ify;   // 1/fx, 1/fy
+};
+
+struct ImgRef {
+  const char* ptr;
+  uint32_t pitch;   // bytes
+  __device__ __forceinline__ const float* row(int y) const { return reinterpret_cast<const float*>(ptr + (size_t)y * pitch); }
+};
+
+// FindCorrespondence (warping.h:204-241): p = d * K^-1 (x,y,1); q = R p + t; pix1 = K q / q.z
+struct Corr {
+  float rrx, rry, rrz;   // R * ray            (ray = ReprojectDepthJacobian, pinhole_camera_impl.h:77-86)
+  float qx, qy, iz;      // q.x, q.y, 1/q.z
+  float u, v;
+  bool valid;
+};
+
+__device__ __forceinline__ Corr find_correspondence(const Geo& g, int x, int y, float d, float border, float min_dpt) {
+  Corr c;
+  const float rx = ((float)x - g.u0) * g.ifx;
+  const float ry = ((float)y - g.v0) * g.ify;
+  c.rrx = g.R[0] * rx + g.R[1] * ry + g.R[2];
+  c.rry = g.R[3] * rx + g.R[4] * ry + g.R[5];
+  c.rrz = g.R[6] * rx + g.R[7] * ry + g.R[8];
+  c.qx = c.rrx * d + g.t[0];
+  c.qy = c.rry * d + g.t[1];
+  const float qz = c.rrz * d + g.t[2];
+  c.iz = 1.0f / qz;
+  c.u = g.fx * c.qx * c.iz + g.u0;
+  c.v = g.fy * c.qy * c.iz + g.v0;
+  // PixelValid (pinhole_camera_impl.h:105-108) in float, exactly `x >= b && x < w - b`; NaN -> invalid
+  c.valid = (qz > min_dpt) && (c.u >= border) && (c.u < g.w - border) && (c.v >= border) && (c.v < g.h - border);
+  return c;
+}
+
+// VisionCore getBilinear convention: floor, lerp in x then y, lerp(a,b,t)=a+t(b-a)
+struct Taps {
+  int ix, iy;
+  float ax, ay;
+};
+__device__ __forceinline__ Taps make_taps(float u, float v) {
+  Taps t;
+  const float fu = floorf(u), fv = floorf(v);
+  t.ix = (int)fu; t.iy = (int)fv;
+  t.ax = u - fu; t.ay = v - fv;
+  return t;
+}
+__device__ __forceinline__ float lerp1(float a, float b, float t) { return a + t * (b - a); }
+
+__device__ __forceinline__ float sample_img(const ImgRef& I, const Taps& t) {
+  const float* r0 = I.row(t.iy) + t.ix;
+  const float* r1 = I.row(t.iy + 1) + t.ix;
+  const f32x2_u a = *reinterpret_cast<const f32x2_u*>(r0);
+  const f32x2_u b = *reinterpret_cast<const f32x2_u*>(r1);
+  return lerp1(lerp1(a.x, a.y, t.ax), lerp1(b.x, b.y, t.ax), t.ay);
+}
+__device__ __forceinline__ void sample_grad(const ImgRef& G, const Taps& t, float& gx, float& gy) {
+  const float* r0 = G.row(t.iy) + 2 * t.ix;
+  const float* r1 = G.row(t.iy + 1) + 2 * t.ix;
+  const f32x4_u8 a = *reinterpret_cast<const f32x4_u8*>(r0);
+  const f32x4_u8 b = *reinterpret_cast<const f32x4_u8*>(r1);
+  gx = lerp1(lerp1(a.x, a.z, t.ax), lerp1(b.x, b.z, t.ax), t.ay);
+  gy = lerp1(lerp1(a.y, a.w, t.ax), lerp1(b.y, b.w, t.ax), t.ay);
+}
+
+// HuberWeight (m_estimators.h:50-56): sqrt-weight for both J and r
+__device__ __forceinline__ float huber_weight(float r, float delta) {
+  const float aa = fabsf(r);
+  const float wo = sqrtf(delta * (2.0f * aa - delta)) / aa;
+  return aa <= delta ? 1.0f : wo;
+}
+
+// -grad * ProjectPointJacobian(q) * [I | -hat(R p)]   (warping.h:156-164,247-257; Rp = rr * d, no translation)
+__device__ __forceinline__ void pose_row(const Geo& g, const Corr& c, float d, float gx, float gy, float* gC /*6*/,
+                                         float& D00, float& D02, float& D11, float& D12) {
+  D00 = g.fx * c.iz;
+  D11 = g.fy * c.iz;
+  D02 = -(g.fx * c.qx) * c.iz * c.iz;
+  D12 = -(g.fy * c.qy) * c.iz * c.iz;
+  const float vx = c.rrx * d, vy = c.rry * d, vz = c.rrz * d;   // R p
+  const float C03 = D02 * vy, C04 = D00 * vz - D02 * vx, C05 = -D00 * vy;
+  const float C13 = -D11 * vz + D12 * vy, C14 = -D12 * vx, C15 = D11 * vx;
+  gC[0] = -(gx * D00);
+  gC[1] = -(gy * D11);
+  gC[2] = -(gx * D02 + gy * D12);
+  gC[3] = -(gx * C03 + gy * C13);
+  gC[4] = -(gx * C04 + gy * C14);
+  gC[5] = -(gx * C05 + gy * C15);
+}
+
+// v_mul_legacy_f32: DX9 multiply, 0 * anything (NaN, Inf) = 0.  Used to apply zero weights safely.
+__device__ __forceinline__ float mul_zero_wins(float a, float b) {
+  float r;
+  asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// 64-lane sum via shuffles (wave = 64 on gfx950)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+}  // namespace dfx

@@ -1,0 +1,71 @@
+// dfx_kernels.hpp -- launcher declarations shared between the kernel TUs and the C-ABI TU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dfx {
+
+// Device-side descriptor of one keyframe->frame pair (argument list of SfmAligner::RunStep,
+// cu_sfmaligner.h:76-86, after the host has folded RelativePose + its Jacobians, cu_sfmaligner.cpp:166).
+struct SfmPairDev {
+  float R[9], t[3];   // pose_10
+  float M[9];         // Ra^T, Ra = R(pose1):  pose10_J_pose0 = blkdiag(M, M)            (warping.h:128-134)
+  float HM[9];        // hat(Ra^T (ta - tb)) Ra^T: pose10_J_pose1 = [[-M, -HM], [0, -M]]  (warping.h:119-126)
+  float fx, fy, u0, v0, w, h;
+  const float* img0;
+  const float* img1;
+  const float* dpt0;
+  float* valid0;      // may be null
+  const float* jac;   // [H][W*CS]
+  const float* grad1; // [H][W][2]
+  uint32_t pitch_img0, pitch_img1, pitch_dpt0, pitch_valid0, pitch_jac, pitch_grad1;   // bytes
+};
+
+struct SfmParamsDev {
+  float huber_delta, avg_dpt, min_dpt, border;
+};
+
+struct SimplePairDev {   // SE3Aligner / EvaluateError / Warp
+  float R[9], t[3];
+  float fx, fy, u0, v0, w, h;
+  const float* img0;
+  const float* img1;
+  const float* dpt0;
+  const float* grad1;   // null for error / warp
+  float* img2;          // warp output or null
+  uint32_t pitch_img0, pitch_img1, pitch_dpt0, pitch_grad1, pitch_img2;
+};
+
+// z-space size of the SfM step partials: blocks of 16x16 for the upper block-triangle over
+// (P = 12 pose + r + ..., C0..C{ncb-1}); see dfx_sfm_step.hip
+inline int sfm_nacc(int ncb) { return (1 + ncb) * (2 + ncb) / 2; }
+inline int sfm_zdim(int ncb) { return sfm_nacc(ncb) * 256; }
+
+// All launchers enqueue on `stream` and return the HIP status of the launch.
+// ev_begin/ev_end (optional) bracket the step kernel only.
+hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm,
+                           int blocks_per_pair, float* partials_dev, void* items_dev, size_t item_stride,
+                           hipStream_t stream, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
+size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair);
+
+hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
+                           void* item_dev, hipStream_t stream);
+hipError_t launch_sfm_error(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
+                            void* corr_item_dev, hipStream_t stream);
+hipError_t launch_se3_warp(const SimplePairDev& p, int W, int H, int blocks, float* partials_dev, void* corr_item_dev,
+                           hipStream_t stream);
+hipError_t launch_update_depth(int cs, const float* code_dev, const float* prx_orig, uint32_t pitch_prx, const float* jac,
+                               uint32_t pitch_jac, float avg_dpt, float* dpt_out, uint32_t pitch_out, int W, int H,
+                               hipStream_t stream);
+hipError_t launch_sobel(const float* img, uint32_t pitch, float* grad, uint32_t gpitch, int W, int H, hipStream_t stream);
+hipError_t launch_blur_down(const float* in, uint32_t pitch, int W, int H, float* out, uint32_t opitch, int OW, int OH,
+                            hipStream_t stream);
+hipError_t launch_squared_error(const float* a, uint32_t pitch_a, const float* b, uint32_t pitch_b, int W, int H, int blocks,
+                                float* partials_dev, float* out_dev, hipStream_t stream);
+hipError_t launch_depth_aligner_step(int cs, const SfmPairDev* pair_dev, int W, int H, float avg_dpt, int blocks,
+                                     float* partials_dev, void* item_dev, hipStream_t stream);
+
+constexpr int kSimpleRow = 32;       // floats per block partial of the VALU reduction kernels
+constexpr int kMaxSimpleBlocks = 1024;
+
+}  // namespace dfx

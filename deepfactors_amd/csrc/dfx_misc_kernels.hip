@@ -1,0 +1,336 @@
+// dfx_misc_kernels.hip -- the HBM/latency-bound siblings of the SfM step for gfx950:
+//   SE3Aligner::RunStep / Warp   (reference sources/cuda/cu_se3aligner.cpp:37-176, lucas_kanade_se3.h:41-77)
+//   SfmAligner::EvaluateError    (cu_sfmaligner.cpp:72-147, dense_sfm.h:79-119)
+//   UpdateDepth, SobelGradients, GaussianBlurDown, SquaredError (cu_image_proc.cpp:57-277)
+//   DepthAligner::RunStep        (cu_depthaligner.cpp:32-110)
+// All reductions: lane = pixel, grid-stride over 64-pixel chunks, wave shuffle (64 wide) -> LDS across the
+// 4 waves in fixed order -> one 32-float partial per workgroup -> k_finalize_rows sums the partials in double
+// in fixed order.  Inlier counts travel as exact floats (< 2^24 per workgroup) and are summed in double.
+#include "dfx_device.hpp"
+#include "dfx_kernels.hpp"
+
+namespace dfx {
+
+constexpr int kT = 256;   // threads per workgroup (4 waves)
+
+template <int N>
+__device__ __forceinline__ void block_reduce_store(float (&v)[N], float* __restrict__ out_row) {
+  static_assert(N <= kSimpleRow, "partial row too small");
+  __shared__ float red[kT / 64][kSimpleRow];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    const float s = wave_sum(v[q]);
+    if (lane == 0) red[wave][q] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < kSimpleRow) {
+    float s = 0.f;
+    if (threadIdx.x < N) s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    out_row[threadIdx.x] = s;
+  }
+}
+
+__device__ __forceinline__ Geo geo_from(const SimplePairDev& p) {
+  Geo g;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) g.R[q] = p.R[q];
+  g.t[0] = p.t[0]; g.t[1] = p.t[1]; g.t[2] = p.t[2];
+  g.fx = p.fx; g.fy = p.fy; g.u0 = p.u0; g.v0 = p.v0; g.w = p.w; g.h = p.h;
+  g.ifx = 1.0f / p.fx; g.ify = 1.0f / p.fy;
+  return g;
+}
+
+// ---- SE3 step: 21 JtJ + 6 Jtr + r^2 + inliers = 29 floats per lane -----------------------------------------
+__global__ __launch_bounds__(kT) void k_se3_step(const SimplePairDev p, const int W, const int H, const float huber_delta,
+                                                 float* __restrict__ partials) {
+  const Geo g = geo_from(p);
+  const ImgRef I0{ (const char*)p.img0, p.pitch_img0 }, I1{ (const char*)p.img1, p.pitch_img1 };
+  const ImgRef D0{ (const char*)p.dpt0, p.pitch_dpt0 }, G1{ (const char*)p.grad1, p.pitch_grad1 };
+  float acc[29];
+#pragma unroll
+  for (int q = 0; q < 29; ++q) acc[q] = 0.f;
+  const int npx = W * H;
+  for (int i = blockIdx.x * kT + threadIdx.x; i < npx; i += gridDim.x * kT) {
+    const int y = i / W, x = i - y * W;
+    const float d = D0.row(y)[x];
+    const float i0 = I0.row(y)[x];
+    const Corr c = find_correspondence(g, x, y, d, 1.0f, 0.0f);
+    if (c.valid) {
+      const Taps tp = make_taps(c.u, c.v);
+      float gx, gy;
+      sample_grad(G1, tp, gx, gy);
+      const float samp = sample_img(I1, tp);
+      float J[6], D00, D02, D11, D12;
+      pose_row(g, c, d, gx, gy, J, D00, D02, D11, D12);
+      float r = i0 - samp;
+      const float wgt = huber_weight(r, huber_delta);
+      r *= wgt;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) J[j] *= wgt;
+      int k = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b) acc[k++] += J[a] * J[b];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;
+      acc[27] += r * r;
+      acc[28] += 1.0f;
+    }
+  }
+  block_reduce_store<29>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
+}
+
+// ---- SfM error: sum (w r)^2, inliers -----------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void k_sfm_error(const SimplePairDev p, const int W, const int H, const float huber_delta,
+                                                  float* __restrict__ partials) {
+  const Geo g = geo_from(p);
+  const ImgRef I0{ (const char*)p.img0, p.pitch_img0 }, I1{ (const char*)p.img1, p.pitch_img1 };
+  const ImgRef D0{ (const char*)p.dpt0, p.pitch_dpt0 };
+  float acc[2] = { 0.f, 0.f };
+  const int npx = W * H;
+  for (int i = blockIdx.x * kT + threadIdx.x; i < npx; i += gridDim.x * kT) {
+    const int y = i / W, x = i - y * W;
+    const float d = D0.row(y)[x];
+    const float i0 = I0.row(y)[x];
+    const Corr c = find_correspondence(g, x, y, d, 1.0f, 0.0f);   // dense_sfm.h:91: default border 1, min_dpt 0
+    if (c.valid) {
+      const Taps tp = make_taps(c.u, c.v);
+      float r = i0 - sample_img(I1, tp);
+      r *= huber_weight(r, huber_delta);
+      acc[0] += r * r;
+      acc[1] += 1.0f;
+    }
+  }
+  block_reduce_store<2>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
+}
+
+// ---- Warp: render img1 into frame 0, SIGNED residual sum (cu_se3aligner.cpp:106) ----------------------------
+__global__ __launch_bounds__(kT) void k_se3_warp(const SimplePairDev p, const int W, const int H, float* __restrict__ partials) {
+  const Geo g = geo_from(p);
+  const ImgRef I0{ (const char*)p.img0, p.pitch_img0 }, I1{ (const char*)p.img1, p.pitch_img1 };
+  const ImgRef D0{ (const char*)p.dpt0, p.pitch_dpt0 };
+  float acc[2] = { 0.f, 0.f };
+  const int npx = W * H;
+  for (int i = blockIdx.x * kT + threadIdx.x; i < npx; i += gridDim.x * kT) {
+    const int y = i / W, x = i - y * W;
+    const float d = D0.row(y)[x];
+    const float i0 = I0.row(y)[x];
+    const Corr c = find_correspondence(g, x, y, d, 1.0f, 0.0f);   // `depth <= 0 -> skip`, PixelValid(pix1, 1)
+    float outv = 0.f;
+    if (c.valid) {
+      const Taps tp = make_taps(c.u, c.v);
+      outv = sample_img(I1, tp);
+      acc[0] += i0 - outv;
+      acc[1] += 1.0f;
+    }
+    reinterpret_cast<float*>((char*)p.img2 + (size_t)y * p.pitch_img2)[x] = outv;
+  }
+  block_reduce_store<2>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
+}
+
+// ---- SquaredError ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void k_squared_error(const float* __restrict__ a, const uint32_t pa, const float* __restrict__ b,
+                                                      const uint32_t pb, const int W, const int H, float* __restrict__ partials) {
+  float acc[1] = { 0.f };
+  const int npx = W * H;
+  for (int i = blockIdx.x * kT + threadIdx.x; i < npx; i += gridDim.x * kT) {
+    const int y = i / W, x = i - y * W;
+    const float d = reinterpret_cast<const float*>((const char*)a + (size_t)y * pa)[x] -
+                    reinterpret_cast<const float*>((const char*)b + (size_t)y * pb)[x];
+    acc[0] += d * d;
+  }
+  block_reduce_store<1>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
+}
+
+// ---- finalize: out[e] = sum_b partials[b][e] in double, fixed order; layout-specific scatter -------------------
+enum FinalKind { kFinalItem6 = 0, kFinalCorr = 1, kFinalScalar = 2 };
+
+__global__ __launch_bounds__(1024) void k_finalize_rows(const float* __restrict__ partials, const int nblocks, const int kind,
+                                                        char* __restrict__ out) {
+  __shared__ double red[32][kSimpleRow];
+  const int e = threadIdx.x & 31, rg = threadIdx.x >> 5;   // 32 row groups
+  double s = 0.0;
+  for (int b = rg; b < nblocks; b += 32) s += (double)partials[(size_t)b * kSimpleRow + e];
+  red[rg][e] = s;
+  __syncthreads();
+  if (rg != 0) return;
+  s = 0.0;
+  for (int q = 0; q < 32; ++q) s += red[q][e];
+  if (kind == kFinalItem6) {
+    // JTJJrReductionItem<float,6>: 21 + 6 + 1 floats, then u64 inliers at byte 112
+    if (e < 28) reinterpret_cast<float*>(out)[e] = (float)s;
+    else if (e == 28) *reinterpret_cast<unsigned long long*>(out + 112) = (unsigned long long)(s + 0.5);
+  } else if (kind == kFinalCorr) {
+    if (e == 0) reinterpret_cast<float*>(out)[0] = (float)s;
+    else if (e == 1) *reinterpret_cast<unsigned long long*>(out + 8) = (unsigned long long)(s + 0.5);
+  } else {
+    if (e == 0) reinterpret_cast<float*>(out)[0] = (float)s;
+  }
+}
+
+// ---- UpdateDepth: dpt = a / (prx0 + jac . code) - a  (the code-Jacobian decoder, GEMV, 8 + 4 CS bytes / pixel) ---
+// LPP = CS/4 lanes share one pixel (float4 each -> every wave-load is 1 KiB contiguous); 64 pixels per wave step so
+// that the prx read and the depth write are single coalesced 256-byte accesses.
+template <int CS>
+__global__ __launch_bounds__(kT) void k_update_depth(const float* __restrict__ code, const float* __restrict__ prx,
+                                                     const uint32_t pitch_prx, const float* __restrict__ jac,
+                                                     const uint32_t pitch_jac, const float avg_dpt, float* __restrict__ out,
+                                                     const uint32_t pitch_out, const int W, const int H) {
+  constexpr int LPP = CS / 4;        // lanes per pixel
+  constexpr int PPL = 64 / LPP;      // pixels per wave-load
+  constexpr int NSUB = 64 / PPL;     // wave-loads per 64-pixel chunk (== LPP)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane % LPP, grp = lane / LPP;
+  const f32x4 c4 = *reinterpret_cast<const f32x4*>(code + 4 * q);
+  const int npx = W * H;
+  const int nchunks = (npx + 63) >> 6;
+  for (int chunk = blockIdx.x * (kT / 64) + wave; chunk < nchunks; chunk += gridDim.x * (kT / 64)) {
+    const int base = chunk << 6;
+    const int y0 = base / W, x0 = base - y0 * W;
+    // sub-step s: lane group `grp` handles pixel base + grp*NSUB + s  -> after NSUB steps lane l owns pixel base + l
+    f32x4 v[NSUB];
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+      const int off = grp * NSUB + s;
+      int x = x0 + off, y = y0;
+      while (x >= W) { x -= W; ++y; }
+      f32x4 t = f32x4{ 0.f, 0.f, 0.f, 0.f };
+      if (base + off < npx) t = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>((const char*)jac + (size_t)y * pitch_jac) + (size_t)x * CS + 4 * q);
+      v[s] = t;
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+      float d = v[s].x * c4.x + v[s].y * c4.y + v[s].z * c4.z + v[s].w * c4.w;
+#pragma unroll
+      for (int m = 1; m < LPP; m <<= 1) d += __shfl_xor(d, m, 64);
+      if (q == s) mine = d;   // lane l = grp*LPP + q keeps pixel grp*NSUB + q = l (NSUB == LPP)
+    }
+    int x = x0 + lane, y = y0;
+    while (x >= W) { x -= W; ++y; }
+    if (base + lane < npx) {
+      const float p0 = reinterpret_cast<const float*>((const char*)prx + (size_t)y * pitch_prx)[x];
+      const float pr = p0 + mine;
+      reinterpret_cast<float*>((char*)out + (size_t)y * pitch_out)[x] = avg_dpt / pr - avg_dpt;
+    }
+  }
+}
+
+// ---- Sobel / 8 with clamped borders (cu_image_proc.cpp:57-92) ---------------------------------------------------
+__global__ __launch_bounds__(kT) void k_sobel(const float* __restrict__ img, const uint32_t pitch, float* __restrict__ grad,
+                                              const uint32_t gpitch, const int W, const int H) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  const int xm = max(x - 1, 0), xp = min(x + 1, W - 1), ym = max(y - 1, 0), yp = min(y + 1, H - 1);
+  const float* r0 = reinterpret_cast<const float*>((const char*)img + (size_t)ym * pitch);
+  const float* r1 = reinterpret_cast<const float*>((const char*)img + (size_t)y * pitch);
+  const float* r2 = reinterpret_cast<const float*>((const char*)img + (size_t)yp * pitch);
+  const float a = r0[xm], b = r0[x], c = r0[xp], d = r1[xm], f = r1[xp], g = r2[xm], h = r2[x], i = r2[xp];
+  // same tap order as the reference loop (py outer, px inner), zero taps skipped
+  float sx = 0.f, sy = 0.f;
+  sx += a * -1.f; sy += a * -1.f;
+  sy += b * -2.f;
+  sx += c * 1.f;  sy += c * -1.f;
+  sx += d * -2.f;
+  sx += f * 2.f;
+  sx += g * -1.f; sy += g * 1.f;
+  sy += h * 2.f;
+  sx += i * 1.f;  sy += i * 1.f;
+  f32x2 o = { sx / 8.f, sy / 8.f };
+  *reinterpret_cast<f32x2*>(reinterpret_cast<float*>((char*)grad + (size_t)y * gpitch) + 2 * x) = o;
+}
+
+// ---- 5x5 binomial blur + decimate (cu_image_proc.cpp:134-164) ----------------------------------------------------
+__global__ __launch_bounds__(kT) void k_blur_down(const float* __restrict__ in, const uint32_t pitch, const int W, const int H,
+                                                  float* __restrict__ out, const uint32_t opitch, const int OW, const int OH) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= OW || y >= OH) return;
+  const float B[5] = { 1.f, 4.f, 6.f, 4.f, 1.f };
+  float sum = 0.f, wall = 0.f;
+#pragma unroll
+  for (int py = 0; py < 5; ++py) {
+    const int ny = min(max(2 * y + py - 2, 0), H - 1);
+    const float* r = reinterpret_cast<const float*>((const char*)in + (size_t)ny * pitch);
+#pragma unroll
+    for (int px = 0; px < 5; ++px) {
+      const int nx = min(max(2 * x + px - 2, 0), W - 1);
+      const float k = B[px] * B[py];
+      sum += r[nx] * k;
+      wall += k;
+    }
+  }
+  reinterpret_cast<float*>((char*)out + (size_t)y * opitch)[x] = sum / wall;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------------
+hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
+                           void* item_dev, hipStream_t stream) {
+  hipLaunchKernelGGL(k_se3_step, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalItem6, (char*)item_dev);
+  return hipGetLastError();
+}
+
+hipError_t launch_sfm_error(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
+                            void* corr_item_dev, hipStream_t stream) {
+  hipLaunchKernelGGL(k_sfm_error, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalCorr, (char*)corr_item_dev);
+  return hipGetLastError();
+}
+
+hipError_t launch_se3_warp(const SimplePairDev& p, int W, int H, int blocks, float* partials_dev, void* corr_item_dev,
+                           hipStream_t stream) {
+  hipLaunchKernelGGL(k_se3_warp, dim3(blocks), dim3(kT), 0, stream, p, W, H, partials_dev);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalCorr, (char*)corr_item_dev);
+  return hipGetLastError();
+}
+
+hipError_t launch_squared_error(const float* a, uint32_t pitch_a, const float* b, uint32_t pitch_b, int W, int H, int blocks,
+                                float* partials_dev, float* out_dev, hipStream_t stream) {
+  hipLaunchKernelGGL(k_squared_error, dim3(blocks), dim3(kT), 0, stream, a, pitch_a, b, pitch_b, W, H, partials_dev);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalScalar, (char*)out_dev);
+  return hipGetLastError();
+}
+
+hipError_t launch_update_depth(int cs, const float* code_dev, const float* prx_orig, uint32_t pitch_prx, const float* jac,
+                               uint32_t pitch_jac, float avg_dpt, float* dpt_out, uint32_t pitch_out, int W, int H,
+                               hipStream_t stream) {
+  const int nchunks = (W * H + 63) / 64;
+  int blocks = (nchunks + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  switch (cs) {
+    case 16: hipLaunchKernelGGL(k_update_depth<16>, dim3(blocks), dim3(kT), 0, stream, code_dev, prx_orig, pitch_prx, jac, pitch_jac, avg_dpt, dpt_out, pitch_out, W, H); break;
+    case 32: hipLaunchKernelGGL(k_update_depth<32>, dim3(blocks), dim3(kT), 0, stream, code_dev, prx_orig, pitch_prx, jac, pitch_jac, avg_dpt, dpt_out, pitch_out, W, H); break;
+    case 64: hipLaunchKernelGGL(k_update_depth<64>, dim3(blocks), dim3(kT), 0, stream, code_dev, prx_orig, pitch_prx, jac, pitch_jac, avg_dpt, dpt_out, pitch_out, W, H); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_sobel(const float* img, uint32_t pitch, float* grad, uint32_t gpitch, int W, int H, hipStream_t stream) {
+  hipLaunchKernelGGL(k_sobel, dim3((W + 63) / 64, (H + 3) / 4), dim3(kT), 0, stream, img, pitch, grad, gpitch, W, H);
+  return hipGetLastError();
+}
+
+hipError_t launch_blur_down(const float* in, uint32_t pitch, int W, int H, float* out, uint32_t opitch, int OW, int OH,
+                            hipStream_t stream) {
+  hipLaunchKernelGGL(k_blur_down, dim3((OW + 63) / 64, (OH + 3) / 4), dim3(kT), 0, stream, in, pitch, W, H, out, opitch, OW, OH);
+  return hipGetLastError();
+}
+
+}  // namespace dfx

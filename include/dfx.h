@@ -1,0 +1,177 @@
+/* dfx.h -- C ABI of libdfx.so: MI355X-native (gfx950, HIP) dense photometric alignment kernels that
+ * replace the CUDA hot path of jczarnowski/DeepFactors behind its own operator interface.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the reference
+ * repository root).  The reference has no C ABI; its path sits behind C++ templates explicitly
+ * instantiated in libdf_cuda.so (sources/cuda/CMakeLists.txt:51-63).  include/dfx_shim.hpp holds
+ * the header-compatible C++17 classes (df::SfmAligner<float,CS>, df::SE3Aligner<float>,
+ * df::UpdateDepth) a maintainer drops in; they forward here.  See INTEGRATION.md.
+ *
+ * Conventions
+ *  - All image pointers are DEVICE pointers (HIP) to fp32 data, row-pitched like VisionCore's
+ *    Buffer2DView: element (x, y) lives at (char*)ptr + y*pitch_bytes + x*sizeof(elem).
+ *    `grad` images hold interleaved (gx, gy) float pairs (Eigen::Matrix<float,1,2>), `prx_jac`
+ *    images have w = W*CS floats per row (mapping/keyframe.h:52).
+ *  - Poses are Sophus::SE3f by value: unit quaternion (x, y, z, w) + translation.
+ *  - Every function returns 0 on success, a negative DFX_E_* code otherwise, and never throws;
+ *    dfx_last_error() returns the thread-local message (the shim rethrows it, mirroring
+ *    CudaCheckLastError, sources/cuda/launch_utils.h:26-32).
+ *  - "No overlap" is signalled in-band like the reference: inliers == 0 (photometric_factor.cpp:213-216).
+ *  - Synchronous calls block until the result is on the host, like the reference (cudaDeviceSynchronize
+ *    + blocking copy, cu_sfmaligner.cpp:175-183).  *_async / *_batch variants only enqueue on the
+ *    context's stream and leave results in device memory.
+ */
+#ifndef DFX_H_
+#define DFX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(_WIN32)
+#define DFX_API
+#else
+#define DFX_API __attribute__((visibility("default")))
+#endif
+
+#define DFX_OK 0
+#define DFX_E_INVALID (-1)   /* bad argument (null pointer, unsupported code size, misaligned jacobian ...) */
+#define DFX_E_HIP (-2)       /* HIP runtime error; message in dfx_last_error() */
+#define DFX_E_NOGPU (-3)     /* no usable HIP device / built without device code for it */
+
+typedef struct dfx_ctx dfx_ctx; /* device id + stream + scratch; one per host thread */
+
+/* vc::Image2DView<float,TargetDeviceCUDA> (VisionCore; used at cu_sfmaligner.h:74-75) */
+typedef struct dfx_img {
+  void* ptr;          /* device pointer */
+  size_t pitch_bytes; /* row pitch */
+  uint32_t w, h;      /* in ELEMENTS of the image's own type (floats; float pairs for grad; W*CS for prx_jac) */
+} dfx_img;
+
+/* Sophus::SE3f */
+typedef struct dfx_se3 {
+  float q[4]; /* x y z w */
+  float t[3];
+} dfx_se3;
+
+/* df::PinholeCamera<float> (common/algorithm/pinhole_camera.h): fx fy u0 v0 width height */
+typedef struct dfx_cam {
+  float fx, fy, u0, v0, w, h;
+} dfx_cam;
+
+/* df::DenseSfmParams (common/algorithm/dense_sfm.h:36-43).  ocl_th is unused by the reference and dropped. */
+typedef struct dfx_sfm_params {
+  float huber_delta; /* 0.1 */
+  float avg_dpt;     /* 2.0 */
+  float min_dpt;     /* 0.0 */
+  int32_t valid_border; /* 2 */
+} dfx_sfm_params;
+
+/* df::CorrespondenceReductionItem<float> (cuda/reduction_items.h:35-71): 16 bytes */
+typedef struct dfx_corr_item {
+  float residual;
+  uint32_t _pad;
+  uint64_t inliers;
+} dfx_corr_item;
+
+/* df::JTJJrReductionItem<float,NP> (cuda/reduction_items.h:77-143) is a variable-size POD:
+ *   float JtJ[NP*(NP+1)/2]   packed upper triangle, row-major ((0,0),(0,1)..(0,NP-1),(1,1)..)
+ *   float Jtr[NP]
+ *   float residual
+ *   (pad to 8)  uint64_t inliers
+ * NP = 6 (SE3Aligner, 120 bytes), 12+CS (SfmAligner, 4152 bytes for CS=32), CS (DepthAligner).
+ * Parameter order for SfmAligner: [pose0 (tx,ty,tz,wx,wy,wz), pose1 (6), code0 (CS)]. */
+static inline size_t dfx_item_jtj_len(int np) { return (size_t)np * (size_t)(np + 1) / 2; }
+static inline size_t dfx_item_inliers_offset(int np) {
+  return ((dfx_item_jtj_len(np) + (size_t)np + 1) * sizeof(float) + 7) & ~(size_t)7;
+}
+static inline size_t dfx_item_size(int np) { return dfx_item_inliers_offset(np) + sizeof(uint64_t); }
+static inline const float* dfx_item_jtj(const void* item) { return (const float*)item; }
+static inline const float* dfx_item_jtr(const void* item, int np) { return (const float*)item + dfx_item_jtj_len(np); }
+static inline float dfx_item_residual(const void* item, int np) { return ((const float*)item)[dfx_item_jtj_len(np) + np]; }
+static inline uint64_t dfx_item_inliers(const void* item, int np) {
+  return *(const uint64_t*)((const char*)item + dfx_item_inliers_offset(np));
+}
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* Replaces cuda::Init / per-aligner scratch buffers (cu_sfmaligner.cpp:101-114, cu_se3aligner.cpp:120).
+ * `stream` is a hipStream_t to enqueue on (e.g. the caller's), or NULL to let the context own one. */
+DFX_API int dfx_ctx_create(int device, void* stream, dfx_ctx** out);
+DFX_API void dfx_ctx_destroy(dfx_ctx* ctx);
+DFX_API const char* dfx_last_error(void);
+DFX_API const char* dfx_version(void);
+/* Waits for everything enqueued on the context's stream. */
+DFX_API int dfx_sync(dfx_ctx* ctx);
+/* SfmAligner::SetStepThreadsBlocks (cu_sfmaligner.cpp:196-203): workgroups per pair for the step
+ * kernel; 0 = automatic (sized from the CU count).  Threads per workgroup are fixed at 256 (4 waves). */
+DFX_API int dfx_sfm_set_step_blocks(dfx_ctx* ctx, int blocks_per_pair);
+DFX_API int dfx_device_cu_count(dfx_ctx* ctx);
+/* Measurement hook (no reference counterpart; the reference times with std::clock around blocking calls,
+ * tools/kernel_benchmark.cpp:145-180): when enabled, every SfM step launch is bracketed by HIP events on the
+ * context's stream -- around the step kernel only, excluding the finalize kernel and copies.
+ * dfx_profile_read waits for the stream, returns the number of bracketed launches and their summed
+ * duration in milliseconds since the last read, and resets the counters. */
+DFX_API int dfx_set_profiling(dfx_ctx* ctx, int enable);
+DFX_API int dfx_profile_read(dfx_ctx* ctx, int* n_launches, double* total_ms);
+
+/* ---- SE3Aligner<float> (cuda/cu_se3aligner.h:52-72) ----------------------------------------- */
+/* RunStep (cu_se3aligner.cpp:153-176): out_item = JTJJrReductionItem<float,6> on the HOST (120 bytes). */
+DFX_API int dfx_se3_step(dfx_ctx* ctx, const dfx_se3* pose_10, const dfx_cam* cam, const dfx_img* img0,
+                         const dfx_img* img1, const dfx_img* dpt0, const dfx_img* grad1, float huber_delta,
+                         void* out_item);
+/* Warp (cu_se3aligner.cpp:125-151): renders img1 into frame 0 (img2), signed residual sum + inliers. */
+DFX_API int dfx_se3_warp(dfx_ctx* ctx, const dfx_se3* pose_10, const dfx_cam* cam, const dfx_img* img0,
+                         const dfx_img* img1, const dfx_img* dpt0, const dfx_img* img2_out, dfx_corr_item* out);
+
+/* ---- SfmAligner<float,CS> (cuda/cu_sfmaligner.h:50-97) -------------------------------------- */
+/* RunStep (cu_sfmaligner.cpp:149-185).  cs in {16, 32, 64}.  std0 may be NULL (dead input in the reference,
+ * dense_sfm.h:58-67); valid0 may be NULL (otherwise written 1.0 where a pixel is an inlier, never cleared,
+ * dense_sfm.h:161).  out_item = JTJJrReductionItem<float,12+cs> on the HOST. */
+DFX_API int dfx_sfm_step(dfx_ctx* ctx, int cs, const dfx_se3* pose0, const dfx_se3* pose1, const dfx_cam* cam,
+                         const dfx_sfm_params* params, const dfx_img* img0, const dfx_img* img1, const dfx_img* dpt0,
+                         const dfx_img* std0, const dfx_img* valid0, const dfx_img* prx0_jac, const dfx_img* grad1,
+                         void* out_item);
+/* EvaluateError (cu_sfmaligner.cpp:120-147): border 1, min_dpt 0 (FindCorrespondence defaults, dense_sfm.h:91). */
+DFX_API int dfx_sfm_error(dfx_ctx* ctx, const dfx_se3* pose0, const dfx_se3* pose1, const dfx_cam* cam,
+                          const dfx_sfm_params* params, const dfx_img* img0, const dfx_img* img1, const dfx_img* dpt0,
+                          const dfx_img* std0, const dfx_img* grad1, dfx_corr_item* out);
+
+/* One keyframe->frame pair of a batch: the argument list of SfmAligner::RunStep as a POD. */
+typedef struct dfx_sfm_pair {
+  dfx_se3 pose0, pose1;
+  dfx_cam cam;
+  dfx_img img0, img1, dpt0, valid0 /* ptr may be NULL */, prx0_jac, grad1;
+} dfx_sfm_pair;
+
+/* Batched RunStep over n independent pairs in ONE launch (new; the reference evaluates pairs one by one
+ * from PhotometricFactor::linearize, photometric_factor.cpp:267-274).  Enqueues on the context's stream and
+ * returns immediately; item p is written to DEVICE memory at (char*)out_items_dev + p*dfx_item_size(12+cs).
+ * All pairs must share (w, h) -- one pyramid level per batch. */
+DFX_API int dfx_sfm_step_batch_async(dfx_ctx* ctx, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs,
+                                     int n, void* out_items_dev);
+/* Same, then copies the n items to `out_items_host` and waits. */
+DFX_API int dfx_sfm_step_batch(dfx_ctx* ctx, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
+                               void* out_items_host);
+
+/* ---- image-proc free functions (cuda/cu_image_proc.h:27-46) ---------------------------------- */
+/* UpdateDepth (cu_image_proc.cpp:248-277): dpt = a/(prx_orig + prx_jac . code) - a; code is a HOST array of cs floats. */
+DFX_API int dfx_update_depth(dfx_ctx* ctx, int cs, const float* code, const dfx_img* prx_orig, const dfx_img* prx_jac,
+                             float avg_dpt, const dfx_img* dpt_out);
+/* SobelGradients (cu_image_proc.cpp:57-112): grad = (gx, gy)/8 with clamped borders. */
+DFX_API int dfx_sobel_gradients(dfx_ctx* ctx, const dfx_img* img, const dfx_img* grad_out);
+/* GaussianBlurDown (cu_image_proc.cpp:134-186): 5x5 binomial + decimate by 2; out is (w/2, h/2). */
+DFX_API int dfx_gaussian_blur_down(dfx_ctx* ctx, const dfx_img* in, const dfx_img* out);
+/* SquaredError (cu_image_proc.cpp:190-240): sum (a-b)^2. */
+DFX_API int dfx_squared_error(dfx_ctx* ctx, const dfx_img* a, const dfx_img* b, float* out);
+
+/* ---- DepthAligner<float,CS>::RunStep (cuda/cu_depthaligner.cpp:32-110); avg_dpt is 2 in the reference. */
+DFX_API int dfx_depth_aligner_step(dfx_ctx* ctx, int cs, const float* code, const dfx_img* target_dpt,
+                                   const dfx_img* prx_orig, const dfx_img* prx_jac, float avg_dpt, void* out_item);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFX_H_ */

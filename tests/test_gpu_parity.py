@@ -1,0 +1,199 @@
+"""HIP path (through the C ABI of libdfx.so) vs the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_item_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(dfx, w, h, cs, seed, **kw):
+    from deepfactors_amd import synth
+    p = synth.make_pair(w, h, cs, seed=seed, device="cpu", **kw)
+    return p, synth.to_numpy(p), synth.to_device(p, "cuda")
+
+
+@pytest.mark.parametrize("w,h,cs", [(160, 120, 32), (320, 240, 32), (100, 77, 32), (64, 48, 16), (96, 64, 64), (640, 480, 32)])
+def test_sfm_step_matches_oracle(dfx, oracle, w, h, cs):
+    p, n, g = _pair(dfx, w, h, cs, seed=0xDF02 + w)
+    # perturb the pose a little so the gradient is not ~0
+    pose1 = n["pose1"].copy(); pose1[4] += 0.01
+    al = dfx.SfmAligner(code_size=cs)
+    valid_gpu = torch.zeros_like(g["img0"])
+    got = al.RunStep(n["pose0"], pose1, n["code"], n["cam"], g["img0"], g["img1"], g["dpt0"], g["std0"], valid_gpu,
+                     g["prx_jac"], g["grad1"])
+    valid_ref = np.zeros_like(n["img0"])
+    ref = oracle.sfm_step(n["pose0"], pose1, n["cam"], n["img0"], n["img1"], n["dpt0"], n["prx_jac"], n["grad1"],
+                          valid0=valid_ref, accum_f64=True)
+    assert ref.inliers > 0.5 * w * h
+    assert_item_close(got, ref, w, h, what=f"sfm_step {w}x{h} cs={cs}")
+    # valid0 is written 1.0 exactly where the oracle does (up to boundary flips)
+    assert int((valid_gpu.cpu().numpy() != valid_ref).sum()) <= max(1, int(1e-5 * w * h))
+
+
+def test_sfm_step_reference_test_poses(dfx, oracle):
+    """Poses of ut_sfmaligner.cpp:254-268 (pose1 = inverse(exp(0.1,0.1,0), t=(-.5,-.5,0)), huber 0.5), scaled by 0.1."""
+    from deepfactors_amd import synth
+    w, h, cs = 256, 192, 32
+    p, n, g = _pair(dfx, w, h, cs, seed=7)
+    R = synth.so3_exp(np.array([0.1, 0.1, 0.0]) * 0.1)
+    t = np.array([-0.5, -0.5, 0.0]) * 0.1
+    pose1 = synth.pose_qt(R.T, -R.T @ t)
+    params = dfx.SfmAlignerParams(dfx.DenseSfmParams(huber_delta=0.5))
+    al = dfx.SfmAligner(params, code_size=cs)
+    got = al.RunStep(n["pose0"], pose1, n["code"], n["cam"], g["img0"], g["img1"], g["dpt0"], None, None, g["prx_jac"], g["grad1"])
+    ref = oracle.sfm_step(n["pose0"], pose1, n["cam"], n["img0"], n["img1"], n["dpt0"], n["prx_jac"], n["grad1"], huber_delta=0.5)
+    assert_item_close(got, ref, w, h)
+    # the reference's own GPU-vs-CPU bar (ut_sfmaligner.cpp:320-326): inliers equal, |dJtJ| <= 1e-1 abs
+    assert abs(got.inliers - ref.inliers) <= 1
+    assert np.abs(got.toDenseMatrix() - ref.dense()).max() <= 1e-1 or np.abs(ref.JtJ).max() > 1e3
+
+
+def test_sfm_step_batch(dfx, oracle):
+    w, h, cs = 128, 96, 32
+    al = dfx.SfmAligner(code_size=cs)
+    host, dev = [], []
+    for k in range(5):
+        p, n, g = _pair(dfx, w, h, cs, seed=100 + k, motion_scale=0.5 + 0.3 * k)
+        host.append(n); dev.append(g)
+    arr = al.make_pairs([dict(pose0=n["pose0"], pose1=n["pose1"], cam=n["cam"], img0=g["img0"], img1=g["img1"], dpt0=g["dpt0"],
+                              prx0_jac=g["prx_jac"], grad1=g["grad1"]) for n, g in zip(host, dev)])
+    items = al.RunStepBatch(arr)
+    for k, (n, it) in enumerate(zip(host, items)):
+        ref = oracle.sfm_step(n["pose0"], n["pose1"], n["cam"], n["img0"], n["img1"], n["dpt0"], n["prx_jac"], n["grad1"])
+        assert_item_close(it, ref, w, h, what=f"batch item {k}")
+    # async variant into device memory gives the same bytes
+    out = torch.zeros(len(arr) * dfx.item_size(12 + cs), dtype=torch.uint8, device="cuda")
+    al.RunStepBatchAsync(arr, out)
+    al.ctx.sync()
+    items2 = al.items_from_bytes(out.cpu().numpy(), cs)
+    for a, b in zip(items, items2):
+        assert np.array_equal(a.JtJ, b.JtJ) and np.array_equal(a.Jtr, b.Jtr) and a.inliers == b.inliers
+
+
+def test_sfm_step_deterministic(dfx):
+    p, n, g = _pair(dfx, 320, 240, 32, seed=3)
+    al = dfx.SfmAligner(code_size=32)
+    a = al.RunStep(n["pose0"], n["pose1"], n["code"], n["cam"], g["img0"], g["img1"], g["dpt0"], None, None, g["prx_jac"], g["grad1"])
+    for _ in range(3):
+        b = al.RunStep(n["pose0"], n["pose1"], n["code"], n["cam"], g["img0"], g["img1"], g["dpt0"], None, None, g["prx_jac"], g["grad1"])
+        assert np.array_equal(a.raw, b.raw)
+
+
+def test_sfm_step_masked_nan_jacobian(dfx, oracle):
+    """Garbage (NaN) in the code Jacobian / depth of pixels that are not inliers must not reach the sums."""
+    w, h, cs = 128, 96, 32
+    p, n, g = _pair(dfx, w, h, cs, seed=11)
+    n["dpt0"][10:20, 30:50] = np.nan
+    jac = n["prx_jac"].reshape(h, w, cs)
+    jac[10:20, 30:50, :] = np.nan
+    g["dpt0"] = torch.from_numpy(n["dpt0"]).cuda()
+    g["prx_jac"] = torch.from_numpy(n["prx_jac"]).cuda()
+    al = dfx.SfmAligner(code_size=cs)
+    got = al.RunStep(n["pose0"], n["pose1"], n["code"], n["cam"], g["img0"], g["img1"], g["dpt0"], None, None, g["prx_jac"], g["grad1"])
+    ref = oracle.sfm_step(n["pose0"], n["pose1"], n["cam"], n["img0"], n["img1"], n["dpt0"], n["prx_jac"], n["grad1"])
+    assert np.isfinite(got.JtJ).all() and np.isfinite(got.Jtr).all()
+    assert_item_close(got, ref, w, h)
+
+
+def test_sfm_step_no_overlap(dfx):
+    """inliers == 0 is the in-band 'no overlap' signal (photometric_factor.cpp:279-282)."""
+    p, n, g = _pair(dfx, 128, 96, 32, seed=5)
+    pose1 = n["pose1"].copy(); pose1[4:] = [100.0, 0.0, 0.0]
+    al = dfx.SfmAligner(code_size=32)
+    got = al.RunStep(n["pose0"], pose1, n["code"], n["cam"], g["img0"], g["img1"], g["dpt0"], None, None, g["prx_jac"], g["grad1"])
+    assert got.inliers == 0 and got.residual == 0.0 and not got.JtJ.any()
+
+
+@pytest.mark.parametrize("w,h", [(160, 120), (320, 240), (101, 67), (640, 480)])
+def test_se3_step_and_error_and_warp(dfx, oracle, w, h):
+    from deepfactors_amd import synth
+    p, n, g = _pair(dfx, w, h, 16, seed=21 + w, with_decoder=False)
+    se3 = synth.IDENTITY.copy()
+    al = dfx.SE3Aligner()
+    al.SetHuberDelta(0.1)
+    got = al.RunStep(se3, n["cam"], g["img0"], g["img1"], g["dpt0"], g["grad1"])
+    ref = oracle.se3_step(se3, n["cam"], n["img0"], n["img1"], n["dpt0"], n["grad1"], 0.1)
+    assert_item_close(got, ref, w, h, what="se3_step")
+    # error
+    sal = dfx.SfmAligner(code_size=32)
+    e = sal.EvaluateError(n["pose0"], n["pose1"], n["cam"], g["img0"], g["img1"], g["dpt0"], None, g["grad1"])
+    er, en = oracle.sfm_error(n["pose0"], n["pose1"], n["cam"], n["img0"], n["img1"], n["dpt0"], 0.1)
+    assert abs(e.inliers - en) <= 1 and abs(e.residual - er) <= 1e-4 * max(er, 1e-3) + 1e-6
+    # warp
+    img2 = torch.full_like(g["img0"], -1.0)
+    wi = al.Warp(n["pose10_true"], n["cam"], g["img0"], g["img1"], g["dpt0"], img2)
+    img2_ref, wr, wn = oracle.se3_warp(n["pose10_true"], n["cam"], n["img0"], n["img1"], n["dpt0"])
+    assert abs(wi.inliers - wn) <= 1
+    diff = np.abs(img2.cpu().numpy() - img2_ref)
+    assert (diff > 1e-5).sum() <= 2   # boundary flips only
+    assert abs(wi.residual - wr) <= 1e-3 * max(abs(wr), 1.0) + 1e-3
+
+
+@pytest.mark.parametrize("w,h,cs", [(160, 120, 32), (101, 67, 32), (64, 48, 16), (96, 64, 64), (640, 480, 32)])
+def test_update_depth(dfx, oracle, w, h, cs):
+    p, n, g = _pair(dfx, w, h, cs, seed=31 + w)
+    out = torch.empty_like(g["img0"])
+    dfx.UpdateDepth(n["code"], g["prx_orig"], g["prx_jac"], 2.0, out)
+    ref = oracle.update_depth(n["code"], n["prx_orig"], n["prx_jac"], 2.0)
+    got = out.cpu().numpy()
+    # dpt = a/prx - a: fp32 summation-order differences in the dot product scale by a/prx^2
+    assert np.abs(got - ref).max() <= 2e-6 * float(((2.0 + ref) ** 2 / 2.0).max())
+
+
+@pytest.mark.parametrize("w,h", [(160, 120), (101, 67), (640, 480)])
+def test_image_proc(dfx, oracle, w, h):
+    p, n, g = _pair(dfx, w, h, 16, seed=41 + w, with_decoder=False)
+    grad = torch.empty((h, w, 2), dtype=torch.float32, device="cuda")
+    dfx.SobelGradients(g["img0"], grad)
+    assert np.array_equal(grad.cpu().numpy(), oracle.sobel(n["img0"]))       # exact: taps are x1, x2, /8
+    out = torch.empty((h // 2, w // 2), dtype=torch.float32, device="cuda")
+    dfx.GaussianBlurDown(g["img0"], out)
+    assert np.abs(out.cpu().numpy() - oracle.blur_down(n["img0"])).max() <= 1e-6
+    se = dfx.SquaredError(g["img0"], g["img1"])
+    sr = oracle.squared_error(n["img0"], n["img1"])
+    assert abs(se - sr) <= 1e-5 * sr
+
+
+@pytest.mark.parametrize("cs", [16, 32])
+def test_depth_aligner(dfx, oracle, cs):
+    w, h = 128, 96
+    p, n, g = _pair(dfx, w, h, cs, seed=51)
+    tgt = n["dpt0"] * 1.05 + 0.02
+    code = n["code"] * 0.5
+    al = dfx.DepthAligner(code_size=cs)
+    got = al.RunStep(code, torch.from_numpy(tgt).cuda(), g["prx_orig"], g["prx_jac"], 2.0)
+    ref = oracle.depth_aligner_step(code, tgt, n["prx_orig"], n["prx_jac"], 2.0)
+    assert got.inliers == ref.inliers == w * h
+    assert_item_close(got, ref, w, h, what="depth_aligner")
+
+
+def test_pitched_rows(dfx, oracle):
+    """VisionCore device images are pitched; the ABI carries pitch_bytes."""
+    w, h, cs = 100, 60, 32
+    p, n, g = _pair(dfx, w, h, cs, seed=61)
+
+    def pitched(t, pad):
+        shape = list(t.shape); shape[1] += pad
+        big = torch.full(shape, float("nan"), dtype=t.dtype, device=t.device)
+        big[:, : t.shape[1]] = t
+        return big[:, : t.shape[1]]
+
+    al = dfx.SfmAligner(code_size=cs)
+    got = al.RunStep(n["pose0"], n["pose1"], n["code"], n["cam"], pitched(g["img0"], 28), pitched(g["img1"], 12),
+                     pitched(g["dpt0"], 4), None, None, pitched(g["prx_jac"], 64), pitched(g["grad1"], 6), )
+    ref = oracle.sfm_step(n["pose0"], n["pose1"], n["cam"], n["img0"], n["img1"], n["dpt0"], n["prx_jac"], n["grad1"])
+    assert_item_close(got, ref, w, h)
+
+
+def test_errors_are_loud(dfx):
+    p, n, g = _pair(dfx, 64, 48, 32, seed=71)
+    al = dfx.SfmAligner(code_size=32)
+    with pytest.raises(dfx.DfxError):   # CPU tensor: there is no CPU path
+        al.RunStep(n["pose0"], n["pose1"], n["code"], n["cam"], g["img0"].cpu(), g["img1"], g["dpt0"], None, None, g["prx_jac"], g["grad1"])
+    with pytest.raises(dfx.DfxError):   # size mismatch
+        al.RunStep(n["pose0"], n["pose1"], n["code"], n["cam"], g["img0"], g["img1"][:-1], g["dpt0"], None, None, g["prx_jac"], g["grad1"])
+    with pytest.raises(dfx.DfxError):   # unsupported code size
+        dfx.SfmAligner(code_size=48).RunStep(n["pose0"], n["pose1"], n["code"], n["cam"], g["img0"], g["img1"], g["dpt0"], None, None,
+                                             torch.zeros((48, 64 * 48), device="cuda"), g["grad1"])
