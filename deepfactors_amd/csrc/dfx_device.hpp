@@ -22,7 +22,6 @@ struct Geo {
   float R[9];   // rotation of pose_10 = pose1^-1 * pose0, row-major
   float t[3];
   float fx, fy, u0, v0, w, h;
-  float ifx, ify;   // 1/fx, 1/fy
 };
 
 struct ImgRef {
@@ -34,24 +33,34 @@ struct ImgRef {
 // FindCorrespondence (warping.h:204-241): p = d * K^-1 (x,y,1); q = R p + t; pix1 = K q / q.z
 struct Corr {
   float rrx, rry, rrz;   // R * ray            (ray = ReprojectDepthJacobian, pinhole_camera_impl.h:77-86)
-  float qx, qy, iz;      // q.x, q.y, 1/q.z
+  float vx, vy, vz;      // R * p              (p = ray * d; TransformJacobianPose uses this without +t)
+  float qx, qy, iz;      // q.x, q.y, 1/q.z    (q = R p + t)
   float u, v;
   bool valid;
 };
 
+// The validity predicate decides which pixels enter the sums, so this function follows the reference's operation
+// order exactly (Reproject -> se3 * pt -> Project -> PixelValid) with IEEE division and NO fma contraction: the
+// inlier set is then bit-identical to a host evaluation of the same formulas (the oracle), even for degenerate
+// poses (identity) where projected coordinates land exactly on the border.
 __device__ __forceinline__ Corr find_correspondence(const Geo& g, int x, int y, float d, float border, float min_dpt) {
+#pragma clang fp contract(off)
   Corr c;
-  const float rx = ((float)x - g.u0) * g.ifx;
-  const float ry = ((float)y - g.v0) * g.ify;
+  const float rx = ((float)x - g.u0) / g.fx;
+  const float ry = ((float)y - g.v0) / g.fy;
+  const float px = rx * d, py = ry * d, pz = d;
+  c.vx = g.R[0] * px + g.R[1] * py + g.R[2] * pz;
+  c.vy = g.R[3] * px + g.R[4] * py + g.R[5] * pz;
+  c.vz = g.R[6] * px + g.R[7] * py + g.R[8] * pz;
   c.rrx = g.R[0] * rx + g.R[1] * ry + g.R[2];
   c.rry = g.R[3] * rx + g.R[4] * ry + g.R[5];
   c.rrz = g.R[6] * rx + g.R[7] * ry + g.R[8];
-  c.qx = c.rrx * d + g.t[0];
-  c.qy = c.rry * d + g.t[1];
-  const float qz = c.rrz * d + g.t[2];
+  c.qx = c.vx + g.t[0];
+  c.qy = c.vy + g.t[1];
+  const float qz = c.vz + g.t[2];
   c.iz = 1.0f / qz;
-  c.u = g.fx * c.qx * c.iz + g.u0;
-  c.v = g.fy * c.qy * c.iz + g.v0;
+  c.u = g.fx * c.qx / qz + g.u0;
+  c.v = g.fy * c.qy / qz + g.v0;
   // PixelValid (pinhole_camera_impl.h:105-108) in float, exactly `x >= b && x < w - b`; NaN -> invalid
   c.valid = (qz > min_dpt) && (c.u >= border) && (c.u < g.w - border) && (c.v >= border) && (c.v < g.h - border);
   return c;
@@ -69,7 +78,10 @@ __device__ __forceinline__ Taps make_taps(float u, float v) {
   t.ax = u - fu; t.ay = v - fv;
   return t;
 }
-__device__ __forceinline__ float lerp1(float a, float b, float t) { return a + t * (b - a); }
+__device__ __forceinline__ float lerp1(float a, float b, float t) {
+#pragma clang fp contract(off)
+  return a + t * (b - a);   // separate mul + add: sampled values are bit-identical to a host evaluation
+}
 
 __device__ __forceinline__ float sample_img(const ImgRef& I, const Taps& t) {
   const float* r0 = I.row(t.iy) + t.ix;
@@ -101,7 +113,7 @@ __device__ __forceinline__ void pose_row(const Geo& g, const Corr& c, float d, f
   D11 = g.fy * c.iz;
   D02 = -(g.fx * c.qx) * c.iz * c.iz;
   D12 = -(g.fy * c.qy) * c.iz * c.iz;
-  const float vx = c.rrx * d, vy = c.rry * d, vz = c.rrz * d;   // R p
+  const float vx = c.vx, vy = c.vy, vz = c.vz;   // R p
   const float C03 = D02 * vy, C04 = D00 * vz - D02 * vx, C05 = -D00 * vy;
   const float C13 = -D11 * vz + D12 * vy, C14 = -D12 * vx, C15 = D11 * vx;
   gC[0] = -(gx * D00);
@@ -113,11 +125,10 @@ __device__ __forceinline__ void pose_row(const Geo& g, const Corr& c, float d, f
 }
 
 // v_mul_legacy_f32: DX9 multiply, 0 * anything (NaN, Inf) = 0.  Used to apply zero weights safely.
-__device__ __forceinline__ float mul_zero_wins(float a, float b) {
-  float r;
-  asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
+// Bound to the LLVM intrinsic (not inline asm): hipcc pads no hazards around an asm statement, and the product
+// feeds an MFMA operand (VALU write -> MFMA read needs wait states the compiler must see).
+extern "C" __device__ float dfx_llvm_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");
+__device__ __forceinline__ float mul_zero_wins(float a, float b) { return dfx_llvm_fmul_legacy(a, b); }
 
 // 64-lane sum via shuffles (wave = 64 on gfx950)
 __device__ __forceinline__ float wave_sum(float v) {

@@ -37,7 +37,6 @@ __device__ __forceinline__ Geo geo_from(const SimplePairDev& p) {
   for (int q = 0; q < 9; ++q) g.R[q] = p.R[q];
   g.t[0] = p.t[0]; g.t[1] = p.t[1]; g.t[2] = p.t[2];
   g.fx = p.fx; g.fy = p.fy; g.u0 = p.u0; g.v0 = p.v0; g.w = p.w; g.h = p.h;
-  g.ifx = 1.0f / p.fx; g.ify = 1.0f / p.fy;
   return g;
 }
 

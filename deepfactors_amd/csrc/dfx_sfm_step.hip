@@ -67,7 +67,6 @@ __global__ __launch_bounds__(kThreads) void k_sfm_step(const SfmPairDev* __restr
   for (int q = 0; q < 9; ++q) g.R[q] = P.R[q];
   g.t[0] = P.t[0]; g.t[1] = P.t[1]; g.t[2] = P.t[2];
   g.fx = P.fx; g.fy = P.fy; g.u0 = P.u0; g.v0 = P.v0; g.w = P.w; g.h = P.h;
-  g.ifx = 1.0f / P.fx; g.ify = 1.0f / P.fy;
   const ImgRef I0{ (const char*)P.img0, P.pitch_img0 }, I1{ (const char*)P.img1, P.pitch_img1 };
   const ImgRef D0{ (const char*)P.dpt0, P.pitch_dpt0 }, G1{ (const char*)P.grad1, P.pitch_grad1 };
   const char* jac_base = (const char*)P.jac;

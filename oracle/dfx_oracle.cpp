@@ -54,17 +54,20 @@ template <typename S> struct Rigid {   // a Sophus::SE3 as rotation matrix (row-
   S t[3];
 };
 
-// Eigen::Quaternion::toRotationMatrix convention, q = (x, y, z, w) as stored by Sophus::SO3.
+// Rotation matrix of q = (x, y, z, w) as stored by Sophus::SO3 (Eigen::Quaternion::toRotationMatrix convention).
+// Once-per-pair host algebra is done in double and rounded once to the Scalar type (the reference does it in
+// fp32 through Sophus' quaternion product; exact bits of that are unpinned -- see header).  libdfx's host code
+// (deepfactors_amd/csrc/dfx_api.cpp) uses the same formulas in the same order, so both sides feed identical
+// fp32 rotation/translation/Jacobian constants to the per-pixel math.
 template <typename S>
 static void quat_to_R(const S* q, S* R) {
-  const S x = q[0], y = q[1], z = q[2], w = q[3];
-  const S tx = 2 * x, ty = 2 * y, tz = 2 * z;
-  const S twx = tx * w, twy = ty * w, twz = tz * w;
-  const S txx = tx * x, txy = ty * x, txz = tz * x;
-  const S tyy = ty * y, tyz = tz * y, tzz = tz * z;
-  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
-  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
-  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+  double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double n = std::sqrt(x * x + y * y + z * z + w * w);
+  if (n > 0) { x /= n; y /= n; z /= n; w /= n; }
+  const double Rd[9] = { 1 - 2 * (y * y + z * z), 2 * (x * y - z * w),     2 * (x * z + y * w),
+                         2 * (x * y + z * w),     1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                         2 * (x * z - y * w),     2 * (y * z + x * w),     1 - 2 * (x * x + y * y) };
+  for (int i = 0; i < 9; ++i) R[i] = S(Rd[i]);
 }
 
 template <typename S>
@@ -73,6 +76,16 @@ static Rigid<S> rigid_from_qt(const S* qt) {   // qt = qx qy qz qw tx ty tz
   quat_to_R(qt, T.R);
   T.t[0] = qt[4]; T.t[1] = qt[5]; T.t[2] = qt[6];
   return T;
+}
+
+template <typename S>
+static void quat_to_Rd(const S* q, double* R) {
+  double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double n = std::sqrt(x * x + y * y + z * z + w * w);
+  if (n > 0) { x /= n; y /= n; z /= n; w /= n; }
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
 }
 
 template <typename S>
@@ -113,35 +126,41 @@ static void so3_exp(const S* w, S* R) {
 //   jac_a = [[-Ra^T, -hat(Ra^T (ta - tb)) Ra^T], [0, -Ra^T]],  jac_b = blkdiag(Ra^T, Ra^T)
 // Tangent order (tx,ty,tz,wx,wy,wz); 6x6 row-major.
 // ---------------------------------------------------------------------------------------------
+// a_qt, b_qt are the (qx qy qz qw tx ty tz) poses; all algebra in double, results rounded once.
 template <typename S>
-static Rigid<S> relative_pose(const Rigid<S>& a, const Rigid<S>& b, S* jac_a, S* jac_b) {
+static Rigid<S> relative_pose(const S* a_qt, const S* b_qt, S* jac_a, S* jac_b) {
+  double Ra[9], Rb[9];
+  quat_to_Rd(a_qt, Ra);
+  quat_to_Rd(b_qt, Rb);
+  double Rat[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rat[i * 3 + j] = Ra[j * 3 + i];
   Rigid<S> ab;
-  S Rat[9];
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rat[i * 3 + j] = a.R[j * 3 + i];
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
-    S s = 0; for (int k = 0; k < 3; ++k) s += Rat[i * 3 + k] * b.R[k * 3 + j];
-    ab.R[i * 3 + j] = s;
+    double s = 0; for (int k = 0; k < 3; ++k) s += Rat[i * 3 + k] * Rb[k * 3 + j];
+    ab.R[i * 3 + j] = S(s);
   }
-  const Vec3<S> d_ba{ b.t[0] - a.t[0], b.t[1] - a.t[1], b.t[2] - a.t[2] };
-  const Vec3<S> tab = rot(Rat, d_ba);
-  ab.t[0] = tab.x; ab.t[1] = tab.y; ab.t[2] = tab.z;
+  const double d_ba[3] = { double(b_qt[4]) - double(a_qt[4]), double(b_qt[5]) - double(a_qt[5]), double(b_qt[6]) - double(a_qt[6]) };
+  double tab[3];
+  for (int i = 0; i < 3; ++i) {
+    tab[i] = Rat[i * 3] * d_ba[0] + Rat[i * 3 + 1] * d_ba[1] + Rat[i * 3 + 2] * d_ba[2];
+    ab.t[i] = S(tab[i]);
+  }
   if (jac_a && jac_b) {
-    const Vec3<S> d_ab{ a.t[0] - b.t[0], a.t[1] - b.t[1], a.t[2] - b.t[2] };
-    const Vec3<S> v = rot(Rat, d_ab);
-    S H[9]; hat(v, H);
-    S HR[9];
+    const double v[3] = { -tab[0], -tab[1], -tab[2] };   // Ra^T (ta - tb)
+    const double H[9] = { 0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0 };
+    double HR[9];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
-      S s = 0; for (int k = 0; k < 3; ++k) s += H[i * 3 + k] * Rat[k * 3 + j];
+      double s = 0; for (int k = 0; k < 3; ++k) s += H[i * 3 + k] * Rat[k * 3 + j];
       HR[i * 3 + j] = s;
     }
     std::fill(jac_a, jac_a + 36, S(0));
     std::fill(jac_b, jac_b + 36, S(0));
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
-      jac_a[i * 6 + j] = -Rat[i * 3 + j];
-      jac_a[i * 6 + 3 + j] = -HR[i * 3 + j];
-      jac_a[(3 + i) * 6 + 3 + j] = -Rat[i * 3 + j];
-      jac_b[i * 6 + j] = Rat[i * 3 + j];
-      jac_b[(3 + i) * 6 + 3 + j] = Rat[i * 3 + j];
+      jac_a[i * 6 + j] = -S(Rat[i * 3 + j]);
+      jac_a[i * 6 + 3 + j] = -S(HR[i * 3 + j]);
+      jac_a[(3 + i) * 6 + 3 + j] = -S(Rat[i * 3 + j]);
+      jac_b[i * 6 + j] = S(Rat[i * 3 + j]);
+      jac_b[(3 + i) * 6 + 3 + j] = S(Rat[i * 3 + j]);
     }
   }
   return ab;
@@ -402,9 +421,8 @@ static void sfm_step(const S* pose0_qt, const S* pose1_qt, const S* camv, int cs
                      const S* dpt0, const S* jac, const S* grad1, S* valid0, int w, int h, std::size_t pitch,
                      std::size_t jpitch, std::size_t gpitch, S huber_delta, S avg_dpt, S min_dpt, int border,
                      int accum_f64, int threads, S* jtj, S* jtr, S* residual, std::uint64_t* inliers) {
-  const Rigid<S> P0 = rigid_from_qt(pose0_qt), P1 = rigid_from_qt(pose1_qt);
   S J1[36], J0[36];
-  const Rigid<S> T10 = relative_pose(P1, P0, J1, J0);   // jac_a -> pose1, jac_b -> pose0
+  const Rigid<S> T10 = relative_pose(pose1_qt, pose0_qt, J1, J0);   // jac_a -> pose1, jac_b -> pose0
   const Cam<S> cam = cam_from(camv);
   const int np = 12 + cs;
   const Img<S> I0{ img0, pitch, w, h }, I1{ img1, pitch, w, h }, D0{ dpt0, pitch, w, h };
@@ -423,8 +441,7 @@ static void sfm_step(const S* pose0_qt, const S* pose1_qt, const S* camv, int cs
 template <typename S>
 static void sfm_error(const S* pose0_qt, const S* pose1_qt, const S* camv, const S* img0, const S* img1, const S* dpt0,
                       int w, int h, std::size_t pitch, S huber_delta, int accum_f64, S* residual, std::uint64_t* inliers) {
-  const Rigid<S> P0 = rigid_from_qt(pose0_qt), P1 = rigid_from_qt(pose1_qt);
-  const Rigid<S> T10 = relative_pose<S>(P1, P0, nullptr, nullptr);
+  const Rigid<S> T10 = relative_pose<S>(pose1_qt, pose0_qt, nullptr, nullptr);
   const Cam<S> cam = cam_from(camv);
   const Img<S> I0{ img0, pitch, w, h }, I1{ img1, pitch, w, h }, D0{ dpt0, pitch, w, h };
   double accd = 0; S accs = 0; std::uint64_t n = 0;
@@ -635,8 +652,7 @@ static void perturb_pose(const S* qt_in, int idx, S eps, S* qt_out) {
 
 #define ORC_DEFINE(SFX, S)                                                                                              \
   ORC_API void orc_relative_pose_##SFX(const S* a_qt, const S* b_qt, S* R9, S* t3, S* jac_a36, S* jac_b36) {            \
-    const orc::Rigid<S> A = orc::rigid_from_qt(a_qt), B = orc::rigid_from_qt(b_qt);                                     \
-    const orc::Rigid<S> AB = orc::relative_pose(A, B, jac_a36, jac_b36);                                                \
+    const orc::Rigid<S> AB = orc::relative_pose(a_qt, b_qt, jac_a36, jac_b36);                                          \
     std::memcpy(R9, AB.R, sizeof(AB.R)); std::memcpy(t3, AB.t, sizeof(AB.t));                                           \
   }                                                                                                                     \
   ORC_API void orc_quat_to_R_##SFX(const S* q, S* R9) { orc::quat_to_R(q, R9); }                                        \
