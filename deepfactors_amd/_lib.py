@@ -8,12 +8,14 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdfx.so")
+LIB_PATH = os.environ.get("DFX_LIB") or os.path.join(_HERE, "libdfx.so")   # DFX_LIB: tuning variants (tools/ab_variants.sh)
 
 DFX_OK = 0
 DFX_E_INVALID = -1
 DFX_E_HIP = -2
 DFX_E_NOGPU = -3
+DFX_MFMA_F32_CHAIN = 0
+DFX_MFMA_BF16X3 = 1
 
 
 class DfxError(RuntimeError):
@@ -72,8 +74,10 @@ _PROTOS = {
     "dfx_sync": (C.c_int, [C.c_void_p]),
     "dfx_sfm_set_step_blocks": (C.c_int, [C.c_void_p, C.c_int]),
     "dfx_device_cu_count": (C.c_int, [C.c_void_p]),
+    "dfx_set_mfma_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "dfx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "dfx_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "dfx_debug_read_partials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "dfx_se3_step": (C.c_int, [C.c_void_p, C.POINTER(SE3), C.POINTER(Cam), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img),
                                C.POINTER(Img), C.c_float, C.c_void_p]),
     "dfx_se3_warp": (C.c_int, [C.c_void_p, C.POINTER(SE3), C.POINTER(Cam), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img),

@@ -46,6 +46,7 @@ struct dfx_ctx {
   bool own_stream = false;
   int cu_count = 0;
   int step_blocks = 0;   // 0 = auto
+  int mfma_mode = DFX_MFMA_BF16X3;
 
   float* partials = nullptr;   // device scratch for workgroup partials
   size_t partials_bytes = 0;
@@ -79,14 +80,16 @@ int ensure_device(dfx_ctx* c) {
   return DFX_OK;
 }
 
-int grow_dev(void** p, size_t* cap, size_t need) {
+// Grows a device scratch buffer; callers drain the stream first when the old buffer may still be in use.
+// The clear is enqueued on the context's stream so that it is ordered before the kernels that use the buffer.
+int grow_dev(void** p, size_t* cap, size_t need, hipStream_t stream) {
   if (*cap >= need) return DFX_OK;
   if (*p) DFX_HIP(hipFree(*p));
   *p = nullptr;
   *cap = 0;
   size_t n = need + need / 2;
   DFX_HIP(hipMalloc(p, n));
-  DFX_HIP(hipMemset(*p, 0, n));
+  DFX_HIP(hipMemsetAsync(*p, 0, n, stream));
   *cap = n;
   return DFX_OK;
 }
@@ -174,7 +177,7 @@ int check_img(const dfx_img* im, const char* name, uint32_t w, uint32_t h, size_
   if (!img_ok(im)) return fail(DFX_E_INVALID, "%s: null or empty image view", name);
   if (im->w != w || im->h != h) return fail(DFX_E_INVALID, "%s: size %ux%u, expected %ux%u", name, im->w, im->h, w, h);
   if (im->pitch_bytes < (size_t)w * elem_bytes) return fail(DFX_E_INVALID, "%s: pitch %zu < row bytes %zu", name, im->pitch_bytes, (size_t)w * elem_bytes);
-  if (im->pitch_bytes > 0xffffffffull) return fail(DFX_E_INVALID, "%s: pitch too large", name);
+  if (im->pitch_bytes * (size_t)h >= 0x70000000ull) return fail(DFX_E_INVALID, "%s: image of %zu bytes exceeds the 0x70000000-byte buffer-resource limit", name, im->pitch_bytes * (size_t)h);
   if (((uintptr_t)im->ptr | im->pitch_bytes) & 3) return fail(DFX_E_INVALID, "%s: pointer/pitch not 4-byte aligned", name);
   return DFX_OK;
 }
@@ -294,13 +297,9 @@ DFX_API int dfx_ctx_create(int device, void* stream, dfx_ctx** out) {
   dfx_ctx* c = new dfx_ctx();
   c->device = device;
   c->cu_count = prop.multiProcessorCount;
-  if (stream) {
-    c->stream = (hipStream_t)stream;
-  } else {
-    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete c; return fail(DFX_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
-    c->own_stream = true;
-  }
+  // NULL = the device's default stream, on which the reference runs everything (cuda/launch_utils.h:26-32): work is
+  // then ordered with any other default-stream producer of the images (e.g. PyTorch ops on its default stream).
+  c->stream = (hipStream_t)stream;
   for (int i = 0; i < kStageSlots; ++i) {
     e = hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming);
     if (e != hipSuccess) { delete c; return fail(DFX_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(e)); }
@@ -341,11 +340,26 @@ DFX_API int dfx_sfm_set_step_blocks(dfx_ctx* c, int blocks_per_pair) {
 
 DFX_API int dfx_device_cu_count(dfx_ctx* c) { return c ? c->cu_count : 0; }
 
+DFX_API int dfx_set_mfma_mode(dfx_ctx* c, int mode) {
+  if (!c) return fail(DFX_E_INVALID, "null context");
+  if (mode != DFX_MFMA_F32_CHAIN && mode != DFX_MFMA_BF16X3) return fail(DFX_E_INVALID, "unknown MFMA mode %d", mode);
+  c->mfma_mode = mode;
+  return DFX_OK;
+}
+
 DFX_API int dfx_set_profiling(dfx_ctx* c, int enable) {
   if (!c) return fail(DFX_E_INVALID, "null context");
   DFX_HIP(hipStreamSynchronize(c->stream));
   c->profiling = enable != 0;
   c->prof_used = 0;
+  return DFX_OK;
+}
+
+DFX_API int dfx_debug_read_partials(dfx_ctx* c, void* host, size_t bytes) {
+  if (!c || !host) return fail(DFX_E_INVALID, "null argument");
+  if (bytes > c->partials_bytes) return fail(DFX_E_INVALID, "only %zu bytes of partials exist", c->partials_bytes);
+  DFX_HIP(hipStreamSynchronize(c->stream));
+  DFX_HIP(hipMemcpy(host, c->partials, bytes, hipMemcpyDeviceToHost));
   return DFX_OK;
 }
 
@@ -404,7 +418,7 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
   const int bpp = auto_step_blocks(c, W, H, n);
   const size_t pbytes = dfx::sfm_step_partials_bytes(cs, n, bpp);
   if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
-  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes))) return rc;
+  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
 
   dfx::SfmParamsDev prm{ params->huber_delta, params->avg_dpt, params->min_dpt, (float)params->valid_border };
   hipEvent_t eb = nullptr, ee = nullptr;
@@ -419,7 +433,11 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
     ee = c->prof_pool[c->prof_used].second;
     c->prof_used++;
   }
-  DFX_HIP(dfx::launch_sfm_step(cs, dd, n, (int)W, (int)H, prm, bpp, c->partials, out_items_dev, dfx_item_size(12 + cs), c->stream, eb, ee));
+  // the dense-stream variant needs every pair's Jacobian rows back to back; one pitched pair selects the general kernel
+  bool jac_dense = true;
+  for (int p = 0; p < n; ++p) jac_dense = jac_dense && (hd[p].pitch_jac == W * (uint32_t)cs * 4u);
+  DFX_HIP(dfx::launch_sfm_step(cs, dd, n, (int)W, (int)H, prm, bpp, c->partials, out_items_dev, dfx_item_size(12 + cs), c->stream,
+                               jac_dense, c->mfma_mode, eb, ee));
   return DFX_OK;
 }
 
@@ -432,7 +450,7 @@ DFX_API int dfx_sfm_step_batch(dfx_ctx* c, int cs, const dfx_sfm_params* params,
   if ((rc = ensure_device(c))) return rc;
   const size_t bytes = dfx_item_size(12 + cs) * (size_t)n;
   if (c->items_bytes < bytes) DFX_HIP(hipStreamSynchronize(c->stream));
-  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, bytes))) return rc;
+  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, bytes, c->stream))) return rc;
   if ((rc = dfx_sfm_step_batch_async(c, cs, params, pairs, n, c->items_dev))) return rc;
   return fetch_result(c, c->items_dev, out_items_host, bytes);
 }
@@ -468,8 +486,8 @@ DFX_API int dfx_sfm_error(dfx_ctx* c, const dfx_se3* pose0, const dfx_se3* pose1
   const int blocks = simple_blocks(img0->w, img0->h);
   const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
   if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
-  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes))) return rc;
-  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, 256))) return rc;
+  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
+  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, 256, c->stream))) return rc;
   DFX_HIP(dfx::launch_sfm_error(d, (int)img0->w, (int)img0->h, params->huber_delta, blocks, c->partials, c->items_dev, c->stream));
   return fetch_result(c, c->items_dev, out, sizeof(dfx_corr_item));
 }
@@ -485,8 +503,8 @@ DFX_API int dfx_se3_step(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam,
   const int blocks = simple_blocks(img0->w, img0->h);
   const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
   if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
-  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes))) return rc;
-  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, 256))) return rc;
+  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
+  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, 256, c->stream))) return rc;
   DFX_HIP(dfx::launch_se3_step(d, (int)img0->w, (int)img0->h, huber_delta, blocks, c->partials, c->items_dev, c->stream));
   return fetch_result(c, c->items_dev, out_item, dfx_item_size(6));
 }
@@ -501,8 +519,8 @@ DFX_API int dfx_se3_warp(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam,
   const int blocks = simple_blocks(img0->w, img0->h);
   const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
   if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
-  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes))) return rc;
-  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, 256))) return rc;
+  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
+  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, 256, c->stream))) return rc;
   DFX_HIP(dfx::launch_se3_warp(d, (int)img0->w, (int)img0->h, blocks, c->partials, c->items_dev, c->stream));
   return fetch_result(c, c->items_dev, out, sizeof(dfx_corr_item));
 }
@@ -580,8 +598,8 @@ DFX_API int dfx_squared_error(dfx_ctx* c, const dfx_img* a, const dfx_img* b, fl
   const int blocks = simple_blocks(a->w, a->h);
   const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
   if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
-  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes))) return rc;
-  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, 256))) return rc;
+  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
+  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, 256, c->stream))) return rc;
   DFX_HIP(dfx::launch_squared_error((const float*)a->ptr, (uint32_t)a->pitch_bytes, (const float*)b->ptr, (uint32_t)b->pitch_bytes,
                                     (int)a->w, (int)a->h, blocks, c->partials, (float*)c->items_dev, c->stream));
   return fetch_result(c, c->items_dev, out, sizeof(float));
@@ -602,7 +620,7 @@ DFX_API int dfx_depth_aligner_step(dfx_ctx* c, int cs, const float* code, const 
   // current depth into scratch (the kernel body of the reference recomputes DepthFromCode per pixel)
   const size_t dbytes = (size_t)W * H * sizeof(float);
   if (c->depth_scratch_bytes < dbytes) DFX_HIP(hipStreamSynchronize(c->stream));
-  if ((rc = grow_dev((void**)&c->depth_scratch, &c->depth_scratch_bytes, dbytes))) return rc;
+  if ((rc = grow_dev((void**)&c->depth_scratch, &c->depth_scratch_bytes, dbytes, c->stream))) return rc;
   float* code_dev;
   if ((rc = upload_code(c, cs, code, &code_dev))) return rc;
   DFX_HIP(dfx::launch_update_depth(cs, code_dev, (const float*)prx_orig->ptr, (uint32_t)prx_orig->pitch_bytes,
@@ -628,11 +646,12 @@ DFX_API int dfx_depth_aligner_step(dfx_ctx* c, int cs, const float* code, const 
   const int bpp = auto_step_blocks(c, W, H, 1);
   const size_t pbytes = dfx::sfm_step_partials_bytes(cs, 1, bpp);
   if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
-  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes))) return rc;
+  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
   const size_t ibytes = dfx_item_size(cs);
   if (c->items_bytes < ibytes) DFX_HIP(hipStreamSynchronize(c->stream));
-  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, ibytes))) return rc;
-  DFX_HIP(dfx::launch_depth_aligner_step(cs, dd, (int)W, (int)H, avg_dpt, bpp, c->partials, c->items_dev, c->stream));
+  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, ibytes, c->stream))) return rc;
+  DFX_HIP(dfx::launch_depth_aligner_step(cs, dd, (int)W, (int)H, avg_dpt, bpp, c->partials, c->items_dev, c->stream,
+                                         prx_jac->pitch_bytes == (size_t)W * cs * 4, c->mfma_mode));
   return fetch_result(c, c->items_dev, out_item, ibytes);
 }
 

@@ -14,8 +14,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // 4-byte-aligned views for bilinear taps: (ix, ix+1) pairs start at arbitrary dword addresses.
 // gfx950 global loads only need dword alignment for multi-dword accesses.
-struct __attribute__((packed, aligned(4))) f32x2_u { float x, y; };
-struct __attribute__((packed, aligned(8))) f32x4_u8 { float x, y, z, w; };
+typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+typedef float f32x4_u8 __attribute__((ext_vector_type(4), aligned(8)));
 
 // Wave-uniform geometry of one (keyframe -> frame) pair; lives in kernarg/SGPRs.
 struct Geo {
@@ -24,10 +24,38 @@ struct Geo {
   float fx, fy, u0, v0, w, h;
 };
 
+// Pointers arrive inside descriptor structs, so the compiler cannot infer their address space and would emit
+// flat_load (which also ties up lgkmcnt).  Everything image-like is HBM: say so explicitly.
+#define DFX_GLOBAL __attribute__((address_space(1)))
+typedef const DFX_GLOBAL float* gfptr;
+template <typename T>
+__device__ __forceinline__ T gload(const void* p) { return *(const DFX_GLOBAL T*)(p); }
+template <typename T>
+__device__ __forceinline__ void gstore(void* p, const T& v) { *(DFX_GLOBAL T*)(p) = v; }
+
+// Raw buffer resource (V#) over a wave-uniform base: loads past `bytes` return 0 and move no data, which replaces
+// every tail / "no next chunk" branch on the streaming loads (cdna_hip_programming.md T8).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOobOffset = 0xF0000000u;   // far beyond any image; API enforces images < 0x70000000 bytes
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned off, float*) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ f32x2 bload(__amdgpu_buffer_rsrc_t r, unsigned off, f32x2*) {
+  return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4*) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+
 struct ImgRef {
   const char* ptr;
   uint32_t pitch;   // bytes
-  __device__ __forceinline__ const float* row(int y) const { return reinterpret_cast<const float*>(ptr + (size_t)y * pitch); }
+  __device__ __forceinline__ const char* rowb(int y) const { return ptr + (size_t)y * pitch; }
+  __device__ __forceinline__ float at(int x, int y) const { return gload<float>(rowb(y) + (size_t)x * 4); }
 };
 
 // FindCorrespondence (warping.h:204-241): p = d * K^-1 (x,y,1); q = R p + t; pix1 = K q / q.z
@@ -84,17 +112,15 @@ __device__ __forceinline__ float lerp1(float a, float b, float t) {
 }
 
 __device__ __forceinline__ float sample_img(const ImgRef& I, const Taps& t) {
-  const float* r0 = I.row(t.iy) + t.ix;
-  const float* r1 = I.row(t.iy + 1) + t.ix;
-  const f32x2_u a = *reinterpret_cast<const f32x2_u*>(r0);
-  const f32x2_u b = *reinterpret_cast<const f32x2_u*>(r1);
+  const char* r0 = I.rowb(t.iy) + (size_t)t.ix * 4;
+  const f32x2_u a = gload<f32x2_u>(r0);
+  const f32x2_u b = gload<f32x2_u>(r0 + I.pitch);
   return lerp1(lerp1(a.x, a.y, t.ax), lerp1(b.x, b.y, t.ax), t.ay);
 }
 __device__ __forceinline__ void sample_grad(const ImgRef& G, const Taps& t, float& gx, float& gy) {
-  const float* r0 = G.row(t.iy) + 2 * t.ix;
-  const float* r1 = G.row(t.iy + 1) + 2 * t.ix;
-  const f32x4_u8 a = *reinterpret_cast<const f32x4_u8*>(r0);
-  const f32x4_u8 b = *reinterpret_cast<const f32x4_u8*>(r1);
+  const char* r0 = G.rowb(t.iy) + (size_t)t.ix * 8;
+  const f32x4_u8 a = gload<f32x4_u8>(r0);
+  const f32x4_u8 b = gload<f32x4_u8>(r0 + G.pitch);
   gx = lerp1(lerp1(a.x, a.z, t.ax), lerp1(b.x, b.z, t.ax), t.ay);
   gy = lerp1(lerp1(a.y, a.w, t.ax), lerp1(b.y, b.w, t.ax), t.ay);
 }

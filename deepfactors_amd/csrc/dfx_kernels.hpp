@@ -45,7 +45,7 @@ inline int sfm_zdim(int ncb) { return sfm_nacc(ncb) * 256; }
 // ev_begin/ev_end (optional) bracket the step kernel only.
 hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm,
                            int blocks_per_pair, float* partials_dev, void* items_dev, size_t item_stride,
-                           hipStream_t stream, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
+                           hipStream_t stream, bool jac_dense, int prec, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair);
 
 hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
@@ -63,7 +63,7 @@ hipError_t launch_blur_down(const float* in, uint32_t pitch, int W, int H, float
 hipError_t launch_squared_error(const float* a, uint32_t pitch_a, const float* b, uint32_t pitch_b, int W, int H, int blocks,
                                 float* partials_dev, float* out_dev, hipStream_t stream);
 hipError_t launch_depth_aligner_step(int cs, const SfmPairDev* pair_dev, int W, int H, float avg_dpt, int blocks,
-                                     float* partials_dev, void* item_dev, hipStream_t stream);
+                                     float* partials_dev, void* item_dev, hipStream_t stream, bool jac_dense, int prec);
 
 constexpr int kSimpleRow = 32;       // floats per block partial of the VALU reduction kernels
 constexpr int kMaxSimpleBlocks = 1024;

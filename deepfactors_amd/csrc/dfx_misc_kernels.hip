@@ -52,8 +52,8 @@ __global__ __launch_bounds__(kT) void k_se3_step(const SimplePairDev p, const in
   const int npx = W * H;
   for (int i = blockIdx.x * kT + threadIdx.x; i < npx; i += gridDim.x * kT) {
     const int y = i / W, x = i - y * W;
-    const float d = D0.row(y)[x];
-    const float i0 = I0.row(y)[x];
+    const float d = D0.at(x, y);
+    const float i0 = I0.at(x, y);
     const Corr c = find_correspondence(g, x, y, d, 1.0f, 0.0f);
     if (c.valid) {
       const Taps tp = make_taps(c.u, c.v);
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(kT) void k_sfm_error(const SimplePairDev p, const i
   const int npx = W * H;
   for (int i = blockIdx.x * kT + threadIdx.x; i < npx; i += gridDim.x * kT) {
     const int y = i / W, x = i - y * W;
-    const float d = D0.row(y)[x];
-    const float i0 = I0.row(y)[x];
+    const float d = D0.at(x, y);
+    const float i0 = I0.at(x, y);
     const Corr c = find_correspondence(g, x, y, d, 1.0f, 0.0f);   // dense_sfm.h:91: default border 1, min_dpt 0
     if (c.valid) {
       const Taps tp = make_taps(c.u, c.v);
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(kT) void k_se3_warp(const SimplePairDev p, const in
   const int npx = W * H;
   for (int i = blockIdx.x * kT + threadIdx.x; i < npx; i += gridDim.x * kT) {
     const int y = i / W, x = i - y * W;
-    const float d = D0.row(y)[x];
-    const float i0 = I0.row(y)[x];
+    const float d = D0.at(x, y);
+    const float i0 = I0.at(x, y);
     const Corr c = find_correspondence(g, x, y, d, 1.0f, 0.0f);   // `depth <= 0 -> skip`, PixelValid(pix1, 1)
     float outv = 0.f;
     if (c.valid) {
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kT) void k_se3_warp(const SimplePairDev p, const in
       acc[0] += i0 - outv;
       acc[1] += 1.0f;
     }
-    reinterpret_cast<float*>((char*)p.img2 + (size_t)y * p.pitch_img2)[x] = outv;
+    gstore<float>((char*)p.img2 + (size_t)y * p.pitch_img2 + (size_t)x * 4, outv);
   }
   block_reduce_store<2>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
 }

@@ -17,9 +17,11 @@
 //     Huber weight; the 16-float P row goes to LDS component-major (stride 66 -> conflict-free both ways).
 //   Phase B (lane = (i = lane&15, k = lane>>4)): the code Jacobian is loaded from HBM directly in MFMA operand
 //     layout -- lane (i,k) reads NCB consecutive floats of pixel 4g+k, i.e. every wave-load is one fully
-//     contiguous 256*NCB-byte run of the [H][W*CS] stream (86 % of all bytes); loads are issued before phase A
-//     so their latency hides under it.  Zero weights use v_mul_legacy (0 * NaN = 0) so that garbage in
-//     the Jacobian of a masked pixel cannot poison the sums.
+//     contiguous 256*NCB-byte run of the [H][W*CS] stream (86 % of all bytes).  The 16 operand registers are a
+//     ring: as soon as the MFMAs of group g have consumed jv[g] it is refilled with the same group of the wave's
+//     NEXT chunk, so every wave keeps ~8 KB of the stream in flight through both phases (no VGPR double buffer).
+//     Zero weights use v_mul_legacy (0 * NaN = 0) so that garbage in the Jacobian of a masked pixel cannot
+//     poison the sums.
 //   Epilogue: waves fold their accumulators through LDS in fixed order; each workgroup writes one z-space partial;
 //     k_sfm_finalize sums the partials of a pair in double, in fixed order (bit-reproducible for a given launch
 //     shape), and scatters into the reference's JTJJrReductionItem layout (reduction_items.h:77-143).
@@ -27,6 +29,26 @@
 #include "dfx_kernels.hpp"
 
 namespace dfx {
+
+// ---- tuning switches (A/B-tested on MI355X; defaults are the measured best) ----------
+#ifndef DFX_MIN_WAVES
+#define DFX_MIN_WAVES 3      // __launch_bounds__ waves per SIMD the register allocator must allow
+#endif
+#ifndef DFX_SETPRIO
+#define DFX_SETPRIO 0        // 1: raise wave priority during the MFMA phase
+#endif
+#ifndef DFX_TRACE
+#define DFX_TRACE 0          // 1: per-wave s_memtime sums of phase A / phase B in the junk row 15 of the (P,P) partial
+#endif
+#ifndef DFX_ABLATE
+#define DFX_ABLATE 0         // diagnosis only (wrong results): 1 = no MFMAs, 2 = no phase-A math/gathers, 4 = no ring loads
+#endif
+#ifndef DFX_DEBUG_DRAIN
+#define DFX_DEBUG_DRAIN 0
+#endif
+#ifndef DFX_JIT
+#define DFX_JIT 0            // 1: pin each ring refill load right behind its consumer (sched_barrier per group)
+#endif
 
 constexpr int kWaves = 4;                 // waves per workgroup
 constexpr int kThreads = kWaves * 64;
@@ -43,18 +65,58 @@ template <> __device__ __forceinline__ float jv_get<1>(const float& v, int) { re
 template <> __device__ __forceinline__ float jv_get<2>(const f32x2& v, int b) { return b == 0 ? v.x : v.y; }
 template <> __device__ __forceinline__ float jv_get<4>(const f32x4& v, int b) { return b == 0 ? v.x : (b == 1 ? v.y : (b == 2 ? v.z : v.w)); }
 
+// Byte offset of one code-Jacobian operand vector of the ring inside the [H][W*CS] image: pixel (pbase + 4*gq + lk),
+// codes NCB*li .. NCB*li+NCB-1.  JDENSE (rows back to back) makes the stream linear in the pixel index; the pitched
+// variant pays one integer division per vector.  Offsets of pixels past the image fall outside the buffer resource
+// (dense) or are replaced by kOobOffset (pitched), so the hardware returns 0 without touching memory.
+template <int NCB, bool JDENSE>
+__device__ __forceinline__ unsigned jv_offset(unsigned pbase, int gq, int li, int lk, unsigned W, unsigned npx, unsigned jac_pitch) {
+  constexpr unsigned VB = 4u * NCB;   // bytes per operand vector
+  const unsigned p = pbase + 4u * gq + lk;
+  if (JDENSE) return (p * 16u + li) * VB;
+  const unsigned y = p / W, x = p - y * W;
+  return p < npx ? y * jac_pitch + (x * 16u + li) * VB : kOobOffset;
+}
+
 // MODE 0: SfmAligner::RunStep.  MODE 1: DepthAligner::RunStep (cu_depthaligner.cpp:32-72) -- same rank-1 GEMM with
 // z = [0 (12), diff, s, 1, 0 | s * jac], s = -2 |diff| * dDepth/dPrx; `img0` carries the target depth and `dpt0`
 // the current depth (already decoded by k_update_depth); every pixel is an inlier.
-template <int NCB, int MODE>
-__global__ __launch_bounds__(kThreads) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmParamsDev prm,
+// fp32 -> three bf16 pieces, exactly: x = h + m + l (8 + 8 + 8 mantissa bits, truncation).  Packed as the two
+// operand forms of v_mfma_f32_16x16x32_bf16 for one pixel (8 of the 32 K slots of its lane group):
+//   A = [h h h m m m l l],  B = [h m l h m l h m]  ->  sum_K A.B = hh + hm + hl + mh + mm + ml + lh + lm = x*y - l*l'
+// Every partial product is exact in fp32 (8x8 bits); the dropped l*l' term is < 2^-32 relative.  10 VALU ops.
+struct Split3 { u32x4 A, B; };
+__device__ __forceinline__ Split3 split3(float x) {
+  const unsigned xb = __builtin_bit_cast(unsigned, x);
+  const float r = x - __builtin_bit_cast(float, xb & 0xFFFF0000u);
+  const unsigned rb = __builtin_bit_cast(unsigned, r);
+  const float r2 = r - __builtin_bit_cast(float, rb & 0xFFFF0000u);
+  const unsigned lb = __builtin_bit_cast(unsigned, r2);
+  constexpr unsigned HI2 = 0x07060302u;   // v_perm_b32: (lo16 = top half of src1, hi16 = top half of src0)
+  Split3 o;
+  const unsigned hm = __builtin_amdgcn_perm(rb, xb, HI2);
+  o.A = u32x4{ __builtin_amdgcn_perm(xb, xb, HI2), hm, __builtin_amdgcn_perm(rb, rb, HI2), __builtin_amdgcn_perm(lb, lb, HI2) };
+  o.B = u32x4{ hm, __builtin_amdgcn_perm(xb, lb, HI2), __builtin_amdgcn_perm(lb, rb, HI2), hm };
+  return o;
+}
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma_split(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// PREC 0: v_mfma_f32_16x16x4_f32 (bitwise an fp32 fmaf chain; shares the FP32 datapath with the VALU work).
+// PREC 1: the same products through exact bf16x3 operand splits on the bf16 matrix cores (fp32-accurate, overlaps VALU).
+template <int NCB, int MODE, bool JDENSE, int PREC>
+__global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmParamsDev prm,
                                                        const int W, const int H, float* __restrict__ partials) {
-  constexpr int CS = 16 * NCB;
   constexpr int NBLK = 1 + NCB;
   constexpr int NACC = NBLK * (NBLK + 1) / 2;
   constexpr int ZDIM = NACC * 256;
   constexpr int LDS_FLOATS = (kWaves * kUFloats > ZDIM) ? kWaves * kUFloats : ZDIM;
   typedef typename JV<NCB>::T jv_t;
+  // "No next chunk" is handled by re-reading the wave's current chunk (L2-hot, results never consumed), NOT by
+  // out-of-range offsets: a wave-load whose lanes are all out of range completes without touching memory and may
+  // retire ahead of older real loads, which breaks the counted vmcnt waits (observed as run-to-run differences).
 
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
@@ -67,10 +129,18 @@ __global__ __launch_bounds__(kThreads) void k_sfm_step(const SfmPairDev* __restr
   for (int q = 0; q < 9; ++q) g.R[q] = P.R[q];
   g.t[0] = P.t[0]; g.t[1] = P.t[1]; g.t[2] = P.t[2];
   g.fx = P.fx; g.fy = P.fy; g.u0 = P.u0; g.v0 = P.v0; g.w = P.w; g.h = P.h;
-  const ImgRef I0{ (const char*)P.img0, P.pitch_img0 }, I1{ (const char*)P.img1, P.pitch_img1 };
-  const ImgRef D0{ (const char*)P.dpt0, P.pitch_dpt0 }, G1{ (const char*)P.grad1, P.pitch_grad1 };
-  const char* jac_base = (const char*)P.jac;
   const uint32_t jac_pitch = P.pitch_jac;
+  const uint32_t pitch_d0 = P.pitch_dpt0, pitch_i0 = P.pitch_img0, pitch_i1 = P.pitch_img1, pitch_g1 = P.pitch_grad1;
+  const __amdgpu_buffer_rsrc_t i1_rs = make_rsrc(P.img1, (unsigned)H * pitch_i1);
+  const __amdgpu_buffer_rsrc_t g1_rs = make_rsrc(P.grad1, (unsigned)H * pitch_g1);
+  float Mm[9], HMm[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) { Mm[q] = P.M[q]; HMm[q] = P.HM[q]; }
+  float* const valid0 = P.valid0;
+  const uint32_t pitch_v0 = P.pitch_valid0;
+  const __amdgpu_buffer_rsrc_t jac_rs = make_rsrc(P.jac, (unsigned)H * jac_pitch);
+  const __amdgpu_buffer_rsrc_t d0_rs = make_rsrc(P.dpt0, (unsigned)H * pitch_d0);
+  const __amdgpu_buffer_rsrc_t i0_rs = make_rsrc(P.img0, (unsigned)H * pitch_i0);
   const float inv_a = 1.0f / prm.avg_dpt;
 
   float* U = lds + wave * kUFloats;
@@ -83,62 +153,144 @@ __global__ __launch_bounds__(kThreads) void k_sfm_step(const SfmPairDev* __restr
   const int npx = W * H;
   const int nchunks = (npx + 63) >> 6;
   const int li = lane & 15, lk = lane >> 4;
+  const int cstride = gridDim.x * kWaves;
 
-  for (int chunk = blockIdx.x * kWaves + wave; chunk < nchunks; chunk += gridDim.x * kWaves) {
-    const int base = chunk << 6;
-    const int y0 = base / W;
-    const int x0 = base - y0 * W;
+  int chunk = blockIdx.x * kWaves + wave;
 
-    // ---- issue the code-Jacobian loads in MFMA operand layout (independent of phase A)
-    jv_t jv[16];
-#pragma unroll
-    for (int gq = 0; gq < 16; ++gq) {
-      const int off = 4 * gq + lk;
-      int x = x0 + off, y = y0;
-      while (x >= W) { x -= W; ++y; }
-      const bool inb = (base + off) < npx;
-      const jv_t* src = reinterpret_cast<const jv_t*>(jac_base + (size_t)y * jac_pitch) + (x * 16 + li);
-      jv_t v;
-      if (inb) v = *src; else v = jv_t(0.f);
-      jv[gq] = v;
+  // Per-lane pipeline registers.  Loads complete in order, so anything a phase waits for must be ISSUED before the
+  // younger streaming loads it does not need:
+  //   iteration c:  A2(c)   consume the gathers of chunk c (issued one iteration ago), write the P rows to LDS
+  //                 A1(c+1) geometry of chunk c+1 from its prefetched depth, issue its img1 / grad1 gathers
+  //                 prefetch depth / intensity of chunk c+2
+  //                 B(c)    MFMAs; ring refilled with the Jacobian of chunk c+1
+  // Every memory latency therefore hides under a full MFMA phase; nothing younger sits in front of a wait.
+  struct Pix {            // one chunk's per-lane state between its A1 and A2
+    int x, y;
+    float d, i0;
+    f32x2 ia, ib;         // img1 taps (row iy, row iy+1)
+    f32x4 ga, gb;         // grad1 taps
+    Corr c;               // correspondence of A1 (kept: cheaper than re-deriving it, 5 IEEE divisions)
+    float ax, ay;         // bilinear fractions
+    bool ok;
+  };
+  // (x, y) of a lane advance by a fixed pixel stride per iteration: no per-chunk integer division
+  const unsigned pstride = (unsigned)cstride << 6;
+  const int sdy = pstride / (unsigned)W, sdx = pstride - (unsigned)sdy * W;
+  auto advance_xy = [&](int& x, int& y) {
+    x += sdx; y += sdy;
+    const bool wrap = x >= W;
+    x -= wrap ? W : 0; y += wrap ? 1 : 0;
+  };
+  auto prefetch_di0 = [&](unsigned pbase, Pix& q) {   // coalesced depth / intensity of the chunk at pixel pbase; q.x, q.y set by caller
+    const unsigned p = pbase + lane;
+    const bool inb = p < (unsigned)npx;
+    unsigned od = q.y * pitch_d0 + q.x * 4u, oi = q.y * pitch_i0 + q.x * 4u;
+    od = inb ? od : kOobOffset; oi = inb ? oi : kOobOffset;
+    q.d = bload(d0_rs, od, (float*)nullptr);
+    q.i0 = bload(i0_rs, oi, (float*)nullptr);
+  };
+  // A1: warp the pixel and issue its 4 bilinear tap loads.  Branch-free on purpose: a conditional load would make the
+  // number of loads younger than the ring path-dependent and force the compiler's vmcnt to the conservative minimum
+  // (i.e. wait for these very gathers at the start of phase B).  Lanes without a correspondence read at kOobOffset:
+  // the buffer unit returns 0 and moves no data.
+  auto issue_gathers = [&](unsigned pbase, Pix& q) {
+    if (MODE == 0) {
+      const Corr c = find_correspondence(g, q.x, q.y, q.d, prm.border, prm.min_dpt);
+      const Taps tp = make_taps(c.u, c.v);
+      const bool ok = c.valid && (pbase + lane < (unsigned)npx);
+      q.c = c; q.ax = tp.ax; q.ay = tp.ay; q.ok = ok;
+      unsigned oi = (unsigned)tp.iy * pitch_i1 + (unsigned)tp.ix * 4u, oi2 = oi + pitch_i1;
+      unsigned og = (unsigned)tp.iy * pitch_g1 + (unsigned)tp.ix * 8u, og2 = og + pitch_g1;
+      oi = ok ? oi : kOobOffset; oi2 = ok ? oi2 : kOobOffset;
+      og = ok ? og : kOobOffset; og2 = ok ? og2 : kOobOffset;
+      q.ia = bload(i1_rs, oi, (f32x2*)nullptr);
+      q.ib = bload(i1_rs, oi2, (f32x2*)nullptr);
+      q.ga = bload(g1_rs, og, (f32x4*)nullptr);
+      q.gb = bload(g1_rs, og2, (f32x4*)nullptr);
+    } else {
+      q.ia = f32x2{ 0.f, 0.f }; q.ib = q.ia;
+      q.ga = f32x4{ 0.f, 0.f, 0.f, 0.f }; q.gb = q.ga;
+      q.ok = false; q.ax = q.ay = 0.f;
     }
+  };
 
-    // ---- phase A: lane = pixel
+  // ---- prologue: ring + state of the first chunk, depth of the second
+  jv_t jv[16];
+  Pix cur, nxt;
+  {
+    const unsigned base = (chunk < nchunks) ? (unsigned)chunk << 6 : 0u;   // idle wave: harmless loads of chunk 0
     {
-      int x = x0 + lane, y = y0;
-      while (x >= W) { x -= W; ++y; }
+      const unsigned p = base + lane;   // the only integer division: first chunk of the wave
+      cur.y = p / (unsigned)W;
+      cur.x = p - cur.y * W;
+    }
+    prefetch_di0(base, cur);
+    const bool has1 = chunk + cstride < nchunks;
+    const unsigned nb0 = has1 ? (unsigned)(chunk + cstride) << 6 : base;
+    nxt.x = cur.x; nxt.y = cur.y;
+    if (has1) advance_xy(nxt.x, nxt.y);
+    prefetch_di0(nb0, nxt);
+    issue_gathers(base, cur);
+    // Keep the issue order of the loop body (gathers, depth prefetch, THEN ring): the waitcnt bookkeeping at the loop
+    // header merges this path with the back edge, and a younger gather here would cost a full drain every iteration.
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int gq = 0; gq < 16; ++gq) jv[gq] = bload(jac_rs, jv_offset<NCB, JDENSE>(base, gq, li, lk, W, npx, jac_pitch), (jv_t*)nullptr);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+#if DFX_TRACE
+  unsigned long long trA = 0, trB = 0, trN = 0;
+  const unsigned long long trStart = __builtin_amdgcn_s_memtime();
+#endif
+  for (; chunk < nchunks; chunk += cstride) {
+#if DFX_TRACE
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    const int base = chunk << 6;
+    const bool has2 = chunk + 2 * cstride < nchunks;                                                           // wave-uniform
+    const unsigned nbase = (chunk + cstride < nchunks) ? (unsigned)(chunk + cstride) << 6 : (unsigned)base;    // else: re-read this chunk
+    const unsigned nnbase = has2 ? (unsigned)(chunk + 2 * cstride) << 6 : nbase;
+
+    // ---- A2(c): lane = pixel; taps of this chunk were issued one iteration ago
+    {
+      const int x = cur.x, y = cur.y;
       const bool inb = (base + lane) < npx;
       float u16[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) u16[q] = 0.f;
       if (MODE == 1) {
         if (inb) {
-          const float d = D0.row(y)[x];
-          const float diff = I0.row(y)[x] - d;
+          const float d = cur.d;
+          const float diff = cur.i0 - d;
           const float apd = prm.avg_dpt + d;
           u16[12] = diff;
           u16[13] = 2.0f * fabsf(diff) * (apd * apd) * inv_a;   // -2 |diff| * (-a / prx^2), prx = a / (a + d)
           u16[14] = 1.0f;
         }
+      } else if (DFX_ABLATE & 2) {
+        u16[0] = cur.d; u16[12] = cur.i0; u16[13] = 1.0f; u16[14] = 1.0f;
       } else if (inb) {
-        const float d = D0.row(y)[x];
-        const float i0 = I0.row(y)[x];
-        const Corr c = find_correspondence(g, x, y, d, prm.border, prm.min_dpt);
-        if (c.valid) {
-          const Taps tp = make_taps(c.u, c.v);
-          float gx, gy;
-          sample_grad(G1, tp, gx, gy);
-          const float samp = sample_img(I1, tp);
+        const float d = cur.d;
+        const float i0 = cur.i0;
+        const Corr& c = cur.c;
+        if (cur.ok) {
+          const float tax = cur.ax, tay = cur.ay;
+          const float gx = lerp1(lerp1(cur.ga.x, cur.ga.z, tax), lerp1(cur.gb.x, cur.gb.z, tax), tay);
+          const float gy = lerp1(lerp1(cur.ga.y, cur.ga.w, tax), lerp1(cur.gb.y, cur.gb.w, tax), tay);
+          const float samp = lerp1(lerp1(cur.ia.x, cur.ia.y, tax), lerp1(cur.ib.x, cur.ib.y, tax), tay);
           float gC[6], D00, D02, D11, D12;
           pose_row(g, c, d, gx, gy, gC, D00, D02, D11, D12);
           // J0 = gC * blkdiag(M, M);  J1 = gC * [[-M, -HM], [0, -M]]
           float J[12];
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
-            J[j] = gC[0] * P.M[j] + gC[1] * P.M[3 + j] + gC[2] * P.M[6 + j];
-            J[3 + j] = gC[3] * P.M[j] + gC[4] * P.M[3 + j] + gC[5] * P.M[6 + j];
+            J[j] = gC[0] * Mm[j] + gC[1] * Mm[3 + j] + gC[2] * Mm[6 + j];
+            J[3 + j] = gC[3] * Mm[j] + gC[4] * Mm[3 + j] + gC[5] * Mm[6 + j];
             J[6 + j] = -J[j];
-            J[9 + j] = -(gC[0] * P.HM[j] + gC[1] * P.HM[3 + j] + gC[2] * P.HM[6 + j]) - J[3 + j];
+            J[9 + j] = -(gC[0] * HMm[j] + gC[1] * HMm[3 + j] + gC[2] * HMm[6 + j]) - J[3 + j];
           }
           // d pix1 / d prx = D * (R ray) * (-a / prx^2),  prx = a / (a + d)   (warping.h:44-50,259-291)
           const float apd = prm.avg_dpt + d;
@@ -153,17 +305,66 @@ __global__ __launch_bounds__(kThreads) void k_sfm_step(const SfmPairDev* __restr
           u16[12] = wgt * r;
           u16[13] = wgt * e;
           u16[14] = 1.0f;
-          if (P.valid0) reinterpret_cast<float*>((char*)P.valid0 + (size_t)y * P.pitch_valid0)[x] = 1.0f;   // dense_sfm.h:161
+          if (valid0) gstore<float>((char*)valid0 + (size_t)y * pitch_v0 + (size_t)x * 4, 1.0f);   // dense_sfm.h:161
         }
       }
 #pragma unroll
       for (int q = 0; q < 15; ++q) U[q * kUStride + lane] = u16[q];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- A1(c+1) and the depth prefetch of c+2: issued BEFORE the ring refills of phase B
+    cur.x = nxt.x; cur.y = nxt.y; cur.d = nxt.d; cur.i0 = nxt.i0;
+#if !(DFX_ABLATE & 2)
+    issue_gathers(nbase, cur);
+#endif
+    if (has2) advance_xy(nxt.x, nxt.y);   // otherwise nxt keeps pointing at the last real chunk
+    prefetch_di0(nnbase, nxt);
+    __builtin_amdgcn_wave_barrier();   // LDS hand-over inside one wave: program order is enough for the hardware
+#if DFX_DEBUG_DRAIN & 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#if DFX_DEBUG_DRAIN & 2
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 
-    // ---- phase B: rank-4 updates on the matrix cores
+#if DFX_TRACE
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long tr1 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    // ---- phase B: rank-4 updates on the matrix cores; operand ring refilled behind the consumer
+#if DFX_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
+#if DFX_JIT
+    float uP = U[li * kUStride + lk];
+    float s = U[13 * kUStride + lk];
+#pragma unroll
+    for (int gq = 0; gq < 16; ++gq) {
+      float uPn = 0.f, sn = 0.f;
+      if (gq < 15) {   // LDS operands of the next group, ahead of this group's MFMAs
+        uPn = U[li * kUStride + 4 * (gq + 1) + lk];
+        sn = U[13 * kUStride + 4 * (gq + 1) + lk];
+      }
+      float sc[NCB];
+#pragma unroll
+      for (int b = 0; b < NCB; ++b) sc[b] = mul_zero_wins(s, jv_get<NCB>(jv[gq], b));
+      jv[gq] = bload(jac_rs, jv_offset<NCB, JDENSE>(nbase, gq, li, lk, W, npx, jac_pitch), (jv_t*)nullptr);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uP, uP, acc[0], 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < NCB; ++b) acc[1 + b] = __builtin_amdgcn_mfma_f32_16x16x4f32(uP, sc[b], acc[1 + b], 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < NCB; ++b)
+#pragma unroll
+        for (int b2 = b; b2 < NCB; ++b2) {
+          const int a = 1 + NCB + (b * NCB - b * (b - 1) / 2) + (b2 - b);
+          acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[b], sc[b2], acc[a], 0, 0, 0);
+        }
+      uP = uPn;
+      s = sn;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
 #pragma unroll
     for (int gq = 0; gq < 16; ++gq) {
       const int pp = 4 * gq + lk;
@@ -172,6 +373,32 @@ __global__ __launch_bounds__(kThreads) void k_sfm_step(const SfmPairDev* __restr
       float sc[NCB];
 #pragma unroll
       for (int b = 0; b < NCB; ++b) sc[b] = mul_zero_wins(s, jv_get<NCB>(jv[gq], b));
+#if !(DFX_ABLATE & 4)
+      jv[gq] = bload(jac_rs, jv_offset<NCB, JDENSE>(nbase, gq, li, lk, W, npx, jac_pitch), (jv_t*)nullptr);
+#endif
+#if DFX_ABLATE & 1
+      acc[0][0] += uP;
+#pragma unroll
+      for (int b = 0; b < NCB; ++b) acc[1 + b][0] += sc[b];
+      continue;
+#endif
+      if (PREC == 1) {
+        const Split3 sp = split3(uP);
+        Split3 sq[NCB];
+#pragma unroll
+        for (int b = 0; b < NCB; ++b) sq[b] = split3(sc[b]);
+        acc[0] = mfma_split(sp.A, sp.B, acc[0]);
+#pragma unroll
+        for (int b = 0; b < NCB; ++b) acc[1 + b] = mfma_split(sp.A, sq[b].B, acc[1 + b]);
+#pragma unroll
+        for (int b = 0; b < NCB; ++b)
+#pragma unroll
+          for (int b2 = b; b2 < NCB; ++b2) {
+            const int a = 1 + NCB + (b * NCB - b * (b - 1) / 2) + (b2 - b);
+            acc[a] = mfma_split(sq[b].A, sq[b2].B, acc[a]);
+          }
+        continue;
+      }
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uP, uP, acc[0], 0, 0, 0);
 #pragma unroll
       for (int b = 0; b < NCB; ++b) acc[1 + b] = __builtin_amdgcn_mfma_f32_16x16x4f32(uP, sc[b], acc[1 + b], 0, 0, 0);
@@ -183,6 +410,16 @@ __global__ __launch_bounds__(kThreads) void k_sfm_step(const SfmPairDev* __restr
           acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[b], sc[b2], acc[a], 0, 0, 0);
         }
     }
+#endif
+#if DFX_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#if DFX_TRACE
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long tr2 = __builtin_amdgcn_s_memtime();
+    trA += tr1 - tr0; trB += tr2 - tr1; trN += 1;
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     __builtin_amdgcn_wave_barrier();
   }
 
@@ -203,6 +440,16 @@ __global__ __launch_bounds__(kThreads) void k_sfm_step(const SfmPairDev* __restr
   }
   float* out = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ZDIM;
   for (int e = threadIdx.x; e < ZDIM; e += kThreads) out[e] = lds[e];
+#if DFX_TRACE
+  __syncthreads();
+  if (lane == 0) {   // (P,P) row 15 is padding: 16 floats = 4 waves x {phase A cycles, phase B cycles, chunks, total}
+    const unsigned long long trEnd = __builtin_amdgcn_s_memtime();
+    out[15 * 16 + wave * 4 + 0] = (float)trA;
+    out[15 * 16 + wave * 4 + 1] = (float)trB;
+    out[15 * 16 + wave * 4 + 2] = (float)trN;
+    out[15 * 16 + wave * 4 + 3] = (float)(trEnd - trStart);
+  }
+#endif
 }
 
 // ---- finalize: sum the workgroup partials of each pair (double, fixed order) and scatter into the item layout
@@ -259,12 +506,16 @@ size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair) {
 
 template <int NCB, int MODE>
 static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm, int bpp,
-                           float* partials_dev, void* items_dev, size_t item_stride, hipStream_t stream,
+                           float* partials_dev, void* items_dev, size_t item_stride, hipStream_t stream, bool jac_dense, int prec,
                            hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr) {
   constexpr int NACC = (1 + NCB) * (2 + NCB) / 2;
   hipError_t e;
   if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL((k_sfm_step<NCB, MODE>), dim3(bpp, npairs), dim3(kThreads), 0, stream, pairs_dev, prm, W, H, partials_dev);
+  const dim3 grid(bpp, npairs), block(kThreads);
+  if (jac_dense && prec == 1) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, true, 1>), grid, block, 0, stream, pairs_dev, prm, W, H, partials_dev);
+  else if (jac_dense) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, true, 0>), grid, block, 0, stream, pairs_dev, prm, W, H, partials_dev);
+  else if (prec == 1) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, false, 1>), grid, block, 0, stream, pairs_dev, prm, W, H, partials_dev);
+  else hipLaunchKernelGGL((k_sfm_step<NCB, MODE, false, 0>), grid, block, 0, stream, pairs_dev, prm, W, H, partials_dev);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
@@ -275,23 +526,23 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
 
 hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm,
                            int blocks_per_pair, float* partials_dev, void* items_dev, size_t item_stride,
-                           hipStream_t stream, hipEvent_t eb, hipEvent_t ee) {
+                           hipStream_t stream, bool jac_dense, int prec, hipEvent_t eb, hipEvent_t ee) {
   switch (cs) {
-    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, eb, ee);
-    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, eb, ee);
-    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, eb, ee);
+    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee);
+    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee);
+    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee);
     default: return hipErrorInvalidValue;
   }
 }
 
 // DepthAligner::RunStep: `pair_dev` describes ONE pseudo-pair with img0 = target depth, dpt0 = current depth, jac.
 hipError_t launch_depth_aligner_step(int cs, const SfmPairDev* pair_dev, int W, int H, float avg_dpt, int blocks,
-                                     float* partials_dev, void* item_dev, hipStream_t stream) {
+                                     float* partials_dev, void* item_dev, hipStream_t stream, bool jac_dense, int prec) {
   SfmParamsDev prm{ 0.f, avg_dpt, 0.f, 0.f };
   switch (cs) {
-    case 16: return launch_t<1, 1>(pair_dev, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream);
-    case 32: return launch_t<2, 1>(pair_dev, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream);
-    case 64: return launch_t<4, 1>(pair_dev, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream);
+    case 16: return launch_t<1, 1>(pair_dev, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec);
+    case 32: return launch_t<2, 1>(pair_dev, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec);
+    case 64: return launch_t<4, 1>(pair_dev, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec);
     default: return hipErrorInvalidValue;
   }
 }

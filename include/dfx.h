@@ -98,7 +98,8 @@ static inline uint64_t dfx_item_inliers(const void* item, int np) {
 
 /* ---- context ------------------------------------------------------------------------------- */
 /* Replaces cuda::Init / per-aligner scratch buffers (cu_sfmaligner.cpp:101-114, cu_se3aligner.cpp:120).
- * `stream` is a hipStream_t to enqueue on (e.g. the caller's), or NULL to let the context own one. */
+ * `stream` is the hipStream_t every call of this context enqueues on; NULL = the device's default stream (what the
+ * reference uses).  The caller's producers of the input images must be ordered with that stream. */
 DFX_API int dfx_ctx_create(int device, void* stream, dfx_ctx** out);
 DFX_API void dfx_ctx_destroy(dfx_ctx* ctx);
 DFX_API const char* dfx_last_error(void);
@@ -109,6 +110,16 @@ DFX_API int dfx_sync(dfx_ctx* ctx);
  * kernel; 0 = automatic (sized from the CU count).  Threads per workgroup are fixed at 256 (4 waves). */
 DFX_API int dfx_sfm_set_step_blocks(dfx_ctx* ctx, int blocks_per_pair);
 DFX_API int dfx_device_cu_count(dfx_ctx* ctx);
+/* How the JtJ/Jtr outer products of the SfM / DepthAligner step are evaluated on the matrix cores (fp32 in, fp32 out both ways):
+ *  DFX_MFMA_F32_CHAIN  v_mfma_f32_16x16x4_f32 -- bitwise an fp32 fmaf chain over the pixels of a wave.  On gfx950 this
+ *                      instruction shares the FP32 datapath with the vector ALU, so it cannot overlap the per-pixel math.
+ *  DFX_MFMA_BF16X3     (default) every fp32 operand is split EXACTLY into three bf16 pieces (x = h + m + l) and the 8
+ *                      significant partial products run on the bf16 matrix cores with fp32 accumulation; each partial
+ *                      product is exact, the one dropped term (l*l') is < 2^-32 relative.  fp32-accurate, not bit-equal
+ *                      to the chain; measured error vs an fp64 reference is the same class. */
+#define DFX_MFMA_F32_CHAIN 0
+#define DFX_MFMA_BF16X3 1
+DFX_API int dfx_set_mfma_mode(dfx_ctx* ctx, int mode);
 /* Measurement hook (no reference counterpart; the reference times with std::clock around blocking calls,
  * tools/kernel_benchmark.cpp:145-180): when enabled, every SfM step launch is bracketed by HIP events on the
  * context's stream -- around the step kernel only, excluding the finalize kernel and copies.
@@ -116,6 +127,8 @@ DFX_API int dfx_device_cu_count(dfx_ctx* ctx);
  * duration in milliseconds since the last read, and resets the counters. */
 DFX_API int dfx_set_profiling(dfx_ctx* ctx, int enable);
 DFX_API int dfx_profile_read(dfx_ctx* ctx, int* n_launches, double* total_ms);
+/* Debug: copies the first `bytes` of the workgroup-partials scratch of the last launch to the host. */
+DFX_API int dfx_debug_read_partials(dfx_ctx* ctx, void* host, size_t bytes);
 
 /* ---- SE3Aligner<float> (cuda/cu_se3aligner.h:52-72) ----------------------------------------- */
 /* RunStep (cu_se3aligner.cpp:153-176): out_item = JTJJrReductionItem<float,6> on the HOST (120 bytes). */
