@@ -46,54 +46,6 @@ def parse():
     return ap.parse_args()
 
 
-class NormalEquations:
-    """Block-tridiagonal Gauss-Newton system over a chain of frames: frame k carries (pose 6, code CS); pair k links
-    keyframe k -> frame k+1 and contributes blocks at (pose_k, pose_{k+1}, code_k) exactly as PhotometricFactor::linearize
-    slices the 44x44 system into G11..G33 / g1..g3 (photometric_factor.cpp:105-161).  Built once; assemble() is a
-    device-side gather + index_add into [F][2][D][D] (diag, upper off-diag) and [F][D]."""
-
-    def __init__(self, n_frames, cs, device):
-        D = 6 + cs
-        NP = 12 + cs
-        self.D, self.F, self.NP = D, n_frames, NP
-        self.H = torch.zeros((n_frames, 2, D, D), dtype=torch.float32, device=device)
-        self.g = torch.zeros((n_frames, D), dtype=torch.float32, device=device)
-        nt = NP * (NP + 1) // 2
-        iu = np.triu_indices(NP)
-        packed = np.zeros((NP, NP), np.int64)
-        packed[iu] = np.arange(nt)
-        packed = packed + np.triu(packed, 1).T          # full symmetric -> packed index
-        # item parameter n -> (frame offset, local index): pose0 -> (0, 0..5), pose1 -> (1, 0..5), code0 -> (0, 6..)
-        fo = np.array([0] * 6 + [1] * 6 + [0] * cs)
-        li = np.array(list(range(6)) + list(range(6)) + list(range(6, 6 + cs)))
-        src, dst = [], []
-        Hs = 2 * D * D
-        for a in range(NP):
-            for b in range(NP):
-                fa, fb = fo[a], fo[b]
-                if fa == fb:
-                    off = fa * Hs + 0 * D * D + li[a] * D + li[b]
-                elif fa == 0 and fb == 1:
-                    off = 0 * Hs + 1 * D * D + li[a] * D + li[b]
-                else:
-                    continue   # lower off-diagonal block = transpose of the stored one
-                src.append(packed[a, b]); dst.append(off)
-        self.src = torch.tensor(src, dtype=torch.int64, device=device)
-        self.dst = torch.tensor(dst, dtype=torch.int64, device=device)
-        self.gsrc = torch.tensor(nt + np.arange(NP), dtype=torch.int64, device=device)
-        self.gdst = torch.tensor(fo * D + li, dtype=torch.int64, device=device)
-        self.Hs = Hs
-        self.item_floats = None
-
-    def assemble(self, items_u8, first_frame, n_pairs, item_size):
-        f = items_u8.view(torch.float32).view(n_pairs, item_size // 4)
-        base = (torch.arange(n_pairs, device=f.device, dtype=torch.int64) + first_frame)
-        self.H.zero_()
-        self.g.zero_()
-        self.H.view(-1).index_add_(0, (base[:, None] * self.Hs + self.dst[None, :]).reshape(-1), f[:, self.src].reshape(-1))
-        self.g.view(-1).index_add_(0, (base[:, None] * self.D + self.gdst[None, :]).reshape(-1), f[:, self.gsrc].reshape(-1))
-
-
 def cpu_baseline(w, h, cs, seconds):
     """The oracle (a port of the reference's host loop over DenseSfm<...,TargetHost>, ut_sfmaligner.cpp:307-315), fp32
     accumulate, OpenMP over rows on all host cores.  Bounded sample: the same 640x480x32 pair, repeated ~`seconds`."""
@@ -137,6 +89,7 @@ def main():
 
     import deepfactors_amd as dfx
     from deepfactors_amd import synth
+    from deepfactors_amd.dist import NormalEquations
 
     W, H, CS, P = a.width, a.height, a.cs, a.pairs
     ctx = dfx.Context(local)
@@ -158,8 +111,7 @@ def main():
         al.RunStepBatchAsync(arr, items)                       # hot path: one launch over P pairs (+ finalize)
         neq.assemble(items, rank * P, P, isz)                  # normal-equation blocks of this rank's pairs
         if dist is not None:
-            dist.all_reduce(neq.H)                             # RCCL over xGMI
-            dist.all_reduce(neq.g)
+            neq.all_reduce(dist)                               # RCCL over xGMI
 
     def barrier():
         if dist is not None:
