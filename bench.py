@@ -109,7 +109,7 @@ def main():
 
     def step():
         al.RunStepBatchAsync(arr, items)                       # hot path: one launch over P pairs (+ finalize)
-        neq.assemble(items, rank * P, P, isz)                  # normal-equation blocks of this rank's pairs
+        neq.assemble_native(ctx, items, rank * P, P)           # normal-equation blocks of this rank's pairs (one kernel)
         if dist is not None:
             neq.all_reduce(dist)                               # RCCL over xGMI
 

@@ -46,7 +46,7 @@ struct dfx_ctx {
   bool own_stream = false;
   int cu_count = 0;
   int step_blocks = 0;   // 0 = auto
-  int mfma_mode = DFX_MFMA_BF16X3;
+  int mfma_mode = DFX_MFMA_F32_CHAIN;
 
   float* partials = nullptr;   // device scratch for workgroup partials
   size_t partials_bytes = 0;
@@ -213,14 +213,18 @@ int fill_sfm_pair(int cs, const dfx_se3* pose0, const dfx_se3* pose1, const dfx_
   return DFX_OK;
 }
 
+// Workgroups per pair for the step kernel.  Measured on MI355X: short waves (about 5 chunks of
+// 64 pixels each) spread the launch over many more workgroups than resident slots, which hides the 2x spread of wave
+// lifetimes; the total is capped so that huge batches still give every wave a long enough pipeline.
 int auto_step_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int npairs) {
   const int nchunks = (int)(((size_t)W * H + 63) / 64);
   int maxb = (nchunks + 3) / 4;   // one chunk per wave at most
   if (maxb < 1) maxb = 1;
   int b = c->step_blocks;
   if (b <= 0) {
-    const int target_total = c->cu_count * 3;   // 3 workgroups (12 waves) per CU
-    b = (target_total + npairs - 1) / npairs;
+    b = (nchunks + 19) / 20;                                   // ~5 chunks per wave (4 waves per workgroup)
+    const int cap = (64 * c->cu_count + npairs - 1) / npairs;   // at most 64 workgroups per CU over the whole batch
+    if (b > cap) b = cap;
     if (b < 1) b = 1;
   }
   return b < maxb ? b : maxb;
@@ -438,6 +442,18 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
   for (int p = 0; p < n; ++p) jac_dense = jac_dense && (hd[p].pitch_jac == W * (uint32_t)cs * 4u);
   DFX_HIP(dfx::launch_sfm_step(cs, dd, n, (int)W, (int)H, prm, bpp, c->partials, out_items_dev, dfx_item_size(12 + cs), c->stream,
                                jac_dense, c->mfma_mode, eb, ee));
+  return DFX_OK;
+}
+
+DFX_API int dfx_neq_assemble_async(dfx_ctx* c, int cs, const void* items_dev, int n_pairs, int first_frame, int n_frames,
+                                   float* H_dev, float* g_dev, int zero_first) {
+  if (!c || !items_dev || !H_dev || !g_dev) return fail(DFX_E_INVALID, "dfx_neq_assemble: null argument");
+  if (!cs_supported(cs)) return fail(DFX_E_INVALID, "unsupported code size %d (16, 32, 64)", cs);
+  if (n_pairs <= 0 || first_frame < 0 || first_frame + n_pairs + 1 > n_frames)
+    return fail(DFX_E_INVALID, "pairs [%d, %d) do not fit a chain of %d frames", first_frame, first_frame + n_pairs, n_frames);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  DFX_HIP(dfx::launch_neq_assemble(cs, items_dev, dfx_item_size(12 + cs), n_pairs, first_frame, n_frames, H_dev, g_dev, zero_first != 0, c->stream));
   return DFX_OK;
 }
 

@@ -47,6 +47,8 @@ hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int 
                            int blocks_per_pair, float* partials_dev, void* items_dev, size_t item_stride,
                            hipStream_t stream, bool jac_dense, int prec, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair);
+hipError_t launch_neq_assemble(int cs, const void* items_dev, size_t item_stride, int n_pairs, int first_frame, int n_frames,
+                               float* H_dev, float* g_dev, bool zero_first, hipStream_t stream);
 
 hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
                            void* item_dev, hipStream_t stream);

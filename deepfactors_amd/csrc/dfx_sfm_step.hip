@@ -452,27 +452,32 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
 #endif
 }
 
-// ---- finalize: sum the workgroup partials of each pair (double, fixed order) and scatter into the item layout
+// ---- finalize: sum the workgroup partials of each pair (double, fixed order) and scatter into the item layout.
+// grid = (4 * NACC, npairs): each 256-thread workgroup owns 64 columns of one 16x16 accumulator block; its 4 row
+// groups stride over the pair's `bpp` partials (256-byte coalesced reads) and are folded in fixed order.
 template <int NCB, int NPOSE>
-__global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__ partials, const int bpp,
-                                                       char* __restrict__ items, const size_t item_stride) {
+__global__ __launch_bounds__(256) void k_sfm_finalize(const float* __restrict__ partials, const int bpp,
+                                                      char* __restrict__ items, const size_t item_stride) {
   constexpr int CS = 16 * NCB;
   constexpr int NP = NPOSE + CS;
   constexpr int NBLK = 1 + NCB;
   constexpr int NACC = NBLK * (NBLK + 1) / 2;
   constexpr int ZDIM = NACC * 256;
   constexpr int NT = NP * (NP + 1) / 2;
-  __shared__ double red[4][256];
+  __shared__ double red[4][64];
 
-  const int a = blockIdx.x, pair = blockIdx.y;
-  const int col = threadIdx.x & 255, rg = threadIdx.x >> 8;
+  const int a = blockIdx.x >> 2, pair = blockIdx.y;
+  const int c64 = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = (blockIdx.x & 3) * 64 + c64;
   const float* src = partials + (size_t)pair * bpp * ZDIM + a * 256 + col;
-  double s = 0.0;
-  for (int b = rg; b < bpp; b += 4) s += (double)src[(size_t)b * ZDIM];
-  red[rg][col] = s;
+  double s0 = 0.0, s1 = 0.0;   // two chains: more loads in flight, still a fixed summation order
+  int b = rg;
+  for (; b + 4 < bpp; b += 8) { s0 += (double)src[(size_t)b * ZDIM]; s1 += (double)src[(size_t)(b + 4) * ZDIM]; }
+  if (b < bpp) s0 += (double)src[(size_t)b * ZDIM];
+  red[rg][c64] = s0 + s1;
   __syncthreads();
   if (rg != 0) return;
-  s = ((red[0][col] + red[1][col]) + red[2][col]) + red[3][col];
+  const double s = ((red[0][c64] + red[1][c64]) + red[2][c64]) + red[3][c64];
 
   // block pair (bi <= bj) of accumulator a
   int bi = 0, bj = 0;
@@ -500,6 +505,52 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
   }
 }
 
+// ---- Gauss-Newton normal-equation assembly over a chain of frames (the exchange buffer of the multi-GPU reduce).
+// Frame k carries (pose 6, code CS); pair p links keyframe (first_frame + p) -> frame (first_frame + p + 1) and adds its
+// 44x44 system exactly as PhotometricFactor::linearize slices it into G11..G33 / g1..g3 (photometric_factor.cpp:105-161):
+//   H[f][0] (D x D) diagonal block of frame f, H[f][1] off-diagonal block (frame f rows, frame f+1 columns), g[f] (D).
+// Only the (pose1, pose1) block of pair p and the (pose0, pose0) block of pair p+1 meet in one destination; two
+// commutative float adds into a zeroed buffer are order-independent, so the result is deterministic.
+template <int CS>
+__global__ __launch_bounds__(256) void k_neq_assemble(const char* __restrict__ items, const size_t item_stride, const int first_frame,
+                                                      float* __restrict__ Hm, float* __restrict__ gv) {
+  constexpr int NP = 12 + CS, D = 6 + CS, NT = NP * (NP + 1) / 2;
+  const int p = blockIdx.x;
+  const float* it = reinterpret_cast<const float*>(items + (size_t)p * item_stride);
+  float* H0 = Hm + (size_t)(first_frame + p) * 2 * D * D;
+  for (int e = threadIdx.x; e < NP * NP; e += 256) {
+    const int a = e / NP, b = e - a * NP;
+    const int fa = (a >= 6 && a < 12), fb = (b >= 6 && b < 12);          // 1 = belongs to frame k+1 (pose1)
+    const int la = a < 6 ? a : (a < 12 ? a - 6 : a - 6), lb = b < 6 ? b : (b < 12 ? b - 6 : b - 6);
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    const float v = it[lo * NP - lo * (lo - 1) / 2 + (hi - lo)];
+    if (fa == fb) atomicAdd(H0 + (size_t)fa * 2 * D * D + la * D + lb, v);
+    else if (fa == 0) H0[D * D + la * D + lb] = v;                           // (frame k rows, frame k+1 cols): single writer
+  }
+  for (int a = threadIdx.x; a < NP; a += 256) {
+    const int fa = (a >= 6 && a < 12);
+    const int la = a < 6 ? a : a - 6;
+    atomicAdd(gv + (size_t)(first_frame + p + fa) * D + la, it[NT + a]);
+  }
+}
+
+hipError_t launch_neq_assemble(int cs, const void* items_dev, size_t item_stride, int n_pairs, int first_frame, int n_frames,
+                               float* H_dev, float* g_dev, bool zero_first, hipStream_t stream) {
+  const size_t D = 6 + (size_t)cs;
+  hipError_t e;
+  if (zero_first) {
+    if ((e = hipMemsetAsync(H_dev, 0, (size_t)n_frames * 2 * D * D * sizeof(float), stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(g_dev, 0, (size_t)n_frames * D * sizeof(float), stream)) != hipSuccess) return e;
+  }
+  switch (cs) {
+    case 16: hipLaunchKernelGGL(k_neq_assemble<16>, dim3(n_pairs), dim3(256), 0, stream, (const char*)items_dev, item_stride, first_frame, H_dev, g_dev); break;
+    case 32: hipLaunchKernelGGL(k_neq_assemble<32>, dim3(n_pairs), dim3(256), 0, stream, (const char*)items_dev, item_stride, first_frame, H_dev, g_dev); break;
+    case 64: hipLaunchKernelGGL(k_neq_assemble<64>, dim3(n_pairs), dim3(256), 0, stream, (const char*)items_dev, item_stride, first_frame, H_dev, g_dev); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair) {
   return (size_t)npairs * blocks_per_pair * sfm_zdim(cs / 16) * sizeof(float);
 }
@@ -519,7 +570,7 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL((k_sfm_finalize<NCB, MODE == 0 ? 12 : 0>), dim3(NACC, npairs), dim3(1024), 0, stream,
+  hipLaunchKernelGGL((k_sfm_finalize<NCB, MODE == 0 ? 12 : 0>), dim3(4 * NACC, npairs), dim3(256), 0, stream,
                      (const float*)partials_dev, bpp, (char*)items_dev, item_stride);
   return hipGetLastError();
 }

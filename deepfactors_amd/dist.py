@@ -65,6 +65,13 @@ class NormalEquations:
         self.H.view(-1).index_add_(0, (base[:, None] * self.Hs + self.dst[None, :]).reshape(-1), f[:, self.src].reshape(-1))
         self.g.view(-1).index_add_(0, (base[:, None] * self.D + self.gdst[None, :]).reshape(-1), f[:, self.gsrc].reshape(-1))
 
+    def assemble_native(self, ctx, items_u8, first_frame, n_pairs):
+        """Same as assemble(), as ONE libdfx kernel on the context's stream (dfx_neq_assemble_async); GPU only."""
+        import ctypes as C
+        from . import _lib
+        _lib.check(_lib.lib().dfx_neq_assemble_async(ctx.handle, self.cs, C.c_void_p(items_u8.data_ptr()), int(n_pairs), int(first_frame),
+                                                     self.F, C.c_void_p(self.H.data_ptr()), C.c_void_p(self.g.data_ptr()), 1))
+
     def all_reduce(self, dist):
         """The exchange step: sum the ranks' partial systems (RCCL ring all-reduce over xGMI on MI355X nodes)."""
         dist.all_reduce(self.H)

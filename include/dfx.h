@@ -111,9 +111,9 @@ DFX_API int dfx_sync(dfx_ctx* ctx);
 DFX_API int dfx_sfm_set_step_blocks(dfx_ctx* ctx, int blocks_per_pair);
 DFX_API int dfx_device_cu_count(dfx_ctx* ctx);
 /* How the JtJ/Jtr outer products of the SfM / DepthAligner step are evaluated on the matrix cores (fp32 in, fp32 out both ways):
- *  DFX_MFMA_F32_CHAIN  v_mfma_f32_16x16x4_f32 -- bitwise an fp32 fmaf chain over the pixels of a wave.  On gfx950 this
- *                      instruction shares the FP32 datapath with the vector ALU, so it cannot overlap the per-pixel math.
- *  DFX_MFMA_BF16X3     (default) every fp32 operand is split EXACTLY into three bf16 pieces (x = h + m + l) and the 8
+ *  DFX_MFMA_F32_CHAIN  (default) v_mfma_f32_16x16x4_f32 -- bitwise an fp32 fmaf chain over the pixels of a wave.  On
+ *                      gfx950 this instruction shares the FP32 datapath with the vector ALU (measured: their times add).
+ *  DFX_MFMA_BF16X3     every fp32 operand is split EXACTLY into three bf16 pieces (x = h + m + l) and the 8
  *                      significant partial products run on the bf16 matrix cores with fp32 accumulation; each partial
  *                      product is exact, the one dropped term (l*l') is < 2^-32 relative.  fp32-accurate, not bit-equal
  *                      to the chain; measured error vs an fp64 reference is the same class. */
@@ -168,6 +168,14 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* ctx, int cs, const dfx_sfm_params*
 /* Same, then copies the n items to `out_items_host` and waits. */
 DFX_API int dfx_sfm_step_batch(dfx_ctx* ctx, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
                                void* out_items_host);
+
+/* Gauss-Newton normal-equation assembly (new; the reference hands each pair's 44x44 system to its own gtsam::HessianFactor,
+ * photometric_factor.cpp:105-180, and lets iSAM2 sum them).  Scatter-adds n_pairs device-resident items into the
+ * block-tridiagonal system of a frame chain: pair p links keyframe (first_frame+p) -> frame (first_frame+p+1); frame f
+ * owns D = 6+cs unknowns (pose, code).  H_dev = float[n_frames][2][D][D] (diagonal block, upper off-diagonal block),
+ * g_dev = float[n_frames][D].  This is the buffer the multi-GPU path all-reduces (RCCL).  Enqueue only. */
+DFX_API int dfx_neq_assemble_async(dfx_ctx* ctx, int cs, const void* items_dev, int n_pairs, int first_frame, int n_frames,
+                                   float* H_dev, float* g_dev, int zero_first);
 
 /* ---- image-proc free functions (cuda/cu_image_proc.h:27-46) ---------------------------------- */
 /* UpdateDepth (cu_image_proc.cpp:248-277): dpt = a/(prx_orig + prx_jac . code) - a; code is a HOST array of cs floats. */

@@ -98,6 +98,29 @@ def test_sfm_step_batch(dfx, oracle):
         assert np.array_equal(a.JtJ, b.JtJ) and np.array_equal(a.Jtr, b.Jtr) and a.inliers == b.inliers
 
 
+def test_native_normal_equation_assembly_matches_torch(dfx):
+    """dfx_neq_assemble_async == the torch index_add formulation (deepfactors_amd/dist.py), bit for bit."""
+    from deepfactors_amd.dist import NormalEquations
+    w, h, cs, n = 96, 64, 32, 5
+    al = dfx.SfmAligner(code_size=cs)
+    dev = []
+    for k in range(n):
+        p, nn, g = _pair(dfx, w, h, cs, seed=300 + k)
+        dev.append((nn, g))
+    arr = al.make_pairs([dict(pose0=nn["pose0"], pose1=nn["pose1"], cam=nn["cam"], img0=g["img0"], img1=g["img1"], dpt0=g["dpt0"],
+                              prx0_jac=g["prx_jac"], grad1=g["grad1"]) for nn, g in dev])
+    items = torch.zeros(n * dfx.item_size(12 + cs), dtype=torch.uint8, device="cuda")
+    al.RunStepBatchAsync(arr, items)
+    a = NormalEquations(n + 3, cs, "cuda")
+    b = NormalEquations(n + 3, cs, "cuda")
+    a.assemble(items, 1, n, dfx.item_size(12 + cs))
+    b.assemble_native(al.ctx, items, 1, n)
+    al.ctx.sync()
+    assert torch.equal(a.H, b.H) and torch.equal(a.g, b.g)
+    D = a.dense()
+    assert torch.allclose(D, D.T) and float(D.abs().max()) > 0
+
+
 def test_sfm_step_deterministic(dfx):
     p, n, g = _pair(dfx, 320, 240, 32, seed=3)
     al = dfx.SfmAligner(code_size=32)
