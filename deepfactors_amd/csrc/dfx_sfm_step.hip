@@ -259,8 +259,10 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
       const int x = cur.x, y = cur.y;
       const bool inb = (base + lane) < npx;
       float u16[16];
+      if (MODE == 1 || (DFX_ABLATE & 2)) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) u16[q] = 0.f;
+        for (int q = 0; q < 16; ++q) u16[q] = 0.f;
+      }
       if (MODE == 1) {
         if (inb) {
           const float d = cur.d;
@@ -272,41 +274,42 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
         }
       } else if (DFX_ABLATE & 2) {
         u16[0] = cur.d; u16[12] = cur.i0; u16[13] = 1.0f; u16[14] = 1.0f;
-      } else if (inb) {
+      } else {
+        // Branch-free: every lane computes its row; lanes without a correspondence (or past the image) get weight 0
+        // through v_mul_legacy (0 * NaN = 0), so no zero-init / masked overwrite and no exec juggling.
         const float d = cur.d;
         const float i0 = cur.i0;
         const Corr& c = cur.c;
-        if (cur.ok) {
-          const float tax = cur.ax, tay = cur.ay;
-          const float gx = lerp1(lerp1(cur.ga.x, cur.ga.z, tax), lerp1(cur.gb.x, cur.gb.z, tax), tay);
-          const float gy = lerp1(lerp1(cur.ga.y, cur.ga.w, tax), lerp1(cur.gb.y, cur.gb.w, tax), tay);
-          const float samp = lerp1(lerp1(cur.ia.x, cur.ia.y, tax), lerp1(cur.ib.x, cur.ib.y, tax), tay);
-          float gC[6], D00, D02, D11, D12;
-          pose_row(g, c, d, gx, gy, gC, D00, D02, D11, D12);
-          // J0 = gC * blkdiag(M, M);  J1 = gC * [[-M, -HM], [0, -M]]
-          float J[12];
+        const bool ok = cur.ok && inb;
+        const float tax = cur.ax, tay = cur.ay;
+        const float gx = lerp1(lerp1(cur.ga.x, cur.ga.z, tax), lerp1(cur.gb.x, cur.gb.z, tax), tay);
+        const float gy = lerp1(lerp1(cur.ga.y, cur.ga.w, tax), lerp1(cur.gb.y, cur.gb.w, tax), tay);
+        const float samp = lerp1(lerp1(cur.ia.x, cur.ia.y, tax), lerp1(cur.ib.x, cur.ib.y, tax), tay);
+        float gC[6], D00, D02, D11, D12;
+        pose_row(g, c, d, gx, gy, gC, D00, D02, D11, D12);
+        // J0 = gC * blkdiag(M, M);  J1 = gC * [[-M, -HM], [0, -M]]
+        float J[12];
 #pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            J[j] = gC[0] * Mm[j] + gC[1] * Mm[3 + j] + gC[2] * Mm[6 + j];
-            J[3 + j] = gC[3] * Mm[j] + gC[4] * Mm[3 + j] + gC[5] * Mm[6 + j];
-            J[6 + j] = -J[j];
-            J[9 + j] = -(gC[0] * HMm[j] + gC[1] * HMm[3 + j] + gC[2] * HMm[6 + j]) - J[3 + j];
-          }
-          // d pix1 / d prx = D * (R ray) * (-a / prx^2),  prx = a / (a + d)   (warping.h:44-50,259-291)
-          const float apd = prm.avg_dpt + d;
-          const float dprx = -(apd * apd) * inv_a;
-          const float pj0 = (D00 * c.rrx + D02 * c.rrz) * dprx;
-          const float pj1 = (D11 * c.rry + D12 * c.rrz) * dprx;
-          const float e = -(gx * pj0 + gy * pj1);
-          const float r = i0 - samp;
-          const float wgt = huber_weight(r, prm.huber_delta);   // * DenseSfm_UncertaintyWeight == 1 (dense_sfm.h:66)
-#pragma unroll
-          for (int j = 0; j < 12; ++j) u16[j] = wgt * J[j];
-          u16[12] = wgt * r;
-          u16[13] = wgt * e;
-          u16[14] = 1.0f;
-          if (valid0) gstore<float>((char*)valid0 + (size_t)y * pitch_v0 + (size_t)x * 4, 1.0f);   // dense_sfm.h:161
+        for (int j = 0; j < 3; ++j) {
+          J[j] = gC[0] * Mm[j] + gC[1] * Mm[3 + j] + gC[2] * Mm[6 + j];
+          J[3 + j] = gC[3] * Mm[j] + gC[4] * Mm[3 + j] + gC[5] * Mm[6 + j];
+          J[6 + j] = -J[j];
+          J[9 + j] = -(gC[0] * HMm[j] + gC[1] * HMm[3 + j] + gC[2] * HMm[6 + j]) - J[3 + j];
         }
+        // d pix1 / d prx = D * (R ray) * (-a / prx^2),  prx = a / (a + d)   (warping.h:44-50,259-291)
+        const float apd = prm.avg_dpt + d;
+        const float dprx = -(apd * apd) * inv_a;
+        const float pj0 = (D00 * c.rrx + D02 * c.rrz) * dprx;
+        const float pj1 = (D11 * c.rry + D12 * c.rrz) * dprx;
+        const float e = -(gx * pj0 + gy * pj1);
+        const float r = i0 - samp;
+        const float wgt = ok ? huber_weight(r, prm.huber_delta) : 0.0f;   // * DenseSfm_UncertaintyWeight == 1 (dense_sfm.h:66)
+#pragma unroll
+        for (int j = 0; j < 12; ++j) u16[j] = mul_zero_wins(wgt, J[j]);
+        u16[12] = mul_zero_wins(wgt, r);
+        u16[13] = mul_zero_wins(wgt, e);
+        u16[14] = ok ? 1.0f : 0.0f;
+        if (valid0 && ok) gstore<float>((char*)valid0 + (size_t)y * pitch_v0 + (size_t)x * 4, 1.0f);   // dense_sfm.h:161
       }
 #pragma unroll
       for (int q = 0; q < 15; ++q) U[q * kUStride + lane] = u16[q];
