@@ -47,6 +47,15 @@ class CorrItem(C.Structure):
     _fields_ = [("residual", C.c_float), ("_pad", C.c_uint32), ("inliers", C.c_uint64)]
 
 
+class TrackLevel(C.Structure):
+    _fields_ = [("cam", Cam), ("img0", Img), ("img1", Img), ("dpt0", Img), ("grad1", Img), ("iterations", C.c_int32)]
+
+
+class TrackResult(C.Structure):
+    _fields_ = [("pose_ck", SE3), ("inliers_frac", C.c_float), ("error", C.c_float), ("residual", C.c_float), ("inliers", C.c_uint64),
+                ("iterations", C.c_int32), ("solver_failures", C.c_int32)]
+
+
 class SfmPair(C.Structure):
     _fields_ = [("pose0", SE3), ("pose1", SE3), ("cam", Cam), ("img0", Img), ("img1", Img), ("dpt0", Img),
                 ("valid0", Img), ("prx0_jac", Img), ("grad1", Img)]
@@ -82,6 +91,7 @@ _PROTOS = {
                                C.POINTER(Img), C.c_float, C.c_void_p]),
     "dfx_se3_warp": (C.c_int, [C.c_void_p, C.POINTER(SE3), C.POINTER(Cam), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img),
                                C.POINTER(Img), C.POINTER(CorrItem)]),
+    "dfx_track_frame": (C.c_int, [C.c_void_p, C.POINTER(SE3), C.POINTER(TrackLevel), C.c_int, C.c_float, C.POINTER(TrackResult)]),
     "dfx_sfm_step": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SE3), C.POINTER(SE3), C.POINTER(Cam), C.POINTER(SfmParams),
                                C.POINTER(Img), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img),
                                C.POINTER(Img), C.c_void_p]),

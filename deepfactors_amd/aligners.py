@@ -351,3 +351,65 @@ def SquaredError(buf1, buf2, ctx=None):
     out = C.c_float(0)
     check(_lib.lib().dfx_squared_error(ctx.handle, C.byref(a), C.byref(b), C.byref(out)))
     return float(out.value)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# CameraTracker (core/system/camera_tracker.{h,cpp}) -- device-resident coarse-to-fine Gauss-Newton
+# ------------------------------------------------------------------------------------------------------------
+class TrackerConfig:
+    """``df::CameraTracker::TrackerConfig`` (camera_tracker.h): pyramid_levels, iterations_per_level (index = level,
+    0 = finest; flags ``tracking_iters=5,5,10`` are given coarse-to-fine in data/flags/common.flags:9), huber_delta."""
+
+    def __init__(self, pyramid_levels=3, iterations_per_level=(10, 5, 5), huber_delta=0.1):
+        if len(iterations_per_level) != pyramid_levels:   # LOG(FATAL) at camera_tracker.cpp:31-32
+            raise DfxError(_lib.DFX_E_INVALID, "CameraTracker config error: iterations_per_level size not equal pyramid_levels")
+        self.pyramid_levels, self.iterations_per_level, self.huber_delta = pyramid_levels, tuple(iterations_per_level), huber_delta
+
+
+class CameraTracker:
+    """``df::CameraTracker``: TrackFrame runs the whole schedule on the device (dfx_track_frame); pose_ck is the pose of the
+    keyframe in the current camera's frame, exactly the `se3` handed to SE3Aligner::RunStep (camera_tracker.cpp:53)."""
+
+    def __init__(self, camera_pyr, config=None, ctx=None):
+        self.config_ = config or TrackerConfig(len(camera_pyr))
+        if len(camera_pyr) != self.config_.pyramid_levels:
+            raise DfxError(_lib.DFX_E_INVALID, "camera pyramid depth != pyramid_levels")
+        self.camera_pyr_ = [np.asarray(c, np.float32) for c in camera_pyr]
+        self.ctx = ctx or default_context()
+        self.kf_ = None
+        self.Reset()
+
+    def Reset(self):
+        self.pose_ck_ = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+        self.inliers_, self.error_ = 0.0, float("inf")
+
+    def SetKeyframe(self, pyr_img, pyr_dpt):
+        """Keyframe image and depth pyramids (kf->pyr_img, kf->pyr_dpt), finest level first."""
+        self.kf_ = (list(pyr_img), list(pyr_dpt))
+
+    def SetPoseEstimate(self, pose_ck):
+        self.pose_ck_ = np.asarray(pose_ck, np.float32).copy()
+
+    def TrackFrame(self, pyr_img1, pyr_grad1):
+        if self.kf_ is None:
+            raise RuntimeError("Calling CameraTracker::TrackFrame before a keyframe was set")   # camera_tracker.cpp:44-45
+        n = self.config_.pyramid_levels
+        lv = (_lib.TrackLevel * n)()
+        for l in range(n):
+            lv[l].cam = _cam(self.camera_pyr_[l])
+            lv[l].img0, lv[l].dpt0 = _img(self.kf_[0][l], "kf img"), _img(self.kf_[1][l], "kf dpt")
+            lv[l].img1, lv[l].grad1 = _img(pyr_img1[l], "img1"), _img(pyr_grad1[l], "grad1", 2)
+            lv[l].iterations = int(self.config_.iterations_per_level[l])
+        res = _lib.TrackResult()
+        s = _se3(self.pose_ck_)
+        check(_lib.lib().dfx_track_frame(self.ctx.handle, C.byref(s), lv, n, float(self.config_.huber_delta), C.byref(res)))
+        self.pose_ck_ = np.array(list(res.pose_ck.q) + list(res.pose_ck.t), np.float32)
+        self.inliers_, self.error_ = float(res.inliers_frac), float(res.error)
+        self.last_result_ = res
+        return self.pose_ck_
+
+    def GetInliers(self):
+        return self.inliers_
+
+    def GetError(self):
+        return self.error_

@@ -66,6 +66,7 @@ struct dfx_ctx {
   int stage_next = 0;
   char* result_host = nullptr;
   size_t result_bytes = 0;
+  void* track_state_dev = nullptr;
 
   // measurement hook (dfx_set_profiling): event pairs around the step kernel
   bool profiling = false;
@@ -321,6 +322,7 @@ DFX_API void dfx_ctx_destroy(dfx_ctx* c) {
   if (c->pairs_dev) (void)hipFree(c->pairs_dev);
   if (c->code_dev) (void)hipFree(c->code_dev);
   if (c->depth_scratch) (void)hipFree(c->depth_scratch);
+  if (c->track_state_dev) (void)hipFree(c->track_state_dev);
   if (c->stage_host) (void)hipHostFree(c->stage_host);
   if (c->result_host) (void)hipHostFree(c->result_host);
   for (int i = 0; i < kStageSlots; ++i) if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
@@ -539,6 +541,71 @@ DFX_API int dfx_se3_warp(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam,
   if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, 256, c->stream))) return rc;
   DFX_HIP(dfx::launch_se3_warp(d, (int)img0->w, (int)img0->h, blocks, c->partials, c->items_dev, c->stream));
   return fetch_result(c, c->items_dev, out, sizeof(dfx_corr_item));
+}
+
+DFX_API int dfx_track_frame(dfx_ctx* c, const dfx_se3* pose_init, const dfx_track_level* levels, int n_levels, float huber_delta,
+                            dfx_track_result* out) {
+  if (!c || !pose_init || !levels || !out) return fail(DFX_E_INVALID, "dfx_track_frame: null argument");
+  if (n_levels <= 0 || n_levels > 16) return fail(DFX_E_INVALID, "n_levels %d out of range [1,16]", n_levels);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  // validate every level first (no partial work on a bad argument)
+  std::vector<dfx::SimplePairDev> descs((size_t)n_levels);
+  int max_blocks = 1;
+  const dfx_se3 ident{ { 0, 0, 0, 1 }, { 0, 0, 0 } };
+  for (int l = 0; l < n_levels; ++l) {
+    if (levels[l].iterations < 0) return fail(DFX_E_INVALID, "level %d: negative iteration count", l);
+    if ((rc = fill_simple(&ident, &levels[l].cam, &levels[l].img0, &levels[l].img1, &levels[l].dpt0, &levels[l].grad1, nullptr, &descs[l]))) {
+      g_last_error = "level " + std::to_string(l) + ": " + g_last_error;
+      return rc;
+    }
+    const int b = simple_blocks(levels[l].img0.w, levels[l].img0.h);
+    if (b > max_blocks) max_blocks = b;
+  }
+  const size_t pbytes = (size_t)max_blocks * dfx::kSimpleRow * sizeof(float);
+  if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
+  const size_t sbytes = dfx::track_state_bytes();
+  if (!c->track_state_dev) DFX_HIP(hipMalloc(&c->track_state_dev, sbytes));
+  // upload the initial state through the staging ring
+  int slot;
+  char* host;
+  if ((rc = stage_acquire(c, sbytes, &slot, &host))) return rc;
+  double R[9], t[3] = { pose_init->t[0], pose_init->t[1], pose_init->t[2] };
+  quat_to_R(pose_init->q, R);
+  dfx::track_state_init(host, R, t);
+  DFX_HIP(hipMemcpyAsync(c->track_state_dev, host, sbytes, hipMemcpyHostToDevice, c->stream));
+  if ((rc = stage_release(c, slot))) return rc;
+  for (int l = n_levels - 1; l >= 0; --l) {
+    const int W = (int)levels[l].img0.w, H = (int)levels[l].img0.h;
+    const int blocks = simple_blocks(levels[l].img0.w, levels[l].img0.h);
+    for (int it = 0; it < levels[l].iterations; ++it)
+      DFX_HIP(dfx::launch_track_iteration(descs[l], c->track_state_dev, W, H, huber_delta, blocks, c->partials, c->stream));
+  }
+  if ((rc = ensure_result_host(c, sbytes))) return rc;
+  DFX_HIP(hipMemcpyAsync(c->result_host, c->track_state_dev, sbytes, hipMemcpyDeviceToHost, c->stream));
+  DFX_HIP(hipStreamSynchronize(c->stream));
+  float residual, inl;
+  int fails, iters;
+  dfx::track_state_read(c->result_host, R, t, &residual, &inl, &fails, &iters);
+  // rotation matrix -> unit quaternion (x y z w)
+  double q[4];
+  const double tr = R[0] + R[4] + R[8];
+  if (tr > 0) { const double s = std::sqrt(tr + 1.0) * 2; q[3] = 0.25 * s; q[0] = (R[7] - R[5]) / s; q[1] = (R[2] - R[6]) / s; q[2] = (R[3] - R[1]) / s; }
+  else if (R[0] > R[4] && R[0] > R[8]) { const double s = std::sqrt(1.0 + R[0] - R[4] - R[8]) * 2; q[3] = (R[7] - R[5]) / s; q[0] = 0.25 * s; q[1] = (R[1] + R[3]) / s; q[2] = (R[2] + R[6]) / s; }
+  else if (R[4] > R[8]) { const double s = std::sqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[3] = (R[2] - R[6]) / s; q[0] = (R[1] + R[3]) / s; q[1] = 0.25 * s; q[2] = (R[5] + R[7]) / s; }
+  else { const double s = std::sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[3] = (R[3] - R[1]) / s; q[0] = (R[2] + R[6]) / s; q[1] = (R[5] + R[7]) / s; q[2] = 0.25 * s; }
+  const double qn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int i = 0; i < 4; ++i) out->pose_ck.q[i] = (float)(q[i] / qn);
+  for (int i = 0; i < 3; ++i) out->pose_ck.t[i] = (float)t[i];
+  out->residual = residual;
+  out->inliers = (uint64_t)(inl + 0.5f);
+  const double area = (double)levels[0].img0.w * levels[0].img0.h;
+  out->inliers_frac = (float)(inl / area);
+  out->error = inl > 0 ? residual / inl : INFINITY;
+  out->iterations = iters;
+  out->solver_failures = fails;
+  return DFX_OK;
 }
 
 // ---- image-proc ------------------------------------------------------------------------------------------------

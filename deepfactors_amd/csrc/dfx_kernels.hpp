@@ -67,6 +67,13 @@ hipError_t launch_squared_error(const float* a, uint32_t pitch_a, const float* b
 hipError_t launch_depth_aligner_step(int cs, const SfmPairDev* pair_dev, int W, int H, float avg_dpt, int blocks,
                                      float* partials_dev, void* item_dev, hipStream_t stream, bool jac_dense, int prec);
 
+// device-resident tracker
+size_t track_state_bytes();
+void track_state_init(void* host_state, const double* R, const double* t);
+void track_state_read(const void* host_state, double* R, double* t, float* residual, float* inliers, int* failures, int* iters);
+hipError_t launch_track_iteration(const SimplePairDev& p, void* state_dev, int W, int H, float huber_delta, int blocks, float* partials_dev,
+                                  hipStream_t stream);
+
 constexpr int kSimpleRow = 32;       // floats per block partial of the VALU reduction kernels
 constexpr int kMaxSimpleBlocks = 1024;
 

@@ -81,6 +81,142 @@ __global__ __launch_bounds__(kT) void k_se3_step(const SimplePairDev p, const in
   block_reduce_store<29>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
+// ---- device-resident tracker (CameraTracker::TrackFrame, reference core/system/camera_tracker.cpp:42-71) -------------
+// The pose lives in device memory between iterations: k_se3_step_dev reads it, k_track_update folds the workgroup
+// partials (double, fixed order), solves the 6x6 normal equations by LDL^T in double and applies the reference's update
+// (t += dt, R = exp(dw) R; lucas_kanade_se3.h:85-95).  A whole coarse-to-fine schedule is enqueued without host syncs.
+struct TrackState {      // device-resident
+  double R[9], t[3];     // pose_ck, kept in double across iterations
+  float Rf[9], tf[3];    // fp32 copy consumed by the step kernel
+  float last_residual; float last_inliers; int solver_failures; int iterations_done;
+};
+
+__global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev p, const TrackState* __restrict__ st, const int W, const int H,
+                                                     const float huber_delta, float* __restrict__ partials) {
+  Geo g = geo_from(p);
+#pragma unroll
+  for (int q = 0; q < 9; ++q) g.R[q] = st->Rf[q];
+  g.t[0] = st->tf[0]; g.t[1] = st->tf[1]; g.t[2] = st->tf[2];
+  const ImgRef I0{ (const char*)p.img0, p.pitch_img0 }, I1{ (const char*)p.img1, p.pitch_img1 };
+  const ImgRef D0{ (const char*)p.dpt0, p.pitch_dpt0 }, G1{ (const char*)p.grad1, p.pitch_grad1 };
+  float acc[29];
+#pragma unroll
+  for (int q = 0; q < 29; ++q) acc[q] = 0.f;
+  const int npx = W * H;
+  for (int i = blockIdx.x * kT + threadIdx.x; i < npx; i += gridDim.x * kT) {
+    const int y = i / W, x = i - y * W;
+    const float d = D0.at(x, y);
+    const float i0 = I0.at(x, y);
+    const Corr c = find_correspondence(g, x, y, d, 1.0f, 0.0f);
+    if (c.valid) {
+      const Taps tp = make_taps(c.u, c.v);
+      float gx, gy;
+      sample_grad(G1, tp, gx, gy);
+      const float samp = sample_img(I1, tp);
+      float J[6], D00, D02, D11, D12;
+      pose_row(g, c, d, gx, gy, J, D00, D02, D11, D12);
+      float r = i0 - samp;
+      const float wgt = huber_weight(r, huber_delta);
+      r *= wgt;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) J[j] *= wgt;
+      int k = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b) acc[k++] += J[a] * J[b];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;
+      acc[27] += r * r;
+      acc[28] += 1.0f;
+    }
+  }
+  block_reduce_store<29>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
+}
+
+__global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__ partials, const int nblocks, TrackState* __restrict__ st) {
+  __shared__ double red[32][kSimpleRow];
+  __shared__ double sum[kSimpleRow];
+  const int e = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  double s = 0.0;
+  for (int b = rg; b < nblocks; b += 32) s += (double)partials[(size_t)b * kSimpleRow + e];
+  red[rg][e] = s;
+  __syncthreads();
+  if (rg == 0) {
+    s = 0.0;
+    for (int q = 0; q < 32; ++q) s += red[q][e];
+    sum[e] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  // reference precision: the item is fp32 (JTJJrReductionItem<float,6>) before the solve (camera_tracker.cpp:59)
+  double A[36], bvec[6];
+  int k = 0;
+  for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { const double v = (double)(float)sum[k++]; A[a * 6 + b] = v; A[b * 6 + a] = v; }
+  for (int a = 0; a < 6; ++a) bvec[a] = (double)(float)sum[21 + a];
+  st->last_residual = (float)sum[27];
+  st->last_inliers = (float)sum[28];
+  st->iterations_done += 1;
+  // LDL^T
+  double L[36], D[6], yv[6], x[6];
+  bool ok = sum[28] > 0.0;
+  for (int i = 0; i < 36; ++i) L[i] = 0.0;
+  for (int j = 0; j < 6 && ok; ++j) {
+    double d = A[j * 6 + j];
+    for (int q = 0; q < j; ++q) d -= L[j * 6 + q] * L[j * 6 + q] * D[q];
+    if (!(fabs(d) > 0.0)) { ok = false; break; }
+    D[j] = d; L[j * 6 + j] = 1.0;
+    for (int i = j + 1; i < 6; ++i) {
+      double v = A[i * 6 + j];
+      for (int q = 0; q < j; ++q) v -= L[i * 6 + q] * L[j * 6 + q] * D[q];
+      L[i * 6 + j] = v / d;
+    }
+  }
+  if (!ok) { st->solver_failures += 1; return; }
+  for (int i = 0; i < 6; ++i) { double v = bvec[i]; for (int q = 0; q < i; ++q) v -= L[i * 6 + q] * yv[q]; yv[i] = v; }
+  for (int i = 5; i >= 0; --i) { double v = yv[i] / D[i]; for (int q = i + 1; q < 6; ++q) v -= L[q * 6 + i] * x[q]; x[i] = v; }
+  // update = -x ; t += update[0:3] ; R = exp(update[3:6]) * R
+  const double w0 = -x[3], w1 = -x[4], w2 = -x[5];
+  const double th2 = w0 * w0 + w1 * w1 + w2 * w2, th = sqrt(th2);
+  const double Ac = th < 1e-9 ? 1.0 - th2 / 6.0 : sin(th) / th, Bc = th < 1e-9 ? 0.5 - th2 / 24.0 : (1.0 - cos(th)) / th2;
+  const double K[9] = { 0, -w2, w1, w2, 0, -w0, -w1, w0, 0 };
+  double E[9], Rn[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    double k2 = 0; for (int q = 0; q < 3; ++q) k2 += K[i * 3 + q] * K[q * 3 + j];
+    E[i * 3 + j] = (i == j ? 1.0 : 0.0) + Ac * K[i * 3 + j] + Bc * k2;
+  }
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    double v = 0; for (int q = 0; q < 3; ++q) v += E[i * 3 + q] * st->R[q * 3 + j];
+    Rn[i * 3 + j] = v;
+  }
+  for (int i = 0; i < 9; ++i) { st->R[i] = Rn[i]; st->Rf[i] = (float)Rn[i]; }
+  for (int i = 0; i < 3; ++i) { st->t[i] -= x[i]; st->tf[i] = (float)st->t[i]; }
+}
+
+size_t track_state_bytes() { return sizeof(TrackState); }
+
+hipError_t launch_track_iteration(const SimplePairDev& p, void* state_dev, int W, int H, float huber_delta, int blocks, float* partials_dev,
+                                  hipStream_t stream) {
+  hipLaunchKernelGGL(k_se3_step_dev, dim3(blocks), dim3(kT), 0, stream, p, (const TrackState*)state_dev, W, H, huber_delta, partials_dev);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_track_update, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (TrackState*)state_dev);
+  return hipGetLastError();
+}
+
+void track_state_init(void* host_state, const double* R, const double* t) {
+  TrackState* s = (TrackState*)host_state;
+  for (int i = 0; i < 9; ++i) { s->R[i] = R[i]; s->Rf[i] = (float)R[i]; }
+  for (int i = 0; i < 3; ++i) { s->t[i] = t[i]; s->tf[i] = (float)t[i]; }
+  s->last_residual = 0.f; s->last_inliers = 0.f; s->solver_failures = 0; s->iterations_done = 0;
+}
+void track_state_read(const void* host_state, double* R, double* t, float* residual, float* inliers, int* failures, int* iters) {
+  const TrackState* s = (const TrackState*)host_state;
+  for (int i = 0; i < 9; ++i) R[i] = s->R[i];
+  for (int i = 0; i < 3; ++i) t[i] = s->t[i];
+  *residual = s->last_residual; *inliers = s->last_inliers; *failures = s->solver_failures; *iters = s->iterations_done;
+}
+
 // ---- SfM error: sum (w r)^2, inliers -----------------------------------------------------------------------
 __global__ __launch_bounds__(kT) void k_sfm_error(const SimplePairDev p, const int W, const int H, const float huber_delta,
                                                   float* __restrict__ partials) {

@@ -30,12 +30,9 @@
 
 namespace dfx {
 
-// ---- tuning switches (A/B-tested on MI355X; defaults are the measured best) ----------
+// ---- build-time switches: launch shape (A/B-tested on MI355X) and diagnosis-only instrumentation ----
 #ifndef DFX_MIN_WAVES
 #define DFX_MIN_WAVES 3      // __launch_bounds__ waves per SIMD the register allocator must allow
-#endif
-#ifndef DFX_SETPRIO
-#define DFX_SETPRIO 0        // 1: raise wave priority during the MFMA phase
 #endif
 #ifndef DFX_TRACE
 #define DFX_TRACE 0          // 1: per-wave s_memtime sums of phase A / phase B in the junk row 15 of the (P,P) partial
@@ -43,14 +40,11 @@ namespace dfx {
 #ifndef DFX_ABLATE
 #define DFX_ABLATE 0         // diagnosis only (wrong results): 1 = no MFMAs, 2 = no phase-A math/gathers, 4 = no ring loads
 #endif
-#ifndef DFX_DEBUG_DRAIN
-#define DFX_DEBUG_DRAIN 0
-#endif
-#ifndef DFX_JIT
-#define DFX_JIT 0            // 1: pin each ring refill load right behind its consumer (sched_barrier per group)
-#endif
 
-constexpr int kWaves = 4;                 // waves per workgroup
+#ifndef DFX_WAVES
+#define DFX_WAVES 4
+#endif
+constexpr int kWaves = DFX_WAVES;         // waves per workgroup
 constexpr int kThreads = kWaves * 64;
 constexpr int kUStride = 66;              // floats; 16 rows x 66: bank = (2*i + p) % 32 -> conflict-free
 constexpr int kUFloats = 16 * kUStride;   // per wave
@@ -322,12 +316,6 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
     if (has2) advance_xy(nxt.x, nxt.y);   // otherwise nxt keeps pointing at the last real chunk
     prefetch_di0(nnbase, nxt);
     __builtin_amdgcn_wave_barrier();   // LDS hand-over inside one wave: program order is enough for the hardware
-#if DFX_DEBUG_DRAIN & 1
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-#if DFX_DEBUG_DRAIN & 2
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
 
 #if DFX_TRACE
     __builtin_amdgcn_sched_barrier(0);
@@ -336,38 +324,6 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
     __builtin_amdgcn_sched_barrier(0);
 #endif
     // ---- phase B: rank-4 updates on the matrix cores; operand ring refilled behind the consumer
-#if DFX_SETPRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
-#if DFX_JIT
-    float uP = U[li * kUStride + lk];
-    float s = U[13 * kUStride + lk];
-#pragma unroll
-    for (int gq = 0; gq < 16; ++gq) {
-      float uPn = 0.f, sn = 0.f;
-      if (gq < 15) {   // LDS operands of the next group, ahead of this group's MFMAs
-        uPn = U[li * kUStride + 4 * (gq + 1) + lk];
-        sn = U[13 * kUStride + 4 * (gq + 1) + lk];
-      }
-      float sc[NCB];
-#pragma unroll
-      for (int b = 0; b < NCB; ++b) sc[b] = mul_zero_wins(s, jv_get<NCB>(jv[gq], b));
-      jv[gq] = bload(jac_rs, jv_offset<NCB, JDENSE>(nbase, gq, li, lk, W, npx, jac_pitch), (jv_t*)nullptr);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uP, uP, acc[0], 0, 0, 0);
-#pragma unroll
-      for (int b = 0; b < NCB; ++b) acc[1 + b] = __builtin_amdgcn_mfma_f32_16x16x4f32(uP, sc[b], acc[1 + b], 0, 0, 0);
-#pragma unroll
-      for (int b = 0; b < NCB; ++b)
-#pragma unroll
-        for (int b2 = b; b2 < NCB; ++b2) {
-          const int a = 1 + NCB + (b * NCB - b * (b - 1) / 2) + (b2 - b);
-          acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[b], sc[b2], acc[a], 0, 0, 0);
-        }
-      uP = uPn;
-      s = sn;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#else
 #pragma unroll
     for (int gq = 0; gq < 16; ++gq) {
       const int pp = 4 * gq + lk;
@@ -413,10 +369,6 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
           acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[b], sc[b2], acc[a], 0, 0, 0);
         }
     }
-#endif
-#if DFX_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
 #if DFX_TRACE
     __builtin_amdgcn_sched_barrier(0);
     const unsigned long long tr2 = __builtin_amdgcn_s_memtime();

@@ -139,6 +139,28 @@ DFX_API int dfx_se3_step(dfx_ctx* ctx, const dfx_se3* pose_10, const dfx_cam* ca
 DFX_API int dfx_se3_warp(dfx_ctx* ctx, const dfx_se3* pose_10, const dfx_cam* cam, const dfx_img* img0,
                          const dfx_img* img1, const dfx_img* dpt0, const dfx_img* img2_out, dfx_corr_item* out);
 
+/* ---- CameraTracker::TrackFrame (core/system/camera_tracker.cpp:42-71), device-resident -------
+ * The reference loops on the host: RunStep (kernel + finalize + sync + 120-byte copy) -> 6x6 ldlt().solve -> retract, per
+ * iteration.  Here the whole coarse-to-fine schedule is enqueued at once: the pose stays in device memory, the solve
+ * (LDL^T in double) and the update (t += dt, R = exp(dw) R) run in the finalize kernel; one copy back at the end.
+ * levels[0] is the finest level; levels are processed from n_levels-1 down to 0 with levels[l].iterations steps each. */
+typedef struct dfx_track_level {
+  dfx_cam cam;
+  dfx_img img0, img1, dpt0, grad1; /* keyframe image, live image, keyframe depth, live gradient at this level */
+  int32_t iterations;
+} dfx_track_level;
+typedef struct dfx_track_result {
+  dfx_se3 pose_ck;       /* updated estimate */
+  float inliers_frac;    /* inliers / area of the last level-0 iteration (camera_tracker.cpp:67) */
+  float error;           /* residual / inliers of that iteration, +inf if no inliers (camera_tracker.cpp:68) */
+  float residual;
+  uint64_t inliers;
+  int32_t iterations;        /* total Gauss-Newton iterations run */
+  int32_t solver_failures;   /* iterations skipped because the 6x6 system was singular / had no inliers */
+} dfx_track_result;
+DFX_API int dfx_track_frame(dfx_ctx* ctx, const dfx_se3* pose_ck_init, const dfx_track_level* levels, int n_levels,
+                            float huber_delta, dfx_track_result* out);
+
 /* ---- SfmAligner<float,CS> (cuda/cu_sfmaligner.h:50-97) -------------------------------------- */
 /* RunStep (cu_sfmaligner.cpp:149-185).  cs in {16, 32, 64}.  std0 may be NULL (dead input in the reference,
  * dense_sfm.h:58-67); valid0 may be NULL (otherwise written 1.0 where a pixel is an inlier, never cleared,

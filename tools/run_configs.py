@@ -63,6 +63,18 @@ gt = p["pose10_true"]
 out["cfg1_se3_tracker"] = dict(ms_per_frame=timed(lambda: track(), 5, 1) * 1e3, iterations=20,
                                us_per_step_level0=timed(lambda: se3.RunStep(gt, cams[0], lv[0]["img0"], lv[0]["img1"], lv[0]["dpt0"], lv[0]["grad1"]), 50) * 1e6,
                                final_err=float(r.residual / max(r.inliers, 1)), dt=float(np.linalg.norm(qt[4:] - gt[4:])), dq=float(np.linalg.norm(qt[:4] - gt[:4])))
+trk = dfx.CameraTracker(cams, dfx.TrackerConfig(3, (10, 5, 5), 0.1), ctx)
+trk.SetKeyframe([l["img0"] for l in lv], [l["dpt0"] for l in lv])
+
+
+def track_dev():
+    trk.Reset()
+    return trk.TrackFrame([l["img1"] for l in lv], [l["grad1"] for l in lv])
+
+
+pd = track_dev()
+out["cfg1_se3_tracker"].update(device_resident_ms_per_frame=timed(track_dev, 20, 2) * 1e3, device_dt=float(np.linalg.norm(pd[4:] - gt[4:])),
+                               device_dq=float(np.linalg.norm(pd[:4] - gt[:4])))
 n0 = synth.to_numpy({k: lv[0][k] for k in lv[0]})
 t0 = time.perf_counter()
 for _ in range(5):
