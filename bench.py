@@ -80,7 +80,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run: use RCCL even for one rank (exercises the exchange step)
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

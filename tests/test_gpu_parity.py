@@ -246,3 +246,35 @@ def test_errors_are_loud(dfx):
     with pytest.raises(dfx.DfxError):   # unsupported code size
         dfx.SfmAligner(code_size=48).RunStep(n["pose0"], n["pose1"], n["code"], n["cam"], g["img0"], g["img1"], g["dpt0"], None, None,
                                              torch.zeros((48, 64 * 48), device="cuda"), g["grad1"])
+
+
+@pytest.mark.parametrize("w,h", [(40, 30), (17, 9), (64, 1), (8, 8)])
+def test_tiny_and_narrow_images(dfx, oracle, w, h):
+    """Images narrower than one 64-pixel chunk (a chunk wraps several rows) and smaller than one chunk."""
+    from deepfactors_amd import synth
+    cs = 32
+    p, n, g = _pair(dfx, max(w, 16), max(h, 16), cs, seed=90 + w)
+    # crop the synthetic pair to (h, w); keep the camera of the crop consistent (principal point inside)
+    def crop(a, c=1):
+        return np.ascontiguousarray(a[:h, : w * c] if a.ndim == 2 else a[:h, :w])
+    n2 = dict(img0=crop(n["img0"]), img1=crop(n["img1"]), dpt0=crop(n["dpt0"]), grad1=crop(n["grad1"]),
+              prx_jac=np.ascontiguousarray(n["prx_jac"].reshape(n["img0"].shape[0], -1, cs)[:h, :w].reshape(h, w * cs)),
+              prx_orig=crop(n["prx_orig"]))
+    cam = np.array([w * 0.9, h * 1.2, w / 2, h / 2, w, h], np.float32)
+    g2 = {k: torch.from_numpy(v).cuda() for k, v in n2.items()}
+    pose0, pose1 = synth.IDENTITY.copy(), synth.IDENTITY.copy()
+    pose1[4:] = [0.002, -0.001, 0.003]
+    al = dfx.SfmAligner(code_size=cs)
+    got = al.RunStep(pose0, pose1, n["code"], cam, g2["img0"], g2["img1"], g2["dpt0"], None, None, g2["prx_jac"], g2["grad1"])
+    ref = oracle.sfm_step(pose0, pose1, cam, n2["img0"], n2["img1"], n2["dpt0"], n2["prx_jac"], n2["grad1"])
+    assert got.inliers == ref.inliers
+    if ref.inliers:
+        assert_item_close(got, ref, w, h, what=f"tiny {w}x{h}")
+    se3 = dfx.SE3Aligner()
+    s_got = se3.RunStep(pose1, cam, g2["img0"], g2["img1"], g2["dpt0"], g2["grad1"])
+    s_ref = oracle.se3_step(pose1, cam, n2["img0"], n2["img1"], n2["dpt0"], n2["grad1"], 0.1)
+    assert s_got.inliers == s_ref.inliers
+    out = torch.empty_like(g2["img0"])
+    dfx.UpdateDepth(n["code"], g2["prx_orig"], g2["prx_jac"], 2.0, out)
+    d_ref = oracle.update_depth(n["code"], n2["prx_orig"], n2["prx_jac"], 2.0)
+    assert np.abs(out.cpu().numpy() - d_ref).max() <= 2e-6 * float(((2.0 + d_ref) ** 2 / 2.0).max())
