@@ -138,8 +138,7 @@ __global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__
   __shared__ double red[32][kSimpleRow];
   __shared__ double sum[kSimpleRow];
   const int e = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  double s = 0.0;
-  for (int b = rg; b < nblocks; b += 32) s += (double)partials[(size_t)b * kSimpleRow + e];
+  double s = strided_sum_f64<32>(partials + e, rg, nblocks, kSimpleRow);
   red[rg][e] = s;
   __syncthreads();
   if (rg == 0) {
@@ -286,8 +285,7 @@ __global__ __launch_bounds__(1024) void k_finalize_rows(const float* __restrict_
                                                         char* __restrict__ out) {
   __shared__ double red[32][kSimpleRow];
   const int e = threadIdx.x & 31, rg = threadIdx.x >> 5;   // 32 row groups
-  double s = 0.0;
-  for (int b = rg; b < nblocks; b += 32) s += (double)partials[(size_t)b * kSimpleRow + e];
+  double s = strided_sum_f64<32>(partials + e, rg, nblocks, kSimpleRow);
   red[rg][e] = s;
   __syncthreads();
   if (rg != 0) return;

@@ -425,11 +425,7 @@ __global__ __launch_bounds__(256) void k_sfm_finalize(const float* __restrict__ 
   const int c64 = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int col = (blockIdx.x & 3) * 64 + c64;
   const float* src = partials + (size_t)pair * bpp * ZDIM + a * 256 + col;
-  double s0 = 0.0, s1 = 0.0;   // two chains: more loads in flight, still a fixed summation order
-  int b = rg;
-  for (; b + 4 < bpp; b += 8) { s0 += (double)src[(size_t)b * ZDIM]; s1 += (double)src[(size_t)(b + 4) * ZDIM]; }
-  if (b < bpp) s0 += (double)src[(size_t)b * ZDIM];
-  red[rg][c64] = s0 + s1;
+  red[rg][c64] = strided_sum_f64<4>(src, rg, bpp, ZDIM);
   __syncthreads();
   if (rg != 0) return;
   const double s = ((red[0][c64] + red[1][c64]) + red[2][c64]) + red[3][c64];
