@@ -4,7 +4,7 @@ reference's own operator interface.  The product is libdfx.so (C ABI, include/df
 host-side mirror of the reference interface plus the device-memory/stream plumbing (PyTorch)."""
 from ._lib import DfxError, EXPORTED_SYMBOLS, LIB_PATH, item_size  # noqa: F401
 from .aligners import (CameraTracker, Context, CorrespondenceReductionItem, DenseSfmParams, DepthAligner, GaussianBlurDown,  # noqa: F401
-                       JTJJrReductionItem, SE3Aligner, SfmAligner, SfmAlignerParams, SobelGradients, SquaredError,
+                       JTJJrReductionItem, SE3Aligner, SfmAligner, SfmAlignerParams, SobelGradients, SparseGeometricFactor, SquaredError,
                        TrackerConfig, UpdateDepth, default_context)
 
 __version__ = "0.1.0"

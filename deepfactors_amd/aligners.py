@@ -413,3 +413,40 @@ class CameraTracker:
 
     def GetError(self):
         return self.error_
+
+
+# ------------------------------------------------------------------------------------------------------------
+# SparseGeometricFactor (core/gtsam/sparse_geometric_factor.{h,cpp})
+# ------------------------------------------------------------------------------------------------------------
+class SparseGeometricFactor:
+    """The data-parallel part of ``df::SparseGeometricFactor<float,CS>``: linearize() returns the [N][12 + 2 CS + 1]
+    row-major Jacobian rows [A_pose0 | A_pose1 | A_code0 | A_code1 | b] the reference packs into a gtsam::JacobianFactor
+    (keys pose0, pose1, code0, code1); error() = 0.5 * sum b^2 (sparse_geometric_factor.cpp:90-142, with the validity
+    check of linearize applied)."""
+
+    def __init__(self, cam, points, kf0, kf1, huber_delta, code_size=32, avg_dpt=2.0, ctx=None):
+        """kf0 = dict(prx_orig, prx_jac); kf1 = dict(prx_orig, prx_jac, dpt_grad) of device tensors; points = [N][2] ints."""
+        self.cam_, self.kf0_, self.kf1_ = np.asarray(cam, np.float32), kf0, kf1
+        self.points_ = np.ascontiguousarray(np.asarray(points, np.int32).reshape(-1, 2))
+        self.huber_delta_, self.CS, self.avg_dpt_ = float(huber_delta), int(code_size), float(avg_dpt)
+        self.ctx = ctx or default_context()
+
+    def linearize(self, pose0, pose1, code0, code1):
+        n, nc = len(self.points_), 12 + 2 * self.CS + 1
+        rows = np.zeros((n, nc), np.float32)
+        c0 = np.ascontiguousarray(np.asarray(code0, np.float32).reshape(self.CS))
+        c1 = np.ascontiguousarray(np.asarray(code1, np.float32).reshape(self.CS))
+        s0, s1, cm = _se3(pose0), _se3(pose1), _cam(self.cam_)
+        p0, j0 = _img(self.kf0_["prx_orig"], "prx0_orig"), _img(self.kf0_["prx_jac"], "prx0_jac")
+        p1, j1 = _img(self.kf1_["prx_orig"], "prx1_orig"), _img(self.kf1_["prx_jac"], "prx1_jac")
+        dg = _img(self.kf1_["dpt_grad"], "dpt1_grad", 2)
+        fp = C.POINTER(C.c_float)
+        check(_lib.lib().dfx_sparse_geometric_linearize(self.ctx.handle, self.CS, C.byref(s0), C.byref(s1), c0.ctypes.data_as(fp),
+                                                        c1.ctypes.data_as(fp), C.byref(cm), self.points_.ctypes.data_as(C.POINTER(C.c_int32)), n,
+                                                        C.byref(p0), C.byref(j0), C.byref(p1), C.byref(j1), C.byref(dg), self.huber_delta_,
+                                                        self.avg_dpt_, rows.ctypes.data_as(fp)))
+        return rows
+
+    def error(self, pose0, pose1, code0, code1):
+        rows = self.linearize(pose0, pose1, code0, code1)
+        return 0.5 * float(np.sum(rows[:, -1].astype(np.float64) ** 2))

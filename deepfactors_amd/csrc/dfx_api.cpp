@@ -67,6 +67,8 @@ struct dfx_ctx {
   char* result_host = nullptr;
   size_t result_bytes = 0;
   void* track_state_dev = nullptr;
+  char* sg_dev = nullptr;      // sparse geometric: codes + points + rows
+  size_t sg_bytes = 0;
 
   // measurement hook (dfx_set_profiling): event pairs around the step kernel
   bool profiling = false;
@@ -323,6 +325,7 @@ DFX_API void dfx_ctx_destroy(dfx_ctx* c) {
   if (c->code_dev) (void)hipFree(c->code_dev);
   if (c->depth_scratch) (void)hipFree(c->depth_scratch);
   if (c->track_state_dev) (void)hipFree(c->track_state_dev);
+  if (c->sg_dev) (void)hipFree(c->sg_dev);
   if (c->stage_host) (void)hipHostFree(c->stage_host);
   if (c->result_host) (void)hipHostFree(c->result_host);
   for (int i = 0; i < kStageSlots; ++i) if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
@@ -606,6 +609,56 @@ DFX_API int dfx_track_frame(dfx_ctx* c, const dfx_se3* pose_init, const dfx_trac
   out->iterations = iters;
   out->solver_failures = fails;
   return DFX_OK;
+}
+
+DFX_API int dfx_sparse_geometric_linearize(dfx_ctx* c, int cs, const dfx_se3* pose0, const dfx_se3* pose1, const float* code0,
+                                           const float* code1, const dfx_cam* cam, const int32_t* points_xy, int n_points,
+                                           const dfx_img* prx0_orig, const dfx_img* prx0_jac, const dfx_img* prx1_orig,
+                                           const dfx_img* prx1_jac, const dfx_img* dpt1_grad, float huber_delta, float avg_dpt,
+                                           float* rows_host) {
+  if (!c || !pose0 || !pose1 || !code0 || !code1 || !cam || !points_xy || !rows_host) return fail(DFX_E_INVALID, "dfx_sparse_geometric_linearize: null argument");
+  if (!cs_supported(cs)) return fail(DFX_E_INVALID, "unsupported code size %d (16, 32, 64)", cs);
+  if (n_points <= 0 || n_points > (1 << 20)) return fail(DFX_E_INVALID, "n_points %d out of range", n_points);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  if (!img_ok(prx0_orig)) return fail(DFX_E_INVALID, "prx0_orig: null or empty image view");
+  const uint32_t W = prx0_orig->w, H = prx0_orig->h;
+  if ((rc = check_img(prx0_orig, "prx0_orig", W, H, 4))) return rc;
+  if ((rc = check_img(prx1_orig, "prx1_orig", W, H, 4))) return rc;
+  if ((rc = check_img(prx0_jac, "prx0_jac", W * (uint32_t)cs, H, 4))) return rc;
+  if ((rc = check_img(prx1_jac, "prx1_jac", W * (uint32_t)cs, H, 4))) return rc;
+  if ((rc = check_img(dpt1_grad, "dpt1_grad", W, H, 8))) return rc;
+  if (((uintptr_t)dpt1_grad->ptr | dpt1_grad->pitch_bytes) & 7) return fail(DFX_E_INVALID, "dpt1_grad: pointer/pitch must be 8-byte aligned");
+  for (int i = 0; i < n_points; ++i)
+    if (points_xy[2 * i] < 0 || points_xy[2 * i] >= (int)W || points_xy[2 * i + 1] < 0 || points_xy[2 * i + 1] >= (int)H)
+      return fail(DFX_E_INVALID, "point %d = (%d, %d) outside the %ux%u image", i, points_xy[2 * i], points_xy[2 * i + 1], W, H);
+  const int nc = 12 + 2 * cs + 1;
+  const size_t off_pts = 2 * 64 * sizeof(float), off_rows = off_pts + (((size_t)n_points * 8 + 255) & ~(size_t)255);
+  const size_t need = off_rows + (size_t)n_points * nc * sizeof(float);
+  if (c->sg_bytes < need) DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = grow_dev((void**)&c->sg_dev, &c->sg_bytes, need, c->stream))) return rc;
+  // stage codes + points
+  int slot;
+  char* host;
+  const size_t up = off_pts + (size_t)n_points * 8;
+  if ((rc = stage_acquire(c, up, &slot, &host))) return rc;
+  std::memset(host, 0, off_pts);
+  std::memcpy(host, code0, sizeof(float) * (size_t)cs);
+  std::memcpy(host + 64 * sizeof(float), code1, sizeof(float) * (size_t)cs);
+  std::memcpy(host + off_pts, points_xy, (size_t)n_points * 8);
+  DFX_HIP(hipMemcpyAsync(c->sg_dev, host, up, hipMemcpyHostToDevice, c->stream));
+  if ((rc = stage_release(c, slot))) return rc;
+  float R10[9], t10[3], M[9], HM[9];
+  relative_pose(*pose0, *pose1, R10, t10, M, HM);
+  const float cam6[6] = { cam->fx, cam->fy, cam->u0, cam->v0, cam->w, cam->h };
+  std::vector<char> desc(dfx::sparse_geo_desc_bytes());
+  dfx::sparse_geo_fill(desc.data(), R10, t10, M, HM, cam6, (const float*)prx0_orig->ptr, (uint32_t)prx0_orig->pitch_bytes,
+                       (const float*)prx0_jac->ptr, (uint32_t)prx0_jac->pitch_bytes, (const float*)prx1_orig->ptr, (uint32_t)prx1_orig->pitch_bytes,
+                       (const float*)prx1_jac->ptr, (uint32_t)prx1_jac->pitch_bytes, (const float*)dpt1_grad->ptr, (uint32_t)dpt1_grad->pitch_bytes,
+                       huber_delta, avg_dpt);
+  DFX_HIP(dfx::launch_sparse_geometric(cs, desc.data(), (const float*)c->sg_dev, (const float*)c->sg_dev + 64, (const int*)(c->sg_dev + off_pts),
+                                       n_points, (float*)(c->sg_dev + off_rows), c->stream));
+  return fetch_result(c, c->sg_dev + off_rows, rows_host, (size_t)n_points * nc * sizeof(float));
 }
 
 // ---- image-proc ------------------------------------------------------------------------------------------------

@@ -216,6 +216,108 @@ void track_state_read(const void* host_state, double* R, double* t, float* resid
   *residual = s->last_residual; *inliers = s->last_inliers; *failures = s->solver_failures; *iters = s->iterations_done;
 }
 
+// ---- SparseGeometricFactor::linearize (reference core/gtsam/sparse_geometric_factor.cpp:147-275) ---------------------------
+// One lane per sampled point (N <= a few thousand): decode depth at the point in kf0, warp, decode kf1's depth at the
+// nearest-neighbour pixel of the projection, residual err = dpt1 - (R p + t).z, Huber weight, one row
+// [err_J_pose0 (6) | err_J_pose1 (6) | err_J_cde0 (CS) | err_J_cde1 (CS) | err] per point (zero row if no correspondence).
+struct SparseGeoDev {
+  float R[9], t[3], M[9], HM[9];
+  float fx, fy, u0, v0, w, h;
+  const float* prx0; const float* jac0; const float* prx1; const float* jac1; const float* dgrad1;
+  uint32_t pitch_prx0, pitch_jac0, pitch_prx1, pitch_jac1, pitch_dgrad1;
+  float huber_delta, avg_dpt;
+};
+
+template <int CS>
+__global__ __launch_bounds__(64) void k_sparse_geometric(const SparseGeoDev P, const float* __restrict__ code0, const float* __restrict__ code1,
+                                                         const int* __restrict__ pts, const int npts, float* __restrict__ rows) {
+  constexpr int NC = 12 + 2 * CS + 1;
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= npts) return;
+  float* row = rows + (size_t)i * NC;
+  const int x = pts[2 * i], y = pts[2 * i + 1];
+  Geo g;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) g.R[q] = P.R[q];
+  g.t[0] = P.t[0]; g.t[1] = P.t[1]; g.t[2] = P.t[2];
+  g.fx = P.fx; g.fy = P.fy; g.u0 = P.u0; g.v0 = P.v0; g.w = P.w; g.h = P.h;
+  const char* j0p = (const char*)P.jac0 + (size_t)y * P.pitch_jac0 + (size_t)x * CS * 4;
+  float dot0 = 0.f;
+  {
+#pragma clang fp contract(off)
+    for (int k = 0; k < CS; ++k) dot0 += gload<float>(j0p + 4 * k) * code0[k];   // sequential, like DepthFromCode
+  }
+  const float a = P.avg_dpt;
+  const float d0 = a / (gload<float>((const char*)P.prx0 + (size_t)y * P.pitch_prx0 + (size_t)x * 4) + dot0) - a;
+  const Corr c = find_correspondence(g, x, y, d0, 1.0f, 0.0f);
+  if (!c.valid) {
+    for (int k = 0; k < NC; ++k) row[k] = 0.f;
+    return;
+  }
+  const int nx = (int)c.u, ny = (int)c.v;   // cast<int>: truncation (sparse_geometric_factor.cpp:207)
+  const char* j1p = (const char*)P.jac1 + (size_t)ny * P.pitch_jac1 + (size_t)nx * CS * 4;
+  float dot1 = 0.f;
+  {
+#pragma clang fp contract(off)
+    for (int k = 0; k < CS; ++k) dot1 += gload<float>(j1p + 4 * k) * code1[k];
+  }
+  const float d1 = a / (gload<float>((const char*)P.prx1 + (size_t)ny * P.pitch_prx1 + (size_t)nx * 4) + dot1) - a;
+  const float qz = 1.0f / c.iz;
+  const float err = d1 - (c.vz + g.t[2]);
+  (void)qz;
+  const f32x2 dg = gload<f32x2>((const char*)P.dgrad1 + (size_t)ny * P.pitch_dgrad1 + (size_t)nx * 8);
+  // gC = -(dgrad . C) with C = D [I | -hat(R p)]; third row of [I | -hat(R p)] is (0, 0, 1, v.y, -v.x, 0)
+  float gC[6], D00, D02, D11, D12;
+  pose_row(g, c, d0, dg.x, dg.y, gC, D00, D02, D11, D12);
+  const float a10[6] = { gC[0], gC[1], 1.0f + gC[2], c.vy + gC[3], -c.vx + gC[4], gC[5] };
+  float e0[6], e1[6];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    e0[j] = a10[0] * P.M[j] + a10[1] * P.M[3 + j] + a10[2] * P.M[6 + j];
+    e0[3 + j] = a10[3] * P.M[j] + a10[4] * P.M[3 + j] + a10[5] * P.M[6 + j];
+    e1[j] = -e0[j];
+    e1[3 + j] = -(a10[0] * P.HM[j] + a10[1] * P.HM[3 + j] + a10[2] * P.HM[6 + j]) - e0[3 + j];
+  }
+  const float apd0 = a + d0, apd1 = a + d1;
+  const float dprx0 = -(apd0 * apd0) / a;
+  const float pj0 = D00 * c.rrx + D02 * c.rrz, pj1 = D11 * c.rry + D12 * c.rrz;
+  const float sc0 = (c.rrz - (dg.x * pj0 + dg.y * pj1)) * dprx0;
+  const float sc1 = (apd1 * apd1) / a;   // -DepthJacobianPrx(dpt1)
+  const float wgt = huber_weight(err, P.huber_delta);
+#pragma unroll
+  for (int j = 0; j < 6; ++j) { row[j] = e0[j] * wgt; row[6 + j] = e1[j] * wgt; }
+  for (int k = 0; k < CS; ++k) {
+    row[12 + k] = sc0 * gload<float>(j0p + 4 * k) * wgt;
+    row[12 + CS + k] = sc1 * gload<float>(j1p + 4 * k) * wgt;
+  }
+  row[12 + 2 * CS] = err * wgt;
+}
+
+size_t sparse_geo_desc_bytes() { return sizeof(SparseGeoDev); }
+void sparse_geo_fill(void* desc, const float* R, const float* t, const float* M, const float* HM, const float* cam6, const float* prx0,
+                     uint32_t pp0, const float* jac0, uint32_t pj0, const float* prx1, uint32_t pp1, const float* jac1, uint32_t pj1,
+                     const float* dgrad1, uint32_t pg1, float huber_delta, float avg_dpt) {
+  SparseGeoDev* d = (SparseGeoDev*)desc;
+  for (int i = 0; i < 9; ++i) { d->R[i] = R[i]; d->M[i] = M[i]; d->HM[i] = HM[i]; }
+  for (int i = 0; i < 3; ++i) d->t[i] = t[i];
+  d->fx = cam6[0]; d->fy = cam6[1]; d->u0 = cam6[2]; d->v0 = cam6[3]; d->w = cam6[4]; d->h = cam6[5];
+  d->prx0 = prx0; d->jac0 = jac0; d->prx1 = prx1; d->jac1 = jac1; d->dgrad1 = dgrad1;
+  d->pitch_prx0 = pp0; d->pitch_jac0 = pj0; d->pitch_prx1 = pp1; d->pitch_jac1 = pj1; d->pitch_dgrad1 = pg1;
+  d->huber_delta = huber_delta; d->avg_dpt = avg_dpt;
+}
+hipError_t launch_sparse_geometric(int cs, const void* desc_host, const float* code0_dev, const float* code1_dev, const int* pts_dev, int npts,
+                                   float* rows_dev, hipStream_t stream) {
+  const SparseGeoDev& P = *(const SparseGeoDev*)desc_host;
+  const int blocks = (npts + 63) / 64;
+  switch (cs) {
+    case 16: hipLaunchKernelGGL(k_sparse_geometric<16>, dim3(blocks), dim3(64), 0, stream, P, code0_dev, code1_dev, pts_dev, npts, rows_dev); break;
+    case 32: hipLaunchKernelGGL(k_sparse_geometric<32>, dim3(blocks), dim3(64), 0, stream, P, code0_dev, code1_dev, pts_dev, npts, rows_dev); break;
+    case 64: hipLaunchKernelGGL(k_sparse_geometric<64>, dim3(blocks), dim3(64), 0, stream, P, code0_dev, code1_dev, pts_dev, npts, rows_dev); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 // ---- SfM error: sum (w r)^2, inliers -----------------------------------------------------------------------
 __global__ __launch_bounds__(kT) void k_sfm_error(const SimplePairDev p, const int W, const int H, const float huber_delta,
                                                   float* __restrict__ partials) {

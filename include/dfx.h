@@ -210,6 +210,19 @@ DFX_API int dfx_gaussian_blur_down(dfx_ctx* ctx, const dfx_img* in, const dfx_im
 /* SquaredError (cu_image_proc.cpp:190-240): sum (a-b)^2. */
 DFX_API int dfx_squared_error(dfx_ctx* ctx, const dfx_img* a, const dfx_img* b, float* out);
 
+/* ---- SparseGeometricFactor<float,CS>::linearize (core/gtsam/sparse_geometric_factor.cpp:147-275) ----
+ * The reference evaluates the N sampled points on the CPU (forcing a device->host sync of both keyframes' 39 MB Jacobians).
+ * Here: one lane per point, everything read from device memory.  `points_xy` is a HOST array of N (x, y) int pairs
+ * (uniform_sampler.h:28-32), code0/code1 are HOST arrays of cs floats, kf0 = {prx_orig, prx_jac}, kf1 = {prx_orig, prx_jac,
+ * dpt_grad} with dpt_grad the Sobel gradient of kf1's depth (mapper.cpp:998-1000).  rows_host receives the N x (12 + 2 cs + 1)
+ * row-major matrix [A0 | A1 | A2 | A3 | b] of the gtsam::JacobianFactor (all-zero rows for points without a correspondence).
+ * avg_dpt is 2.0 in the reference (:170). */
+DFX_API int dfx_sparse_geometric_linearize(dfx_ctx* ctx, int cs, const dfx_se3* pose0, const dfx_se3* pose1, const float* code0,
+                                           const float* code1, const dfx_cam* cam, const int32_t* points_xy, int n_points,
+                                           const dfx_img* prx0_orig, const dfx_img* prx0_jac, const dfx_img* prx1_orig,
+                                           const dfx_img* prx1_jac, const dfx_img* dpt1_grad, float huber_delta, float avg_dpt,
+                                           float* rows_host);
+
 /* ---- DepthAligner<float,CS>::RunStep (cuda/cu_depthaligner.cpp:32-110); avg_dpt is 2 in the reference. */
 DFX_API int dfx_depth_aligner_step(dfx_ctx* ctx, int cs, const float* code, const dfx_img* target_dpt,
                                    const dfx_img* prx_orig, const dfx_img* prx_jac, float avg_dpt, void* out_item);

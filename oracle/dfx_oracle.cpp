@@ -520,6 +520,68 @@ static void depth_aligner_step(int cs, const S* code, const S* tgt, const S* prx
   else { Accum<S> a(cs); reduce_rows<S, S>(w, h, cs, 1, f, a); export_accum(a, jtj, jtr, residual, inliers); }
 }
 
+// sparse_geometric_factor.cpp:147-275 SparseGeometricFactor::linearize -- one Jacobian row per sampled point:
+//   row = w * [err_J_pose0 (6) | err_J_pose1 (6) | err_J_cde0 (CS) | err_J_cde1 (CS) | err],  err = dpt1 - (R p + t).z
+// with dpt1 decoded at the NEAREST-NEIGHBOUR pixel of the projection (truncation, :207) and kf1's depth gradient sampled
+// there (:220).  Invalid points (FindCorrespondence defaults: border 1, min_dpt 0) give an all-zero row (:190-198).
+// The signs are the reference's: every Jacobian block is the negative of d(err)/dx, i.e. the Jacobian of
+// (dpt1_p - dpt1), and the last column is b = err -- consistent with a gtsam::JacobianFactor ||A x - b||^2.
+template <typename S>
+static void sparse_geometric(const S* pose0_qt, const S* pose1_qt, const S* code0, const S* code1, const S* camv, int cs,
+                             const int* pts_xy, int npts, const S* prx0, const S* jac0, const S* prx1, const S* jac1,
+                             const S* dgrad1, int w, int h, std::size_t pitch, std::size_t jpitch, std::size_t gpitch, S huber_delta,
+                             S avg_dpt, S* rows /* [npts][12 + 2cs + 1] */) {
+  S J1[36], J0[36];
+  const Rigid<S> T = relative_pose(pose1_qt, pose0_qt, J1, J0);
+  const Cam<S> cam = cam_from(camv);
+  const Img<S> P0{ prx0, pitch, w, h }, P1{ prx1, pitch, w, h }, JA0{ jac0, jpitch, w * cs, h }, JA1{ jac1, jpitch, w * cs, h };
+  const Img<S> DG{ dgrad1, gpitch, w, h };
+  const int nc = 12 + 2 * cs + 1;
+  for (int i = 0; i < npts; ++i) {
+    S* row = rows + std::size_t(i) * nc;
+    for (int k = 0; k < nc; ++k) row[k] = 0;
+    const int x = pts_xy[2 * i], y = pts_xy[2 * i + 1];
+    const S* j0 = JA0.row(y) + std::size_t(x) * cs;
+    S dot0 = 0;
+    for (int k = 0; k < cs; ++k) dot0 += j0[k] * code0[k];
+    const S d0 = prox_to_depth(P0.at(x, y) + dot0, avg_dpt);
+    const Corresp<S> c = find_correspondence(x, y, d0, cam, T, 1, S(0));
+    if (!c.valid) continue;
+    const int nx = int(c.u), ny = int(c.v);   // cast<int>: truncation
+    const S* j1 = JA1.row(ny) + std::size_t(nx) * cs;
+    S dot1 = 0;
+    for (int k = 0; k < cs; ++k) dot1 += j1[k] * code1[k];
+    const S d1 = prox_to_depth(P1.at(nx, ny) + dot1, avg_dpt);
+    S err = d1 - c.tpt.z;
+    const S gx = DG.row(ny)[2 * nx], gy = DG.row(ny)[2 * nx + 1];
+    S C[12], D[6];
+    corresp_jac_pose(c, cam, T, C, D);
+    // third row of [I | -hat(R p)]
+    const Vec3<S> rp = rot(T.R, c.pt);
+    const S dz[6] = { 0, 0, 1, -rp.y, rp.x, 0 };   // -hat(v) row 2 = (v.y, -v.x, 0) ... see below
+    // -hat(v) = [[0, v.z, -v.y], [-v.z, 0, v.x], [v.y, -v.x, 0]]
+    S dzr[6] = { 0, 0, 1, rp.y, -rp.x, 0 };
+    (void)dz;
+    S a10[6];   // dpt1p_J_pose10 - dpt_grad * corr_J_pose10   (1x6, w.r.t. pose10)
+    for (int k = 0; k < 6; ++k) a10[k] = dzr[k] - (gx * C[k] + gy * C[6 + k]);
+    S e0[6], e1[6];
+    for (int j = 0; j < 6; ++j) {
+      S s0 = 0, s1 = 0;
+      for (int k = 0; k < 6; ++k) { s0 += a10[k] * J0[k * 6 + j]; s1 += a10[k] * J1[k * 6 + j]; }
+      e0[j] = s0; e1[j] = s1;
+    }
+    const Vec3<S> rr = rot(T.R, c.ray);
+    const S dprx0 = depth_jacobian_prx(d0, avg_dpt);
+    const S pj0 = D[0] * rr.x + D[1] * rr.y + D[2] * rr.z, pj1 = D[3] * rr.x + D[4] * rr.y + D[5] * rr.z;
+    const S sc0 = (rr.z - (gx * pj0 + gy * pj1)) * dprx0;
+    const S sc1 = -depth_jacobian_prx(d1, avg_dpt);
+    const S wgt = huber_weight(err, huber_delta);
+    for (int j = 0; j < 6; ++j) { row[j] = e0[j] * wgt; row[6 + j] = e1[j] * wgt; }
+    for (int k = 0; k < cs; ++k) { row[12 + k] = sc0 * j0[k] * wgt; row[12 + cs + k] = sc1 * j1[k] * wgt; }
+    row[12 + 2 * cs] = err * wgt;
+  }
+}
+
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // cu_image_proc.cpp:34-92 Sobel /8, clamped borders; out = (gx,gy) interleaved
@@ -710,6 +772,12 @@ static void perturb_pose(const S* qt_in, int idx, S eps, S* qt_out) {
                                             int w, int h, size_t pitch, size_t jpitch, int accum_f64, S* jtj, S* jtr,   \
                                             S* residual, uint64_t* inliers) {                                           \
     orc::depth_aligner_step(cs, code, tgt, prx, jac, avg_dpt, w, h, pitch, jpitch, accum_f64, jtj, jtr, residual, inliers); \
+  }                                                                                                                     \
+  ORC_API void orc_sparse_geometric_##SFX(const S* p0, const S* p1, const S* c0, const S* c1, const S* cam, int cs, const int* pts,  \
+                                          int npts, const S* prx0, const S* jac0, const S* prx1, const S* jac1, const S* dgrad1,      \
+                                          int w, int h, size_t pitch, size_t jpitch, size_t gpitch, S huber, S avg_dpt, S* rows) {    \
+    orc::sparse_geometric(p0, p1, c0, c1, cam, cs, pts, npts, prx0, jac0, prx1, jac1, dgrad1, w, h, pitch, jpitch, gpitch, huber,     \
+                          avg_dpt, rows);                                                                                             \
   }                                                                                                                     \
   ORC_API void orc_sobel_##SFX(const S* img, S* grad, int w, int h, size_t pitch, size_t gpitch) {                      \
     orc::sobel(img, grad, w, h, pitch, gpitch);                                                                         \

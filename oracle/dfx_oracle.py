@@ -296,6 +296,22 @@ def depth_aligner_step(code, tgt_dpt, prx_orig, prx_jac, avg_dpt=2.0, accum_f64=
     return res
 
 
+def sparse_geometric(pose0_qt, pose1_qt, code0, code1, cam, points, prx0, jac0, prx1, jac1, dpt_grad1, huber_delta, avg_dpt=2.0):
+    """SparseGeometricFactor::linearize (sparse_geometric_factor.cpp:147-275): rows [N][12 + 2 CS + 1]."""
+    dt = np.asarray(prx0).dtype
+    f, ct = _fn("sparse_geometric", dt)
+    prx0, jac0, prx1, jac1, dpt_grad1 = (_img(a, dt) for a in (prx0, jac0, prx1, jac1, dpt_grad1))
+    h, w = prx0.shape
+    j0, j1 = jac0.reshape(h, -1), jac1.reshape(h, -1)
+    cs = j0.shape[1] // w
+    pts = np.ascontiguousarray(np.asarray(points, np.int32).reshape(-1, 2))
+    rows = np.zeros((len(pts), 12 + 2 * cs + 1), dt)
+    f(_p(_arr(pose0_qt, dt)), _p(_arr(pose1_qt, dt)), _p(_arr(code0, dt)), _p(_arr(code1, dt)), _p(_arr(cam, dt)), C.c_int(cs), _p(pts),
+      C.c_int(len(pts)), _p(prx0), _p(j0), _p(prx1), _p(j1), _p(dpt_grad1), C.c_int(w), C.c_int(h), C.c_size_t(prx0.strides[0]),
+      C.c_size_t(j0.strides[0]), C.c_size_t(dpt_grad1.strides[0]), ct(huber_delta), ct(avg_dpt), _p(rows))
+    return rows
+
+
 def sobel(img):
     """df::SobelGradients (cu_image_proc.cpp:57-112): returns [H][W][2] = (gx, gy)/8, clamped borders."""
     img = np.ascontiguousarray(img)
