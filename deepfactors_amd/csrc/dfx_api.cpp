@@ -70,6 +70,10 @@ struct dfx_ctx {
   char* sg_dev = nullptr;      // sparse geometric: codes + points + rows
   size_t sg_bytes = 0;
 
+  // per-camera ray tables of the SfM step kernel: [W] (x - u0) / fx, [H + kRayTabSlack] (y - v0) / fy
+  struct RayTab { float fx, fy, u0, v0; uint32_t W, H; float* dev; };
+  std::vector<RayTab> ray_tabs;
+
   // measurement hook (dfx_set_profiling): event pairs around the step kernel
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;   // all created pairs
@@ -174,6 +178,30 @@ void relative_pose(const dfx_se3& p0, const dfx_se3& p1, float* R10, float* t10,
   }
 }
 
+// K^-1 (x, y, 1) per column / row, evaluated on the host with the IEEE float expressions of ReprojectDepth
+// (pinhole_camera_impl.h:77-86) -- bit-identical to the per-pixel evaluation it replaces.  One table per camera
+// (pyramid level), created on first use; the upload is synchronous, so it is ordered before any later launch.
+int ray_table(dfx_ctx* c, const dfx_cam* cam, uint32_t W, uint32_t H, const float** out) {
+  for (const auto& t : c->ray_tabs)
+    if (t.fx == cam->fx && t.fy == cam->fy && t.u0 == cam->u0 && t.v0 == cam->v0 && t.W == W && t.H == H) { *out = t.dev; return DFX_OK; }
+  if (c->ray_tabs.size() >= 256) {   // a caller cycling through cameras: start over once nothing is in flight
+    DFX_HIP(hipStreamSynchronize(c->stream));
+    for (auto& t : c->ray_tabs) (void)hipFree(t.dev);
+    c->ray_tabs.clear();
+  }
+  const size_t n = (size_t)W + H + dfx::kRayTabSlack;
+  std::vector<float> h(n, 0.0f);
+  volatile float fx = cam->fx, fy = cam->fy, u0 = cam->u0, v0 = cam->v0;   // volatile: no reciprocal / contraction rewrites
+  for (uint32_t x = 0; x < W; ++x) { const float d = (float)x - u0; h[x] = d / fx; }
+  for (uint32_t y = 0; y < H; ++y) { const float d = (float)y - v0; h[W + y] = d / fy; }
+  float* dev = nullptr;
+  DFX_HIP(hipMalloc((void**)&dev, n * sizeof(float)));
+  DFX_HIP(hipMemcpy(dev, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  c->ray_tabs.push_back({ cam->fx, cam->fy, cam->u0, cam->v0, W, H, dev });
+  *out = dev;
+  return DFX_OK;
+}
+
 bool img_ok(const dfx_img* im) { return im && im->ptr && im->w > 0 && im->h > 0 && im->pitch_bytes > 0; }
 
 int check_img(const dfx_img* im, const char* name, uint32_t w, uint32_t h, size_t elem_bytes) {
@@ -185,7 +213,7 @@ int check_img(const dfx_img* im, const char* name, uint32_t w, uint32_t h, size_
   return DFX_OK;
 }
 
-int fill_sfm_pair(int cs, const dfx_se3* pose0, const dfx_se3* pose1, const dfx_cam* cam, const dfx_img* img0,
+int fill_sfm_pair(dfx_ctx* c, int cs, const dfx_se3* pose0, const dfx_se3* pose1, const dfx_cam* cam, const dfx_img* img0,
                   const dfx_img* img1, const dfx_img* dpt0, const dfx_img* valid0, const dfx_img* jac, const dfx_img* grad1,
                   uint32_t W, uint32_t H, dfx::SfmPairDev* d) {
   int rc;
@@ -207,6 +235,7 @@ int fill_sfm_pair(int cs, const dfx_se3* pose0, const dfx_se3* pose1, const dfx_
     d->pitch_valid0 = 0;
   }
   relative_pose(*pose0, *pose1, d->R, d->t, d->M, d->HM);
+  if ((rc = ray_table(c, cam, W, H, &d->ray_tab))) return rc;
   d->fx = cam->fx; d->fy = cam->fy; d->u0 = cam->u0; d->v0 = cam->v0; d->w = cam->w; d->h = cam->h;
   d->img0 = (const float*)img0->ptr; d->img1 = (const float*)img1->ptr; d->dpt0 = (const float*)dpt0->ptr;
   d->jac = (const float*)jac->ptr; d->grad1 = (const float*)grad1->ptr;
@@ -326,6 +355,7 @@ DFX_API void dfx_ctx_destroy(dfx_ctx* c) {
   if (c->depth_scratch) (void)hipFree(c->depth_scratch);
   if (c->track_state_dev) (void)hipFree(c->track_state_dev);
   if (c->sg_dev) (void)hipFree(c->sg_dev);
+  for (auto& t : c->ray_tabs) (void)hipFree(t.dev);
   if (c->stage_host) (void)hipHostFree(c->stage_host);
   if (c->result_host) (void)hipHostFree(c->result_host);
   for (int i = 0; i < kStageSlots; ++i) if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
@@ -406,7 +436,7 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
   dfx::SfmPairDev* hd = reinterpret_cast<dfx::SfmPairDev*>(host);
   for (int p = 0; p < n; ++p) {
     const dfx_sfm_pair& q = pairs[p];
-    if ((rc = fill_sfm_pair(cs, &q.pose0, &q.pose1, &q.cam, &q.img0, &q.img1, &q.dpt0, &q.valid0, &q.prx0_jac, &q.grad1, W, H, &hd[p]))) {
+    if ((rc = fill_sfm_pair(c, cs, &q.pose0, &q.pose1, &q.cam, &q.img0, &q.img1, &q.dpt0, &q.valid0, &q.prx0_jac, &q.grad1, W, H, &hd[p]))) {
       g_last_error = "pair " + std::to_string(p) + ": " + g_last_error;
       return rc;
     }

@@ -71,11 +71,11 @@ struct Corr {
 // order exactly (Reproject -> se3 * pt -> Project -> PixelValid) with IEEE division and NO fma contraction: the
 // inlier set is then bit-identical to a host evaluation of the same formulas (the oracle), even for degenerate
 // poses (identity) where projected coordinates land exactly on the border.
-__device__ __forceinline__ Corr find_correspondence(const Geo& g, int x, int y, float d, float border, float min_dpt) {
+// (rx, ry) = K^-1 (x, y, 1) is handed in: the step kernel reads it from a per-camera table (dfx_api.cpp ray_table, the same
+// IEEE expression evaluated once per column / row on the host) instead of paying two divisions per pixel.
+__device__ __forceinline__ Corr find_correspondence_ray(const Geo& g, float rx, float ry, float d, float border, float min_dpt) {
 #pragma clang fp contract(off)
   Corr c;
-  const float rx = ((float)x - g.u0) / g.fx;
-  const float ry = ((float)y - g.v0) / g.fy;
   const float px = rx * d, py = ry * d, pz = d;
   c.vx = g.R[0] * px + g.R[1] * py + g.R[2] * pz;
   c.vy = g.R[3] * px + g.R[4] * py + g.R[5] * pz;
@@ -92,6 +92,12 @@ __device__ __forceinline__ Corr find_correspondence(const Geo& g, int x, int y, 
   // PixelValid (pinhole_camera_impl.h:105-108) in float, exactly `x >= b && x < w - b`; NaN -> invalid
   c.valid = (qz > min_dpt) && (c.u >= border) && (c.u < g.w - border) && (c.v >= border) && (c.v < g.h - border);
   return c;
+}
+__device__ __forceinline__ Corr find_correspondence(const Geo& g, int x, int y, float d, float border, float min_dpt) {
+#pragma clang fp contract(off)
+  const float rx = ((float)x - g.u0) / g.fx;
+  const float ry = ((float)y - g.v0) / g.fy;
+  return find_correspondence_ray(g, rx, ry, d, border, min_dpt);
 }
 
 // VisionCore getBilinear convention: floor, lerp in x then y, lerp(a,b,t)=a+t(b-a)
@@ -125,10 +131,11 @@ __device__ __forceinline__ void sample_grad(const ImgRef& G, const Taps& t, floa
   gy = lerp1(lerp1(a.y, a.w, t.ax), lerp1(b.y, b.w, t.ax), t.ay);
 }
 
-// HuberWeight (m_estimators.h:50-56): sqrt-weight for both J and r
+// HuberWeight (m_estimators.h:50-56): sqrt-weight for both J and r.  The weight is a smooth factor, not a decision:
+// v_sqrt_f32 * v_rcp_f32 (1 ulp each) instead of the IEEE sqrt + division sequences (~25 VALU ops per pixel).
 __device__ __forceinline__ float huber_weight(float r, float delta) {
   const float aa = fabsf(r);
-  const float wo = sqrtf(delta * (2.0f * aa - delta)) / aa;
+  const float wo = __builtin_amdgcn_sqrtf(delta * (2.0f * aa - delta)) * __builtin_amdgcn_rcpf(aa);
   return aa <= delta ? 1.0f : wo;
 }
 

@@ -18,8 +18,10 @@ struct SfmPairDev {
   float* valid0;      // may be null
   const float* jac;   // [H][W*CS]
   const float* grad1; // [H][W][2]
+  const float* ray_tab;   // [W] (x - u0) / fx, then [H + kRayTabSlack] (y - v0) / fy   (SfmAligner::RunStep only)
   uint32_t pitch_img0, pitch_img1, pitch_dpt0, pitch_valid0, pitch_jac, pitch_grad1;   // bytes
 };
+constexpr int kRayTabSlack = 80;   // rows a lane past the last pixel may index (<= 64 / W + 1), zero-filled
 
 struct SfmParamsDev {
   float huber_delta, avg_dpt, min_dpt, border;

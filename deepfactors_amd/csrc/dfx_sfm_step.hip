@@ -7,11 +7,18 @@
 //   one rank-1-update GEMM  Z += z z^T  over pixels, executed on the matrix cores with exact-fp32 MFMA
 //   (v_mfma_f32_16x16x4_f32: k = 4 pixels per instruction, bitwise an fmaf chain).
 //   z (per pixel, "z-space") is laid out in 16-row blocks:
-//     block P : [ w*J_pose0 (6), w*J_pose1 (6), w*r, s, inlier(1.0), 0 ]        s = w * dE/dprx
+//     block P : [ w*gC (6), 0 (6), w*r, s, inlier(1.0), 0 ]                     s = w * dE/dprx
 //     block Cb: [ s * jac[NCB*i + b] ]_{i=0..15}, b = 0..NCB-1                  (NCB = CS/16)
+//   gC is the 1x6 Jacobian of the residual w.r.t. the RELATIVE pose (warping.h:156-164,247-257).  The chain rule onto
+//   (pose0, pose1), J = gC * [blkdiag(M,M) | [[-M,-HM],[0,-M]]] (warping.h:119-134), is a per-pair constant 6 -> 12 map
+//   T, so it is applied to the reduced sums by k_sfm_finalize (T G T^T, T X, T g in double) instead of to every pixel:
+//   -36 VALU ops per pixel and -18 SGPRs (no more SGPR spills in the loop) -- VALU and MFMA time add on gfx950.
 //   Only the upper block-triangle is accumulated: (P,P), (P,Cb), (Cb,Cb') b<=b'  -> 6 MFMAs per 4 pixels at CS=32.
-//   (P,P)[12][12] = sum (w r)^2 = residual, (P,P)[14][14] = inliers, (P,*)[12][*] = Jtr: everything comes out of
-//   the same accumulators.  Block P row 13 (s) only exists so that lanes can broadcast s; its products are ignored.
+//   (P,P)[12][12] = sum (w r)^2 = residual, (P,P)[14][14] = inliers, (P,*)[12][*] = Jtr.
+//   Block P row 13 (s) only exists so that lanes can broadcast s; its products are ignored.
+//   The (P,P) block itself holds only 29 useful sums (6x6 upper triangle, 6 Jtr, r^2, inliers).  MFMA and VALU time add on
+//   gfx950, so a 16x16x4 MFMA that is 11 % useful (512 cycles per chunk) loses to 29 per-lane fmas in phase A (~130
+//   cycles): the block is accumulated per lane and reduced across the wave once, in the epilogue (DFX_PP_VALU).
 //
 //   Phase A (lane = pixel): coalesced img0/dpt0 loads, warp, bilinear gathers of img1/grad1, Jacobian row,
 //     Huber weight; the 16-float P row goes to LDS component-major (stride 66 -> conflict-free both ways).
@@ -33,6 +40,18 @@ namespace dfx {
 // ---- build-time switches: launch shape (A/B-tested on MI355X) and diagnosis-only instrumentation ----
 #ifndef DFX_MIN_WAVES
 #define DFX_MIN_WAVES 3      // __launch_bounds__ waves per SIMD the register allocator must allow
+#endif
+#ifndef DFX_MIN_WAVES_CS64
+#define DFX_MIN_WAVES_CS64 2 // same for NCB = 4 (15 accumulators + a 64-register ring: 168 VGPRs spill a little, 256 do not)
+#endif
+#ifndef DFX_PP_VALU
+#define DFX_PP_VALU 0        // 1: (P,P) block on the vector ALU (29 useful products per pixel = 11 % of a 16x16 MFMA's outputs)
+#endif
+#ifndef DFX_EXTRA_LDS
+#define DFX_EXTRA_LDS 0      // diagnosis only: dynamic LDS bytes added to the step launch to cap the workgroups per CU
+#endif
+#ifndef DFX_BANDED
+#define DFX_BANDED 1         // chunk -> wave map: 1 = vertical bands (taps of consecutive chunks share image rows), 0 = interleaved
 #endif
 #ifndef DFX_TRACE
 #define DFX_TRACE 0          // 1: per-wave s_memtime sums of phase A / phase B in the junk row 15 of the (P,P) partial
@@ -93,6 +112,12 @@ __device__ __forceinline__ Split3 split3(float x) {
   o.B = u32x4{ hm, __builtin_amdgcn_perm(xb, lb, HI2), __builtin_amdgcn_perm(lb, rb, HI2), hm };
   return o;
 }
+// lanes of the banks in BANKS (4-lane groups of every 16-lane row) <- src shifted inside its row (CTRL: 0x110 + n = row_shr:n,
+// 0x100 + n = row_shl:n); the other lanes keep `old`.  One v_mov_b32_dpp.
+template <int CTRL, int BANKS>
+__device__ __forceinline__ float dpp_merge(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, 0xF, BANKS, false));
+}
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 mfma_split(const u32x4& a, const u32x4& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -101,7 +126,7 @@ __device__ __forceinline__ f32x4 mfma_split(const u32x4& a, const u32x4& b, cons
 // PREC 0: v_mfma_f32_16x16x4_f32 (bitwise an fp32 fmaf chain; shares the FP32 datapath with the VALU work).
 // PREC 1: the same products through exact bf16x3 operand splits on the bf16 matrix cores (fp32-accurate, overlaps VALU).
 template <int NCB, int MODE, bool JDENSE, int PREC>
-__global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmParamsDev prm,
+__global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_WAVES) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmParamsDev prm,
                                                        const int W, const int H, float* __restrict__ partials) {
   constexpr int NBLK = 1 + NCB;
   constexpr int NACC = NBLK * (NBLK + 1) / 2;
@@ -127,29 +152,68 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
   const uint32_t pitch_d0 = P.pitch_dpt0, pitch_i0 = P.pitch_img0, pitch_i1 = P.pitch_img1, pitch_g1 = P.pitch_grad1;
   const __amdgpu_buffer_rsrc_t i1_rs = make_rsrc(P.img1, (unsigned)H * pitch_i1);
   const __amdgpu_buffer_rsrc_t g1_rs = make_rsrc(P.grad1, (unsigned)H * pitch_g1);
-  float Mm[9], HMm[9];
-#pragma unroll
-  for (int q = 0; q < 9; ++q) { Mm[q] = P.M[q]; HMm[q] = P.HM[q]; }
   float* const valid0 = P.valid0;
   const uint32_t pitch_v0 = P.pitch_valid0;
   const __amdgpu_buffer_rsrc_t jac_rs = make_rsrc(P.jac, (unsigned)H * jac_pitch);
+  // Dense Jacobian stream: the ring's addresses are (wave-uniform chunk base) + (per-lane constant) + (compile-time group
+  // offset).  Re-basing the buffer resource per chunk keeps the first term on the scalar unit and the last in the
+  // instruction's immediate, so the 16 refills cost no VALU op (a VGPR offset per load cost 19 v_or/v_add per chunk);
+  // num_records shrinks with the base, so reads past the image still return 0.
+  const char* const jac_ptr = reinterpret_cast<const char*>(P.jac);
+  const unsigned jac_bytes = (unsigned)H * jac_pitch;
+  auto ring_rsrc = [&](unsigned pbase) {
+    const unsigned b = pbase * (64u * NCB);
+    return make_rsrc(jac_ptr + b, jac_bytes - b);
+  };
   const __amdgpu_buffer_rsrc_t d0_rs = make_rsrc(P.dpt0, (unsigned)H * pitch_d0);
   const __amdgpu_buffer_rsrc_t i0_rs = make_rsrc(P.img0, (unsigned)H * pitch_i0);
   const float inv_a = 1.0f / prm.avg_dpt;
+  const char* const ray_tab = reinterpret_cast<const char*>(P.ray_tab);
 
   float* U = lds + wave * kUFloats;
   U[15 * kUStride + lane] = 0.f;   // row 15 of block P is padding
+#pragma unroll
+  for (int q = 6; q < 12; ++q) U[q * kUStride + lane] = 0.f;   // rows 6..11: unused (were pose1 before the z-space basis change)
 
   f32x4 acc[NACC];
 #pragma unroll
   for (int a = 0; a < NACC; ++a) acc[a] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+  constexpr int NPP = 29;   // 21 (gC x gC, i <= j) + 6 (gC x wr) + wr^2 + inliers
+  float pp[NPP];
+#pragma unroll
+  for (int k = 0; k < NPP; ++k) pp[k] = 0.f;
 
   const int npx = W * H;
   const int nchunks = (npx + 63) >> 6;
   const int li = lane & 15, lk = lane >> 4;
-  const int cstride = gridDim.x * kWaves;
-
-  int chunk = blockIdx.x * kWaves + wave;
+  const unsigned ring_lane_off = (unsigned)(lk * 16 + li) * (4u * NCB);
+  // `lo` is the lane offset made opaque once per chunk (ring_opaque_off): the group offsets then fold into the
+  // instructions' 12-bit immediates (+ one v_add per 4 KB step) instead of LICM hoisting sixteen offset VGPRs.
+  auto ring_opaque_off = [&]() { unsigned lo = ring_lane_off; asm volatile("" : "+v"(lo)); return lo; };
+  auto ring_load = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned lo, unsigned pbase, int gq) -> jv_t {
+    if (JDENSE) return bload(rs, lo + (unsigned)gq * (256u * NCB), (jv_t*)nullptr);
+    return bload(jac_rs, jv_offset<NCB, false>(pbase, gq, li, lk, W, npx, jac_pitch), (jv_t*)nullptr);
+  };
+  // Chunk -> wave map.  Banded (default): a wave walks DOWN the image -- chunk, chunk + one image row, ... -- so the
+  // img1 / grad1 rows its bilinear taps share with the chunk below are re-read by the same CU (L2 hit) instead of by a
+  // wave on another XCD (a second HBM fetch).  The Jacobian stream is still one contiguous 256*NCB*16-byte run per chunk.
+  // Grids with fewer waves than chunks per row fall back to the interleaved map (wave w: w, w + #waves, ...).
+  const int total_waves = gridDim.x * kWaves;
+  const int wid = blockIdx.x * kWaves + wave;
+  const int vs = (W + 32) >> 6;   // chunk stride of one image row (exact when W % 64 == 0)
+  int chunk, cstride, cend;
+  if (DFX_BANDED && vs >= 1 && total_waves >= vs) {
+    const int crows = (nchunks + vs - 1) / vs;
+    const int nbands = total_waves / vs;
+    const int per = (crows + nbands - 1) / nbands;   // chunk rows per band = chunks per wave
+    const int b = wid / vs, j = wid - b * vs;
+    chunk = b * per * vs + j;
+    cstride = vs;
+    cend = (b < nbands) ? min(nchunks, (b * per + per) * vs) : 0;
+    if (b >= nbands) chunk = nchunks;   // surplus waves idle
+  } else {
+    chunk = wid; cstride = total_waves; cend = nchunks;
+  }
 
   // Per-lane pipeline registers.  Loads complete in order, so anything a phase waits for must be ISSUED before the
   // younger streaming loads it does not need:
@@ -161,6 +225,7 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
   struct Pix {            // one chunk's per-lane state between its A1 and A2
     int x, y;
     float d, i0;
+    float rx, ry;         // K^-1 (x, y, 1) from the per-camera table
     f32x2 ia, ib;         // img1 taps (row iy, row iy+1)
     f32x4 ga, gb;         // grad1 taps
     Corr c;               // correspondence of A1 (kept: cheaper than re-deriving it, 5 IEEE divisions)
@@ -182,6 +247,10 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
     od = inb ? od : kOobOffset; oi = inb ? oi : kOobOffset;
     q.d = bload(d0_rs, od, (float*)nullptr);
     q.i0 = bload(i0_rs, oi, (float*)nullptr);
+    if (MODE == 0) {   // table rows are padded (kRayTabSlack), so lanes past the last pixel stay inside the allocation
+      q.rx = gload<float>(ray_tab + (unsigned)q.x * 4u);
+      q.ry = gload<float>(ray_tab + (unsigned)(W + q.y) * 4u);
+    }
   };
   // A1: warp the pixel and issue its 4 bilinear tap loads.  Branch-free on purpose: a conditional load would make the
   // number of loads younger than the ring path-dependent and force the compiler's vmcnt to the conservative minimum
@@ -189,7 +258,7 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
   // the buffer unit returns 0 and moves no data.
   auto issue_gathers = [&](unsigned pbase, Pix& q) {
     if (MODE == 0) {
-      const Corr c = find_correspondence(g, q.x, q.y, q.d, prm.border, prm.min_dpt);
+      const Corr c = find_correspondence_ray(g, q.rx, q.ry, q.d, prm.border, prm.min_dpt);
       const Taps tp = make_taps(c.u, c.v);
       const bool ok = c.valid && (pbase + lane < (unsigned)npx);
       q.c = c; q.ax = tp.ax; q.ay = tp.ay; q.ok = ok;
@@ -212,14 +281,14 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
   jv_t jv[16];
   Pix cur, nxt;
   {
-    const unsigned base = (chunk < nchunks) ? (unsigned)chunk << 6 : 0u;   // idle wave: harmless loads of chunk 0
+    const unsigned base = (chunk < cend) ? (unsigned)chunk << 6 : 0u;   // idle wave: harmless loads of chunk 0
     {
       const unsigned p = base + lane;   // the only integer division: first chunk of the wave
       cur.y = p / (unsigned)W;
       cur.x = p - cur.y * W;
     }
     prefetch_di0(base, cur);
-    const bool has1 = chunk + cstride < nchunks;
+    const bool has1 = chunk + cstride < cend;
     const unsigned nb0 = has1 ? (unsigned)(chunk + cstride) << 6 : base;
     nxt.x = cur.x; nxt.y = cur.y;
     if (has1) advance_xy(nxt.x, nxt.y);
@@ -228,24 +297,26 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
     // Keep the issue order of the loop body (gathers, depth prefetch, THEN ring): the waitcnt bookkeeping at the loop
     // header merges this path with the back edge, and a younger gather here would cost a full drain every iteration.
     __builtin_amdgcn_sched_barrier(0);
+    const __amdgpu_buffer_rsrc_t rs0 = ring_rsrc(base);
 #pragma unroll
-    for (int gq = 0; gq < 16; ++gq) jv[gq] = bload(jac_rs, jv_offset<NCB, JDENSE>(base, gq, li, lk, W, npx, jac_pitch), (jv_t*)nullptr);
+    for (int gq = 0; gq < 16; ++gq) jv[gq] = ring_load(rs0, ring_lane_off, base, gq);
     __builtin_amdgcn_sched_barrier(0);
   }
 
 #if DFX_TRACE
   unsigned long long trA = 0, trB = 0, trN = 0;
   const unsigned long long trStart = __builtin_amdgcn_s_memtime();
+  const unsigned long long trRealStart = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz
 #endif
-  for (; chunk < nchunks; chunk += cstride) {
+  for (; chunk < cend; chunk += cstride) {
 #if DFX_TRACE
     __builtin_amdgcn_sched_barrier(0);
     const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_sched_barrier(0);
 #endif
     const int base = chunk << 6;
-    const bool has2 = chunk + 2 * cstride < nchunks;                                                           // wave-uniform
-    const unsigned nbase = (chunk + cstride < nchunks) ? (unsigned)(chunk + cstride) << 6 : (unsigned)base;    // else: re-read this chunk
+    const bool has2 = chunk + 2 * cstride < cend;                                                           // wave-uniform
+    const unsigned nbase = (chunk + cstride < cend) ? (unsigned)(chunk + cstride) << 6 : (unsigned)base;    // else: re-read this chunk
     const unsigned nnbase = has2 ? (unsigned)(chunk + 2 * cstride) << 6 : nbase;
 
     // ---- A2(c): lane = pixel; taps of this chunk were issued one iteration ago
@@ -281,15 +352,6 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
         const float samp = lerp1(lerp1(cur.ia.x, cur.ia.y, tax), lerp1(cur.ib.x, cur.ib.y, tax), tay);
         float gC[6], D00, D02, D11, D12;
         pose_row(g, c, d, gx, gy, gC, D00, D02, D11, D12);
-        // J0 = gC * blkdiag(M, M);  J1 = gC * [[-M, -HM], [0, -M]]
-        float J[12];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          J[j] = gC[0] * Mm[j] + gC[1] * Mm[3 + j] + gC[2] * Mm[6 + j];
-          J[3 + j] = gC[3] * Mm[j] + gC[4] * Mm[3 + j] + gC[5] * Mm[6 + j];
-          J[6 + j] = -J[j];
-          J[9 + j] = -(gC[0] * HMm[j] + gC[1] * HMm[3 + j] + gC[2] * HMm[6 + j]) - J[3 + j];
-        }
         // d pix1 / d prx = D * (R ray) * (-a / prx^2),  prx = a / (a + d)   (warping.h:44-50,259-291)
         const float apd = prm.avg_dpt + d;
         const float dprx = -(apd * apd) * inv_a;
@@ -299,17 +361,31 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
         const float r = i0 - samp;
         const float wgt = ok ? huber_weight(r, prm.huber_delta) : 0.0f;   // * DenseSfm_UncertaintyWeight == 1 (dense_sfm.h:66)
 #pragma unroll
-        for (int j = 0; j < 12; ++j) u16[j] = mul_zero_wins(wgt, J[j]);
+        for (int j = 0; j < 6; ++j) u16[j] = mul_zero_wins(wgt, gC[j]);   // relative-pose basis; (pose0, pose1) in k_sfm_finalize
         u16[12] = mul_zero_wins(wgt, r);
         u16[13] = mul_zero_wins(wgt, e);
         u16[14] = ok ? 1.0f : 0.0f;
         if (valid0 && ok) gstore<float>((char*)valid0 + (size_t)y * pitch_v0 + (size_t)x * 4, 1.0f);   // dense_sfm.h:161
       }
 #pragma unroll
-      for (int q = 0; q < 15; ++q) U[q * kUStride + lane] = u16[q];
+      for (int q = 0; q < 15; ++q)
+        if (q < 6 || q >= 12) U[q * kUStride + lane] = u16[q];
+      if (DFX_PP_VALU && !(DFX_ABLATE & 2)) {
+        int k = 0;
+        if (MODE == 0) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j, ++k) pp[k] = __builtin_fmaf(u16[i], u16[j], pp[k]);
+#pragma unroll
+          for (int i = 0; i < 6; ++i) pp[21 + i] = __builtin_fmaf(u16[i], u16[12], pp[21 + i]);
+        }
+        pp[27] = __builtin_fmaf(u16[12], u16[12], pp[27]);
+        pp[28] += u16[14];
+      }
     }
     // ---- A1(c+1) and the depth prefetch of c+2: issued BEFORE the ring refills of phase B
-    cur.x = nxt.x; cur.y = nxt.y; cur.d = nxt.d; cur.i0 = nxt.i0;
+    cur.x = nxt.x; cur.y = nxt.y; cur.d = nxt.d; cur.i0 = nxt.i0; cur.rx = nxt.rx; cur.ry = nxt.ry;
 #if !(DFX_ABLATE & 2)
     issue_gathers(nbase, cur);
 #endif
@@ -324,6 +400,8 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
     __builtin_amdgcn_sched_barrier(0);
 #endif
     // ---- phase B: rank-4 updates on the matrix cores; operand ring refilled behind the consumer
+    const __amdgpu_buffer_rsrc_t nrs = ring_rsrc(nbase);
+    const unsigned rlo = ring_opaque_off();
 #pragma unroll
     for (int gq = 0; gq < 16; ++gq) {
       const int pp = 4 * gq + lk;
@@ -333,7 +411,7 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
 #pragma unroll
       for (int b = 0; b < NCB; ++b) sc[b] = mul_zero_wins(s, jv_get<NCB>(jv[gq], b));
 #if !(DFX_ABLATE & 4)
-      jv[gq] = bload(jac_rs, jv_offset<NCB, JDENSE>(nbase, gq, li, lk, W, npx, jac_pitch), (jv_t*)nullptr);
+      jv[gq] = ring_load(nrs, rlo, nbase, gq);
 #endif
 #if DFX_ABLATE & 1
       acc[0][0] += uP;
@@ -346,7 +424,7 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
         Split3 sq[NCB];
 #pragma unroll
         for (int b = 0; b < NCB; ++b) sq[b] = split3(sc[b]);
-        acc[0] = mfma_split(sp.A, sp.B, acc[0]);
+        if (!DFX_PP_VALU) acc[0] = mfma_split(sp.A, sp.B, acc[0]);
 #pragma unroll
         for (int b = 0; b < NCB; ++b) acc[1 + b] = mfma_split(sp.A, sq[b].B, acc[1 + b]);
 #pragma unroll
@@ -358,7 +436,7 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
           }
         continue;
       }
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uP, uP, acc[0], 0, 0, 0);
+      if (!DFX_PP_VALU && !(DFX_ABLATE & 8)) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uP, uP, acc[0], 0, 0, 0);
 #pragma unroll
       for (int b = 0; b < NCB; ++b) acc[1 + b] = __builtin_amdgcn_mfma_f32_16x16x4f32(uP, sc[b], acc[1 + b], 0, 0, 0);
 #pragma unroll
@@ -366,6 +444,11 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
 #pragma unroll
         for (int b2 = b; b2 < NCB; ++b2) {
           const int a = 1 + NCB + (b * NCB - b * (b - 1) / 2) + (b2 - b);   // row-major upper block-triangle
+          if ((DFX_ABLATE & 8) && a == NACC - 1) {   // what-if: 4 MFMAs + 4 operand-shuffle VALU ops per group (wrong results)
+            acc[a][0] += dpp_merge<0x118, 0xC>(uP, sc[0]) + dpp_merge<0x108, 0x3>(sc[1], sc[0]);
+            acc[a][1] += dpp_merge<0x118, 0xC>(uP, sc[1]);
+            continue;
+          }
           acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[b], sc[b2], acc[a], 0, 0, 0);
         }
     }
@@ -381,15 +464,32 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
   // ---- epilogue: fold the waves' accumulators in fixed order (wave 0, 1, 2, 3), one partial per workgroup.
   // C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
   __syncthreads();
+  if (DFX_PP_VALU) {   // wave totals of the per-lane (P,P) sums, fixed shuffle tree; lane 0 owns them
+#pragma unroll
+    for (int k = 0; k < NPP; ++k) pp[k] = wave_sum(pp[k]);
+    for (int e = threadIdx.x; e < 256; e += kThreads) lds[e] = 0.f;   // the unused entries of block 0
+    __syncthreads();
+  }
   for (int wv = 0; wv < kWaves; ++wv) {
     if (wave == wv) {
 #pragma unroll
-      for (int a = 0; a < NACC; ++a)
+      for (int a = DFX_PP_VALU ? 1 : 0; a < NACC; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int idx = a * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15);
           if (wv == 0) lds[idx] = acc[a][r]; else lds[idx] += acc[a][r];
         }
+      if (DFX_PP_VALU && lane == 0) {   // upper triangle only: k_sfm_finalize reads S[min][max]
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = i; j < 6; ++j, ++k) lds[i * 16 + j] += pp[k];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) lds[i * 16 + 12] += pp[21 + i];
+        lds[12 * 16 + 12] += pp[27];
+        lds[14 * 16 + 14] += pp[28];
+      }
     }
     __syncthreads();
   }
@@ -397,38 +497,56 @@ __global__ __launch_bounds__(kThreads, DFX_MIN_WAVES) void k_sfm_step(const SfmP
   for (int e = threadIdx.x; e < ZDIM; e += kThreads) out[e] = lds[e];
 #if DFX_TRACE
   __syncthreads();
-  if (lane == 0) {   // (P,P) row 15 is padding: 16 floats = 4 waves x {phase A cycles, phase B cycles, chunks, total}
+  if (lane == 0) {   // (P,P) rows 15 and 11 are padding: per wave {phase A cycles, phase B cycles, start mod 2^24, lifetime}, {HW_ID, XCC_ID}
     const unsigned long long trEnd = __builtin_amdgcn_s_memtime();
     out[15 * 16 + wave * 4 + 0] = (float)trA;
     out[15 * 16 + wave * 4 + 1] = (float)trB;
-    out[15 * 16 + wave * 4 + 2] = (float)trN;
+    out[15 * 16 + wave * 4 + 2] = (float)(trStart & 0xFFFFFFull);
     out[15 * 16 + wave * 4 + 3] = (float)(trEnd - trStart);
+    out[11 * 16 + wave * 4 + 0] = (float)__builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (15 << 11));
+    out[11 * 16 + wave * 4 + 1] = (float)__builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (3 << 11));
+    out[11 * 16 + wave * 4 + 2] = (float)trN;
+    out[11 * 16 + wave * 4 + 3] = (float)(__builtin_amdgcn_s_memrealtime() - trRealStart);
   }
 #endif
 }
 
-// ---- finalize: sum the workgroup partials of each pair (double, fixed order) and scatter into the item layout.
-// grid = (4 * NACC, npairs): each 256-thread workgroup owns 64 columns of one 16x16 accumulator block; its 4 row
-// groups stride over the pair's `bpp` partials (256-byte coalesced reads) and are folded in fixed order.
+// ---- finalize: sum the workgroup partials of each pair (double, fixed order), map the relative-pose basis onto
+// (pose0, pose1) and scatter into the item layout.
+// grid = (NACC, npairs), 1024 threads: thread = (element of one 16x16 accumulator block, 1 of 4 partial groups); groups
+// stride over the pair's `bpp` partials (1 KB coalesced reads, 8 in flight) and are folded in fixed order.
 template <int NCB, int NPOSE>
-__global__ __launch_bounds__(256) void k_sfm_finalize(const float* __restrict__ partials, const int bpp,
-                                                      char* __restrict__ items, const size_t item_stride) {
+__global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs,
+                                                       char* __restrict__ items, const size_t item_stride) {
   constexpr int CS = 16 * NCB;
   constexpr int NP = NPOSE + CS;
   constexpr int NBLK = 1 + NCB;
   constexpr int NACC = NBLK * (NBLK + 1) / 2;
   constexpr int ZDIM = NACC * 256;
   constexpr int NT = NP * (NP + 1) / 2;
-  __shared__ double red[4][64];
+  __shared__ double red[4][256];
+  __shared__ double T[12][6];   // d(pose0, pose1) <- d(relative pose): J = gC * T^T
 
-  const int a = blockIdx.x >> 2, pair = blockIdx.y;
-  const int c64 = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int col = (blockIdx.x & 3) * 64 + c64;
-  const float* src = partials + (size_t)pair * bpp * ZDIM + a * 256 + col;
-  red[rg][c64] = strided_sum_f64<4>(src, rg, bpp, ZDIM);
+  const int a = blockIdx.x, pair = blockIdx.y;
+  const int el = threadIdx.x & 255, rg = threadIdx.x >> 8;
+  const float* src = partials + (size_t)pair * bpp * ZDIM + a * 256 + el;
+  red[rg][el] = strided_sum_f64<4>(src, rg, bpp, ZDIM);
+  if (NPOSE == 12 && threadIdx.x < 72) {
+    const int n = threadIdx.x / 6, i = threadIdx.x - n * 6;
+    const float* M = pairs[pair].M;
+    const float* HM = pairs[pair].HM;
+    const int j = n % 3, grp = n / 3;   // grp 0: pose0 trs, 1: pose0 rot, 2: pose1 trs, 3: pose1 rot
+    double v = 0.0;
+    if (grp == 0) v = i < 3 ? (double)M[3 * i + j] : 0.0;
+    else if (grp == 1) v = i >= 3 ? (double)M[3 * (i - 3) + j] : 0.0;
+    else if (grp == 2) v = i < 3 ? -(double)M[3 * i + j] : 0.0;
+    else v = i < 3 ? -(double)HM[3 * i + j] : -(double)M[3 * (i - 3) + j];
+    T[n][i] = v;
+  }
   __syncthreads();
-  if (rg != 0) return;
-  const double s = ((red[0][c64] + red[1][c64]) + red[2][c64]) + red[3][c64];
+  if (rg == 0) red[0][el] = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
+  __syncthreads();
+  const double* S = red[0];   // S[i * 16 + j]: row i of block bi, column j of block bj
 
   // block pair (bi <= bj) of accumulator a
   int bi = 0, bj = 0;
@@ -436,23 +554,54 @@ __global__ __launch_bounds__(256) void k_sfm_finalize(const float* __restrict__ 
     int q = a;
     for (bi = 0; bi < NBLK; ++bi) { const int n = NBLK - bi; if (q < n) { bj = bi + q; break; } q -= n; }
   }
-  const int i = col >> 4, j = col & 15;
   float* item = reinterpret_cast<float*>(items + (size_t)pair * item_stride);
-  // z index -> parameter index (or -1), 'r' = row 12 of block P
-  const int n = (bi == 0) ? (i < NPOSE ? i : -1) : NPOSE + NCB * i + (bi - 1);
-  const int m = (bj == 0) ? (j < NPOSE ? j : -1) : NPOSE + NCB * j + (bj - 1);
-  const bool i_is_r = (bi == 0 && i == 12), j_is_r = (bj == 0 && j == 12);
-  if (n >= 0 && m >= 0) {
-    if (bi == bj && i > j) return;   // symmetric duplicate inside a diagonal block
-    const int lo = n < m ? n : m, hi = n < m ? m : n;
-    item[lo * NP - lo * (lo - 1) / 2 + (hi - lo)] = (float)s;
-  } else if (i_is_r && m >= 0) {
-    item[NT + m] = (float)s;                       // Jtr
-  } else if (i_is_r && j_is_r) {
-    item[NT + NP] = (float)s;                      // residual = sum (w r)^2
-  } else if (bi == 0 && bj == 0 && i == 14 && j == 14) {
-    const size_t off = (((size_t)(NT + NP + 1)) * 4 + 7) & ~(size_t)7;
-    *reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(item) + off) = (unsigned long long)(s + 0.5);
+  auto tri = [](int lo, int hi) { return lo * NP - lo * (lo - 1) / 2 + (hi - lo); };
+  const int t = threadIdx.x;
+  if (bi == 0 && bj == 0) {
+    if (NPOSE == 12) {
+      if (t < 144) {                       // pose-pose: T G T^T, G = S[0..5][0..5]
+        const int n = t / 12, m = t - n * 12;
+        if (n <= m) {
+          double v = 0.0;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            double r = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) r += S[(i < j ? i : j) * 16 + (i < j ? j : i)] * T[m][j];
+            v += T[n][i] * r;
+          }
+          item[tri(n, m)] = (float)v;
+        }
+      } else if (t < 156) {                // Jtr (pose): T * S[0..5][12]
+        const int n = t - 144;
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v += T[n][i] * S[i * 16 + 12];
+        item[NT + n] = (float)v;
+      }
+    }
+    if (t == 160) item[NT + NP] = (float)S[12 * 16 + 12];          // residual = sum (w r)^2
+    if (t == 161) {
+      const size_t off = (((size_t)(NT + NP + 1)) * 4 + 7) & ~(size_t)7;
+      *reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(item) + off) = (unsigned long long)(S[14 * 16 + 14] + 0.5);
+    }
+  } else if (bi == 0) {
+    const int b = bj - 1;
+    if (NPOSE == 12 && t < 192) {          // pose-code: T * S[0..5][j]
+      const int n = t >> 4, j = t & 15;
+      double v = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) v += T[n][i] * S[i * 16 + j];
+      item[tri(n, NPOSE + NCB * j + b)] = (float)v;
+    } else if (t >= 192 && t < 208) {      // Jtr (code)
+      const int j = t - 192;
+      item[NT + NPOSE + NCB * j + b] = (float)S[12 * 16 + j];
+    }
+  } else if (t < 256) {                    // code-code
+    const int i = t >> 4, j = t & 15;
+    if (bi == bj && i > j) return;         // symmetric duplicate inside a diagonal block
+    const int n = NPOSE + NCB * i + (bi - 1), m = NPOSE + NCB * j + (bj - 1);
+    item[tri(n < m ? n : m, n < m ? m : n)] = (float)S[i * 16 + j];
   }
 }
 
@@ -514,15 +663,15 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   hipError_t e;
   if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
   const dim3 grid(bpp, npairs), block(kThreads);
-  if (jac_dense && prec == 1) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, true, 1>), grid, block, 0, stream, pairs_dev, prm, W, H, partials_dev);
-  else if (jac_dense) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, true, 0>), grid, block, 0, stream, pairs_dev, prm, W, H, partials_dev);
-  else if (prec == 1) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, false, 1>), grid, block, 0, stream, pairs_dev, prm, W, H, partials_dev);
-  else hipLaunchKernelGGL((k_sfm_step<NCB, MODE, false, 0>), grid, block, 0, stream, pairs_dev, prm, W, H, partials_dev);
+  if (jac_dense && prec == 1) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, true, 1>), grid, block, DFX_EXTRA_LDS, stream, pairs_dev, prm, W, H, partials_dev);
+  else if (jac_dense) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, true, 0>), grid, block, DFX_EXTRA_LDS, stream, pairs_dev, prm, W, H, partials_dev);
+  else if (prec == 1) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, false, 1>), grid, block, DFX_EXTRA_LDS, stream, pairs_dev, prm, W, H, partials_dev);
+  else hipLaunchKernelGGL((k_sfm_step<NCB, MODE, false, 0>), grid, block, DFX_EXTRA_LDS, stream, pairs_dev, prm, W, H, partials_dev);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL((k_sfm_finalize<NCB, MODE == 0 ? 12 : 0>), dim3(4 * NACC, npairs), dim3(256), 0, stream,
-                     (const float*)partials_dev, bpp, (char*)items_dev, item_stride);
+  hipLaunchKernelGGL((k_sfm_finalize<NCB, MODE == 0 ? 12 : 0>), dim3(NACC, npairs), dim3(1024), 0, stream,
+                     (const float*)partials_dev, bpp, pairs_dev, (char*)items_dev, item_stride);
   return hipGetLastError();
 }
 

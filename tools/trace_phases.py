@@ -22,11 +22,46 @@ items = torch.zeros(P * dfx.item_size(12 + CS), dtype=torch.uint8, device=dev)
 for _ in range(3):
     al.RunStepBatchAsync(arr, items)
 ctx.sync()
+ctx.set_profiling(True)
+al.RunStepBatchAsync(arr, items)
+n_l, ms_l = ctx.profile_read()
+ctx.set_profiling(False)
+print(f"step kernel {ms_l / n_l * 1e3:.1f} us (HIP events)")
 nb = P * blocks
 buf = np.zeros(nb * 1536, np.float32)
 _lib.check(_lib.lib().dfx_debug_read_partials(ctx.handle, buf.ctypes.data_as(C.c_void_p), buf.nbytes))
-z = buf.reshape(nb, 1536)[:, 240:256].reshape(nb, 4, 4)
-A, B, N, T = z[..., 0], z[..., 1], z[..., 2], z[..., 3]
-print(f"mode={mode} blocks/pair={blocks} waves={nb*4} chunks/wave avg={N.mean():.2f}")
-print(f"per chunk: phaseA {np.sum(A)/np.sum(N):.0f} cycles, phaseB {np.sum(B)/np.sum(N):.0f} cycles (s_memtime ticks = 100 MHz? see total)")
+zz = buf.reshape(nb, 1536)
+z = zz[:, 240:256].reshape(nb, 4, 4)
+hw = zz[:, 176:192].reshape(nb, 4, 4)
+A, B, S, T = z[..., 0].astype(np.float64), z[..., 1].astype(np.float64), z[..., 2].astype(np.float64), z[..., 3].astype(np.float64)
+N = hw[..., 2].astype(np.float64)
+hwid, xcc = hw[..., 0].astype(np.int64), hw[..., 1].astype(np.int64)
+RT = hw[..., 3].astype(np.float64)   # wave lifetime in 100 MHz ticks
+print(f"core clock while the waves ran: {np.sum(T) / np.sum(RT) * 100:.0f} MHz (s_memtime / s_memrealtime); mean wave lifetime {RT.mean() / 100:.1f} us")
+S0 = S.copy()
+for x in np.unique(xcc):   # the XCDs' counters need not be synchronized: unwrap the 24-bit window and align every XCD on its own first wave
+    m = xcc == x
+    v = S0[m]
+    ref = np.median(v)
+    v = np.where(v < ref - 2 ** 23, v + 2 ** 24, np.where(v > ref + 2 ** 23, v - 2 ** 24, v))
+    S0[m] = v - v.min()
+E = S0 + T
+span = E.max()
+print(f"mode={mode} blocks/pair={blocks} waves={nb*4} chunks/wave avg={N.mean():.2f}; kernel span {span:.0f} ticks = {span / (ms_l / n_l * 1e3):.0f} ticks/us")
+print(f"per chunk per wave: phaseA {np.sum(A)/np.sum(N):.0f} ticks, phaseB {np.sum(B)/np.sum(N):.0f} ticks; prologue+epilogue per wave {np.mean(T-A-B):.0f} ticks")
 print(f"wave lifetime avg {T.mean():.0f} ticks, p10 {np.percentile(T,10):.0f} p50 {np.percentile(T,50):.0f} p90 {np.percentile(T,90):.0f} max {T.max():.0f}; A share {np.sum(A)/np.sum(T):.2f}, B share {np.sum(B)/np.sum(T):.2f}")
+print(f"wave-ticks total {T.sum():.3e} = {T.sum()/span:.0f} waves resident on average (capacity 1024 SIMDs x occupancy)")
+# start-time histogram (launch ramp) and end-time histogram (tail), in 10 bins of the span
+hs, _ = np.histogram(S0, bins=10, range=(0, span)); he, _ = np.histogram(E, bins=10, range=(0, span))
+print("starts per decile of the span:", hs.tolist()); print("ends   per decile of the span:", he.tolist())
+# resident waves over time
+grid = np.linspace(0, span, 41)
+res = [(int(((S0 <= g) & (E > g)).sum())) for g in grid]
+print("resident waves at 41 time points:", res)
+simd = (hwid >> 4) & 3; cu = (hwid >> 8) & 15; se = (hwid >> 13) & 7
+key = ((xcc * 8 + se) * 16 + cu) * 4 + simd
+u, cnt = np.unique(key, return_counts=True)
+print(f"distinct (xcc,se,cu,simd) slots used: {len(u)}; waves per SIMD min {cnt.min()} max {cnt.max()}; xcc values {np.unique(xcc).tolist()}")
+busy = np.zeros(len(u)); idx = {k: i for i, k in enumerate(u)}
+for k, a_, b_ in zip(key.ravel(), A.ravel(), B.ravel()): busy[idx[k]] += a_ + b_
+print(f"per-SIMD sum of (A+B) wave-ticks / span: mean {busy.mean()/span:.2f} min {busy.min()/span:.2f} max {busy.max()/span:.2f}  (= average number of waves in a timed phase)")
