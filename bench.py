@@ -108,8 +108,9 @@ def main():
     neq = NormalEquations(world * P + 1, CS, dev)
 
     def step():
-        al.RunStepBatchAsync(arr, items)                       # hot path: one launch over P pairs (+ finalize)
-        neq.assemble_native(ctx, items, rank * P, P)           # normal-equation blocks of this rank's pairs (one kernel)
+        # hot path: one launch over P pairs; its finalize kernel also scatter-adds the items into the normal-equation
+        # blocks of this rank's pairs (dfx_sfm_step_batch_neq_async = RunStepBatchAsync + assemble_native, fused)
+        al.RunStepBatchAssembleAsync(arr, items, neq, rank * P)
         if dist is not None:
             neq.all_reduce(dist)                               # RCCL over xGMI
 

@@ -104,6 +104,8 @@ _PROTOS = {
     "dfx_sfm_step_batch_async": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SfmParams), C.POINTER(SfmPair), C.c_int, C.c_void_p]),
     "dfx_sfm_step_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SfmParams), C.POINTER(SfmPair), C.c_int, C.c_void_p]),
     "dfx_neq_assemble_async": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "dfx_sfm_step_batch_neq_async": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SfmParams), C.POINTER(SfmPair), C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                               C.c_void_p, C.c_void_p]),
     "dfx_update_depth": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(Img), C.POINTER(Img), C.c_float,
                                    C.POINTER(Img)]),
     "dfx_sobel_gradients": (C.c_int, [C.c_void_p, C.POINTER(Img), C.POINTER(Img)]),

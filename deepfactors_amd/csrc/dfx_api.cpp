@@ -245,16 +245,23 @@ int fill_sfm_pair(dfx_ctx* c, int cs, const dfx_se3* pose0, const dfx_se3* pose1
   return DFX_OK;
 }
 
-// Workgroups per pair for the step kernel.  Measured on MI355X: short waves (about 5 chunks of
-// 64 pixels each) spread the launch over many more workgroups than resident slots, which hides the 2x spread of wave
-// lifetimes; the total is capped so that huge batches still give every wave a long enough pipeline.
-int auto_step_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int npairs) {
+// Workgroups per pair for the step kernel, from launch-shape sweeps on MI355X (1 / 4 / 16 / 64
+// pairs of 640x480, 16 x 320x240, 4 x 1280x960 CS 64).  A wave's prologue + epilogue cost about as much as two chunks, so
+// waves should be long; but the batch needs a few thousand waves for the hardware to balance the 2x spread of wave
+// lifetimes.  Chunks per wave: 5 while the batch is small, up to 10 (CS <= 32; a CS 64 chunk carries 2.5x the matrix
+// work) once that still leaves ~3840 waves.
+int auto_step_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int npairs, int cs) {
   const int nchunks = (int)(((size_t)W * H + 63) / 64);
   int maxb = (nchunks + 3) / 4;   // one chunk per wave at most
   if (maxb < 1) maxb = 1;
   int b = c->step_blocks;
   if (b <= 0) {
-    b = (nchunks + 19) / 20;                                   // ~5 chunks per wave (4 waves per workgroup)
+    const long long total_chunks = (long long)nchunks * npairs;
+    int cpw = (int)(total_chunks / 3840);
+    const int cpw_max = cs >= 64 ? 5 : 10;
+    if (cpw < 5) cpw = 5;
+    if (cpw > cpw_max) cpw = cpw_max;
+    b = (nchunks + 4 * cpw - 1) / (4 * cpw);
     const int cap = (64 * c->cu_count + npairs - 1) / npairs;   // at most 64 workgroups per CU over the whole batch
     if (b > cap) b = cap;
     if (b < 1) b = 1;
@@ -418,8 +425,27 @@ DFX_API int dfx_profile_read(dfx_ctx* c, int* n_launches, double* total_ms) {
 }
 
 // ---- SfmAligner ------------------------------------------------------------------------------------------------
+namespace {
+int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n, void* out_items_dev,
+                        const dfx::NeqDev& neq);
+}
+
 DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
                                      void* out_items_dev) {
+  return sfm_step_batch_impl(c, cs, params, pairs, n, out_items_dev, dfx::NeqDev{ nullptr, nullptr, 0 });
+}
+
+DFX_API int dfx_sfm_step_batch_neq_async(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
+                                         void* out_items_dev, int first_frame, int n_frames, float* H_dev, float* g_dev) {
+  if (!H_dev || !g_dev) return fail(DFX_E_INVALID, "dfx_sfm_step_batch_neq: null normal-equation buffer");
+  if (n <= 0 || first_frame < 0 || first_frame + n + 1 > n_frames)
+    return fail(DFX_E_INVALID, "pairs [%d, %d) do not fit a chain of %d frames", first_frame, first_frame + n, n_frames);
+  return sfm_step_batch_impl(c, cs, params, pairs, n, out_items_dev, dfx::NeqDev{ H_dev, g_dev, first_frame });
+}
+
+namespace {
+int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n, void* out_items_dev,
+                        const dfx::NeqDev& neq) {
   if (!c || !params || !pairs || !out_items_dev) return fail(DFX_E_INVALID, "dfx_sfm_step_batch: null argument");
   if (!cs_supported(cs)) return fail(DFX_E_INVALID, "unsupported code size %d (16, 32, 64)", cs);
   if (n <= 0 || n > 65535) return fail(DFX_E_INVALID, "batch size %d out of range [1,65535]", n);
@@ -454,7 +480,7 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
   DFX_HIP(hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, c->stream));
   if ((rc = stage_release(c, slot))) return rc;
 
-  const int bpp = auto_step_blocks(c, W, H, n);
+  const int bpp = auto_step_blocks(c, W, H, n, cs);
   const size_t pbytes = dfx::sfm_step_partials_bytes(cs, n, bpp);
   if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
   if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
@@ -476,9 +502,10 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
   bool jac_dense = true;
   for (int p = 0; p < n; ++p) jac_dense = jac_dense && (hd[p].pitch_jac == W * (uint32_t)cs * 4u);
   DFX_HIP(dfx::launch_sfm_step(cs, dd, n, (int)W, (int)H, prm, bpp, c->partials, out_items_dev, dfx_item_size(12 + cs), c->stream,
-                               jac_dense, c->mfma_mode, eb, ee));
+                               jac_dense, c->mfma_mode, eb, ee, neq));
   return DFX_OK;
 }
+}  // namespace
 
 DFX_API int dfx_neq_assemble_async(dfx_ctx* c, int cs, const void* items_dev, int n_pairs, int first_frame, int n_frames,
                                    float* H_dev, float* g_dev, int zero_first) {
@@ -809,7 +836,7 @@ DFX_API int dfx_depth_aligner_step(dfx_ctx* c, int cs, const float* code, const 
   dfx::SfmPairDev* dd = c->pairs_dev + (size_t)slot * c->pairs_cap;
   DFX_HIP(hipMemcpyAsync(dd, hd, sizeof(*hd), hipMemcpyHostToDevice, c->stream));
   if ((rc = stage_release(c, slot))) return rc;
-  const int bpp = auto_step_blocks(c, W, H, 1);
+  const int bpp = auto_step_blocks(c, W, H, 1, cs);
   const size_t pbytes = dfx::sfm_step_partials_bytes(cs, 1, bpp);
   if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
   if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;

@@ -127,7 +127,7 @@ __device__ __forceinline__ f32x4 mfma_split(const u32x4& a, const u32x4& b, cons
 // PREC 1: the same products through exact bf16x3 operand splits on the bf16 matrix cores (fp32-accurate, overlaps VALU).
 template <int NCB, int MODE, bool JDENSE, int PREC>
 __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_WAVES) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmParamsDev prm,
-                                                       const int W, const int H, float* __restrict__ partials) {
+                                                       const int W, const int H, float* __restrict__ partials, const NeqDev neq) {
   constexpr int NBLK = 1 + NCB;
   constexpr int NACC = NBLK * (NBLK + 1) / 2;
   constexpr int ZDIM = NACC * 256;
@@ -142,6 +142,17 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const SfmPairDev& P = pairs[blockIdx.y];
+
+  if (MODE == 0 && neq.H && blockIdx.x == 0) {
+    // fused assembly: clear the normal-equation blocks of this pair's keyframe (the last pair also clears the frame behind
+    // it); k_sfm_finalize adds into them after this kernel has completed.  Replaces two memsets in front of the launch.
+    constexpr int D = 6 + 16 * NCB;
+    const int nfr = (blockIdx.y == gridDim.y - 1) ? 2 : 1;
+    float* Hz = neq.H + (size_t)(neq.first_frame + blockIdx.y) * 2 * D * D;
+    float* gz = neq.g + (size_t)(neq.first_frame + blockIdx.y) * D;
+    for (int e = threadIdx.x; e < nfr * 2 * D * D; e += kThreads) Hz[e] = 0.f;
+    for (int e = threadIdx.x; e < nfr * D; e += kThreads) gz[e] = 0.f;
+  }
 
   Geo g;
 #pragma unroll
@@ -511,13 +522,24 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 #endif
 }
 
+// One entry (a, b) of a pair's (12 + CS)^2 system -> the block-tridiagonal system of the frame chain.  H0 = blocks of the
+// pair's keyframe; parameters 0..5 / 12.. belong to it (pose0, code0), 6..11 to the next frame (pose1).
+template <int CS>
+__device__ __forceinline__ void neq_scatter(float* H0, int a, int b, float v) {
+  constexpr int D = 6 + CS;
+  const int fa = (a >= 6 && a < 12), fb = (b >= 6 && b < 12);
+  const int la = a < 6 ? a : a - 6, lb = b < 6 ? b : b - 6;
+  if (fa == fb) atomicAdd(H0 + (size_t)fa * 2 * D * D + la * D + lb, v);
+  else if (fa == 0) H0[D * D + la * D + lb] = v;   // (frame k rows, frame k+1 cols): single writer
+}
+
 // ---- finalize: sum the workgroup partials of each pair (double, fixed order), map the relative-pose basis onto
 // (pose0, pose1) and scatter into the item layout.
 // grid = (NACC, npairs), 1024 threads: thread = (element of one 16x16 accumulator block, 1 of 4 partial groups); groups
 // stride over the pair's `bpp` partials (1 KB coalesced reads, 8 in flight) and are folded in fixed order.
 template <int NCB, int NPOSE>
 __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs,
-                                                       char* __restrict__ items, const size_t item_stride) {
+                                                       char* __restrict__ items, const size_t item_stride, const NeqDev neq) {
   constexpr int CS = 16 * NCB;
   constexpr int NP = NPOSE + CS;
   constexpr int NBLK = 1 + NCB;
@@ -556,6 +578,23 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
   }
   float* item = reinterpret_cast<float*>(items + (size_t)pair * item_stride);
   auto tri = [](int lo, int hi) { return lo * NP - lo * (lo - 1) / 2 + (hi - lo); };
+  // item entry (lo <= hi) -> packed item and, when the fused assembly is on, the frame chain's block system
+  // (same placement as k_neq_assemble: PhotometricFactor::linearize's G11..G33 slices, photometric_factor.cpp:105-161)
+  float* const H0 = (NPOSE == 12 && neq.H) ? neq.H + (size_t)(neq.first_frame + pair) * 2 * (6 + CS) * (6 + CS) : nullptr;
+  auto put = [&](int lo, int hi, float v) {
+    item[tri(lo, hi)] = v;
+    if (NPOSE == 12 && H0) {
+      neq_scatter<CS>(H0, lo, hi, v);
+      if (lo != hi) neq_scatter<CS>(H0, hi, lo, v);
+    }
+  };
+  auto put_g = [&](int n, float v) {
+    item[NT + n] = v;
+    if (NPOSE == 12 && H0) {
+      const int fa = (n >= 6 && n < 12);
+      atomicAdd(neq.g + (size_t)(neq.first_frame + pair + fa) * (6 + CS) + (n < 6 ? n : n - 6), v);
+    }
+  };
   const int t = threadIdx.x;
   if (bi == 0 && bj == 0) {
     if (NPOSE == 12) {
@@ -570,14 +609,14 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
             for (int j = 0; j < 6; ++j) r += S[(i < j ? i : j) * 16 + (i < j ? j : i)] * T[m][j];
             v += T[n][i] * r;
           }
-          item[tri(n, m)] = (float)v;
+          put(n, m, (float)v);
         }
       } else if (t < 156) {                // Jtr (pose): T * S[0..5][12]
         const int n = t - 144;
         double v = 0.0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) v += T[n][i] * S[i * 16 + 12];
-        item[NT + n] = (float)v;
+        put_g(n, (float)v);
       }
     }
     if (t == 160) item[NT + NP] = (float)S[12 * 16 + 12];          // residual = sum (w r)^2
@@ -592,16 +631,16 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
       double v = 0.0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) v += T[n][i] * S[i * 16 + j];
-      item[tri(n, NPOSE + NCB * j + b)] = (float)v;
+      put(n, NPOSE + NCB * j + b, (float)v);
     } else if (t >= 192 && t < 208) {      // Jtr (code)
       const int j = t - 192;
-      item[NT + NPOSE + NCB * j + b] = (float)S[12 * 16 + j];
+      put_g(NPOSE + NCB * j + b, (float)S[12 * 16 + j]);
     }
   } else if (t < 256) {                    // code-code
     const int i = t >> 4, j = t & 15;
     if (bi == bj && i > j) return;         // symmetric duplicate inside a diagonal block
     const int n = NPOSE + NCB * i + (bi - 1), m = NPOSE + NCB * j + (bj - 1);
-    item[tri(n < m ? n : m, n < m ? m : n)] = (float)S[i * 16 + j];
+    put(n < m ? n : m, n < m ? m : n, (float)S[i * 16 + j]);
   }
 }
 
@@ -620,12 +659,8 @@ __global__ __launch_bounds__(256) void k_neq_assemble(const char* __restrict__ i
   float* H0 = Hm + (size_t)(first_frame + p) * 2 * D * D;
   for (int e = threadIdx.x; e < NP * NP; e += 256) {
     const int a = e / NP, b = e - a * NP;
-    const int fa = (a >= 6 && a < 12), fb = (b >= 6 && b < 12);          // 1 = belongs to frame k+1 (pose1)
-    const int la = a < 6 ? a : (a < 12 ? a - 6 : a - 6), lb = b < 6 ? b : (b < 12 ? b - 6 : b - 6);
     const int lo = a < b ? a : b, hi = a < b ? b : a;
-    const float v = it[lo * NP - lo * (lo - 1) / 2 + (hi - lo)];
-    if (fa == fb) atomicAdd(H0 + (size_t)fa * 2 * D * D + la * D + lb, v);
-    else if (fa == 0) H0[D * D + la * D + lb] = v;                           // (frame k rows, frame k+1 cols): single writer
+    neq_scatter<CS>(H0, a, b, it[lo * NP - lo * (lo - 1) / 2 + (hi - lo)]);
   }
   for (int a = threadIdx.x; a < NP; a += 256) {
     const int fa = (a >= 6 && a < 12);
@@ -658,30 +693,30 @@ size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair) {
 template <int NCB, int MODE>
 static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm, int bpp,
                            float* partials_dev, void* items_dev, size_t item_stride, hipStream_t stream, bool jac_dense, int prec,
-                           hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr) {
+                           hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, const NeqDev& neq = NeqDev{ nullptr, nullptr, 0 }) {
   constexpr int NACC = (1 + NCB) * (2 + NCB) / 2;
   hipError_t e;
   if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
   const dim3 grid(bpp, npairs), block(kThreads);
-  if (jac_dense && prec == 1) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, true, 1>), grid, block, DFX_EXTRA_LDS, stream, pairs_dev, prm, W, H, partials_dev);
-  else if (jac_dense) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, true, 0>), grid, block, DFX_EXTRA_LDS, stream, pairs_dev, prm, W, H, partials_dev);
-  else if (prec == 1) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, false, 1>), grid, block, DFX_EXTRA_LDS, stream, pairs_dev, prm, W, H, partials_dev);
-  else hipLaunchKernelGGL((k_sfm_step<NCB, MODE, false, 0>), grid, block, DFX_EXTRA_LDS, stream, pairs_dev, prm, W, H, partials_dev);
+  if (jac_dense && prec == 1) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, true, 1>), grid, block, DFX_EXTRA_LDS, stream, pairs_dev, prm, W, H, partials_dev, neq);
+  else if (jac_dense) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, true, 0>), grid, block, DFX_EXTRA_LDS, stream, pairs_dev, prm, W, H, partials_dev, neq);
+  else if (prec == 1) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, false, 1>), grid, block, DFX_EXTRA_LDS, stream, pairs_dev, prm, W, H, partials_dev, neq);
+  else hipLaunchKernelGGL((k_sfm_step<NCB, MODE, false, 0>), grid, block, DFX_EXTRA_LDS, stream, pairs_dev, prm, W, H, partials_dev, neq);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
   hipLaunchKernelGGL((k_sfm_finalize<NCB, MODE == 0 ? 12 : 0>), dim3(NACC, npairs), dim3(1024), 0, stream,
-                     (const float*)partials_dev, bpp, pairs_dev, (char*)items_dev, item_stride);
+                     (const float*)partials_dev, bpp, pairs_dev, (char*)items_dev, item_stride, neq);
   return hipGetLastError();
 }
 
 hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm,
                            int blocks_per_pair, float* partials_dev, void* items_dev, size_t item_stride,
-                           hipStream_t stream, bool jac_dense, int prec, hipEvent_t eb, hipEvent_t ee) {
+                           hipStream_t stream, bool jac_dense, int prec, hipEvent_t eb, hipEvent_t ee, const NeqDev& neq) {
   switch (cs) {
-    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee);
-    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee);
-    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee);
+    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, neq);
+    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, neq);
+    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, neq);
     default: return hipErrorInvalidValue;
   }
 }

@@ -199,6 +199,12 @@ DFX_API int dfx_sfm_step_batch(dfx_ctx* ctx, int cs, const dfx_sfm_params* param
 DFX_API int dfx_neq_assemble_async(dfx_ctx* ctx, int cs, const void* items_dev, int n_pairs, int first_frame, int n_frames,
                                    float* H_dev, float* g_dev, int zero_first);
 
+/* dfx_sfm_step_batch_async + dfx_neq_assemble_async(zero_first = 1) in two kernels instead of five operations: the step
+ * kernel clears the blocks of frames [first_frame, first_frame + n] (only those -- the rest of H/g is left untouched), the
+ * finalize kernel writes the items AND scatter-adds them into H/g.  Same results as the two separate calls. */
+DFX_API int dfx_sfm_step_batch_neq_async(dfx_ctx* ctx, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
+                                         void* out_items_dev, int first_frame, int n_frames, float* H_dev, float* g_dev);
+
 /* ---- image-proc free functions (cuda/cu_image_proc.h:27-46) ---------------------------------- */
 /* UpdateDepth (cu_image_proc.cpp:248-277): dpt = a/(prx_orig + prx_jac . code) - a; code is a HOST array of cs floats. */
 DFX_API int dfx_update_depth(dfx_ctx* ctx, int cs, const float* code, const dfx_img* prx_orig, const dfx_img* prx_jac,

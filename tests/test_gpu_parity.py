@@ -119,6 +119,28 @@ def test_native_normal_equation_assembly_matches_torch(dfx):
     assert torch.equal(a.H, b.H) and torch.equal(a.g, b.g)
     D = a.dense()
     assert torch.allclose(D, D.T) and float(D.abs().max()) > 0
+    # fused variant (step kernel clears the touched frames, finalize scatter-adds): same bytes, items included; run twice
+    # into a dirty buffer to prove the clearing
+    c = NormalEquations(n + 3, cs, "cuda")
+    items2 = torch.zeros_like(items)
+    for _ in range(2):
+        al.RunStepBatchAssembleAsync(arr, items2, c, 1)
+    al.ctx.sync()
+    assert torch.equal(items, items2)
+    assert torch.equal(a.H, c.H) and torch.equal(a.g, c.g)
+    for cs2 in (16, 64):   # the other code sizes against the separate kernel
+        al2 = dfx.SfmAligner(code_size=cs2)
+        p2, nn2, g2 = _pair(dfx, 64, 48, cs2, seed=77)
+        arr2 = al2.make_pairs([dict(pose0=nn2["pose0"], pose1=nn2["pose1"], cam=nn2["cam"], img0=g2["img0"], img1=g2["img1"], dpt0=g2["dpt0"],
+                                    prx0_jac=g2["prx_jac"], grad1=g2["grad1"])] * 3)
+        it_a = torch.zeros(3 * dfx.item_size(12 + cs2), dtype=torch.uint8, device="cuda")
+        it_b = torch.zeros_like(it_a)
+        ea, eb = NormalEquations(4, cs2, "cuda"), NormalEquations(4, cs2, "cuda")
+        al2.RunStepBatchAsync(arr2, it_a)
+        ea.assemble_native(al2.ctx, it_a, 0, 3)
+        al2.RunStepBatchAssembleAsync(arr2, it_b, eb, 0)
+        al2.ctx.sync()
+        assert torch.equal(it_a, it_b) and torch.equal(ea.H, eb.H) and torch.equal(ea.g, eb.g)
 
 
 def test_sfm_step_deterministic(dfx):
