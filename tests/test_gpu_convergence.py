@@ -1,0 +1,76 @@
+"""north_star: "converge to the same pose/code estimates on fixed inputs".  A joint Gauss-Newton over (pose1, code0) --
+the unknowns PhotometricFactor exposes per keyframe pair (photometric_factor.cpp:105-161) with pose0 held as the gauge --
+driven once by the HIP path (UpdateDepth + SfmAligner::RunStep through the C ABI) and once by the CPU oracle, same
+solver, same retraction (left-multiplicative rotation, R3 x SO3 split)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _quat_to_R(q):
+    x, y, z, w = [float(v) for v in q]
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _retract(synth, qt, d):
+    R = synth.so3_exp(np.asarray(d[3:], np.float64)) @ _quat_to_R(qt[:4])
+    return np.concatenate([synth.R_to_quat(R), np.asarray(qt[4:], np.float64) + d[:3]]).astype(np.float32)
+
+
+def _gauss_newton(synth, step, update_depth, pose0, pose1, code, cs, iters, lm=1e-4):
+    hist = []
+    for _ in range(iters):
+        r = step(pose0, pose1, update_depth(code))
+        H = np.asarray(r.dense() if hasattr(r, "dense") else r.toDenseMatrix(), np.float64)
+        g = np.asarray(r.Jtr, np.float64)
+        idx = list(range(6, 12 + cs))
+        A = H[np.ix_(idx, idx)]
+        A = A + lm * np.diag(np.diag(A))
+        d = -np.linalg.solve(A, g[idx])
+        pose1 = _retract(synth, pose1, d[:6])
+        code = (code + d[6:]).astype(np.float32)
+        hist.append((float(r.residual), int(r.inliers)))
+    return pose1, code, hist
+
+
+@pytest.mark.parametrize("w,h,cs,seed", [(160, 120, 16, 21), (320, 240, 32, 22)])
+def test_sfm_gauss_newton_converges_like_the_oracle(dfx, oracle, w, h, cs, seed):
+    from deepfactors_amd import synth
+    p = synth.make_pair(w, h, cs, seed=seed, device="cpu")
+    n, g = synth.to_numpy(p), synth.to_device(p, "cuda")
+    pose1_0 = _retract(synth, n["pose1"], np.array([0.01, -0.008, 0.005, 0.004, -0.003, 0.002]))
+    code_0 = (n["code"] * 0.5).astype(np.float32)
+    iters = 10
+
+    al = dfx.SfmAligner(code_size=cs)
+    dpt_dev = torch.empty_like(g["img0"])
+
+    def upd_gpu(code):
+        dfx.UpdateDepth(code, g["prx_orig"], g["prx_jac"], 2.0, dpt_dev, al.ctx)
+        return dpt_dev
+
+    def step_gpu(p0, p1, dpt):
+        return al.RunStep(p0, p1, None, n["cam"], g["img0"], g["img1"], dpt, None, None, g["prx_jac"], g["grad1"])
+
+    def upd_cpu(code):
+        return oracle.update_depth(code, n["prx_orig"], n["prx_jac"], 2.0)
+
+    def step_cpu(p0, p1, dpt):
+        return oracle.sfm_step(p0, p1, n["cam"], n["img0"], n["img1"], dpt, n["prx_jac"], n["grad1"])
+
+    pg, cg, hg = _gauss_newton(synth, step_gpu, upd_gpu, n["pose0"], pose1_0, code_0, cs, iters)
+    pc, cc, hc = _gauss_newton(synth, step_cpu, upd_cpu, n["pose0"], pose1_0, code_0, cs, iters)
+
+    # both converge (the residual drops by > 10x and settles) ...
+    assert hg[-1][0] < 0.1 * hg[0][0] and abs(hg[-1][0] - hg[-2][0]) < 1e-3 * hg[-1][0]
+    # ... to the same estimates: pose within 2e-4 (quaternion / metres), code within 2e-3, residual within 1e-3 relative
+    assert np.abs(pg - pc).max() < 2e-4, (pg, pc)
+    assert np.abs(cg - cc).max() < 2e-3, np.abs(cg - cc).max()
+    assert abs(hg[-1][0] - hc[-1][0]) < 1e-3 * hc[-1][0] and abs(hg[-1][1] - hc[-1][1]) <= max(2, 1e-4 * w * h)
+    # ... which are the generating ones up to the model error of the synthetic pair (Sobel vs bilinear derivative)
+    assert np.abs(pg - n["pose1"]).max() < 2e-3
+    assert np.abs(cg - n["code"]).max() < 0.25 * np.abs(code_0 - n["code"]).max()
