@@ -134,8 +134,23 @@ int ensure_result_host(dfx_ctx* c, size_t bytes) {
   c->result_host = nullptr;
   size_t n = bytes * 2;
   if (n < 8192) n = 8192;
-  DFX_HIP(hipHostMalloc((void**)&c->result_host, n, hipHostMallocDefault));
+  DFX_HIP(hipHostMalloc((void**)&c->result_host, n, hipHostMallocMapped | hipHostMallocCoherent));
   c->result_bytes = n;
+  return DFX_OK;
+}
+
+// Blocking calls with small results: the finalize kernel stores straight into the pinned, device-mapped result area and
+// the call only waits for the stream -- no device->host copy operation behind the kernels.
+constexpr size_t kDirectResultMax = 256 * 1024;
+int result_target(dfx_ctx* c, size_t bytes, void** dev_ptr) {
+  int rc;
+  if ((rc = ensure_result_host(c, bytes))) return rc;
+  DFX_HIP(hipHostGetDevicePointer(dev_ptr, c->result_host, 0));
+  return DFX_OK;
+}
+int finish_result(dfx_ctx* c, void* host_out, size_t bytes) {
+  DFX_HIP(hipStreamSynchronize(c->stream));
+  std::memcpy(host_out, c->result_host, bytes);
   return DFX_OK;
 }
 
@@ -527,6 +542,12 @@ DFX_API int dfx_sfm_step_batch(dfx_ctx* c, int cs, const dfx_sfm_params* params,
   int rc;
   if ((rc = ensure_device(c))) return rc;
   const size_t bytes = dfx_item_size(12 + cs) * (size_t)n;
+  if (bytes <= kDirectResultMax) {
+    void* tgt;
+    if ((rc = result_target(c, bytes, &tgt))) return rc;
+    if ((rc = dfx_sfm_step_batch_async(c, cs, params, pairs, n, tgt))) return rc;
+    return finish_result(c, out_items_host, bytes);
+  }
   if (c->items_bytes < bytes) DFX_HIP(hipStreamSynchronize(c->stream));
   if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, bytes, c->stream))) return rc;
   if ((rc = dfx_sfm_step_batch_async(c, cs, params, pairs, n, c->items_dev))) return rc;
@@ -565,9 +586,10 @@ DFX_API int dfx_sfm_error(dfx_ctx* c, const dfx_se3* pose0, const dfx_se3* pose1
   const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
   if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
   if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
-  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, 256, c->stream))) return rc;
-  DFX_HIP(dfx::launch_sfm_error(d, (int)img0->w, (int)img0->h, params->huber_delta, blocks, c->partials, c->items_dev, c->stream));
-  return fetch_result(c, c->items_dev, out, sizeof(dfx_corr_item));
+  void* tgt;
+  if ((rc = result_target(c, sizeof(dfx_corr_item), &tgt))) return rc;
+  DFX_HIP(dfx::launch_sfm_error(d, (int)img0->w, (int)img0->h, params->huber_delta, blocks, c->partials, tgt, c->stream));
+  return finish_result(c, out, sizeof(dfx_corr_item));
 }
 
 // ---- SE3Aligner ------------------------------------------------------------------------------------------------
@@ -582,9 +604,10 @@ DFX_API int dfx_se3_step(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam,
   const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
   if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
   if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
-  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, 256, c->stream))) return rc;
-  DFX_HIP(dfx::launch_se3_step(d, (int)img0->w, (int)img0->h, huber_delta, blocks, c->partials, c->items_dev, c->stream));
-  return fetch_result(c, c->items_dev, out_item, dfx_item_size(6));
+  void* tgt;
+  if ((rc = result_target(c, dfx_item_size(6), &tgt))) return rc;
+  DFX_HIP(dfx::launch_se3_step(d, (int)img0->w, (int)img0->h, huber_delta, blocks, c->partials, tgt, c->stream));
+  return finish_result(c, out_item, dfx_item_size(6));
 }
 
 DFX_API int dfx_se3_warp(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam, const dfx_img* img0, const dfx_img* img1,
@@ -598,9 +621,10 @@ DFX_API int dfx_se3_warp(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam,
   const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
   if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
   if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
-  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, 256, c->stream))) return rc;
-  DFX_HIP(dfx::launch_se3_warp(d, (int)img0->w, (int)img0->h, blocks, c->partials, c->items_dev, c->stream));
-  return fetch_result(c, c->items_dev, out, sizeof(dfx_corr_item));
+  void* tgt;
+  if ((rc = result_target(c, sizeof(dfx_corr_item), &tgt))) return rc;
+  DFX_HIP(dfx::launch_se3_warp(d, (int)img0->w, (int)img0->h, blocks, c->partials, tgt, c->stream));
+  return finish_result(c, out, sizeof(dfx_corr_item));
 }
 
 DFX_API int dfx_track_frame(dfx_ctx* c, const dfx_se3* pose_init, const dfx_track_level* levels, int n_levels, float huber_delta,
@@ -792,10 +816,11 @@ DFX_API int dfx_squared_error(dfx_ctx* c, const dfx_img* a, const dfx_img* b, fl
   const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
   if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
   if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
-  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, 256, c->stream))) return rc;
+  void* tgt;
+  if ((rc = result_target(c, sizeof(float), &tgt))) return rc;
   DFX_HIP(dfx::launch_squared_error((const float*)a->ptr, (uint32_t)a->pitch_bytes, (const float*)b->ptr, (uint32_t)b->pitch_bytes,
-                                    (int)a->w, (int)a->h, blocks, c->partials, (float*)c->items_dev, c->stream));
-  return fetch_result(c, c->items_dev, out, sizeof(float));
+                                    (int)a->w, (int)a->h, blocks, c->partials, (float*)tgt, c->stream));
+  return finish_result(c, out, sizeof(float));
 }
 
 DFX_API int dfx_depth_aligner_step(dfx_ctx* c, int cs, const float* code, const dfx_img* target_dpt, const dfx_img* prx_orig,
@@ -841,11 +866,11 @@ DFX_API int dfx_depth_aligner_step(dfx_ctx* c, int cs, const float* code, const 
   if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
   if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
   const size_t ibytes = dfx_item_size(cs);
-  if (c->items_bytes < ibytes) DFX_HIP(hipStreamSynchronize(c->stream));
-  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, ibytes, c->stream))) return rc;
-  DFX_HIP(dfx::launch_depth_aligner_step(cs, dd, (int)W, (int)H, avg_dpt, bpp, c->partials, c->items_dev, c->stream,
+  void* tgt;
+  if ((rc = result_target(c, ibytes, &tgt))) return rc;
+  DFX_HIP(dfx::launch_depth_aligner_step(cs, dd, (int)W, (int)H, avg_dpt, bpp, c->partials, tgt, c->stream,
                                          prx_jac->pitch_bytes == (size_t)W * cs * 4, c->mfma_mode));
-  return fetch_result(c, c->items_dev, out_item, ibytes);
+  return finish_result(c, out_item, ibytes);
 }
 
 }  // extern "C"

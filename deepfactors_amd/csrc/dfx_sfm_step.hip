@@ -16,9 +16,6 @@
 //   Only the upper block-triangle is accumulated: (P,P), (P,Cb), (Cb,Cb') b<=b'  -> 6 MFMAs per 4 pixels at CS=32.
 //   (P,P)[12][12] = sum (w r)^2 = residual, (P,P)[14][14] = inliers, (P,*)[12][*] = Jtr.
 //   Block P row 13 (s) only exists so that lanes can broadcast s; its products are ignored.
-//   The (P,P) block itself holds only 29 useful sums (6x6 upper triangle, 6 Jtr, r^2, inliers).  MFMA and VALU time add on
-//   gfx950, so a 16x16x4 MFMA that is 11 % useful (512 cycles per chunk) loses to 29 per-lane fmas in phase A (~130
-//   cycles): the block is accumulated per lane and reduced across the wave once, in the epilogue (DFX_PP_VALU).
 //
 //   Phase A (lane = pixel): coalesced img0/dpt0 loads, warp, bilinear gathers of img1/grad1, Jacobian row,
 //     Huber weight; the 16-float P row goes to LDS component-major (stride 66 -> conflict-free both ways).
@@ -43,9 +40,6 @@ namespace dfx {
 #endif
 #ifndef DFX_MIN_WAVES_CS64
 #define DFX_MIN_WAVES_CS64 2 // same for NCB = 4 (15 accumulators + a 64-register ring: 168 VGPRs spill a little, 256 do not)
-#endif
-#ifndef DFX_PP_VALU
-#define DFX_PP_VALU 0        // 1: (P,P) block on the vector ALU (29 useful products per pixel = 11 % of a 16x16 MFMA's outputs)
 #endif
 #ifndef DFX_EXTRA_LDS
 #define DFX_EXTRA_LDS 0      // diagnosis only: dynamic LDS bytes added to the step launch to cap the workgroups per CU
@@ -131,7 +125,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   constexpr int NBLK = 1 + NCB;
   constexpr int NACC = NBLK * (NBLK + 1) / 2;
   constexpr int ZDIM = NACC * 256;
-  constexpr int LDS_FLOATS = (kWaves * kUFloats > ZDIM) ? kWaves * kUFloats : ZDIM;
+  constexpr int LDS_FLOATS = kWaves * ((kUFloats > ZDIM) ? kUFloats : ZDIM);   // P rows in the loop, accumulators in the epilogue
   typedef typename JV<NCB>::T jv_t;
   // "No next chunk" is handled by re-reading the wave's current chunk (L2-hot, results never consumed), NOT by
   // out-of-range offsets: a wave-load whose lanes are all out of range completes without touching memory and may
@@ -189,10 +183,6 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   f32x4 acc[NACC];
 #pragma unroll
   for (int a = 0; a < NACC; ++a) acc[a] = f32x4{ 0.f, 0.f, 0.f, 0.f };
-  constexpr int NPP = 29;   // 21 (gC x gC, i <= j) + 6 (gC x wr) + wr^2 + inliers
-  float pp[NPP];
-#pragma unroll
-  for (int k = 0; k < NPP; ++k) pp[k] = 0.f;
 
   const int npx = W * H;
   const int nchunks = (npx + 63) >> 6;
@@ -381,19 +371,6 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 #pragma unroll
       for (int q = 0; q < 15; ++q)
         if (q < 6 || q >= 12) U[q * kUStride + lane] = u16[q];
-      if (DFX_PP_VALU && !(DFX_ABLATE & 2)) {
-        int k = 0;
-        if (MODE == 0) {
-#pragma unroll
-          for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = i; j < 6; ++j, ++k) pp[k] = __builtin_fmaf(u16[i], u16[j], pp[k]);
-#pragma unroll
-          for (int i = 0; i < 6; ++i) pp[21 + i] = __builtin_fmaf(u16[i], u16[12], pp[21 + i]);
-        }
-        pp[27] = __builtin_fmaf(u16[12], u16[12], pp[27]);
-        pp[28] += u16[14];
-      }
     }
     // ---- A1(c+1) and the depth prefetch of c+2: issued BEFORE the ring refills of phase B
     cur.x = nxt.x; cur.y = nxt.y; cur.d = nxt.d; cur.i0 = nxt.i0; cur.rx = nxt.rx; cur.ry = nxt.ry;
@@ -435,7 +412,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
         Split3 sq[NCB];
 #pragma unroll
         for (int b = 0; b < NCB; ++b) sq[b] = split3(sc[b]);
-        if (!DFX_PP_VALU) acc[0] = mfma_split(sp.A, sp.B, acc[0]);
+        acc[0] = mfma_split(sp.A, sp.B, acc[0]);
 #pragma unroll
         for (int b = 0; b < NCB; ++b) acc[1 + b] = mfma_split(sp.A, sq[b].B, acc[1 + b]);
 #pragma unroll
@@ -447,7 +424,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
           }
         continue;
       }
-      if (!DFX_PP_VALU && !(DFX_ABLATE & 8)) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uP, uP, acc[0], 0, 0, 0);
+      if (!(DFX_ABLATE & 8)) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uP, uP, acc[0], 0, 0, 0);
 #pragma unroll
       for (int b = 0; b < NCB; ++b) acc[1 + b] = __builtin_amdgcn_mfma_f32_16x16x4f32(uP, sc[b], acc[1 + b], 0, 0, 0);
 #pragma unroll
@@ -472,40 +449,26 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     __builtin_amdgcn_wave_barrier();
   }
 
-  // ---- epilogue: fold the waves' accumulators in fixed order (wave 0, 1, 2, 3), one partial per workgroup.
+  // ---- epilogue: one z-space partial per workgroup = ((wave 0 + wave 1) + wave 2) + wave 3, element by element.
+  // Every wave parks its accumulators in its own LDS region, ONE barrier, then all threads sum and store (the earlier
+  // wave-after-wave read-modify-write needed four barriers with three waves idle each time; same sums, same order).
   // C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+  __syncthreads();   // everybody is done with the P rows
+  {
+    float* mine = lds + wave * ZDIM;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[a * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[a][r];
+  }
   __syncthreads();
-  if (DFX_PP_VALU) {   // wave totals of the per-lane (P,P) sums, fixed shuffle tree; lane 0 owns them
-#pragma unroll
-    for (int k = 0; k < NPP; ++k) pp[k] = wave_sum(pp[k]);
-    for (int e = threadIdx.x; e < 256; e += kThreads) lds[e] = 0.f;   // the unused entries of block 0
-    __syncthreads();
-  }
-  for (int wv = 0; wv < kWaves; ++wv) {
-    if (wave == wv) {
-#pragma unroll
-      for (int a = DFX_PP_VALU ? 1 : 0; a < NACC; ++a)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int idx = a * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15);
-          if (wv == 0) lds[idx] = acc[a][r]; else lds[idx] += acc[a][r];
-        }
-      if (DFX_PP_VALU && lane == 0) {   // upper triangle only: k_sfm_finalize reads S[min][max]
-        int k = 0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-          for (int j = i; j < 6; ++j, ++k) lds[i * 16 + j] += pp[k];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) lds[i * 16 + 12] += pp[21 + i];
-        lds[12 * 16 + 12] += pp[27];
-        lds[14 * 16 + 14] += pp[28];
-      }
-    }
-    __syncthreads();
-  }
   float* out = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ZDIM;
-  for (int e = threadIdx.x; e < ZDIM; e += kThreads) out[e] = lds[e];
+  for (int e = threadIdx.x; e < ZDIM; e += kThreads) {
+    float v = lds[e];
+#pragma unroll
+    for (int wv = 1; wv < kWaves; ++wv) v += lds[wv * ZDIM + e];
+    out[e] = v;
+  }
 #if DFX_TRACE
   __syncthreads();
   if (lane == 0) {   // (P,P) rows 15 and 11 are padding: per wave {phase A cycles, phase B cycles, start mod 2^24, lifetime}, {HW_ID, XCC_ID}
