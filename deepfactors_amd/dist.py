@@ -28,8 +28,11 @@ class NormalEquations:
         D = 6 + cs
         NP = 12 + cs
         self.D, self.F, self.NP, self.cs = D, n_frames, NP, cs
-        self.H = torch.zeros((n_frames, 2, D, D), dtype=torch.float32, device=device)
-        self.g = torch.zeros((n_frames, D), dtype=torch.float32, device=device)
+        # one flat exchange buffer (H then g): the multi-GPU reduction is a single collective
+        nH = n_frames * 2 * D * D
+        self.buf = torch.zeros(nH + n_frames * D, dtype=torch.float32, device=device)
+        self.H = self.buf[:nH].view(n_frames, 2, D, D)
+        self.g = self.buf[nH:].view(n_frames, D)
         nt = NP * (NP + 1) // 2
         iu = np.triu_indices(NP)
         packed = np.zeros((NP, NP), np.int64)
@@ -74,8 +77,7 @@ class NormalEquations:
 
     def all_reduce(self, dist):
         """The exchange step: sum the ranks' partial systems (RCCL ring all-reduce over xGMI on MI355X nodes)."""
-        dist.all_reduce(self.H)
-        dist.all_reduce(self.g)
+        dist.all_reduce(self.buf)
 
     def dense(self):
         """Full symmetric (F*D) x (F*D) matrix -- for tests / small systems only."""

@@ -1,0 +1,75 @@
+// latency_bench.cpp -- blocking-call latency of the drop-in C++ interface (include/dfx_shim.hpp), measured from C++ as a
+// reference call site sees it: PhotometricFactor::RunAlignmentStep calls SfmAligner::RunStep once per linearisation
+// (photometric_factor.cpp:267-274), CameraTracker::TrackFrame calls SE3Aligner::RunStep once per iteration
+// (camera_tracker.cpp:52-58).  Prints one line per operator: mean / min microseconds over N blocking calls at 640x480.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+#include "../../include/dfx_shim.hpp"
+
+using dfx::pod::Grad2;
+using dfx::pod::Image2DView;
+using dfx::pod::PinholeCamera;
+using dfx::pod::SE3f;
+
+template <typename F>
+static void timeit(const char* name, int n, F&& f) {
+  for (int i = 0; i < 5; ++i) f();
+  double tot = 0, mn = 1e30;
+  for (int i = 0; i < n; ++i) {
+    const auto t0 = std::chrono::steady_clock::now();
+    f();
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    tot += us; mn = us < mn ? us : mn;
+  }
+  std::printf("%-44s mean %7.1f us   min %7.1f us   (%d blocking calls)\n", name, tot / n, mn, n);
+}
+
+int main() {
+  const int W = 640, H = 480, CS = 32;
+  const PinholeCamera cam{ 554.256f, 579.411f, 320.f, 240.f, (float)W, (float)H };
+  std::vector<float> img((size_t)W * H), dpt((size_t)W * H), jac((size_t)W * H * CS);
+  for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+    img[(size_t)y * W + x] = 0.5f + 0.3f * std::sin(0.05f * x) * std::cos(0.04f * y);
+    dpt[(size_t)y * W + x] = 2.5f + 0.2f * std::sin(0.01f * x + 0.02f * y);
+  }
+  for (size_t i = 0; i < jac.size(); ++i) jac[i] = 1e-3f * (float)((i * 2654435761u) % 1000) / 1000.f;
+  float *d_img0, *d_img1, *d_dpt, *d_jac, *d_valid, *d_out;
+  Grad2* d_grad;
+  if (hipMalloc(&d_img0, img.size() * 4) != hipSuccess) { std::printf("no HIP device\n"); return 3; }
+  (void)hipMalloc(&d_img1, img.size() * 4); (void)hipMalloc(&d_dpt, img.size() * 4); (void)hipMalloc(&d_valid, img.size() * 4);
+  (void)hipMalloc(&d_out, img.size() * 4); (void)hipMalloc(&d_jac, jac.size() * 4); (void)hipMalloc(&d_grad, img.size() * 8);
+  (void)hipMemcpy(d_img0, img.data(), img.size() * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(d_img1, img.data(), img.size() * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(d_dpt, dpt.data(), img.size() * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(d_jac, jac.data(), jac.size() * 4, hipMemcpyHostToDevice);
+  (void)hipMemset(d_valid, 0, img.size() * 4);
+  const Image2DView<float> v0{ d_img0, (size_t)W * 4, (size_t)W, (size_t)H }, v1{ d_img1, (size_t)W * 4, (size_t)W, (size_t)H };
+  const Image2DView<float> vd{ d_dpt, (size_t)W * 4, (size_t)W, (size_t)H };
+  Image2DView<float> vv{ d_valid, (size_t)W * 4, (size_t)W, (size_t)H };
+  Image2DView<float> vo{ d_out, (size_t)W * 4, (size_t)W, (size_t)H };
+  const Image2DView<float> vj{ d_jac, (size_t)W * CS * 4, (size_t)W * CS, (size_t)H };
+  Image2DView<Grad2> vg{ d_grad, (size_t)W * 8, (size_t)W, (size_t)H };
+  try {
+    df::SobelGradients(v1, vg);
+    SE3f p0, p1;
+    p1.t[0] = 0.01f;
+    df::SE3Aligner<float> se3;
+    timeit("SE3Aligner::RunStep 640x480", 300, [&] { (void)se3.RunStep(p1, cam, v0, v1, vd, vg); });
+    timeit("SE3Aligner::Warp 640x480", 300, [&] { (void)se3.Warp(p1, cam, v0, v1, vd, vo); });
+    df::SfmAligner<float, CS> sfm;
+    float code[CS] = { 0 };
+    timeit("SfmAligner<32>::RunStep 640x480", 300, [&] { (void)sfm.RunStep(p0, p1, code, cam, v0, v1, vd, vd, vv, vj, vg); });
+    timeit("SfmAligner<32>::EvaluateError 640x480", 300, [&] { (void)sfm.EvaluateError(p0, p1, cam, v0, v1, vd, vd, vg); });
+    timeit("UpdateDepth<32> 640x480", 300, [&] { df::UpdateDepth<float, CS>(code, vd, vj, 2.0f, vo); });
+    timeit("SobelGradients 640x480", 300, [&] { df::SobelGradients(v1, vg); });
+  } catch (const std::exception& e) {
+    std::printf("exception: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
