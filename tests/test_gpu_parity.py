@@ -98,6 +98,34 @@ def test_sfm_step_batch(dfx, oracle):
         assert np.array_equal(a.JtJ, b.JtJ) and np.array_equal(a.Jtr, b.Jtr) and a.inliers == b.inliers
 
 
+def test_sfm_step_batch_mixed_cameras(dfx, oracle):
+    """Every pair of a batch may carry its own intrinsics: the per-camera ray tables (dfx_api.cpp ray_table) are looked up
+    per pair, and a context survives more distinct cameras than its table cache holds (256)."""
+    w, h, cs = 96, 64, 16
+    al = dfx.SfmAligner(code_size=cs)
+    host, dev = [], []
+    for k in range(3):
+        p, n, g = _pair(dfx, w, h, cs, seed=400 + k)
+        n["cam"] = n["cam"].copy()
+        n["cam"][0] *= 1.0 + 0.07 * k; n["cam"][1] *= 1.0 - 0.05 * k; n["cam"][2] += 1.5 * k; n["cam"][3] -= 0.75 * k
+        host.append(n); dev.append(g)
+    arr = al.make_pairs([dict(pose0=n["pose0"], pose1=n["pose1"], cam=n["cam"], img0=g["img0"], img1=g["img1"], dpt0=g["dpt0"],
+                              prx0_jac=g["prx_jac"], grad1=g["grad1"]) for n, g in zip(host, dev)])
+    for k, (n, it) in enumerate(zip(host, al.RunStepBatch(arr))):
+        ref = oracle.sfm_step(n["pose0"], n["pose1"], n["cam"], n["img0"], n["img1"], n["dpt0"], n["prx_jac"], n["grad1"])
+        assert_item_close(it, ref, w, h, what=f"mixed-camera item {k}")
+    n, g = host[0], dev[0]
+    first = None
+    for k in range(300):   # 300 distinct cameras through one context: the cache is recycled, results stay right
+        cam = n["cam"].copy(); cam[2] += 1e-3 * k
+        it = al.RunStep(n["pose0"], n["pose1"], None, cam, g["img0"], g["img1"], g["dpt0"], None, None, g["prx_jac"], g["grad1"])
+        if k == 0:
+            first = it
+        assert it.inliers > 0
+    again = al.RunStep(n["pose0"], n["pose1"], None, n["cam"], g["img0"], g["img1"], g["dpt0"], None, None, g["prx_jac"], g["grad1"])
+    assert np.array_equal(first.raw, again.raw)
+
+
 def test_native_normal_equation_assembly_matches_torch(dfx):
     """dfx_neq_assemble_async == the torch index_add formulation (deepfactors_amd/dist.py), bit for bit."""
     from deepfactors_amd.dist import NormalEquations
