@@ -4,8 +4,11 @@
 One "step" = one pass of the hot path over one batch of synthetic input resident in HBM: a single batched launch of
 SfmAligner::RunStep (reference cu_sfmaligner.cpp:149-185) over `--pairs` independent 640x480, 32-code keyframe->frame
 pairs (BASELINE.json configs[1] geometry, batched; every pair has its own keyframe so the working set,
-pairs x 47 MB, exceeds the 256 MB Infinity Cache and the sweep is honestly HBM-resident), followed by the assembly of
-the Gauss-Newton normal-equation blocks and -- for N > 1 -- their RCCL all-reduce over xGMI.
+pairs x 47 MB = 6 GB, is far beyond the 256 MB Infinity Cache and the sweep is honestly HBM-resident), with the assembly
+of the Gauss-Newton normal-equation blocks fused into its finalize kernel and -- for N > 1 -- their RCCL all-reduce over
+xGMI.  The default, 128 pairs per GPU, is the per-GPU shard of BASELINE configs[3] ("~1k pairs sharded across 8 GPUs"):
+`--gpus 8` IS that configuration, `--gpus 1` is one eighth of it (weak scaling).  `--pairs 16` gives the small-batch figure
+quoted in DESIGN.md section 5.
 
 Multi-GPU: one process per GPU (torch.distributed, backend "nccl" = RCCL); pairs are independent units, sharded
 contiguously across ranks (weak scaling: --pairs per GPU); the only exchange step is the all-reduce of the
@@ -34,9 +37,9 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=16, help="keyframe pairs per GPU per step (one batched launch)")
+    ap.add_argument("--pairs", type=int, default=128, help="keyframe pairs per GPU per step (one batched launch)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--cs", type=int, default=32)
@@ -170,7 +173,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1] geometry batched: {P} independent {W}x{H} pairs per GPU per step, "
+            "config": {"workload": f"BASELINE configs[1] geometry in the batch size of configs[3] (1k pairs / 8 GPUs): {P} independent {W}x{H} pairs per GPU per step, "
                                    f"CS={CS}, SfmAligner::RunStep (SE3+code Jacobians, JtJ/Jtr) in one launch, level 0; "
                                    "+ normal-equation block assembly" + (" + RCCL all-reduce" if world > 1 else ""),
                        "pairs_per_gpu": P, "width": W, "height": H, "code_size": CS,
