@@ -92,6 +92,7 @@ _PROTOS = {
     "dfx_se3_warp": (C.c_int, [C.c_void_p, C.POINTER(SE3), C.POINTER(Cam), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img),
                                C.POINTER(Img), C.POINTER(CorrItem)]),
     "dfx_track_frame": (C.c_int, [C.c_void_p, C.POINTER(SE3), C.POINTER(TrackLevel), C.c_int, C.c_float, C.POINTER(TrackResult)]),
+    "dfx_track_frame_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SE3), C.POINTER(TrackLevel), C.c_int, C.c_float, C.POINTER(TrackResult)]),
     "dfx_sparse_geometric_linearize": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SE3), C.POINTER(SE3), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                                  C.POINTER(Cam), C.POINTER(C.c_int32), C.c_int, C.POINTER(Img), C.POINTER(Img), C.POINTER(Img),
                                                  C.POINTER(Img), C.POINTER(Img), C.c_float, C.c_float, C.POINTER(C.c_float)]),

@@ -427,6 +427,39 @@ class CameraTracker:
     def GetError(self):
         return self.error_
 
+    def TrackFrameBatch(self, keyframes, pyr_img1, pyr_grad1, poses_ck=None):
+        """Track ONE live frame against N keyframes at once (dfx_track_frame_batch).  `keyframes` = [(pyr_img, pyr_dpt), ...];
+        every tracker starts from `poses_ck[k]` (identity when None, as after Reset()).  Returns the N TrackResult records.
+        This is the body of the loops in DeepFactors::Relocalize (deepfactors.cpp:713-743) and of the loop detector's geometry
+        check (loop_detector.cpp:146-167), which the reference runs one keyframe after the other."""
+        n, nl = len(keyframes), self.config_.pyramid_levels
+        lv = (_lib.TrackLevel * (n * nl))()
+        for k, (kimg, kdpt) in enumerate(keyframes):
+            for l in range(nl):
+                e = lv[k * nl + l]
+                e.cam = _cam(self.camera_pyr_[l])
+                e.img0, e.dpt0 = _img(kimg[l], "kf img"), _img(kdpt[l], "kf dpt")
+                e.img1, e.grad1 = _img(pyr_img1[l], "img1"), _img(pyr_grad1[l], "grad1", 2)
+                e.iterations = int(self.config_.iterations_per_level[l])
+        poses = (_lib.SE3 * n)()
+        for k in range(n):
+            poses[k] = _se3(np.array([0, 0, 0, 1, 0, 0, 0], np.float32) if poses_ck is None else poses_ck[k])
+        res = (_lib.TrackResult * n)()
+        check(_lib.lib().dfx_track_frame_batch(self.ctx.handle, n, poses, lv, nl, float(self.config_.huber_delta), res))
+        return list(res)
+
+    def Relocalize(self, keyframes, pyr_img1, pyr_grad1):
+        """DeepFactors::Relocalize (deepfactors.cpp:713-743): reset, track against every keyframe, keep the smallest error.
+        Returns (best index, pose_ck of that keyframe); the tracker is left configured on it, as the reference leaves it."""
+        res = self.TrackFrameBatch(keyframes, pyr_img1, pyr_grad1)
+        best = min(range(len(res)), key=lambda k: res[k].error)
+        r = res[best]
+        self.SetKeyframe(*keyframes[best])
+        self.pose_ck_ = np.array(list(r.pose_ck.q) + list(r.pose_ck.t), np.float32)
+        self.inliers_, self.error_ = float(r.inliers_frac), float(r.error)
+        self.last_result_ = r
+        return best, self.pose_ck_
+
 
 # ------------------------------------------------------------------------------------------------------------
 # SparseGeometricFactor (core/gtsam/sparse_geometric_factor.{h,cpp})

@@ -66,7 +66,8 @@ struct dfx_ctx {
   int stage_next = 0;
   char* result_host = nullptr;
   size_t result_bytes = 0;
-  void* track_state_dev = nullptr;
+  void* track_state_dev = nullptr;   // [TrackState x n][SimplePairDev x levels x n]
+  size_t track_bytes = 0;
   char* sg_dev = nullptr;      // sparse geometric: codes + points + rows
   size_t sg_bytes = 0;
 
@@ -627,52 +628,8 @@ DFX_API int dfx_se3_warp(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam,
   return finish_result(c, out, sizeof(dfx_corr_item));
 }
 
-DFX_API int dfx_track_frame(dfx_ctx* c, const dfx_se3* pose_init, const dfx_track_level* levels, int n_levels, float huber_delta,
-                            dfx_track_result* out) {
-  if (!c || !pose_init || !levels || !out) return fail(DFX_E_INVALID, "dfx_track_frame: null argument");
-  if (n_levels <= 0 || n_levels > 16) return fail(DFX_E_INVALID, "n_levels %d out of range [1,16]", n_levels);
-  int rc;
-  if ((rc = ensure_device(c))) return rc;
-  // validate every level first (no partial work on a bad argument)
-  std::vector<dfx::SimplePairDev> descs((size_t)n_levels);
-  int max_blocks = 1;
-  const dfx_se3 ident{ { 0, 0, 0, 1 }, { 0, 0, 0 } };
-  for (int l = 0; l < n_levels; ++l) {
-    if (levels[l].iterations < 0) return fail(DFX_E_INVALID, "level %d: negative iteration count", l);
-    if ((rc = fill_simple(&ident, &levels[l].cam, &levels[l].img0, &levels[l].img1, &levels[l].dpt0, &levels[l].grad1, nullptr, &descs[l]))) {
-      g_last_error = "level " + std::to_string(l) + ": " + g_last_error;
-      return rc;
-    }
-    const int b = simple_blocks(levels[l].img0.w, levels[l].img0.h);
-    if (b > max_blocks) max_blocks = b;
-  }
-  const size_t pbytes = (size_t)max_blocks * dfx::kSimpleRow * sizeof(float);
-  if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
-  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
-  const size_t sbytes = dfx::track_state_bytes();
-  if (!c->track_state_dev) DFX_HIP(hipMalloc(&c->track_state_dev, sbytes));
-  // upload the initial state through the staging ring
-  int slot;
-  char* host;
-  if ((rc = stage_acquire(c, sbytes, &slot, &host))) return rc;
-  double R[9], t[3] = { pose_init->t[0], pose_init->t[1], pose_init->t[2] };
-  quat_to_R(pose_init->q, R);
-  dfx::track_state_init(host, R, t);
-  DFX_HIP(hipMemcpyAsync(c->track_state_dev, host, sbytes, hipMemcpyHostToDevice, c->stream));
-  if ((rc = stage_release(c, slot))) return rc;
-  for (int l = n_levels - 1; l >= 0; --l) {
-    const int W = (int)levels[l].img0.w, H = (int)levels[l].img0.h;
-    const int blocks = simple_blocks(levels[l].img0.w, levels[l].img0.h);
-    for (int it = 0; it < levels[l].iterations; ++it)
-      DFX_HIP(dfx::launch_track_iteration(descs[l], c->track_state_dev, W, H, huber_delta, blocks, c->partials, c->stream));
-  }
-  if ((rc = ensure_result_host(c, sbytes))) return rc;
-  DFX_HIP(hipMemcpyAsync(c->result_host, c->track_state_dev, sbytes, hipMemcpyDeviceToHost, c->stream));
-  DFX_HIP(hipStreamSynchronize(c->stream));
-  float residual, inl;
-  int fails, iters;
-  dfx::track_state_read(c->result_host, R, t, &residual, &inl, &fails, &iters);
-  // rotation matrix -> unit quaternion (x y z w)
+namespace {
+void rot_to_quat(const double* R, float* qout) {   // rotation matrix -> unit quaternion (x y z w)
   double q[4];
   const double tr = R[0] + R[4] + R[8];
   if (tr > 0) { const double s = std::sqrt(tr + 1.0) * 2; q[3] = 0.25 * s; q[0] = (R[7] - R[5]) / s; q[1] = (R[2] - R[6]) / s; q[2] = (R[3] - R[1]) / s; }
@@ -680,16 +637,96 @@ DFX_API int dfx_track_frame(dfx_ctx* c, const dfx_se3* pose_init, const dfx_trac
   else if (R[4] > R[8]) { const double s = std::sqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[3] = (R[2] - R[6]) / s; q[0] = (R[1] + R[3]) / s; q[1] = 0.25 * s; q[2] = (R[5] + R[7]) / s; }
   else { const double s = std::sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[3] = (R[3] - R[1]) / s; q[0] = (R[2] + R[6]) / s; q[1] = (R[5] + R[7]) / s; q[2] = 0.25 * s; }
   const double qn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  for (int i = 0; i < 4; ++i) out->pose_ck.q[i] = (float)(q[i] / qn);
-  for (int i = 0; i < 3; ++i) out->pose_ck.t[i] = (float)t[i];
-  out->residual = residual;
-  out->inliers = (uint64_t)(inl + 0.5f);
+  for (int i = 0; i < 4; ++i) qout[i] = (float)(q[i] / qn);
+}
+
+// n independent trackers with a common schedule; levels is candidate-major: levels[k * n_levels + l].
+int track_frames_impl(dfx_ctx* c, int n, const dfx_se3* pose_init, const dfx_track_level* levels, int n_levels, float huber_delta,
+                      dfx_track_result* out) {
+  if (!c || !pose_init || !levels || !out) return fail(DFX_E_INVALID, "dfx_track_frame: null argument");
+  if (n <= 0 || n > 4096) return fail(DFX_E_INVALID, "candidate count %d out of range [1,4096]", n);
+  if (n_levels <= 0 || n_levels > 16) return fail(DFX_E_INVALID, "n_levels %d out of range [1,16]", n_levels);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  // one staged upload: [TrackState x n][SimplePairDev x n_levels x n (level-major)]
+  const size_t sbytes = dfx::track_state_bytes();
+  const size_t off_desc = ((sbytes * (size_t)n + 15) / 16) * 16;
+  const size_t total = off_desc + sizeof(dfx::SimplePairDev) * (size_t)n * n_levels;
+  int slot;
+  char* host;
+  if ((rc = stage_acquire(c, total, &slot, &host))) return rc;
+  dfx::SimplePairDev* hdesc = reinterpret_cast<dfx::SimplePairDev*>(host + off_desc);
+  // validate every level of every candidate first (no partial work on a bad argument)
+  int max_blocks = 1;
+  const dfx_se3 ident{ { 0, 0, 0, 1 }, { 0, 0, 0 } };
+  for (int k = 0; k < n; ++k)
+    for (int l = 0; l < n_levels; ++l) {
+      const dfx_track_level& L = levels[(size_t)k * n_levels + l];
+      const dfx_track_level& L0 = levels[l];
+      if (L.iterations < 0) return fail(DFX_E_INVALID, "candidate %d level %d: negative iteration count", k, l);
+      if (L.iterations != L0.iterations || L.img0.w != L0.img0.w || L.img0.h != L0.img0.h)
+        return fail(DFX_E_INVALID, "candidate %d level %d: schedule / image size differs from candidate 0", k, l);
+      if ((rc = fill_simple(&ident, &L.cam, &L.img0, &L.img1, &L.dpt0, &L.grad1, nullptr, &hdesc[(size_t)l * n + k]))) {
+        g_last_error = "candidate " + std::to_string(k) + " level " + std::to_string(l) + ": " + g_last_error;
+        return rc;
+      }
+      const int b = simple_blocks(L.img0.w, L.img0.h);
+      if (b > max_blocks) max_blocks = b;
+    }
+  const size_t pbytes = (size_t)n * max_blocks * dfx::kSimpleRow * sizeof(float);
+  if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
+  if (c->track_bytes < total) {
+    DFX_HIP(hipStreamSynchronize(c->stream));
+    if (c->track_state_dev) DFX_HIP(hipFree(c->track_state_dev));
+    c->track_state_dev = nullptr;
+    DFX_HIP(hipMalloc(&c->track_state_dev, total * 2));
+    c->track_bytes = total * 2;
+  }
+  for (int k = 0; k < n; ++k) {
+    double R[9], t[3] = { pose_init[k].t[0], pose_init[k].t[1], pose_init[k].t[2] };
+    quat_to_R(pose_init[k].q, R);
+    dfx::track_state_init(host + sbytes * (size_t)k, R, t);
+  }
+  DFX_HIP(hipMemcpyAsync(c->track_state_dev, host, total, hipMemcpyHostToDevice, c->stream));
+  if ((rc = stage_release(c, slot))) return rc;
+  const dfx::SimplePairDev* ddesc = reinterpret_cast<const dfx::SimplePairDev*>((const char*)c->track_state_dev + off_desc);
+  for (int l = n_levels - 1; l >= 0; --l) {
+    const int W = (int)levels[l].img0.w, H = (int)levels[l].img0.h;
+    const int blocks = simple_blocks(levels[l].img0.w, levels[l].img0.h);
+    for (int it = 0; it < levels[l].iterations; ++it)
+      DFX_HIP(dfx::launch_track_iteration(ddesc + (size_t)l * n, n, c->track_state_dev, W, H, huber_delta, blocks, c->partials, c->stream));
+  }
+  if ((rc = ensure_result_host(c, sbytes * (size_t)n))) return rc;
+  DFX_HIP(hipMemcpyAsync(c->result_host, c->track_state_dev, sbytes * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  DFX_HIP(hipStreamSynchronize(c->stream));
   const double area = (double)levels[0].img0.w * levels[0].img0.h;
-  out->inliers_frac = (float)(inl / area);
-  out->error = inl > 0 ? residual / inl : INFINITY;
-  out->iterations = iters;
-  out->solver_failures = fails;
+  for (int k = 0; k < n; ++k) {
+    double R[9], t[3];
+    float residual, inl;
+    int fails, iters;
+    dfx::track_state_read(c->result_host + sbytes * (size_t)k, R, t, &residual, &inl, &fails, &iters);
+    rot_to_quat(R, out[k].pose_ck.q);
+    for (int i = 0; i < 3; ++i) out[k].pose_ck.t[i] = (float)t[i];
+    out[k].residual = residual;
+    out[k].inliers = (uint64_t)(inl + 0.5f);
+    out[k].inliers_frac = (float)(inl / area);
+    out[k].error = inl > 0 ? residual / inl : INFINITY;
+    out[k].iterations = iters;
+    out[k].solver_failures = fails;
+  }
   return DFX_OK;
+}
+}  // namespace
+
+DFX_API int dfx_track_frame(dfx_ctx* c, const dfx_se3* pose_init, const dfx_track_level* levels, int n_levels, float huber_delta,
+                            dfx_track_result* out) {
+  return track_frames_impl(c, 1, pose_init, levels, n_levels, huber_delta, out);
+}
+
+DFX_API int dfx_track_frame_batch(dfx_ctx* c, int n, const dfx_se3* pose_init, const dfx_track_level* levels, int n_levels,
+                                  float huber_delta, dfx_track_result* out) {
+  return track_frames_impl(c, n, pose_init, levels, n_levels, huber_delta, out);
 }
 
 DFX_API int dfx_sparse_geometric_linearize(dfx_ctx* c, int cs, const dfx_se3* pose0, const dfx_se3* pose1, const float* code0,

@@ -82,8 +82,9 @@ hipError_t launch_depth_aligner_step(int cs, const SfmPairDev* pair_dev, int W, 
 size_t track_state_bytes();
 void track_state_init(void* host_state, const double* R, const double* t);
 void track_state_read(const void* host_state, double* R, double* t, float* residual, float* inliers, int* failures, int* iters);
-hipError_t launch_track_iteration(const SimplePairDev& p, void* state_dev, int W, int H, float huber_delta, int blocks, float* partials_dev,
-                                  hipStream_t stream);
+// one Gauss-Newton iteration of `n` independent trackers at one pyramid level: descs_dev[n], states_dev[n], partials [n][blocks][kSimpleRow]
+hipError_t launch_track_iteration(const SimplePairDev* descs_dev, int n, void* states_dev, int W, int H, float huber_delta, int blocks,
+                                  float* partials_dev, hipStream_t stream);
 
 // SparseGeometricFactor::linearize
 size_t sparse_geo_desc_bytes();

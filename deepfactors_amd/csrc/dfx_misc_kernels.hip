@@ -91,8 +91,13 @@ struct TrackState {      // device-resident
   float last_residual; float last_inliers; int solver_failures; int iterations_done;
 };
 
-__global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev p, const TrackState* __restrict__ st, const int W, const int H,
-                                                     const float huber_delta, float* __restrict__ partials) {
+// blockIdx.y = candidate: Relocalize / the loop-closure geometry checks track ONE live frame against N keyframes
+// (deepfactors.cpp:713-743, loop_detector.cpp:146-167); descriptors, states and partials are arrays over candidates.
+__global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev* __restrict__ descs, const TrackState* __restrict__ states, const int W,
+                                                     const int H, const float huber_delta, float* __restrict__ partials_all) {
+  const SimplePairDev& p = descs[blockIdx.y];
+  const TrackState* st = states + blockIdx.y;
+  float* partials = partials_all + (size_t)blockIdx.y * gridDim.x * kSimpleRow;
   Geo g = geo_from(p);
 #pragma unroll
   for (int q = 0; q < 9; ++q) g.R[q] = st->Rf[q];
@@ -134,7 +139,9 @@ __global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev p, cons
   block_reduce_store<29>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
-__global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__ partials, const int nblocks, TrackState* __restrict__ st) {
+__global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__ partials_all, const int nblocks, TrackState* __restrict__ states) {
+  const float* partials = partials_all + (size_t)blockIdx.x * nblocks * kSimpleRow;
+  TrackState* st = states + blockIdx.x;
   __shared__ double red[32][kSimpleRow];
   __shared__ double sum[kSimpleRow];
   const int e = threadIdx.x & 31, rg = threadIdx.x >> 5;
@@ -194,12 +201,12 @@ __global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__
 
 size_t track_state_bytes() { return sizeof(TrackState); }
 
-hipError_t launch_track_iteration(const SimplePairDev& p, void* state_dev, int W, int H, float huber_delta, int blocks, float* partials_dev,
-                                  hipStream_t stream) {
-  hipLaunchKernelGGL(k_se3_step_dev, dim3(blocks), dim3(kT), 0, stream, p, (const TrackState*)state_dev, W, H, huber_delta, partials_dev);
+hipError_t launch_track_iteration(const SimplePairDev* descs_dev, int n, void* states_dev, int W, int H, float huber_delta, int blocks,
+                                  float* partials_dev, hipStream_t stream) {
+  hipLaunchKernelGGL(k_se3_step_dev, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (const TrackState*)states_dev, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_track_update, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (TrackState*)state_dev);
+  hipLaunchKernelGGL(k_track_update, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (TrackState*)states_dev);
   return hipGetLastError();
 }
 

@@ -160,6 +160,12 @@ typedef struct dfx_track_result {
 } dfx_track_result;
 DFX_API int dfx_track_frame(dfx_ctx* ctx, const dfx_se3* pose_ck_init, const dfx_track_level* levels, int n_levels,
                             float huber_delta, dfx_track_result* out);
+/* N independent trackers in one schedule of launches (grid.y = candidate): DeepFactors::Relocalize tracks the live frame
+ * against every keyframe and keeps the smallest error (core/deepfactors.cpp:713-743), the loop detector's geometry check does
+ * the same over its candidates (core/system/loop_detector.cpp:146-167).  levels[k * n_levels + l] = level l of candidate k;
+ * all candidates share the iteration schedule and the image sizes of candidate 0.  out[k] as for dfx_track_frame. */
+DFX_API int dfx_track_frame_batch(dfx_ctx* ctx, int n, const dfx_se3* pose_ck_init, const dfx_track_level* levels, int n_levels,
+                                  float huber_delta, dfx_track_result* out);
 
 /* ---- SfmAligner<float,CS> (cuda/cu_sfmaligner.h:50-97) -------------------------------------- */
 /* RunStep (cu_sfmaligner.cpp:149-185).  cs in {16, 32, 64}.  std0 may be NULL (dead input in the reference,

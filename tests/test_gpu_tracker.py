@@ -76,3 +76,42 @@ def test_tracker_no_overlap_is_reported(dfx):
     tr.SetPoseEstimate(np.array([0, 0, 0, 1, 100.0, 0, 0], np.float32))
     tr.TrackFrame([p["img1"]], [p["grad1"]])
     assert tr.GetInliers() == 0.0 and tr.GetError() == float("inf") and tr.last_result_.solver_failures == 3
+
+
+def test_relocalize_batch_equals_sequential(dfx, oracle):
+    """DeepFactors::Relocalize (deepfactors.cpp:713-743): the live frame tracked against N keyframes in ONE schedule of
+    launches gives, per keyframe, the bytes the one-after-the-other loop gives, and picks the keyframe it belongs to."""
+    from deepfactors_amd import synth
+    import time
+    cfg = dfx.TrackerConfig(3, (10, 5, 5), 0.1)
+    pairs = [synth.to_numpy(synth.make_pair(320, 240, 16, seed=30 + k, with_decoder=False)) for k in range(5)]
+    cams = synth.camera_pyramid(pairs[0]["cam"], 3)
+    # live frame = img1 of pair 2; keyframes = img0/dpt0 of all five pairs (only keyframe 2 sees the same scene)
+    live = _pyramid_np(oracle, pairs[2]["img0"], pairs[2]["img1"], pairs[2]["dpt0"], 3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    live_img, live_grad = [t(l["img1"]) for l in live], [t(l["grad1"]) for l in live]
+    kfs = []
+    for p in pairs:
+        lv = _pyramid_np(oracle, p["img0"], p["img1"], p["dpt0"], 3)
+        kfs.append(([t(l["img0"]) for l in lv], [t(l["dpt0"]) for l in lv]))
+    tr = dfx.CameraTracker(cams, cfg)
+    seq = []
+    for kimg, kdpt in kfs:   # the reference's loop
+        tr.SetKeyframe(kimg, kdpt)
+        tr.Reset()
+        pose = tr.TrackFrame(live_img, live_grad)
+        seq.append((pose.copy(), tr.GetError(), tr.GetInliers()))
+    res = tr.TrackFrameBatch(kfs, live_img, live_grad)
+    for k, r in enumerate(res):
+        pose = np.array(list(r.pose_ck.q) + list(r.pose_ck.t), np.float32)
+        assert np.array_equal(pose, seq[k][0]), k
+        assert (r.error == seq[k][1] or (np.isinf(r.error) and np.isinf(seq[k][1]))) and r.inliers_frac == np.float32(seq[k][2])
+    best, pose = tr.Relocalize(kfs, live_img, live_grad)
+    assert best == 2 and best == int(np.argmin([s[1] for s in seq]))
+    assert np.array_equal(pose, seq[2][0]) and tr.GetError() == seq[2][1]
+    gt = pairs[2]["pose10_true"]
+    assert np.linalg.norm(pose[4:] - gt[4:]) < 2e-3 and np.linalg.norm(pose[:4] - gt[:4]) < 1e-3
+    # mismatched schedules are rejected before any work
+    with pytest.raises(dfx.DfxError):
+        bad = [(kfs[0][0], kfs[0][1]), ([kfs[1][0][0][:100].contiguous()] + kfs[1][0][1:], kfs[1][1])]
+        tr.TrackFrameBatch(bad, live_img, live_grad)

@@ -75,6 +75,28 @@ def track_dev():
 pd = track_dev()
 out["cfg1_se3_tracker"].update(device_resident_ms_per_frame=timed(track_dev, 20, 2) * 1e3, device_dt=float(np.linalg.norm(pd[4:] - gt[4:])),
                                device_dq=float(np.linalg.norm(pd[:4] - gt[:4])))
+# Relocalize (deepfactors.cpp:713-743): the live frame against 16 keyframes -- one after the other vs one batched schedule
+kf16 = []
+for k in range(16):
+    q = synth.make_pair(640, 480, 16, seed=0xDF10 + k, device=dev, with_decoder=False)
+    lq = pyramid(q, 3)
+    kf16.append(([l["img0"] for l in lq], [l["dpt0"] for l in lq]))
+kf16[5] = ([l["img0"] for l in lv], [l["dpt0"] for l in lv])
+live_img, live_grad = [l["img1"] for l in lv], [l["grad1"] for l in lv]
+
+
+def reloc_seq():
+    best = (float("inf"), -1)
+    for k, (ki, kd) in enumerate(kf16):
+        trk.SetKeyframe(ki, kd); trk.Reset(); trk.TrackFrame(live_img, live_grad)
+        best = min(best, (trk.GetError(), k))
+    return best[1]
+
+
+assert reloc_seq() == 5 and trk.Relocalize(kf16, live_img, live_grad)[0] == 5
+out["relocalize_16_keyframes"] = dict(sequential_ms=timed(reloc_seq, 5, 1) * 1e3,
+                                      batched_ms=timed(lambda: trk.Relocalize(kf16, live_img, live_grad), 10, 2) * 1e3)
+trk.SetKeyframe([l["img0"] for l in lv], [l["dpt0"] for l in lv])
 n0 = synth.to_numpy({k: lv[0][k] for k in lv[0]})
 t0 = time.perf_counter()
 for _ in range(5):
