@@ -6,6 +6,7 @@ from ._lib import DfxError, EXPORTED_SYMBOLS, LIB_PATH, item_size  # noqa: F401
 from .aligners import (CameraTracker, Context, CorrespondenceReductionItem, DenseSfmParams, DepthAligner, GaussianBlurDown,  # noqa: F401
                        JTJJrReductionItem, SE3Aligner, SfmAligner, SfmAlignerParams, SobelGradients, SparseGeometricFactor, SquaredError,
                        TrackerConfig, UpdateDepth, default_context)
-from .keyframe import Frame, Keyframe, KeyframeMap, save_trajectory_tum  # noqa: F401
+from .keyframe import (Frame, Keyframe, KeyframeMap, LoadJsonNetworkConfig, NetworkConfig, save_keyframes, save_results,  # noqa: F401
+                       save_trajectory_tum, write_png)
 
 __version__ = "0.1.0"

@@ -146,3 +146,126 @@ def save_trajectory_tum(path, timestamps, poses_wk):
         for ts, p in zip(timestamps, poses_wk):
             p = np.asarray(p, np.float64)
             f.write(f"{ts:.6f} {p[4]:.6f} {p[5]:.6f} {p[6]:.6f} {p[0]:.6f} {p[1]:.6f} {p[2]:.6f} {p[3]:.6f}\n")
+
+
+# ---- formats at the edges of the path ---------------------------------------------------------------------
+import json as _json
+import os as _os
+import struct as _struct
+import zlib as _zlib
+from dataclasses import dataclass, field
+from typing import List
+
+
+@dataclass
+class NetworkConfig:
+    """``DecoderNetwork::NetworkConfig`` (core/network/decoder_network.h): what the mapper needs to know about the decoder whose
+    outputs feed ``Keyframe.SetDecoderOutputs`` -- input size, pyramid depth, code size, avg_dpt, camera, tensor names."""
+    graph_path: str = ""
+    input_width: int = 0
+    input_height: int = 0
+    pyramid_levels: int = 0
+    code_size: int = 0
+    grayscale: bool = True
+    avg_dpt: float = 2.0
+    input_image_name: str = ""
+    input_code_name: str = ""
+    depth_est_names: List[str] = field(default_factory=list)
+    depth_std_names: List[str] = field(default_factory=list)
+    depth_jac_names: List[str] = field(default_factory=list)
+    depth_pred: bool = False
+    depth_pred_names: List[str] = field(default_factory=list)
+    code_pred_name: str = ""
+    camera: dict = field(default_factory=dict)   # fx fy u0 v0 (of the network's input size)
+
+    def camera_array(self):
+        """[fx, fy, u0, v0, w, h] as the aligners take it."""
+        c = self.camera
+        return np.array([c["fx"], c["fy"], c["u0"], c["v0"], self.input_width, self.input_height], np.float32)
+
+
+def LoadJsonNetworkConfig(cfgpath):
+    """decoder_network.cpp:231-325: same keys, same checks (a missing key is an error), tensor names cut after the last ':',
+    a relative graph_path is resolved against the directory of the cfg file."""
+    try:
+        with open(cfgpath) as fh:
+            root = _json.load(fh)
+    except OSError as e:
+        raise _al.DfxError(-1, f"Could not load network config: {cfgpath} ({e})")
+
+    def need(node, key, what="network config"):
+        if key not in node:
+            raise _al.DfxError(-1, f"{what}: missing key '{key}' in {cfgpath}")
+        return node[key]
+
+    cut = lambda s: s[: s.rfind(":")] if ":" in s else s
+    names = lambda v: [cut(x) for x in v]
+    cfg = NetworkConfig()
+    gp = need(root, "graph_path")
+    cfg.graph_path = gp if gp.startswith("/") else _os.path.join(_os.path.dirname(cfgpath), gp)
+    cfg.input_width, cfg.input_height = int(need(root, "input_width")), int(need(root, "input_height"))
+    cfg.pyramid_levels, cfg.code_size = int(need(root, "pyramid_levels")), int(need(root, "code_size"))
+    cfg.grayscale, cfg.avg_dpt = bool(need(root, "grayscale")), float(need(root, "avg_dpt"))
+    inn = need(root, "input_names")
+    cfg.input_image_name, cfg.input_code_name = cut(need(inn, "image", "input_names")), cut(need(inn, "code", "input_names"))
+    on = need(root, "output_names")
+    for key, attr in (("depth_est", "depth_est_names"), ("depth_stdev", "depth_std_names"), ("depth_jac", "depth_jac_names")):
+        v = need(on, key, "output_names")
+        if not isinstance(v, list):
+            raise _al.DfxError(-1, f"output_names.{key} must be an array in {cfgpath}")
+        setattr(cfg, attr, names(v))
+    if root.get("depth_pred"):
+        cfg.depth_pred = True
+        cfg.depth_pred_names = names(need(on, "depth_pred", "output_names"))
+        cfg.code_pred_name = names(need(on, "code_pred", "output_names"))[0]
+    cam = need(root, "camera")
+    cfg.camera = {k: float(need(cam, k, "camera")) for k in ("fx", "fy", "u0", "v0")}
+    return cfg
+
+
+def write_png(path, img):
+    """Minimal PNG encoder (zlib only): uint8 [H][W] / [H][W][3] or uint16 [H][W] (big-endian samples, as PNG stores them)."""
+    a = np.ascontiguousarray(img)
+    if a.dtype == np.uint16 and a.ndim == 2:
+        depth, ctype, raw = 16, 0, a.astype(">u2").tobytes()
+    elif a.dtype == np.uint8 and a.ndim == 2:
+        depth, ctype, raw = 8, 0, a.tobytes()
+    elif a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == 3:
+        depth, ctype, raw = 8, 2, a.tobytes()
+    else:
+        raise _al.DfxError(-1, f"write_png: unsupported array {a.dtype} {a.shape}")
+    h, w = a.shape[:2]
+    stride = len(raw) // h
+    scan = b"".join(b"\x00" + raw[y * stride:(y + 1) * stride] for y in range(h))   # filter type 0 on every scanline
+
+    def chunk(tag, data):
+        return _struct.pack(">I", len(data)) + tag + data + _struct.pack(">I", _zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", _struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+                + chunk(b"IDAT", _zlib.compress(scan, 6)) + chunk(b"IEND", b""))
+
+
+def save_keyframes(directory, keyframes, cam):
+    """``DeepFactors::SaveKeyframes`` (core/deepfactors.cpp:539-570): per keyframe `<timestamp>_dpt.png` = level-0 depth x 5000 as
+    16-bit PNG (saturating, like cv::Mat::convertTo) and `<timestamp>_rgb.png` when the keyframe carries `color_img`
+    (uint8 [H][W][3]); `intrinsics.txt` = "fx fy u0 v0 w h"."""
+    kdir = _os.path.join(directory, "keyframes")
+    _os.makedirs(kdir, exist_ok=True)
+    for kf in keyframes:
+        ts = f"{kf.timestamp:.6f}"   # std::to_string(double)
+        d = kf.pyr_dpt[0].detach().cpu().numpy().astype(np.float64) * 5000.0
+        write_png(_os.path.join(kdir, ts + "_dpt.png"), np.clip(np.rint(d), 0, 65535).astype(np.uint16))
+        col = getattr(kf, "color_img", None)
+        if col is not None:
+            write_png(_os.path.join(kdir, ts + "_rgb.png"), np.asarray(col, np.uint8))
+    c = np.asarray(cam, np.float64)
+    with open(_os.path.join(kdir, "intrinsics.txt"), "w") as f:
+        f.write(" ".join(f"{v:g}" for v in c[:6]))
+
+
+def save_results(directory, keyframes, cam):
+    """``DeepFactors::SaveResults`` (core/deepfactors.cpp:573-594): trajectory.txt (TUM, keyframe poses) + SaveKeyframes."""
+    _os.makedirs(directory, exist_ok=True)
+    save_trajectory_tum(_os.path.join(directory, "trajectory.txt"), [kf.timestamp for kf in keyframes], [kf.pose_wk for kf in keyframes])
+    save_keyframes(directory, keyframes, cam)

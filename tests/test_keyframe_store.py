@@ -72,3 +72,44 @@ def test_keyframe_build_matches_oracle(dfx, oracle):
         assert float(kf.pyr_vld[i].min()) == 1.0
     assert np.array_equal(kf.dpt_grad.cpu().numpy(), oracle.sobel(kf.pyr_dpt[0].cpu().numpy()))
     assert kf.nbytes() > 0 and kf.IsKeyframe() and kf.Name() == "kf0"
+
+
+def test_network_config_loader(tmp_path):
+    """decoder_network.cpp:231-325 on a config with the reference's keys."""
+    import json
+    from deepfactors_amd import DfxError
+    from deepfactors_amd.keyframe import LoadJsonNetworkConfig
+    cfg = {"graph_path": "net.pb", "input_width": 256, "input_height": 192, "pyramid_levels": 4, "code_size": 32, "grayscale": True,
+           "avg_dpt": 2.0, "input_names": {"image": "input/image:0", "code": "input/code:0"},
+           "output_names": {"depth_est": ["d0:0", "d1:0"], "depth_stdev": ["s0:0", "s1:0"], "depth_jac": ["j0:0", "j1:0"]},
+           "camera": {"fx": 200.5, "fy": 201.5, "u0": 127.5, "v0": 95.5}}
+    p = tmp_path / "scannet256.cfg"
+    p.write_text(json.dumps(cfg))
+    c = LoadJsonNetworkConfig(str(p))
+    assert c.graph_path == str(tmp_path / "net.pb") and (c.input_width, c.input_height, c.pyramid_levels, c.code_size) == (256, 192, 4, 32)
+    assert c.input_image_name == "input/image" and c.depth_jac_names == ["j0", "j1"] and not c.depth_pred
+    assert np.allclose(c.camera_array(), [200.5, 201.5, 127.5, 95.5, 256, 192])
+    del cfg["code_size"]
+    p.write_text(json.dumps(cfg))
+    with pytest.raises(DfxError):
+        LoadJsonNetworkConfig(str(p))
+    with pytest.raises(DfxError):
+        LoadJsonNetworkConfig(str(tmp_path / "missing.cfg"))
+
+
+def test_save_results_formats(tmp_path):
+    """SaveResults / SaveKeyframes (deepfactors.cpp:539-594): TUM trajectory, depth x 5000 as 16-bit PNG, intrinsics.txt."""
+    from PIL import Image
+    from deepfactors_amd.keyframe import Keyframe, save_results
+    kf = Keyframe(1, 16, 12, 16, device="cpu")
+    kf.timestamp, kf.id = 12.5, 3
+    kf.pose_wk = np.array([0, 0, 0, 1, 0.1, 0.2, 0.3], np.float32)
+    d = np.linspace(0.0, 14.0, 16 * 12, dtype=np.float32).reshape(12, 16)   # 14 m x 5000 saturates uint16
+    kf.pyr_dpt[0].copy_(torch.from_numpy(d))
+    kf.color_img = (np.arange(16 * 12 * 3) % 251).astype(np.uint8).reshape(12, 16, 3)
+    save_results(str(tmp_path), [kf], [100.0, 101.0, 8.0, 6.0, 16, 12])
+    got = np.array(Image.open(tmp_path / "keyframes" / "12.500000_dpt.png"))
+    assert got.dtype in (np.uint16, np.int32) and np.array_equal(got.astype(np.int64), np.clip(np.rint(d.astype(np.float64) * 5000), 0, 65535).astype(np.int64))
+    assert np.array_equal(np.array(Image.open(tmp_path / "keyframes" / "12.500000_rgb.png")), kf.color_img)
+    assert (tmp_path / "keyframes" / "intrinsics.txt").read_text() == "100 101 8 6 16 12"
+    assert (tmp_path / "trajectory.txt").read_text().split() == ["12.500000", "0.100000", "0.200000", "0.300000", "0.000000", "0.000000", "0.000000", "1.000000"]
