@@ -1,0 +1,118 @@
+"""The GTSAM seam of the path in plain arrays: ``df::PhotometricFactor<float,CS>`` (core/gtsam/photometric_factor.{h,cpp}).
+
+GTSAM itself is out of scope (and absent here); what the mapper hands to it per factor -- the HessianFactor ingredients
+(keys, G11 G12 G13 G22 G23 G33, g1 g2 g3, f) and the scalar error -- is reproduced value for value, including the
+relinearisation cache (GetJacobiansIfNeeded, photometric_factor.cpp:296-327), the residual rescaling
+(:209-216, :275-282) and the hard-coded avg_dpt = 2.0 of UpdateDepthMaps (:331-341)."""
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+
+from . import aligners as _al
+
+
+def _quat_to_R(q):
+    x, y, z, w = [float(v) for v in q]
+    n = np.sqrt(x * x + y * y + z * z + w * w)
+    x, y, z, w = x / n, y / n, z / n, w / n
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def pose_local(first, second):
+    """gtsam::traits<SE3>::Local (gtsam_traits.h:66-72): (t2 - t1, log(R2 R1^T)); poses are [qx qy qz qw tx ty tz]."""
+    first, second = np.asarray(first, np.float64), np.asarray(second, np.float64)
+    dR = _quat_to_R(second[:4]) @ _quat_to_R(first[:4]).T
+    ang = np.arccos(np.clip((np.trace(dR) - 1.0) / 2.0, -1.0, 1.0))
+    w = np.array([dR[2, 1] - dR[1, 2], dR[0, 2] - dR[2, 0], dR[1, 0] - dR[0, 1]]) / 2.0
+    if ang > 1e-12:
+        w = w * ang / np.sin(ang)
+    return np.concatenate([second[4:] - first[4:], w])
+
+
+def pose_equals(a, b, tol):
+    return float(np.linalg.norm(pose_local(a, b))) < tol
+
+
+@dataclass
+class HessianBlocks:
+    """Arguments of ``gtsam::HessianFactor(keys, Gs, gs, f)`` (photometric_factor.cpp:105-161): e = x^T G x - 2 x^T g + f."""
+    keys: List[object]
+    Gs: List[np.ndarray]   # G11 G12 G13 G22 G23 G33, float64
+    gs: List[np.ndarray]   # g1 g2 g3 = -Jtr blocks, float64
+    f: float               # rescaled residual
+
+
+class PhotometricFactor:
+    """One keyframe -> frame photometric factor at one pyramid level.  `kf` is a ``deepfactors_amd.keyframe.Keyframe``, `fr` a
+    ``Frame`` (or Keyframe); `aligner` a shared ``SfmAligner``.  Values are passed directly instead of a gtsam::Values."""
+
+    def __init__(self, cam, kf, fr, pose0_key, pose1_key, code0_key, pyrlevel, aligner, update_valid=True):
+        self.cam_ = np.asarray(cam, np.float32)
+        self.kf_, self.fr_, self.pyrlevel_, self.aligner_ = kf, fr, int(pyrlevel), aligner
+        self.keys_ = [pose0_key, pose1_key, code0_key]
+        self.update_valid_ = update_valid
+        self.first_ = True
+        self.lin_pose0_ = self.lin_pose1_ = self.lin_code0_ = None
+        self.lin_system_ = None
+        self.linearizations_ = 0   # number of RunAlignmentStep calls (observable effect of the cache)
+
+    def Name(self):
+        return f"PhotometricFactor {self.keys_[0]} -> {self.keys_[1]}, pyrlevel = {self.pyrlevel_}"
+
+    def dim(self):
+        return 12 + self.aligner_.CS
+
+    # -- photometric_factor.cpp:331-341
+    def UpdateDepthMaps(self, code0):
+        i = self.pyrlevel_
+        _al.UpdateDepth(code0, self.kf_.pyr_prx_orig[i], self.kf_.pyr_jac[i], 2.0, self.kf_.pyr_dpt[i], self.aligner_.ctx)
+
+    # -- :197-217
+    def RunWarping(self, pose0, pose1, code0):
+        i = self.pyrlevel_
+        r = self.aligner_.EvaluateError(pose0, pose1, self.cam_, self.kf_.pyr_img[i], self.fr_.pyr_img[i], self.kf_.pyr_dpt[i],
+                                        self.kf_.pyr_stdev[i], self.fr_.pyr_grad[i])
+        residual = r.residual / r.inliers * float(self.cam_[4]) * float(self.cam_[5]) if r.inliers > 0 else float("inf")
+        return residual, r.inliers
+
+    # -- :222-293
+    def RunAlignmentStep(self, pose0, pose1, code0):
+        self.UpdateDepthMaps(code0)
+        i = self.pyrlevel_
+        item = self.aligner_.RunStep(pose0, pose1, code0, self.cam_, self.kf_.pyr_img[i], self.fr_.pyr_img[i], self.kf_.pyr_dpt[i],
+                                     self.kf_.pyr_stdev[i], self.kf_.pyr_vld[i], self.kf_.pyr_jac[i], self.fr_.pyr_grad[i])
+        self.linearizations_ += 1
+        item.scaled_residual = (item.residual / item.inliers * float(self.cam_[4]) * float(self.cam_[5])) if item.inliers > 0 else float("inf")
+        return item
+
+    # -- :296-327: relinearise only when a value moved by >= 1e-6 in its tangent space
+    def GetJacobiansIfNeeded(self, pose0, pose1, code0):
+        eps = 1e-6
+        code0 = np.asarray(code0, np.float64)
+        if (self.first_ or not pose_equals(pose0, self.lin_pose0_, eps) or not pose_equals(pose1, self.lin_pose1_, eps)
+                or not float(np.linalg.norm(code0 - self.lin_code0_)) < eps):
+            self.first_ = False
+            self.lin_system_ = self.RunAlignmentStep(pose0, pose1, code0)
+            self.lin_pose0_, self.lin_pose1_ = np.array(pose0, np.float64), np.array(pose1, np.float64)
+            self.lin_code0_ = code0.copy()
+        return self.lin_system_
+
+    # -- :60-81
+    def error(self, pose0, pose1, code0):
+        self.UpdateDepthMaps(code0)
+        return 0.5 * self.RunWarping(pose0, pose1, code0)[0]
+
+    # -- :85-161
+    def linearize(self, pose0, pose1, code0) -> HessianBlocks:
+        sys = self.GetJacobiansIfNeeded(pose0, pose1, code0)
+        # "No overlap between images": the reference tests `sys.inliers < 0` on an unsigned count (:100), which never fires; like
+        # it, a pair without overlap yields an all-zero system with f = +inf (RunAlignmentStep, :279-282), not a null factor.
+        cs = self.aligner_.CS
+        JtJ = np.asarray(sys.toDenseMatrix(), np.float64)
+        Jtr = -np.asarray(sys.Jtr, np.float64)
+        Gs = [JtJ[0:6, 0:6], JtJ[0:6, 6:12], JtJ[0:6, 12:12 + cs], JtJ[6:12, 6:12], JtJ[6:12, 12:12 + cs], JtJ[12:12 + cs, 12:12 + cs]]
+        gs = [Jtr[0:6], Jtr[6:12], Jtr[12:12 + cs]]
+        return HessianBlocks(list(self.keys_), [g.copy() for g in Gs], [g.copy() for g in gs], float(sys.scaled_residual))

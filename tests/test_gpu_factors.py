@@ -1,0 +1,78 @@
+"""PhotometricFactor mirror (deepfactors_amd/factors.py) vs the oracle: the HessianFactor ingredients the mapper hands to GTSAM."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dfx, w, h, cs, seed):
+    from deepfactors_amd import synth
+    from deepfactors_amd.keyframe import Frame, Keyframe
+    n = synth.to_numpy(synth.make_pair(w, h, cs, seed=seed))
+    kf = Keyframe(1, w, h, cs, device="cuda")
+    kf.FillPyramids(torch.from_numpy(n["img0"]))
+    kf.SetDecoderOutputs([n["prx_orig"]], [np.zeros_like(n["prx_orig"])], [n["prx_jac"].reshape(h, w * cs)])
+    kf.pyr_vld[0].zero_()
+    fr = Frame(1, w, h, device="cuda")
+    fr.FillPyramids(torch.from_numpy(n["img1"]))
+    return n, kf, fr
+
+
+def test_photometric_factor_linearize_and_error(dfx, oracle):
+    w, h, cs = 160, 120, 32
+    n, kf, fr = _setup(dfx, w, h, cs, 41)
+    al = dfx.SfmAligner(code_size=cs)
+    f = dfx.PhotometricFactor(n["cam"], kf, fr, "p0", "p1", "c0", 0, al)
+    pose1 = n["pose1"].copy(); pose1[4] += 0.01
+    code = (n["code"] * 0.7).astype(np.float32)
+    hb = f.linearize(n["pose0"], pose1, code)
+    # oracle: decode depth with the same code, step, rescale
+    dpt = oracle.update_depth(code, n["prx_orig"], n["prx_jac"], 2.0)
+    grad1 = oracle.sobel(n["img1"])
+    ref = oracle.sfm_step(n["pose0"], pose1, n["cam"], n["img0"], n["img1"], dpt, n["prx_jac"], grad1)
+    J = ref.dense().astype(np.float64)
+    scale = np.abs(J).max()
+    blocks = [J[0:6, 0:6], J[0:6, 6:12], J[0:6, 12:], J[6:12, 6:12], J[6:12, 12:], J[12:, 12:]]
+    assert hb.keys == ["p0", "p1", "c0"] and len(hb.Gs) == 6 and len(hb.gs) == 3
+    for g, b in zip(hb.Gs, blocks):
+        assert g.dtype == np.float64 and g.shape == b.shape and np.abs(g - b).max() <= 1e-4 * scale
+    gref = -np.asarray(ref.Jtr, np.float64)
+    gsc = max(np.abs(gref).max(), np.sqrt(scale * ref.residual))
+    assert np.abs(np.concatenate(hb.gs) - gref).max() <= 1e-4 * gsc
+    assert abs(hb.f - ref.residual / ref.inliers * w * h) <= 1e-4 * hb.f
+    # the keyframe's depth and valid maps were updated in place (UpdateDepthMaps; dense_sfm.h:161)
+    assert np.abs(kf.pyr_dpt[0].cpu().numpy() - dpt).max() < 1e-4 and float(kf.pyr_vld[0].sum()) == ref.inliers
+    # error() = 0.5 * rescaled EvaluateError residual
+    e_res, e_inl = oracle.sfm_error(n["pose0"], pose1, n["cam"], n["img0"], n["img1"], dpt)
+    assert abs(f.error(n["pose0"], pose1, code) - 0.5 * e_res / e_inl * w * h) <= 1e-4 * 0.5 * e_res / e_inl * w * h
+
+
+def test_photometric_factor_relinearisation_cache(dfx):
+    """GetJacobiansIfNeeded (photometric_factor.cpp:296-327): a value must move by >= 1e-6 in its tangent space."""
+    w, h, cs = 96, 64, 16
+    n, kf, fr = _setup(dfx, w, h, cs, 42)
+    f = dfx.PhotometricFactor(n["cam"], kf, fr, 0, 1, 2, 0, dfx.SfmAligner(code_size=cs))
+    a = f.linearize(n["pose0"], n["pose1"], n["code"])
+    b = f.linearize(n["pose0"], n["pose1"], n["code"])
+    assert f.linearizations_ == 1 and all(np.array_equal(x, y) for x, y in zip(a.Gs, b.Gs))
+    p1 = n["pose1"].astype(np.float64).copy(); p1[4] += 5e-7
+    f.linearize(n["pose0"], p1, n["code"])
+    assert f.linearizations_ == 1
+    p1[4] += 1e-4
+    f.linearize(n["pose0"], p1, n["code"])
+    assert f.linearizations_ == 2
+    c = n["code"].copy(); c[3] += 1e-3
+    f.linearize(n["pose0"], p1, c)
+    assert f.linearizations_ == 3
+    assert dfx.pose_equals(n["pose1"], n["pose1"], 1e-6) and not dfx.pose_equals(n["pose0"], p1, 1e-6)
+
+
+def test_photometric_factor_no_overlap(dfx):
+    w, h, cs = 96, 64, 16
+    n, kf, fr = _setup(dfx, w, h, cs, 43)
+    f = dfx.PhotometricFactor(n["cam"], kf, fr, 0, 1, 2, 0, dfx.SfmAligner(code_size=cs))
+    far = n["pose1"].copy(); far[4] += 1000.0
+    hb = f.linearize(n["pose0"], far, n["code"])
+    assert np.isinf(hb.f) and all(float(np.abs(g).max()) == 0.0 for g in hb.Gs)
+    assert np.isinf(f.error(n["pose0"], far, n["code"]))
