@@ -11,8 +11,8 @@ xGMI.  The default, 128 pairs per GPU, is the per-GPU shard of BASELINE configs[
 quoted in DESIGN.md section 5.
 
 Multi-GPU: one process per GPU (torch.distributed, backend "nccl" = RCCL); pairs are independent units, sharded
-contiguously across ranks (weak scaling: --pairs per GPU); the only exchange step is the all-reduce of the
-block-tridiagonal normal equations (SURVEY.md section 8e option 2).
+contiguously across ranks (weak scaling: --pairs per GPU); the only exchange step is the RCCL reduce of the
+block-tridiagonal normal equations onto rank 0, where the solve runs (SURVEY.md section 8e option 2).
 
 Output: ONE JSON line on rank 0 (see the driver contract in the task statement), including
   roofline     -- step kernel only: algorithmic bytes (148 B/px x px x pairs per launch) / HIP-event duration
@@ -115,7 +115,7 @@ def main():
         # blocks of this rank's pairs (dfx_sfm_step_batch_neq_async = RunStepBatchAsync + assemble_native, fused)
         al.RunStepBatchAssembleAsync(arr, items, neq, rank * P)
         if dist is not None:
-            neq.all_reduce(dist)                               # RCCL over xGMI
+            neq.reduce(dist, root=0)                           # RCCL reduce over xGMI onto the rank that solves
 
     def barrier():
         if dist is not None:
@@ -175,7 +175,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1] geometry in the batch size of configs[3] (1k pairs / 8 GPUs): {P} independent {W}x{H} pairs per GPU per step, "
                                    f"CS={CS}, SfmAligner::RunStep (SE3+code Jacobians, JtJ/Jtr) in one launch, level 0; "
-                                   "+ normal-equation block assembly" + (" + RCCL all-reduce" if world > 1 else ""),
+                                   "+ normal-equation block assembly" + (" + RCCL reduce to rank 0" if world > 1 else ""),
                        "pairs_per_gpu": P, "width": W, "height": H, "code_size": CS,
                        "parallelism": f"pairs sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -76,8 +76,13 @@ class NormalEquations:
                                                      self.F, C.c_void_p(self.H.data_ptr()), C.c_void_p(self.g.data_ptr()), 1))
 
     def all_reduce(self, dist):
-        """The exchange step: sum the ranks' partial systems (RCCL ring all-reduce over xGMI on MI355X nodes)."""
+        """Exchange step, replicated result: sum the ranks' partial systems on every rank (RCCL all-reduce over xGMI)."""
         dist.all_reduce(self.buf)
+
+    def reduce(self, dist, root=0):
+        """Exchange step, as the solver needs it: sum the ranks' partial systems onto `root`, where the (sequential) solve runs --
+        half the xGMI traffic of an all-reduce.  The buffers of the other ranks are left as they were (partial)."""
+        dist.reduce(self.buf, dst=root)
 
     def dense(self):
         """Full symmetric (F*D) x (F*D) matrix -- for tests / small systems only."""

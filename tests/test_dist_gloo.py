@@ -38,7 +38,7 @@ def _items(n_pairs, cs, seed=0):
     return raw, isz
 
 
-def _worker(rank, world, port, n_pairs, cs, out):
+def _worker(rank, world, port, n_pairs, cs, out, mode="all_reduce"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -47,7 +47,10 @@ def _worker(rank, world, port, n_pairs, cs, out):
     lo, hi = shard_range(n_pairs, rank, world)
     neq = NormalEquations(n_pairs + 1, cs, "cpu")
     neq.assemble(torch.from_numpy(raw[lo:hi].copy()).reshape(-1), lo, hi - lo, isz)
-    neq.all_reduce(dist)
+    if mode == "all_reduce":
+        neq.all_reduce(dist)
+    else:
+        neq.reduce(dist, root=0)   # bench.py's exchange step: the sum lands on the rank that solves
     if rank == 0:
         out["H"] = neq.H.clone()
         out["g"] = neq.g.clone()
@@ -55,8 +58,9 @@ def _worker(rank, world, port, n_pairs, cs, out):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["all_reduce", "reduce"])
 @pytest.mark.parametrize("n_pairs", [5, 8])
-def test_sharded_normal_equations_match_single_process(n_pairs):
+def test_sharded_normal_equations_match_single_process(n_pairs, mode):
     from deepfactors_amd.dist import NormalEquations, shard_range
     cs = 32
     raw, isz = _items(n_pairs, cs)
@@ -66,7 +70,7 @@ def test_sharded_normal_equations_match_single_process(n_pairs):
     mgr = mp.Manager()
     out = mgr.dict()
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, n_pairs, cs, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, n_pairs, cs, out, mode), nprocs=2, join=True)
     assert torch.allclose(out["H"], ref.H, rtol=0, atol=1e-5 * float(ref.H.abs().max()))
     assert torch.allclose(out["g"], ref.g, rtol=0, atol=1e-5 * float(ref.g.abs().max()))
     # shards tile the pair list
