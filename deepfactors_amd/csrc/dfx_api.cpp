@@ -448,7 +448,7 @@ int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params, const 
 
 DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
                                      void* out_items_dev) {
-  return sfm_step_batch_impl(c, cs, params, pairs, n, out_items_dev, dfx::NeqDev{ nullptr, nullptr, 0 });
+  return sfm_step_batch_impl(c, cs, params, pairs, n, out_items_dev, dfx::NeqDev{ nullptr, nullptr, 0, 0 });
 }
 
 DFX_API int dfx_sfm_step_batch_neq_async(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
@@ -456,7 +456,7 @@ DFX_API int dfx_sfm_step_batch_neq_async(dfx_ctx* c, int cs, const dfx_sfm_param
   if (!H_dev || !g_dev) return fail(DFX_E_INVALID, "dfx_sfm_step_batch_neq: null normal-equation buffer");
   if (n <= 0 || first_frame < 0 || first_frame + n + 1 > n_frames)
     return fail(DFX_E_INVALID, "pairs [%d, %d) do not fit a chain of %d frames", first_frame, first_frame + n, n_frames);
-  return sfm_step_batch_impl(c, cs, params, pairs, n, out_items_dev, dfx::NeqDev{ H_dev, g_dev, first_frame });
+  return sfm_step_batch_impl(c, cs, params, pairs, n, out_items_dev, dfx::NeqDev{ H_dev, g_dev, first_frame, n_frames });
 }
 
 namespace {

@@ -27,12 +27,14 @@ struct SfmParamsDev {
   float huber_delta, avg_dpt, min_dpt, border;
 };
 
-// Optional fused normal-equation assembly (dfx_sfm_step_batch_neq_async): the step kernel clears the blocks of the
-// frames its pairs touch, the finalize kernel scatter-adds every item entry as k_neq_assemble would.  H == nullptr: off.
+// Optional fused normal-equation assembly (dfx_sfm_step_batch_neq_async): the step kernel clears the WHOLE system (all
+// n_frames, like dfx_neq_assemble_async with zero_first), the finalize kernel scatter-adds every item entry as
+// k_neq_assemble would.  H == nullptr: off.
 struct NeqDev {
   float* H;          // [n_frames][2][D][D]
   float* g;          // [n_frames][D]
   int first_frame;   // pair p links frame first_frame + p -> first_frame + p + 1
+  int n_frames;
 };
 
 struct SimplePairDev {   // SE3Aligner / EvaluateError / Warp
@@ -56,7 +58,7 @@ inline int sfm_zdim(int ncb) { return sfm_nacc(ncb) * 256; }
 hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm,
                            int blocks_per_pair, float* partials_dev, void* items_dev, size_t item_stride,
                            hipStream_t stream, bool jac_dense, int prec, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr,
-                           const NeqDev& neq = NeqDev{ nullptr, nullptr, 0 });
+                           const NeqDev& neq = NeqDev{ nullptr, nullptr, 0, 0 });
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair);
 hipError_t launch_neq_assemble(int cs, const void* items_dev, size_t item_stride, int n_pairs, int first_frame, int n_frames,
                                float* H_dev, float* g_dev, bool zero_first, hipStream_t stream);

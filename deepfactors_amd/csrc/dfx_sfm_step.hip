@@ -138,14 +138,16 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   const SfmPairDev& P = pairs[blockIdx.y];
 
   if (MODE == 0 && neq.H && blockIdx.x == 0) {
-    // fused assembly: clear the normal-equation blocks of this pair's keyframe (the last pair also clears the frame behind
-    // it); k_sfm_finalize adds into them after this kernel has completed.  Replaces two memsets in front of the launch.
+    // fused assembly: clear the normal-equation system (every frame of the chain, also those other ranks fill: after a
+    // reduce the root's copy holds last step's sums); frame f is cleared by the first workgroup of pair f mod #pairs.
+    // k_sfm_finalize adds into the blocks after this kernel has completed.  Replaces two memsets in front of the launch.
     constexpr int D = 6 + 16 * NCB;
-    const int nfr = (blockIdx.y == gridDim.y - 1) ? 2 : 1;
-    float* Hz = neq.H + (size_t)(neq.first_frame + blockIdx.y) * 2 * D * D;
-    float* gz = neq.g + (size_t)(neq.first_frame + blockIdx.y) * D;
-    for (int e = threadIdx.x; e < nfr * 2 * D * D; e += kThreads) Hz[e] = 0.f;
-    for (int e = threadIdx.x; e < nfr * D; e += kThreads) gz[e] = 0.f;
+    for (int f = blockIdx.y; f < neq.n_frames; f += gridDim.y) {
+      float* Hz = neq.H + (size_t)f * 2 * D * D;
+      float* gz = neq.g + (size_t)f * D;
+      for (int e = threadIdx.x; e < 2 * D * D; e += kThreads) Hz[e] = 0.f;
+      for (int e = threadIdx.x; e < D; e += kThreads) gz[e] = 0.f;
+    }
   }
 
   Geo g;
@@ -656,7 +658,7 @@ size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair) {
 template <int NCB, int MODE>
 static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm, int bpp,
                            float* partials_dev, void* items_dev, size_t item_stride, hipStream_t stream, bool jac_dense, int prec,
-                           hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, const NeqDev& neq = NeqDev{ nullptr, nullptr, 0 }) {
+                           hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, const NeqDev& neq = NeqDev{ nullptr, nullptr, 0, 0 }) {
   constexpr int NACC = (1 + NCB) * (2 + NCB) / 2;
   hipError_t e;
   if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;

@@ -206,8 +206,8 @@ DFX_API int dfx_neq_assemble_async(dfx_ctx* ctx, int cs, const void* items_dev, 
                                    float* H_dev, float* g_dev, int zero_first);
 
 /* dfx_sfm_step_batch_async + dfx_neq_assemble_async(zero_first = 1) in two kernels instead of five operations: the step
- * kernel clears the blocks of frames [first_frame, first_frame + n] (only those -- the rest of H/g is left untouched), the
- * finalize kernel writes the items AND scatter-adds them into H/g.  Same results as the two separate calls. */
+ * kernel clears H/g (all n_frames), the finalize kernel writes the items AND scatter-adds them into the blocks of frames
+ * [first_frame, first_frame + n].  Same results as the two separate calls. */
 DFX_API int dfx_sfm_step_batch_neq_async(dfx_ctx* ctx, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
                                          void* out_items_dev, int first_frame, int n_frames, float* H_dev, float* g_dev);
 

@@ -150,6 +150,7 @@ def test_native_normal_equation_assembly_matches_torch(dfx):
     # fused variant (step kernel clears the touched frames, finalize scatter-adds): same bytes, items included; run twice
     # into a dirty buffer to prove the clearing
     c = NormalEquations(n + 3, cs, "cuda")
+    c.buf.fill_(123.0)   # e.g. the root's copy after a reduce: other ranks' frames hold last step's sums
     items2 = torch.zeros_like(items)
     for _ in range(2):
         al.RunStepBatchAssembleAsync(arr, items2, c, 1)
