@@ -140,9 +140,18 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
 
-    # sanity: results are real (inliers > half of the pixels on every pair)
+    # sanity (untimed): results are real (inliers > half of the pixels on every pair) ...
     its = al.items_from_bytes(items.cpu().numpy(), CS)
     assert all(it.inliers > 0.5 * W * H for it in its), [it.inliers for it in its]
+    # ... and the exchanged system is the sum of all ranks' pairs: every Jtr entry lands in exactly one slot of g, so the
+    # checksum of the reduced g on rank 0 must equal the checksum of all ranks' items (catches stale or double-counted blocks)
+    local = torch.tensor([sum(float(np.sum(it.Jtr.astype(np.float64))) for it in its),
+                          sum(float(np.sum(np.abs(it.Jtr.astype(np.float64)))) for it in its)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(local)
+    if rank == 0:
+        got = float(neq.g.double().sum())
+        assert abs(got - float(local[0])) <= 1e-4 * float(local[1]) + 1e-6, (got, local.tolist())
 
     if rank == 0:
         evals = world * P * a.steps
