@@ -155,8 +155,11 @@ __global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
+  // Thread 0's small matrices live in LDS: as private arrays they are indexed dynamically, land in scratch memory and
+  // made this kernel as slow as the step kernel itself (10.5 us; rocprofv3 kernel trace of the tracker).
+  __shared__ double ws[128];
   // reference precision: the item is fp32 (JTJJrReductionItem<float,6>) before the solve (camera_tracker.cpp:59)
-  double A[36], bvec[6];
+  double* A = ws; double* bvec = ws + 36;
   int k = 0;
   for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { const double v = (double)(float)sum[k++]; A[a * 6 + b] = v; A[b * 6 + a] = v; }
   for (int a = 0; a < 6; ++a) bvec[a] = (double)(float)sum[21 + a];
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__
   st->last_inliers = (float)sum[28];
   st->iterations_done += 1;
   // LDL^T
-  double L[36], D[6], yv[6], x[6];
+  double* L = ws + 42; double* D = ws + 78; double* yv = ws + 84; double* x = ws + 90;
   bool ok = sum[28] > 0.0;
   for (int i = 0; i < 36; ++i) L[i] = 0.0;
   for (int j = 0; j < 6 && ok; ++j) {
@@ -185,8 +188,8 @@ __global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__
   const double w0 = -x[3], w1 = -x[4], w2 = -x[5];
   const double th2 = w0 * w0 + w1 * w1 + w2 * w2, th = sqrt(th2);
   const double Ac = th < 1e-9 ? 1.0 - th2 / 6.0 : sin(th) / th, Bc = th < 1e-9 ? 0.5 - th2 / 24.0 : (1.0 - cos(th)) / th2;
-  const double K[9] = { 0, -w2, w1, w2, 0, -w0, -w1, w0, 0 };
-  double E[9], Rn[9];
+  double* K = ws + 96; double* E = ws + 105; double* Rn = ws + 114;
+  K[0] = 0; K[1] = -w2; K[2] = w1; K[3] = w2; K[4] = 0; K[5] = -w0; K[6] = -w1; K[7] = w0; K[8] = 0;
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
     double k2 = 0; for (int q = 0; q < 3; ++q) k2 += K[i * 3 + q] * K[q * 3 + j];
     E[i * 3 + j] = (i == j ? 1.0 : 0.0) + Ac * K[i * 3 + j] + Bc * k2;
