@@ -106,12 +106,6 @@ __device__ __forceinline__ Split3 split3(float x) {
   o.B = u32x4{ hm, __builtin_amdgcn_perm(xb, lb, HI2), __builtin_amdgcn_perm(lb, rb, HI2), hm };
   return o;
 }
-// lanes of the banks in BANKS (4-lane groups of every 16-lane row) <- src shifted inside its row (CTRL: 0x110 + n = row_shr:n,
-// 0x100 + n = row_shl:n); the other lanes keep `old`.  One v_mov_b32_dpp.
-template <int CTRL, int BANKS>
-__device__ __forceinline__ float dpp_merge(float old, float src) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, 0xF, BANKS, false));
-}
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 mfma_split(const u32x4& a, const u32x4& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -426,7 +420,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
           }
         continue;
       }
-      if (!(DFX_ABLATE & 8)) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uP, uP, acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uP, uP, acc[0], 0, 0, 0);
 #pragma unroll
       for (int b = 0; b < NCB; ++b) acc[1 + b] = __builtin_amdgcn_mfma_f32_16x16x4f32(uP, sc[b], acc[1 + b], 0, 0, 0);
 #pragma unroll
@@ -434,11 +428,6 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 #pragma unroll
         for (int b2 = b; b2 < NCB; ++b2) {
           const int a = 1 + NCB + (b * NCB - b * (b - 1) / 2) + (b2 - b);   // row-major upper block-triangle
-          if ((DFX_ABLATE & 8) && a == NACC - 1) {   // what-if: 4 MFMAs + 4 operand-shuffle VALU ops per group (wrong results)
-            acc[a][0] += dpp_merge<0x118, 0xC>(uP, sc[0]) + dpp_merge<0x108, 0x3>(sc[1], sc[0]);
-            acc[a][1] += dpp_merge<0x118, 0xC>(uP, sc[1]);
-            continue;
-          }
           acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[b], sc[b2], acc[a], 0, 0, 0);
         }
     }
