@@ -136,7 +136,7 @@ class Context:
         return int(_lib.lib().dfx_device_cu_count(self._h))
 
     def set_mfma_mode(self, mode):
-        """_lib.DFX_MFMA_F32_CHAIN (default, bitwise fp32 fmaf chain) or DFX_MFMA_BF16X3 (fp32-accurate exact split on the bf16 matrix cores)."""
+        """_lib.DFX_MFMA_F32_CHAIN (bitwise fp32 fmaf chain) is the only mode; DFX_MFMA_BF16X3 is rejected (see include/dfx.h)."""
         check(_lib.lib().dfx_set_mfma_mode(self._h, int(mode)))
 
     def set_profiling(self, enable):

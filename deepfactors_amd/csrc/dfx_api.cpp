@@ -404,7 +404,10 @@ DFX_API int dfx_device_cu_count(dfx_ctx* c) { return c ? c->cu_count : 0; }
 
 DFX_API int dfx_set_mfma_mode(dfx_ctx* c, int mode) {
   if (!c) return fail(DFX_E_INVALID, "null context");
-  if (mode != DFX_MFMA_F32_CHAIN && mode != DFX_MFMA_BF16X3) return fail(DFX_E_INVALID, "unknown MFMA mode %d", mode);
+  if (mode == DFX_MFMA_BF16X3)
+    return fail(DFX_E_INVALID, "DFX_MFMA_BF16X3 is not available: the exact bf16x3 split was measured slower than the fp32 chain "
+                               "(DESIGN.md section 5) and was dropped with the packed z-space layout");
+  if (mode != DFX_MFMA_F32_CHAIN) return fail(DFX_E_INVALID, "unknown MFMA mode %d", mode);
   c->mfma_mode = mode;
   return DFX_OK;
 }

@@ -48,10 +48,10 @@ struct SimplePairDev {   // SE3Aligner / EvaluateError / Warp
   uint32_t pitch_img0, pitch_img1, pitch_dpt0, pitch_grad1, pitch_img2;
 };
 
-// z-space size of the SfM step partials: blocks of 16x16 for the upper block-triangle over
-// (P = 12 pose + r + ..., C0..C{ncb-1}); see dfx_sfm_step.hip
-inline int sfm_nacc(int ncb) { return (1 + ncb) * (2 + ncb) / 2; }
-inline int sfm_zdim(int ncb) { return sfm_nacc(ncb) * 256; }
+// z-space size of the SfM step partials: one 256-float block for the 29 (P,P) sums + the packed 16x16 MFMA blocks
+// X(b,b'), Pm(b), Dd(q) (see dfx_sfm_step.hip)
+inline int sfm_nacc(int ncb) { return ncb * (ncb - 1) / 2 + ncb + (ncb + 1) / 2; }
+inline int sfm_zdim(int ncb) { return (1 + sfm_nacc(ncb)) * 256; }
 
 // All launchers enqueue on `stream` and return the HIP status of the launch.
 // ev_begin/ev_end (optional) bracket the step kernel only.

@@ -6,16 +6,20 @@
 //   Here a 64-lane wave owns 64 consecutive pixels per step ("chunk") and the JtJ / Jtr / r^2 / inlier sums are
 //   one rank-1-update GEMM  Z += z z^T  over pixels, executed on the matrix cores with exact-fp32 MFMA
 //   (v_mfma_f32_16x16x4_f32: k = 4 pixels per instruction, bitwise an fmaf chain).
-//   z (per pixel, "z-space") is laid out in 16-row blocks:
-//     block P : [ w*gC (6), 0 (6), w*r, s, inlier(1.0), 0 ]                     s = w * dE/dprx
-//     block Cb: [ s * jac[NCB*i + b] ]_{i=0..15}, b = 0..NCB-1                  (NCB = CS/16)
+//   z (per pixel, "z-space") = [ P | C_0 .. C_{NCB-1} ]:
+//     P  : [ w*gC (6), w*r, 0 ]                                                  (8 rows; s = w * dE/dprx rides in LDS row 13)
+//     C_b: [ s * jac[NCB*i + b] ]_{i=0..15}, b = 0..NCB-1                        (NCB = CS/16)
 //   gC is the 1x6 Jacobian of the residual w.r.t. the RELATIVE pose (warping.h:156-164,247-257).  The chain rule onto
 //   (pose0, pose1), J = gC * [blkdiag(M,M) | [[-M,-HM],[0,-M]]] (warping.h:119-134), is a per-pair constant 6 -> 12 map
-//   T, so it is applied to the reduced sums by k_sfm_finalize (T G T^T, T X, T g in double) instead of to every pixel:
-//   -36 VALU ops per pixel and -18 SGPRs (no more SGPR spills in the loop) -- VALU and MFMA time add on gfx950.
-//   Only the upper block-triangle is accumulated: (P,P), (P,Cb), (Cb,Cb') b<=b'  -> 6 MFMAs per 4 pixels at CS=32.
-//   (P,P)[12][12] = sum (w r)^2 = residual, (P,P)[14][14] = inliers, (P,*)[12][*] = Jtr.
-//   Block P row 13 (s) only exists so that lanes can broadcast s; its products are ignored.
+//   T, so it is applied to the reduced sums by k_sfm_finalize (T G T^T, T X, T g in double) instead of to every pixel.
+//   Matrix-core time and vector-ALU time ADD on gfx950, so MFMA slots are not wasted on the symmetric halves of the
+//   diagonal blocks: the 16x16 products are PACKED (A and B are arbitrary 16-row selections of z):
+//     X(b,b') : C_b x C_b'  (b < b')                       all 256 sums needed
+//     Pm(b)   : [ P (8) ; C_b rows 0..7 ] x C_b             pose-code, Jtr(code) and the (i < 8, j) part of C_b x C_b
+//     Dd(q)   : [ C_2q rows 8..15 ; C_2q+1 rows 8..15 ]^2   the (i >= 8, j >= 8) parts of two diagonal blocks
+//   4 MFMAs per 4 pixels at CS = 32 (was 6 for the plain upper block-triangle), 12 at CS = 64 (was 15), 2 at CS = 16 (was 3).
+//   The 29 sums of P x P (6x6 upper triangle, 6 Jtr, r^2, inliers) are per-lane fmas in phase A, reduced across the wave
+//   once in the epilogue.  Mixed operands are built with one v_mov_b32_dpp each (row_shr:8 / row_shl:8 under a bank mask).
 //
 //   Phase A (lane = pixel): coalesced img0/dpt0 loads, warp, bilinear gathers of img1/grad1, Jacobian row,
 //     Huber weight; the 16-float P row goes to LDS component-major (stride 66 -> conflict-free both ways).
@@ -86,39 +90,23 @@ __device__ __forceinline__ unsigned jv_offset(unsigned pbase, int gq, int li, in
 }
 
 // MODE 0: SfmAligner::RunStep.  MODE 1: DepthAligner::RunStep (cu_depthaligner.cpp:32-72) -- same rank-1 GEMM with
-// z = [0 (12), diff, s, 1, 0 | s * jac], s = -2 |diff| * dDepth/dPrx; `img0` carries the target depth and `dpt0`
+// z = [0 (6), diff, 0 | s * jac], s = -2 |diff| * dDepth/dPrx; `img0` carries the target depth and `dpt0`
 // the current depth (already decoded by k_update_depth); every pixel is an inlier.
-// fp32 -> three bf16 pieces, exactly: x = h + m + l (8 + 8 + 8 mantissa bits, truncation).  Packed as the two
-// operand forms of v_mfma_f32_16x16x32_bf16 for one pixel (8 of the 32 K slots of its lane group):
-//   A = [h h h m m m l l],  B = [h m l h m l h m]  ->  sum_K A.B = hh + hm + hl + mh + mm + ml + lh + lm = x*y - l*l'
-// Every partial product is exact in fp32 (8x8 bits); the dropped l*l' term is < 2^-32 relative.  10 VALU ops.
-struct Split3 { u32x4 A, B; };
-__device__ __forceinline__ Split3 split3(float x) {
-  const unsigned xb = __builtin_bit_cast(unsigned, x);
-  const float r = x - __builtin_bit_cast(float, xb & 0xFFFF0000u);
-  const unsigned rb = __builtin_bit_cast(unsigned, r);
-  const float r2 = r - __builtin_bit_cast(float, rb & 0xFFFF0000u);
-  const unsigned lb = __builtin_bit_cast(unsigned, r2);
-  constexpr unsigned HI2 = 0x07060302u;   // v_perm_b32: (lo16 = top half of src1, hi16 = top half of src0)
-  Split3 o;
-  const unsigned hm = __builtin_amdgcn_perm(rb, xb, HI2);
-  o.A = u32x4{ __builtin_amdgcn_perm(xb, xb, HI2), hm, __builtin_amdgcn_perm(rb, rb, HI2), __builtin_amdgcn_perm(lb, lb, HI2) };
-  o.B = u32x4{ hm, __builtin_amdgcn_perm(xb, lb, HI2), __builtin_amdgcn_perm(lb, rb, HI2), hm };
-  return o;
-}
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f32x4 mfma_split(const u32x4& a, const u32x4& b, const f32x4& c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+
+// lanes of the banks in BANKS (4-lane groups of every 16-lane row) <- src shifted inside its row (CTRL: 0x110 + n = row_shr:n,
+// 0x100 + n = row_shl:n); the other lanes keep `old`.  One v_mov_b32_dpp.
+template <int CTRL, int BANKS>
+__device__ __forceinline__ float dpp_merge(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, 0xF, BANKS, false));
 }
 
-// PREC 0: v_mfma_f32_16x16x4_f32 (bitwise an fp32 fmaf chain; shares the FP32 datapath with the VALU work).
-// PREC 1: the same products through exact bf16x3 operand splits on the bf16 matrix cores (fp32-accurate, overlaps VALU).
-template <int NCB, int MODE, bool JDENSE, int PREC>
+template <int NCB, int MODE, bool JDENSE>
 __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_WAVES) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmParamsDev prm,
                                                        const int W, const int H, float* __restrict__ partials, const NeqDev neq) {
-  constexpr int NBLK = 1 + NCB;
-  constexpr int NACC = NBLK * (NBLK + 1) / 2;
-  constexpr int ZDIM = NACC * 256;
+  constexpr int NX = NCB * (NCB - 1) / 2, ND = (NCB + 1) / 2;   // X(b,b'), Dd(q); Pm(b): NCB
+  constexpr int NACC = NX + NCB + ND;
+  constexpr int ZDIM = (1 + NACC) * 256;                         // block 0: the 29 P x P sums
+  constexpr int NPP = 29;                                        // 21 (gC x gC, i <= j) + 6 (gC x wr) + wr^2 + inliers
   constexpr int LDS_FLOATS = kWaves * ((kUFloats > ZDIM) ? kUFloats : ZDIM);   // P rows in the loop, accumulators in the epilogue
   typedef typename JV<NCB>::T jv_t;
   // "No next chunk" is handled by re-reading the wave's current chunk (L2-hot, results never consumed), NOT by
@@ -172,13 +160,14 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   const char* const ray_tab = reinterpret_cast<const char*>(P.ray_tab);
 
   float* U = lds + wave * kUFloats;
-  U[15 * kUStride + lane] = 0.f;   // row 15 of block P is padding
-#pragma unroll
-  for (int q = 6; q < 12; ++q) U[q * kUStride + lane] = 0.f;   // rows 6..11: unused (were pose1 before the z-space basis change)
+  U[7 * kUStride + lane] = 0.f;    // row 7 of P is padding (rows 8..15 of the A operand are overwritten by C_b rows 0..7)
 
   f32x4 acc[NACC];
 #pragma unroll
   for (int a = 0; a < NACC; ++a) acc[a] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+  float psum[NPP];
+#pragma unroll
+  for (int k = 0; k < NPP; ++k) psum[k] = 0.f;
 
   const int npx = W * H;
   const int nchunks = (npx + 63) >> 6;
@@ -330,12 +319,12 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
           const float d = cur.d;
           const float diff = cur.i0 - d;
           const float apd = prm.avg_dpt + d;
-          u16[12] = diff;
+          u16[6] = diff;
           u16[13] = 2.0f * fabsf(diff) * (apd * apd) * inv_a;   // -2 |diff| * (-a / prx^2), prx = a / (a + d)
           u16[14] = 1.0f;
         }
       } else if (DFX_ABLATE & 2) {
-        u16[0] = cur.d; u16[12] = cur.i0; u16[13] = 1.0f; u16[14] = 1.0f;
+        u16[0] = cur.d; u16[6] = cur.i0; u16[13] = 1.0f; u16[14] = 1.0f;
       } else {
         // Branch-free: every lane computes its row; lanes without a correspondence (or past the image) get weight 0
         // through v_mul_legacy (0 * NaN = 0), so no zero-init / masked overwrite and no exec juggling.
@@ -359,14 +348,26 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
         const float wgt = ok ? huber_weight(r, prm.huber_delta) : 0.0f;   // * DenseSfm_UncertaintyWeight == 1 (dense_sfm.h:66)
 #pragma unroll
         for (int j = 0; j < 6; ++j) u16[j] = mul_zero_wins(wgt, gC[j]);   // relative-pose basis; (pose0, pose1) in k_sfm_finalize
-        u16[12] = mul_zero_wins(wgt, r);
+        u16[6] = mul_zero_wins(wgt, r);
         u16[13] = mul_zero_wins(wgt, e);
         u16[14] = ok ? 1.0f : 0.0f;
         if (valid0 && ok) gstore<float>((char*)valid0 + (size_t)y * pitch_v0 + (size_t)x * 4, 1.0f);   // dense_sfm.h:161
       }
 #pragma unroll
-      for (int q = 0; q < 15; ++q)
-        if (q < 6 || q >= 12) U[q * kUStride + lane] = u16[q];
+      for (int q = 0; q < 7; ++q) U[q * kUStride + lane] = u16[q];
+      U[13 * kUStride + lane] = u16[13];
+      // P x P on the vector ALU (29 useful sums would fill 11 % of an MFMA's outputs)
+      if (MODE == 0) {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = i; j < 6; ++j, ++k) psum[k] = __builtin_fmaf(u16[i], u16[j], psum[k]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) psum[21 + i] = __builtin_fmaf(u16[i], u16[6], psum[21 + i]);
+      }
+      psum[27] = __builtin_fmaf(u16[6], u16[6], psum[27]);
+      psum[28] += u16[14];
     }
     // ---- A1(c+1) and the depth prefetch of c+2: issued BEFORE the ring refills of phase B
     cur.x = nxt.x; cur.y = nxt.y; cur.d = nxt.d; cur.i0 = nxt.i0; cur.rx = nxt.rx; cur.ry = nxt.ry;
@@ -400,36 +401,25 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 #if DFX_ABLATE & 1
       acc[0][0] += uP;
 #pragma unroll
-      for (int b = 0; b < NCB; ++b) acc[1 + b][0] += sc[b];
+      for (int b = 0; b < NCB; ++b) acc[b % NACC][1] += sc[b];
       continue;
 #endif
-      if (PREC == 1) {
-        const Split3 sp = split3(uP);
-        Split3 sq[NCB];
+      int a = 0;
 #pragma unroll
-        for (int b = 0; b < NCB; ++b) sq[b] = split3(sc[b]);
-        acc[0] = mfma_split(sp.A, sp.B, acc[0]);
+      for (int b = 0; b < NCB; ++b)        // X(b,b'): C_b x C_b'
 #pragma unroll
-        for (int b = 0; b < NCB; ++b) acc[1 + b] = mfma_split(sp.A, sq[b].B, acc[1 + b]);
+        for (int b2 = b + 1; b2 < NCB; ++b2, ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[b], sc[b2], acc[a], 0, 0, 0);
 #pragma unroll
-        for (int b = 0; b < NCB; ++b)
-#pragma unroll
-          for (int b2 = b; b2 < NCB; ++b2) {
-            const int a = 1 + NCB + (b * NCB - b * (b - 1) / 2) + (b2 - b);
-            acc[a] = mfma_split(sq[b].A, sq[b2].B, acc[a]);
-          }
-        continue;
+      for (int b = 0; b < NCB; ++b, ++a) {   // Pm(b): rows 0..7 = P, rows 8..15 = C_b rows 0..7
+        const float mixed = dpp_merge<0x118, 0xC>(uP, sc[b]);
+        acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(mixed, sc[b], acc[a], 0, 0, 0);
       }
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uP, uP, acc[0], 0, 0, 0);
 #pragma unroll
-      for (int b = 0; b < NCB; ++b) acc[1 + b] = __builtin_amdgcn_mfma_f32_16x16x4f32(uP, sc[b], acc[1 + b], 0, 0, 0);
-#pragma unroll
-      for (int b = 0; b < NCB; ++b)
-#pragma unroll
-        for (int b2 = b; b2 < NCB; ++b2) {
-          const int a = 1 + NCB + (b * NCB - b * (b - 1) / 2) + (b2 - b);   // row-major upper block-triangle
-          acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[b], sc[b2], acc[a], 0, 0, 0);
-        }
+      for (int q = 0; q < ND; ++q, ++a) {    // Dd(q): rows 0..7 = C_2q rows 8..15, rows 8..15 = C_2q+1 rows 8..15
+        const int b0 = 2 * q, b1 = (2 * q + 1 < NCB) ? 2 * q + 1 : 2 * q;
+        const float hi = dpp_merge<0x108, 0x3>(sc[b1], sc[b0]);
+        acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(hi, hi, acc[a], 0, 0, 0);
+      }
     }
 #if DFX_TRACE
     __builtin_amdgcn_sched_barrier(0);
@@ -448,9 +438,18 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   {
     float* mine = lds + wave * ZDIM;
 #pragma unroll
+    for (int k = 0; k < NPP; ++k) psum[k] = wave_sum(psum[k]);   // fixed shuffle tree; lane 0 holds the wave's totals
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mine[lane + 64 * r] = 0.f;   // block 0: psum[k] at index k, the rest stays zero
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < NPP; ++k) mine[k] = psum[k];
+    }
+#pragma unroll
     for (int a = 0; a < NACC; ++a)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) mine[a * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[a][r];
+      for (int r = 0; r < 4; ++r) mine[(1 + a) * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[a][r];
   }
   __syncthreads();
   float* out = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ZDIM;
@@ -462,7 +461,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   }
 #if DFX_TRACE
   __syncthreads();
-  if (lane == 0) {   // (P,P) rows 15 and 11 are padding: per wave {phase A cycles, phase B cycles, start mod 2^24, lifetime}, {HW_ID, XCC_ID}
+  if (lane == 0) {   // block 0 only uses its first 29 floats; rows 15 and 11 of it carry the trace: per wave {phase A cycles, phase B cycles, start mod 2^24, lifetime}, {HW_ID, XCC_ID}
     const unsigned long long trEnd = __builtin_amdgcn_s_memtime();
     out[15 * 16 + wave * 4 + 0] = (float)trA;
     out[15 * 16 + wave * 4 + 1] = (float)trB;
@@ -488,24 +487,24 @@ __device__ __forceinline__ void neq_scatter(float* H0, int a, int b, float v) {
 }
 
 // ---- finalize: sum the workgroup partials of each pair (double, fixed order), map the relative-pose basis onto
-// (pose0, pose1) and scatter into the item layout.
-// grid = (NACC, npairs), 1024 threads: thread = (element of one 16x16 accumulator block, 1 of 4 partial groups); groups
-// stride over the pair's `bpp` partials (1 KB coalesced reads, 8 in flight) and are folded in fixed order.
+// (pose0, pose1) and scatter the packed z-space blocks into the item layout.
+// grid = (1 + NACC, npairs), 1024 threads: thread = (element of one 256-float block, 1 of 4 partial groups); groups
+// stride over the pair's `bpp` partials (1 KB coalesced reads, 8 loads in flight) and are folded in fixed order.
 template <int NCB, int NPOSE>
 __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs,
                                                        char* __restrict__ items, const size_t item_stride, const NeqDev neq) {
   constexpr int CS = 16 * NCB;
   constexpr int NP = NPOSE + CS;
-  constexpr int NBLK = 1 + NCB;
-  constexpr int NACC = NBLK * (NBLK + 1) / 2;
-  constexpr int ZDIM = NACC * 256;
+  constexpr int NX = NCB * (NCB - 1) / 2, ND = (NCB + 1) / 2;
+  constexpr int NACC = NX + NCB + ND;
+  constexpr int ZDIM = (1 + NACC) * 256;
   constexpr int NT = NP * (NP + 1) / 2;
   __shared__ double red[4][256];
   __shared__ double T[12][6];   // d(pose0, pose1) <- d(relative pose): J = gC * T^T
 
-  const int a = blockIdx.x, pair = blockIdx.y;
+  const int blk = blockIdx.x, pair = blockIdx.y;
   const int el = threadIdx.x & 255, rg = threadIdx.x >> 8;
-  const float* src = partials + (size_t)pair * bpp * ZDIM + a * 256 + el;
+  const float* src = partials + (size_t)pair * bpp * ZDIM + blk * 256 + el;
   red[rg][el] = strided_sum_f64<4>(src, rg, bpp, ZDIM);
   if (NPOSE == 12 && threadIdx.x < 72) {
     const int n = threadIdx.x / 6, i = threadIdx.x - n * 6;
@@ -522,14 +521,8 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
   __syncthreads();
   if (rg == 0) red[0][el] = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
   __syncthreads();
-  const double* S = red[0];   // S[i * 16 + j]: row i of block bi, column j of block bj
+  const double* S = red[0];   // the block's 256 sums: S[row * 16 + col] for the MFMA blocks, S[k] = psum[k] for block 0
 
-  // block pair (bi <= bj) of accumulator a
-  int bi = 0, bj = 0;
-  {
-    int q = a;
-    for (bi = 0; bi < NBLK; ++bi) { const int n = NBLK - bi; if (q < n) { bj = bi + q; break; } q -= n; }
-  }
   float* item = reinterpret_cast<float*>(items + (size_t)pair * item_stride);
   auto tri = [](int lo, int hi) { return lo * NP - lo * (lo - 1) / 2 + (hi - lo); };
   // item entry (lo <= hi) -> packed item and, when the fused assembly is on, the frame chain's block system
@@ -542,6 +535,10 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
       if (lo != hi) neq_scatter<CS>(H0, hi, lo, v);
     }
   };
+  auto put_code = [&](int ca, int cb, float v) {   // code-code entry by code indices
+    const int n = NPOSE + ca, m = NPOSE + cb;
+    put(n < m ? n : m, n < m ? m : n, v);
+  };
   auto put_g = [&](int n, float v) {
     item[NT + n] = v;
     if (NPOSE == 12 && H0) {
@@ -549,10 +546,12 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
       atomicAdd(neq.g + (size_t)(neq.first_frame + pair + fa) * (6 + CS) + (n < 6 ? n : n - 6), v);
     }
   };
+  auto ppidx = [](int i, int j) { return i * 6 - i * (i - 1) / 2 + (j - i); };   // psum index of gC_i * gC_j, i <= j
   const int t = threadIdx.x;
-  if (bi == 0 && bj == 0) {
+  if (blk == 0) {
+    // ---- P x P sums: S[0..20] = gC_i gC_j (i <= j), S[21..26] = gC_i * wr, S[27] = (wr)^2, S[28] = inliers
     if (NPOSE == 12) {
-      if (t < 144) {                       // pose-pose: T G T^T, G = S[0..5][0..5]
+      if (t < 144) {                       // pose-pose: T G T^T
         const int n = t / 12, m = t - n * 12;
         if (n <= m) {
           double v = 0.0;
@@ -560,26 +559,35 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
           for (int i = 0; i < 6; ++i) {
             double r = 0.0;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) r += S[(i < j ? i : j) * 16 + (i < j ? j : i)] * T[m][j];
+            for (int j = 0; j < 6; ++j) r += S[i <= j ? ppidx(i, j) : ppidx(j, i)] * T[m][j];
             v += T[n][i] * r;
           }
           put(n, m, (float)v);
         }
-      } else if (t < 156) {                // Jtr (pose): T * S[0..5][12]
+      } else if (t < 156) {                // Jtr (pose): T * (gC . wr)
         const int n = t - 144;
         double v = 0.0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) v += T[n][i] * S[i * 16 + 12];
+        for (int i = 0; i < 6; ++i) v += T[n][i] * S[21 + i];
         put_g(n, (float)v);
       }
     }
-    if (t == 160) item[NT + NP] = (float)S[12 * 16 + 12];          // residual = sum (w r)^2
+    if (t == 160) item[NT + NP] = (float)S[27];          // residual = sum (w r)^2
     if (t == 161) {
       const size_t off = (((size_t)(NT + NP + 1)) * 4 + 7) & ~(size_t)7;
-      *reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(item) + off) = (unsigned long long)(S[14 * 16 + 14] + 0.5);
+      *reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(item) + off) = (unsigned long long)(S[28] + 0.5);
     }
-  } else if (bi == 0) {
-    const int b = bj - 1;
+    return;
+  }
+  const int a = blk - 1;
+  if (a < NX) {
+    // ---- X(b,b'): S[i][j] = C_b[i] * C_b'[j], b < b'
+    int b = 0, b2 = 0;
+    { int q = a; for (b = 0; b < NCB; ++b) { const int n = NCB - 1 - b; if (q < n) { b2 = b + 1 + q; break; } q -= n; } }
+    if (t < 256) put_code(NCB * (t >> 4) + b, NCB * (t & 15) + b2, (float)S[t]);
+  } else if (a < NX + NCB) {
+    // ---- Pm(b): rows 0..5 = gC, row 6 = w r, row 7 unused, rows 8..15 = C_b rows 0..7; columns = C_b
+    const int b = a - NX;
     if (NPOSE == 12 && t < 192) {          // pose-code: T * S[0..5][j]
       const int n = t >> 4, j = t & 15;
       double v = 0.0;
@@ -588,13 +596,19 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
       put(n, NPOSE + NCB * j + b, (float)v);
     } else if (t >= 192 && t < 208) {      // Jtr (code)
       const int j = t - 192;
-      put_g(NPOSE + NCB * j + b, (float)S[12 * 16 + j]);
+      put_g(NPOSE + NCB * j + b, (float)S[6 * 16 + j]);
+    } else if (t >= 256 && t < 384) {      // C_b[i] * C_b[j], i < 8; (i, j) and (j, i) both exist when j < 8
+      const int i = (t - 256) >> 4, j = t & 15;
+      if (i <= j) put_code(NCB * i + b, NCB * j + b, (float)S[(8 + i) * 16 + j]);
     }
-  } else if (t < 256) {                    // code-code
-    const int i = t >> 4, j = t & 15;
-    if (bi == bj && i > j) return;         // symmetric duplicate inside a diagonal block
-    const int n = NPOSE + NCB * i + (bi - 1), m = NPOSE + NCB * j + (bj - 1);
-    put(n < m ? n : m, n < m ? m : n, (float)S[i * 16 + j]);
+  } else if (t < 256) {
+    // ---- Dd(q): index 0..7 = C_2q rows 8..15, 8..15 = C_2q+1 rows 8..15 (duplicate of the first half when 2q+1 == NCB)
+    const int q = a - NX - NCB;
+    const int r = t >> 4, c = t & 15;
+    if (r <= c) {
+      if (c < 8) put_code(NCB * (8 + r) + 2 * q, NCB * (8 + c) + 2 * q, (float)S[t]);
+      else if (r >= 8 && 2 * q + 1 < NCB) put_code(NCB * r + 2 * q + 1, NCB * c + 2 * q + 1, (float)S[t]);
+    }
   }
 }
 
@@ -648,18 +662,17 @@ template <int NCB, int MODE>
 static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm, int bpp,
                            float* partials_dev, void* items_dev, size_t item_stride, hipStream_t stream, bool jac_dense, int prec,
                            hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, const NeqDev& neq = NeqDev{ nullptr, nullptr, 0, 0 }) {
-  constexpr int NACC = (1 + NCB) * (2 + NCB) / 2;
+  constexpr int NACC = NCB * (NCB - 1) / 2 + NCB + (NCB + 1) / 2;
   hipError_t e;
   if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
   const dim3 grid(bpp, npairs), block(kThreads);
-  if (jac_dense && prec == 1) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, true, 1>), grid, block, DFX_EXTRA_LDS, stream, pairs_dev, prm, W, H, partials_dev, neq);
-  else if (jac_dense) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, true, 0>), grid, block, DFX_EXTRA_LDS, stream, pairs_dev, prm, W, H, partials_dev, neq);
-  else if (prec == 1) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, false, 1>), grid, block, DFX_EXTRA_LDS, stream, pairs_dev, prm, W, H, partials_dev, neq);
-  else hipLaunchKernelGGL((k_sfm_step<NCB, MODE, false, 0>), grid, block, DFX_EXTRA_LDS, stream, pairs_dev, prm, W, H, partials_dev, neq);
+  (void)prec;   // one evaluation mode: exact fp32 products on v_mfma_f32_16x16x4_f32
+  if (jac_dense) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, true>), grid, block, DFX_EXTRA_LDS, stream, pairs_dev, prm, W, H, partials_dev, neq);
+  else hipLaunchKernelGGL((k_sfm_step<NCB, MODE, false>), grid, block, DFX_EXTRA_LDS, stream, pairs_dev, prm, W, H, partials_dev, neq);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL((k_sfm_finalize<NCB, MODE == 0 ? 12 : 0>), dim3(NACC, npairs), dim3(1024), 0, stream,
+  hipLaunchKernelGGL((k_sfm_finalize<NCB, MODE == 0 ? 12 : 0>), dim3(1 + NACC, npairs), dim3(1024), 0, stream,
                      (const float*)partials_dev, bpp, pairs_dev, (char*)items_dev, item_stride, neq);
   return hipGetLastError();
 }

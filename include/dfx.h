@@ -110,13 +110,11 @@ DFX_API int dfx_sync(dfx_ctx* ctx);
  * kernel; 0 = automatic (sized from the CU count).  Threads per workgroup are fixed at 256 (4 waves). */
 DFX_API int dfx_sfm_set_step_blocks(dfx_ctx* ctx, int blocks_per_pair);
 DFX_API int dfx_device_cu_count(dfx_ctx* ctx);
-/* How the JtJ/Jtr outer products of the SfM / DepthAligner step are evaluated on the matrix cores (fp32 in, fp32 out both ways):
- *  DFX_MFMA_F32_CHAIN  (default) v_mfma_f32_16x16x4_f32 -- bitwise an fp32 fmaf chain over the pixels of a wave.  On
- *                      gfx950 this instruction shares the FP32 datapath with the vector ALU (measured: their times add).
- *  DFX_MFMA_BF16X3     every fp32 operand is split EXACTLY into three bf16 pieces (x = h + m + l) and the 8
- *                      significant partial products run on the bf16 matrix cores with fp32 accumulation; each partial
- *                      product is exact, the one dropped term (l*l') is < 2^-32 relative.  fp32-accurate, not bit-equal
- *                      to the chain; measured error vs an fp64 reference is the same class. */
+/* How the JtJ/Jtr outer products of the SfM / DepthAligner step are evaluated on the matrix cores (fp32 in, fp32 out):
+ *  DFX_MFMA_F32_CHAIN  the only mode: v_mfma_f32_16x16x4_f32 -- bitwise an fp32 fmaf chain over the pixels of a wave.
+ *  DFX_MFMA_BF16X3     (rejected with DFX_E_INVALID) an exact three-way bf16 split of every fp32 operand on the bf16
+ *                      matrix cores; it was fp32-accurate but 6 % slower than the chain (the splits cost more vector-ALU
+ *                      time than the faster MFMAs save) and is no longer built. */
 #define DFX_MFMA_F32_CHAIN 0
 #define DFX_MFMA_BF16X3 1
 DFX_API int dfx_set_mfma_mode(dfx_ctx* ctx, int mode);

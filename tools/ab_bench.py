@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--cs", type=int, default=32)
-    ap.add_argument("--mode", type=int, default=1, help="0 = f32 chain MFMA, 1 = bf16x3 exact split")
+    ap.add_argument("--mode", type=int, default=0, help="0 = f32 chain MFMA (the only mode since the packed z-space layout)")
     ap.add_argument("--worker", action="store_true")
     a = ap.parse_args()
     if a.worker:
