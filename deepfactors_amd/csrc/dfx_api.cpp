@@ -264,8 +264,8 @@ int fill_sfm_pair(dfx_ctx* c, int cs, const dfx_se3* pose0, const dfx_se3* pose1
 // Workgroups per pair for the step kernel, from launch-shape sweeps on MI355X (1 / 4 / 16 / 64
 // pairs of 640x480, 16 x 320x240, 4 x 1280x960 CS 64).  A wave's prologue + epilogue cost about as much as two chunks, so
 // waves should be long; but the batch needs a few thousand waves for the hardware to balance the 2x spread of wave
-// lifetimes.  Chunks per wave: 5 while the batch is small, up to 10 (CS <= 32; a CS 64 chunk carries 2.5x the matrix
-// work) once that still leaves ~3840 waves.
+// lifetimes.  Chunks per wave: 5 while the batch is small, up to 15 (CS <= 32; a CS 64 chunk carries 2.5x the matrix
+// work) once that still leaves ~3840 waves.  (Sweeps must discard the first ~100 launches of a process: the clocks ramp.)
 int auto_step_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int npairs, int cs) {
   const int nchunks = (int)(((size_t)W * H + 63) / 64);
   int maxb = (nchunks + 3) / 4;   // one chunk per wave at most
@@ -274,7 +274,7 @@ int auto_step_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int npairs, int c
   if (b <= 0) {
     const long long total_chunks = (long long)nchunks * npairs;
     int cpw = (int)(total_chunks / 3840);
-    const int cpw_max = cs >= 64 ? 5 : 10;
+    const int cpw_max = cs >= 64 ? 5 : 15;
     if (cpw < 5) cpw = 5;
     if (cpw > cpw_max) cpw = cpw_max;
     b = (nchunks + 4 * cpw - 1) / (4 * cpw);
