@@ -28,8 +28,9 @@ def worker(a):
                               prx0_jac=t["prx_jac"], grad1=t["grad1"]))
         arr = al.make_pairs(pairs)
         items = torch.zeros(a.pairs * dfx.item_size(12 + a.cs), dtype=torch.uint8, device=dev)
-        for _ in range(3):
+        for _ in range(a.preroll if blocks == int(a.blocks.split(",")[0]) else 5):   # the clocks need ~100 launches after idle
             al.RunStepBatchAsync(arr, items)
+        ctx.sync()
         ctx.set_profiling(True)
         for _ in range(a.steps):
             al.RunStepBatchAsync(arr, items)
@@ -52,6 +53,7 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--cs", type=int, default=32)
     ap.add_argument("--mode", type=int, default=0, help="0 = f32 chain MFMA (the only mode since the packed z-space layout)")
+    ap.add_argument("--preroll", type=int, default=150, help="untimed launches before the first measurement of a process (clock ramp)")
     ap.add_argument("--worker", action="store_true")
     a = ap.parse_args()
     if a.worker:
@@ -62,7 +64,7 @@ def main():
         for lib in libs:
             env = dict(os.environ, DFX_LIB=os.path.abspath(lib))
             cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--blocks", a.blocks, "--pairs", str(a.pairs), "--steps", str(a.steps),
-                   "--width", str(a.width), "--height", str(a.height), "--cs", str(a.cs), "--mode", str(a.mode)]
+                   "--width", str(a.width), "--height", str(a.height), "--cs", str(a.cs), "--mode", str(a.mode), "--preroll", str(a.preroll)]
             try:
                 out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=180, stdin=subprocess.DEVNULL)
                 line = [l for l in out.stdout.splitlines() if l.startswith("ABRESULT ")]
