@@ -28,9 +28,11 @@ n_l, ms_l = ctx.profile_read()
 ctx.set_profiling(False)
 print(f"step kernel {ms_l / n_l * 1e3:.1f} us (HIP events)")
 nb = P * blocks
-buf = np.zeros(nb * 1536, np.float32)
+ncb = CS // 16
+ZD = (1 + ncb * (ncb - 1) // 2 + ncb + (ncb + 1) // 2) * 256   # z-space partial: block 0 (P x P sums + trace slots) + packed MFMA blocks
+buf = np.zeros(nb * ZD, np.float32)
 _lib.check(_lib.lib().dfx_debug_read_partials(ctx.handle, buf.ctypes.data_as(C.c_void_p), buf.nbytes))
-zz = buf.reshape(nb, 1536)
+zz = buf.reshape(nb, ZD)
 z = zz[:, 240:256].reshape(nb, 4, 4)
 hw = zz[:, 176:192].reshape(nb, 4, 4)
 A, B, S, T = z[..., 0].astype(np.float64), z[..., 1].astype(np.float64), z[..., 2].astype(np.float64), z[..., 3].astype(np.float64)
