@@ -8,7 +8,7 @@ OUT=gpurun_out/final; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err < /dev/null; echo "bench rc=$?"
 timeout 300 rocprofv3 --kernel-trace -d $OUT -o kt -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_profiled.json 2> $OUT/kt.err < /dev/null; echo "kt rc=$?"
-timeout 60 python tools/rocpd_summary.py $OUT/kt_results.db --like '%dfx::%' > $OUT/kernel_trace_dfx.csv 2>> $OUT/kt.err < /dev/null
+timeout 60 python tools/rocpd_summary.py $OUT/kt_results.db --like '%dfx::%' --last 20 > $OUT/kernel_trace_dfx.csv 2>> $OUT/kt.err < /dev/null
 timeout 900 tools/profile_pmc.sh $OUT/pmc < /dev/null
 timeout 60 python tools/pmc_summary.py $OUT/pmc > $OUT/pmc_summary.txt 2>&1 < /dev/null
 rm -f $OUT/kt_results.db

@@ -8,6 +8,7 @@ import sys
 def main():
     db = sqlite3.connect(sys.argv[1])
     like = sys.argv[sys.argv.index("--like") + 1] if "--like" in sys.argv else "%"
+    last = int(sys.argv[sys.argv.index("--last") + 1]) if "--last" in sys.argv else 0   # also: average of the last N dispatches per kernel
     cur = db.cursor()
     rows = cur.execute(
         "select name, count(*), avg(end-start), min(end-start), max(end-start), sum(end-start), max(vgpr_count), "
@@ -19,6 +20,14 @@ def main():
         name = r[0].replace(",", ";")
         print(f"\"{name}\",{r[1]},{r[2]/1e3:.3f},{r[3]/1e3:.3f},{r[4]/1e3:.3f},{r[5]/1e3:.3f},{100*r[5]/tot:.2f},"
               f"{r[6]},{r[7]},{r[8]},{r[9]},{r[10]},{r[11]},{r[12]},{r[13]}")
+
+
+    if last:
+        print(f"# average over the last {last} dispatches of each kernel (= the timed steps of bench.py; earlier ones are clock ramp / warm-up)")
+        for r in rows:
+            d = [x[0] for x in cur.execute("select end-start from kernels where name = ? order by start desc limit ?", (r[0], last)).fetchall()]
+            if d:
+                print(f"\"{r[0].replace(',', ';')}\",last{len(d)},{sum(d) / len(d) / 1e3:.3f},{min(d) / 1e3:.3f},{max(d) / 1e3:.3f}")
 
 
 if __name__ == "__main__":
