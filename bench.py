@@ -101,10 +101,10 @@ def main():
     # ---- synthetic, device-resident input: P distinct keyframe->frame pairs per rank
     pairs, keep = [], []
     for k in range(P):
-        p = synth.make_pair(W, H, CS, seed=0xDF02 + 1000 * rank + k, device=dev, motion_scale=0.6 + 0.05 * (k % 8))
+        p = synth.make_pair(W, H, CS, seed=0xDF02 + (0 if os.environ.get("DFX_BENCH_SAME") else 1000 * rank + k), device=dev, motion_scale=(1.0 if os.environ.get("DFX_BENCH_SAME") else 0.6 + 0.05 * (k % 8)))
         keep.append(p)
         pairs.append(dict(pose0=p["pose0"], pose1=p["pose1"], cam=p["cam"], img0=p["img0"], img1=p["img1"], dpt0=p["dpt0"],
-                          prx0_jac=p["prx_jac"], grad1=p["grad1"], valid0=p["valid0"]))
+                          prx0_jac=p["prx_jac"], grad1=p["grad1"], **({} if os.environ.get("DFX_BENCH_NOVALID") else dict(valid0=p["valid0"]))))
     arr = al.make_pairs(pairs)
     isz = dfx.item_size(12 + CS)
     items = torch.zeros(P * isz, dtype=torch.uint8, device=dev)

@@ -158,6 +158,8 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   const __amdgpu_buffer_rsrc_t i0_rs = make_rsrc(P.img0, (unsigned)H * pitch_i0);
   const float inv_a = 1.0f / prm.avg_dpt;
   const char* const ray_tab = reinterpret_cast<const char*>(P.ray_tab);
+  const char* const vld_base = valid0 ? reinterpret_cast<const char*>(valid0) : reinterpret_cast<const char*>(P.dpt0);
+  const uint32_t vld_pitch = valid0 ? pitch_v0 : pitch_d0;
 
   float* U = lds + wave * kUFloats;
   U[7 * kUStride + lane] = 0.f;    // row 7 of P is padding (rows 8..15 of the A operand are overwritten by C_b rows 0..7)
@@ -212,6 +214,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     int x, y;
     float d, i0;
     float rx, ry;         // K^-1 (x, y, 1) from the per-camera table
+    float vl;             // current valid0(x, y): pixels that already hold 1.0 are not written again
     f32x2 ia, ib;         // img1 taps (row iy, row iy+1)
     f32x4 ga, gb;         // grad1 taps
     Corr c;               // correspondence of A1 (kept: cheaper than re-deriving it, 5 IEEE divisions)
@@ -236,6 +239,10 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     if (MODE == 0) {   // table rows are padded (kRayTabSlack), so lanes past the last pixel stay inside the allocation
       q.rx = gload<float>(ray_tab + (unsigned)q.x * 4u);
       q.ry = gload<float>(ray_tab + (unsigned)(W + q.y) * 4u);
+      // valid0 is all ones from BuildKeyframe on (mapper.cpp:937) and only ever set: reading it (4 B/px, coalesced) and
+      // skipping pixels that already hold 1.0 makes the steady state write-free; HBM writes cost about twice their bytes.
+      // Always issued (keeps the load count static): without a valid0 image the read goes to the depth image instead.
+      q.vl = gload<float>(vld_base + (inb ? (unsigned)q.y * vld_pitch + (unsigned)q.x * 4u : 0u));
     }
   };
   // A1: warp the pixel and issue its 4 bilinear tap loads.  Branch-free on purpose: a conditional load would make the
@@ -289,6 +296,24 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     __builtin_amdgcn_sched_barrier(0);
   }
 
+  // valid0 is only ever SET (dense_sfm.h:161).  A store inside the pipelined loop costs 9.6 % of the kernel (it sits in the
+  // in-order vmcnt queue in front of every counted wait and needs an exec-masked branch), so every lane collects its
+  // chunks' validity bits in a register and the wave writes them in one burst per 32 chunks / at the end.
+  unsigned vmask = 0;
+  int vk = 0;                       // wave-uniform: chunks recorded in vmask
+  int vx0 = cur.x, vy0 = cur.y;     // pixel of bit 0
+  auto flush_valid = [&]() {
+    if (MODE == 0 && valid0) {
+      int fx = vx0, fy = vy0;
+      for (int k = 0; k < vk; ++k) {
+        if ((vmask >> k) & 1u) gstore<float>((char*)valid0 + (size_t)fy * pitch_v0 + (size_t)fx * 4, 1.0f);
+        advance_xy(fx, fy);
+      }
+      vx0 = fx; vy0 = fy;
+    }
+    vmask = 0; vk = 0;
+  };
+
 #if DFX_TRACE
   unsigned long long trA = 0, trB = 0, trN = 0;
   const unsigned long long trStart = __builtin_amdgcn_s_memtime();
@@ -307,7 +332,6 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 
     // ---- A2(c): lane = pixel; taps of this chunk were issued one iteration ago
     {
-      const int x = cur.x, y = cur.y;
       const bool inb = (base + lane) < npx;
       float u16[16];
       if (MODE == 1 || (DFX_ABLATE & 2)) {
@@ -351,7 +375,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
         u16[6] = mul_zero_wins(wgt, r);
         u16[13] = mul_zero_wins(wgt, e);
         u16[14] = ok ? 1.0f : 0.0f;
-        if (valid0 && ok) gstore<float>((char*)valid0 + (size_t)y * pitch_v0 + (size_t)x * 4, 1.0f);   // dense_sfm.h:161
+        vmask |= ((ok && cur.vl != 1.0f) ? 1u : 0u) << vk;   // valid0(x, y) = 1 (dense_sfm.h:161), written in bursts: flush_valid
       }
 #pragma unroll
       for (int q = 0; q < 7; ++q) U[q * kUStride + lane] = u16[q];
@@ -368,9 +392,10 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
       }
       psum[27] = __builtin_fmaf(u16[6], u16[6], psum[27]);
       psum[28] += u16[14];
+      if (++vk == 32) flush_valid();
     }
     // ---- A1(c+1) and the depth prefetch of c+2: issued BEFORE the ring refills of phase B
-    cur.x = nxt.x; cur.y = nxt.y; cur.d = nxt.d; cur.i0 = nxt.i0; cur.rx = nxt.rx; cur.ry = nxt.ry;
+    cur.x = nxt.x; cur.y = nxt.y; cur.d = nxt.d; cur.i0 = nxt.i0; cur.rx = nxt.rx; cur.ry = nxt.ry; cur.vl = nxt.vl;
 #if !(DFX_ABLATE & 2)
     issue_gathers(nbase, cur);
 #endif
@@ -429,6 +454,8 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 #endif
     __builtin_amdgcn_wave_barrier();
   }
+
+  flush_valid();
 
   // ---- epilogue: one z-space partial per workgroup = ((wave 0 + wave 1) + wave 2) + wave 3, element by element.
   // Every wave parks its accumulators in its own LDS region, ONE barrier, then all threads sum and store (the earlier

@@ -174,6 +174,15 @@ def test_sfm_step_deterministic(dfx):
     for _ in range(3):
         b = al.RunStep(n["pose0"], n["pose1"], n["code"], n["cam"], g["img0"], g["img1"], g["dpt0"], None, None, g["prx_jac"], g["grad1"])
         assert np.array_equal(a.raw, b.raw)
+    # valid0: set where valid, never cleared, already-set pixels left alone (the kernel reads before it writes): a marker
+    # value survives on invalid pixels, 1.0 everywhere else, and the sums do not depend on the buffer's content
+    vld = torch.full_like(g["img0"], 7.0)
+    c = al.RunStep(n["pose0"], n["pose1"], n["code"], n["cam"], g["img0"], g["img1"], g["dpt0"], None, vld, g["prx_jac"], g["grad1"])
+    assert np.array_equal(a.raw, c.raw)
+    v = vld.cpu().numpy()
+    assert int((v == 1.0).sum()) == a.inliers and int((v == 7.0).sum()) == v.size - a.inliers
+    d = al.RunStep(n["pose0"], n["pose1"], n["code"], n["cam"], g["img0"], g["img1"], g["dpt0"], None, vld, g["prx_jac"], g["grad1"])
+    assert np.array_equal(a.raw, d.raw) and np.array_equal(v, vld.cpu().numpy())
 
 
 def test_sfm_step_masked_nan_jacobian(dfx, oracle):
