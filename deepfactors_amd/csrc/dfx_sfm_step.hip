@@ -55,7 +55,8 @@ namespace dfx {
 #define DFX_TRACE 0          // 1: per-wave s_memtime sums of phase A / phase B in the junk row 15 of the (P,P) partial
 #endif
 #ifndef DFX_ABLATE
-#define DFX_ABLATE 0         // diagnosis only (wrong results): 1 = no MFMAs, 2 = no phase-A math/gathers, 4 = no ring loads
+#define DFX_ABLATE 0         // diagnosis only (wrong results): 1 = no MFMAs, 2 = no phase-A math/gathers, 4 = no ring loads,
+                             // 16 = no P x P fmas, 32 = no ray-table / valid0 reads, 64 = no operand shuffles
 #endif
 
 #ifndef DFX_WAVES
@@ -100,7 +101,7 @@ __device__ __forceinline__ float dpp_merge(float old, float src) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, 0xF, BANKS, false));
 }
 
-template <int NCB, int MODE, bool JDENSE>
+template <int NCB, int MODE, bool JDENSE, bool TABLDS>
 __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_WAVES) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmParamsDev prm,
                                                        const int W, const int H, float* __restrict__ partials, const NeqDev neq) {
   constexpr int NX = NCB * (NCB - 1) / 2, ND = (NCB + 1) / 2;   // X(b,b'), Dd(q); Pm(b): NCB
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   // retire ahead of older real loads, which breaks the counted vmcnt waits (observed as run-to-run differences).
 
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  extern __shared__ float ray_lds[];   // TABLDS: the per-camera ray table, W + H + kRayTabSlack floats (dynamic LDS)
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -161,6 +163,13 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   const char* const vld_base = valid0 ? reinterpret_cast<const char*>(valid0) : reinterpret_cast<const char*>(P.dpt0);
   const uint32_t vld_pitch = valid0 ? pitch_v0 : pitch_d0;
 
+  if (MODE == 0 && TABLDS) {
+    // Stage the ray table in LDS: two global loads per chunk for it cost 9 % of the kernel (the L1 / address unit of a CU is
+    // the busiest shared resource: 28 vector-memory instructions per chunk), two LDS reads cost nothing measurable.
+    const int ntab = W + H + kRayTabSlack;
+    for (int e = threadIdx.x; e < ntab; e += kThreads) ray_lds[e] = gload<float>(ray_tab + (unsigned)e * 4u);
+    __syncthreads();
+  }
   float* U = lds + wave * kUFloats;
   U[7 * kUStride + lane] = 0.f;    // row 7 of P is padding (rows 8..15 of the A operand are overwritten by C_b rows 0..7)
 
@@ -236,9 +245,10 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     od = inb ? od : kOobOffset; oi = inb ? oi : kOobOffset;
     q.d = bload(d0_rs, od, (float*)nullptr);
     q.i0 = bload(i0_rs, oi, (float*)nullptr);
-    if (MODE == 0) {   // table rows are padded (kRayTabSlack), so lanes past the last pixel stay inside the allocation
-      q.rx = gload<float>(ray_tab + (unsigned)q.x * 4u);
-      q.ry = gload<float>(ray_tab + (unsigned)(W + q.y) * 4u);
+    if (DFX_ABLATE & 32) { q.rx = 0.01f * (float)q.x; q.ry = 0.01f * (float)q.y; q.vl = 1.0f; }
+    else if (MODE == 0) {   // table rows are padded (kRayTabSlack), so lanes past the last pixel stay inside the allocation
+      if (TABLDS) { q.rx = ray_lds[q.x]; q.ry = ray_lds[W + q.y]; }
+      else { q.rx = gload<float>(ray_tab + (unsigned)q.x * 4u); q.ry = gload<float>(ray_tab + (unsigned)(W + q.y) * 4u); }
       // valid0 is all ones from BuildKeyframe on (mapper.cpp:937) and only ever set: reading it (4 B/px, coalesced) and
       // skipping pixels that already hold 1.0 makes the steady state write-free; HBM writes cost about twice their bytes.
       // Always issued (keeps the load count static): without a valid0 image the read goes to the depth image instead.
@@ -381,7 +391,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
       for (int q = 0; q < 7; ++q) U[q * kUStride + lane] = u16[q];
       U[13 * kUStride + lane] = u16[13];
       // P x P on the vector ALU (29 useful sums would fill 11 % of an MFMA's outputs)
-      if (MODE == 0) {
+      if (MODE == 0 && !(DFX_ABLATE & 16)) {
         int k = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i)
@@ -436,13 +446,13 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
         for (int b2 = b + 1; b2 < NCB; ++b2, ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[b], sc[b2], acc[a], 0, 0, 0);
 #pragma unroll
       for (int b = 0; b < NCB; ++b, ++a) {   // Pm(b): rows 0..7 = P, rows 8..15 = C_b rows 0..7
-        const float mixed = dpp_merge<0x118, 0xC>(uP, sc[b]);
+        const float mixed = (DFX_ABLATE & 64) ? uP : dpp_merge<0x118, 0xC>(uP, sc[b]);
         acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(mixed, sc[b], acc[a], 0, 0, 0);
       }
 #pragma unroll
       for (int q = 0; q < ND; ++q, ++a) {    // Dd(q): rows 0..7 = C_2q rows 8..15, rows 8..15 = C_2q+1 rows 8..15
         const int b0 = 2 * q, b1 = (2 * q + 1 < NCB) ? 2 * q + 1 : 2 * q;
-        const float hi = dpp_merge<0x108, 0x3>(sc[b1], sc[b0]);
+        const float hi = (DFX_ABLATE & 64) ? sc[b1] : dpp_merge<0x108, 0x3>(sc[b1], sc[b0]);
         acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(hi, hi, acc[a], 0, 0, 0);
       }
     }
@@ -694,8 +704,18 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
   const dim3 grid(bpp, npairs), block(kThreads);
   (void)prec;   // one evaluation mode: exact fp32 products on v_mfma_f32_16x16x4_f32
-  if (jac_dense) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, true>), grid, block, DFX_EXTRA_LDS, stream, pairs_dev, prm, W, H, partials_dev, neq);
-  else hipLaunchKernelGGL((k_sfm_step<NCB, MODE, false>), grid, block, DFX_EXTRA_LDS, stream, pairs_dev, prm, W, H, partials_dev, neq);
+  // the ray table rides in dynamic LDS when it fits beside the static arrays (64 KB per workgroup); MODE 1 has no table
+  constexpr size_t kStaticLds = sizeof(float) * (size_t)kWaves * ((kUFloats > (1 + NACC) * 256) ? kUFloats : (1 + NACC) * 256);
+  const size_t tab_bytes = sizeof(float) * ((size_t)W + H + kRayTabSlack);
+  const bool tab_lds = MODE == 0 && kStaticLds + tab_bytes + DFX_EXTRA_LDS <= 64 * 1024;
+  const size_t dyn = DFX_EXTRA_LDS + (tab_lds ? tab_bytes : 0);
+  if (MODE == 0 && tab_lds) {
+    if (jac_dense) hipLaunchKernelGGL((k_sfm_step<NCB, 0, true, true>), grid, block, dyn, stream, pairs_dev, prm, W, H, partials_dev, neq);
+    else hipLaunchKernelGGL((k_sfm_step<NCB, 0, false, true>), grid, block, dyn, stream, pairs_dev, prm, W, H, partials_dev, neq);
+  } else {
+    if (jac_dense) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, true, false>), grid, block, dyn, stream, pairs_dev, prm, W, H, partials_dev, neq);
+    else hipLaunchKernelGGL((k_sfm_step<NCB, MODE, false, false>), grid, block, dyn, stream, pairs_dev, prm, W, H, partials_dev, neq);
+  }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
