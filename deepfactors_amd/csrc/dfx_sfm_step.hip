@@ -18,8 +18,11 @@
 //     Pm(b)   : [ P (8) ; C_b rows 0..7 ] x C_b             pose-code, Jtr(code) and the (i < 8, j) part of C_b x C_b
 //     Dd(q)   : [ C_2q rows 8..15 ; C_2q+1 rows 8..15 ]^2   the (i >= 8, j >= 8) parts of two diagonal blocks
 //   4 MFMAs per 4 pixels at CS = 32 (was 6 for the plain upper block-triangle), 12 at CS = 64 (was 15), 2 at CS = 16 (was 3).
-//   The 29 sums of P x P (6x6 upper triangle, 6 Jtr, r^2, inliers) are per-lane fmas in phase A, reduced across the wave
-//   once in the epilogue.  Mixed operands are built with one v_mov_b32_dpp each (row_shr:8 / row_shl:8 under a bank mask).
+//   The 29 needed sums of P x P (6x6 upper triangle, 6 Jtr, r^2, inliers; P row 7 = inlier flag) run on
+//   v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 outer products per instruction = the three upper 4x4 tiles of P P^T for
+//   five pixels, 13 instructions (8 cycles each) per chunk, operands straight from the LDS P rows -- 4 accumulator
+//   registers instead of 29 per-lane sums (which cost an occupancy step) and no cross-lane reduction at the end.
+//   Mixed operands are built with one v_mov_b32_dpp each (row_shr:8 / row_shl:8 under a bank mask).
 //
 //   Phase A (lane = pixel): coalesced img0/dpt0 loads, warp, bilinear gathers of img1/grad1, Jacobian row,
 //     Huber weight; the 16-float P row goes to LDS component-major (stride 66 -> conflict-free both ways).
@@ -107,7 +110,6 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   constexpr int NX = NCB * (NCB - 1) / 2, ND = (NCB + 1) / 2;   // X(b,b'), Dd(q); Pm(b): NCB
   constexpr int NACC = NX + NCB + ND;
   constexpr int ZDIM = (1 + NACC) * 256;                         // block 0: the 29 P x P sums
-  constexpr int NPP = 29;                                        // 21 (gC x gC, i <= j) + 6 (gC x wr) + wr^2 + inliers
   constexpr int LDS_FLOATS = kWaves * ((kUFloats > ZDIM) ? kUFloats : ZDIM);   // P rows in the loop, accumulators in the epilogue
   typedef typename JV<NCB>::T jv_t;
   // "No next chunk" is handled by re-reading the wave's current chunk (L2-hot, results never consumed), NOT by
@@ -171,14 +173,17 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     __syncthreads();
   }
   float* U = lds + wave * kUFloats;
-  U[7 * kUStride + lane] = 0.f;    // row 7 of P is padding (rows 8..15 of the A operand are overwritten by C_b rows 0..7)
+  if (lane < 16) U[(lane >> 1) * kUStride + 64 + (lane & 1)] = 0.f;   // padding columns 64, 65 of P rows 0..7 (read as zeros by the 4x4 tiles)
 
   f32x4 acc[NACC];
 #pragma unroll
   for (int a = 0; a < NACC; ++a) acc[a] = f32x4{ 0.f, 0.f, 0.f, 0.f };
-  float psum[NPP];
-#pragma unroll
-  for (int k = 0; k < NPP; ++k) psum[k] = 0.f;
+  f32x4 accpp = f32x4{ 0.f, 0.f, 0.f, 0.f };   // P x P tiles: block b = lane >> 2 holds tile (b % 3) summed over its pixels
+  // 4x4x1 operands: lane (b, i) reads P row 4*tr + i (A) / 4*tc + i (B) of pixel 5*t + b / 3; tiles (tr, tc) = (0,0), (0,1), (1,1);
+  // block 15 and pixel 64 read the zero padding column of the LDS rows
+  const int ppb = lane >> 2, ppi = lane & 3, pptyp = ppb % 3;
+  const int ppoffA = ppb < 15 ? (4 * (pptyp == 2 ? 1 : 0) + ppi) * kUStride + ppb / 3 : 64;
+  const int ppoffB = ppb < 15 ? (4 * (pptyp != 0 ? 1 : 0) + ppi) * kUStride + ppb / 3 : 64;
 
   const int npx = W * H;
   const int nchunks = (npx + 63) >> 6;
@@ -389,19 +394,8 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
       }
 #pragma unroll
       for (int q = 0; q < 7; ++q) U[q * kUStride + lane] = u16[q];
+      U[7 * kUStride + lane] = u16[14];    // inlier flag: its square sums to the inlier count
       U[13 * kUStride + lane] = u16[13];
-      // P x P on the vector ALU (29 useful sums would fill 11 % of an MFMA's outputs)
-      if (MODE == 0 && !(DFX_ABLATE & 16)) {
-        int k = 0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-          for (int j = i; j < 6; ++j, ++k) psum[k] = __builtin_fmaf(u16[i], u16[j], psum[k]);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) psum[21 + i] = __builtin_fmaf(u16[i], u16[6], psum[21 + i]);
-      }
-      psum[27] = __builtin_fmaf(u16[6], u16[6], psum[27]);
-      psum[28] += u16[14];
       if (++vk == 32) flush_valid();
     }
     // ---- A1(c+1) and the depth prefetch of c+2: issued BEFORE the ring refills of phase B
@@ -422,6 +416,11 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     // ---- phase B: rank-4 updates on the matrix cores; operand ring refilled behind the consumer
     const __amdgpu_buffer_rsrc_t nrs = ring_rsrc(nbase);
     const unsigned rlo = ring_opaque_off();
+#if !(DFX_ABLATE & 16)
+#pragma unroll
+    for (int t = 0; t < 13; ++t)   // P x P: five pixels per instruction
+      accpp = __builtin_amdgcn_mfma_f32_4x4x1f32(U[ppoffA + 5 * t], U[ppoffB + 5 * t], accpp, 0, 0, 0);
+#endif
 #pragma unroll
     for (int gq = 0; gq < 16; ++gq) {
       const int pp = 4 * gq + lk;
@@ -475,14 +474,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   {
     float* mine = lds + wave * ZDIM;
 #pragma unroll
-    for (int k = 0; k < NPP; ++k) psum[k] = wave_sum(psum[k]);   // fixed shuffle tree; lane 0 holds the wave's totals
-#pragma unroll
-    for (int r = 0; r < 4; ++r) mine[lane + 64 * r] = 0.f;   // block 0: psum[k] at index k, the rest stays zero
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < NPP; ++k) mine[k] = psum[k];
-    }
+    for (int r = 0; r < 4; ++r) mine[ppb * 16 + r * 4 + ppi] = accpp[r];   // block 0: [4x4 block b][row r][column = lane & 3]
 #pragma unroll
     for (int a = 0; a < NACC; ++a)
 #pragma unroll
@@ -498,7 +490,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   }
 #if DFX_TRACE
   __syncthreads();
-  if (lane == 0) {   // block 0 only uses its first 29 floats; rows 15 and 11 of it carry the trace: per wave {phase A cycles, phase B cycles, start mod 2^24, lifetime}, {HW_ID, XCC_ID}
+  if (lane == 0) {   // trace builds only (their block 11 of P x P is overwritten, results are not valid): rows 15 and 11 of block 0 carry per wave {phase A cycles, phase B cycles, start mod 2^24, lifetime}, {HW_ID, XCC_ID}
     const unsigned long long trEnd = __builtin_amdgcn_s_memtime();
     out[15 * 16 + wave * 4 + 0] = (float)trA;
     out[15 * 16 + wave * 4 + 1] = (float)trB;
@@ -558,7 +550,7 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
   __syncthreads();
   if (rg == 0) red[0][el] = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
   __syncthreads();
-  const double* S = red[0];   // the block's 256 sums: S[row * 16 + col] for the MFMA blocks, S[k] = psum[k] for block 0
+  const double* S = red[0];   // the block's 256 sums: S[row * 16 + col] for the MFMA blocks, 16 4x4 P x P blocks for block 0
 
   float* item = reinterpret_cast<float*>(items + (size_t)pair * item_stride);
   auto tri = [](int lo, int hi) { return lo * NP - lo * (lo - 1) / 2 + (hi - lo); };
@@ -583,10 +575,18 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
       atomicAdd(neq.g + (size_t)(neq.first_frame + pair + fa) * (6 + CS) + (n < 6 ? n : n - 6), v);
     }
   };
-  auto ppidx = [](int i, int j) { return i * 6 - i * (i - 1) / 2 + (j - i); };   // psum index of gC_i * gC_j, i <= j
+  // block 0 = 16 4x4 blocks [b][i][j] of the P x P tiles: block b (< 15) holds tile b % 3 ((0,0), (0,1), (1,1) of the 8x8
+  // matrix P P^T) summed over its pixels; P = (gC_0..5, w r, inlier flag)
+  auto pp = [&](int p, int q) {   // sum over pixels of P_p * P_q, p <= q < 8
+    const int typ = q < 4 ? 0 : (p < 4 ? 1 : 2);
+    const int i = p & 3, j = q & 3;
+    double v = 0.0;
+#pragma unroll
+    for (int b = typ; b < 15; b += 3) v += S[b * 16 + i * 4 + j];
+    return v;
+  };
   const int t = threadIdx.x;
   if (blk == 0) {
-    // ---- P x P sums: S[0..20] = gC_i gC_j (i <= j), S[21..26] = gC_i * wr, S[27] = (wr)^2, S[28] = inliers
     if (NPOSE == 12) {
       if (t < 144) {                       // pose-pose: T G T^T
         const int n = t / 12, m = t - n * 12;
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
           for (int i = 0; i < 6; ++i) {
             double r = 0.0;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) r += S[i <= j ? ppidx(i, j) : ppidx(j, i)] * T[m][j];
+            for (int j = 0; j < 6; ++j) r += (i <= j ? pp(i, j) : pp(j, i)) * T[m][j];
             v += T[n][i] * r;
           }
           put(n, m, (float)v);
@@ -605,14 +605,14 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
         const int n = t - 144;
         double v = 0.0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) v += T[n][i] * S[21 + i];
+        for (int i = 0; i < 6; ++i) v += T[n][i] * pp(i, 6);
         put_g(n, (float)v);
       }
     }
-    if (t == 160) item[NT + NP] = (float)S[27];          // residual = sum (w r)^2
+    if (t == 160) item[NT + NP] = (float)pp(6, 6);          // residual = sum (w r)^2
     if (t == 161) {
       const size_t off = (((size_t)(NT + NP + 1)) * 4 + 7) & ~(size_t)7;
-      *reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(item) + off) = (unsigned long long)(S[28] + 0.5);
+      *reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(item) + off) = (unsigned long long)(pp(7, 7) + 0.5);
     }
     return;
   }
