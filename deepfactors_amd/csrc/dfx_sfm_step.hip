@@ -577,14 +577,21 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
   };
   // block 0 = 16 4x4 blocks [b][i][j] of the P x P tiles: block b (< 15) holds tile b % 3 ((0,0), (0,1), (1,1) of the 8x8
   // matrix P P^T) summed over its pixels; P = (gC_0..5, w r, inlier flag)
-  auto pp = [&](int p, int q) {   // sum over pixels of P_p * P_q, p <= q < 8
-    const int typ = q < 4 ? 0 : (p < 4 ? 1 : 2);
-    const int i = p & 3, j = q & 3;
-    double v = 0.0;
+  __shared__ double G8[8][8];   // block 0 only: P P^T (upper triangle), each entry folded over the five 4x4 blocks that hold it
+  if (blk == 0) {
+    if (threadIdx.x < 64) {
+      const int p = threadIdx.x >> 3, q = threadIdx.x & 7;
+      if (p <= q) {
+        const int typ = q < 4 ? 0 : (p < 4 ? 1 : 2);
+        double v = 0.0;
 #pragma unroll
-    for (int b = typ; b < 15; b += 3) v += S[b * 16 + i * 4 + j];
-    return v;
-  };
+        for (int b = typ; b < 15; b += 3) v += S[b * 16 + (p & 3) * 4 + (q & 3)];
+        G8[p][q] = v;
+      }
+    }
+    __syncthreads();
+  }
+  auto pp = [&](int p, int q) { return G8[p][q]; };   // sum over pixels of P_p * P_q, p <= q < 8
   const int t = threadIdx.x;
   if (blk == 0) {
     if (NPOSE == 12) {
