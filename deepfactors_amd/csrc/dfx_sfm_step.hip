@@ -511,8 +511,12 @@ __device__ __forceinline__ void neq_scatter(float* H0, int a, int b, float v) {
   constexpr int D = 6 + CS;
   const int fa = (a >= 6 && a < 12), fb = (b >= 6 && b < 12);
   const int la = a < 6 ? a : a - 6, lb = b < 6 ? b : b - 6;
-  if (fa == fb) atomicAdd(H0 + (size_t)fa * 2 * D * D + la * D + lb, v);
-  else if (fa == 0) H0[D * D + la * D + lb] = v;   // (frame k rows, frame k+1 cols): single writer
+  // A frame's diagonal block receives this pair's (pose0 | code0) x (pose0 | code0) entries and the PREVIOUS pair's
+  // (pose1, pose1) 6x6: only the pose-pose 6x6 has two writers and needs the (commutative) atomic add into zeroed memory.
+  if (fa == fb) {
+    float* dst = H0 + (size_t)fa * 2 * D * D + la * D + lb;
+    if (la < 6 && lb < 6) atomicAdd(dst, v); else *dst = v;
+  } else if (fa == 0) H0[D * D + la * D + lb] = v;   // (frame k rows, frame k+1 cols): single writer
 }
 
 // ---- finalize: sum the workgroup partials of each pair (double, fixed order), map the relative-pose basis onto
@@ -572,7 +576,8 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
     item[NT + n] = v;
     if (NPOSE == 12 && H0) {
       const int fa = (n >= 6 && n < 12);
-      atomicAdd(neq.g + (size_t)(neq.first_frame + pair + fa) * (6 + CS) + (n < 6 ? n : n - 6), v);
+      float* dst = neq.g + (size_t)(neq.first_frame + pair + fa) * (6 + CS) + (n < 6 ? n : n - 6);
+      if (n < 12) atomicAdd(dst, v); else *dst = v;   // pose entries meet the neighbouring pair's, code entries have one writer
     }
   };
   // block 0 = 16 4x4 blocks [b][i][j] of the P x P tiles: block b (< 15) holds tile b % 3 ((0,0), (0,1), (1,1) of the 8x8
@@ -677,7 +682,8 @@ __global__ __launch_bounds__(256) void k_neq_assemble(const char* __restrict__ i
   for (int a = threadIdx.x; a < NP; a += 256) {
     const int fa = (a >= 6 && a < 12);
     const int la = a < 6 ? a : a - 6;
-    atomicAdd(gv + (size_t)(first_frame + p + fa) * D + la, it[NT + a]);
+    float* dst = gv + (size_t)(first_frame + p + fa) * D + la;
+    if (a < 12) atomicAdd(dst, it[NT + a]); else *dst = it[NT + a];
   }
 }
 
