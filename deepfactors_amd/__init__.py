@@ -8,6 +8,6 @@ from .aligners import (CameraTracker, Context, CorrespondenceReductionItem, Dens
                        TrackerConfig, UpdateDepth, default_context)
 from .keyframe import (Frame, Keyframe, KeyframeMap, LoadJsonNetworkConfig, NetworkConfig, save_keyframes, save_results,  # noqa: F401
                        save_trajectory_tum, write_png)
-from .factors import HessianBlocks, PhotometricFactor, pose_equals, pose_local  # noqa: F401
+from .factors import HessianBlocks, PhotometricFactor, linearize_all, pose_equals, pose_local  # noqa: F401
 
 __version__ = "0.1.0"
