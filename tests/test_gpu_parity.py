@@ -303,6 +303,17 @@ def test_errors_are_loud(dfx):
                                              torch.zeros((48, 64 * 48), device="cuda"), g["grad1"])
 
 
+def test_very_wide_image_uses_the_global_ray_table(dfx, oracle):
+    """W + H too large for the LDS copy of the ray table (64 KB per workgroup): the kernel variant that reads it from global
+    memory must give the same answer."""
+    w, h, cs = 12288, 2, 16
+    p, n, g = _pair(dfx, w, h, cs, seed=91)
+    al = dfx.SfmAligner(code_size=cs)
+    got = al.RunStep(n["pose0"], n["pose1"], n["code"], n["cam"], g["img0"], g["img1"], g["dpt0"], None, None, g["prx_jac"], g["grad1"])
+    ref = oracle.sfm_step(n["pose0"], n["pose1"], n["cam"], n["img0"], n["img1"], n["dpt0"], n["prx_jac"], n["grad1"])
+    assert_item_close(got, ref, w, h, what="12288x2")
+
+
 @pytest.mark.parametrize("w,h", [(40, 30), (17, 9), (64, 1), (8, 8)])
 def test_tiny_and_narrow_images(dfx, oracle, w, h):
     """Images narrower than one 64-pixel chunk (a chunk wraps several rows) and smaller than one chunk."""
