@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 import deepfactors_amd as dfx
 from deepfactors_amd import synth, _lib
 p = synth.make_pair(320, 240, 32, seed=3, device="cpu"); n = synth.to_numpy(p); g = synth.to_device(p, "cuda")
-for mode in (1, 0):
+for mode in (0,):   # the fp32 chain is the only evaluation mode
     for blocks in (300, 300, 0, 37):
         ctx = dfx.Context(0); ctx.set_mfma_mode(mode)
         al = dfx.SfmAligner(dfx.SfmAlignerParams(step_blocks=blocks), code_size=32, ctx=ctx)

@@ -9,7 +9,7 @@ from deepfactors_amd import synth, _lib
 
 P, W, H, CS = 16, 640, 480, 32
 blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-mode = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 dev = torch.device("cuda", 0)
 base = synth.make_pair(W, H, CS, seed=0xDF02, device=dev)
 ctx = dfx.Context(0)
