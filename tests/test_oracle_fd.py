@@ -123,3 +123,27 @@ def test_se3_gauss_newton_recovers_synthetic_motion(oracle):
         qt = oracle.se3_solve_update(r.JtJ, r.Jtr, qt)
     gt = n["pose10_true"]
     assert np.linalg.norm(qt[4:] - gt[4:]) < 2e-3 and np.linalg.norm(qt[:4] - gt[:4]) < 1e-3
+
+
+def test_pose_local_is_the_inverse_of_the_reference_retraction(oracle):
+    """deepfactors_amd.factors.pose_local (gtsam_traits.h:66-72, used by PhotometricFactor's relinearisation cache) inverts the
+    perturbation the Jacobians are defined against (gtsam_traits.h:48-58; oracle.perturb_pose): Local(p, Retract(p, d)) = d."""
+    from deepfactors_amd.factors import pose_equals, pose_local
+    rng = np.random.default_rng(9)
+    for _ in range(5):
+        p = rand_pose(rng, oracle)
+        d = rng.normal(0, 1e-2, 6)
+        q = p.copy()
+        for i in range(3):          # translations add ...
+            q = oracle.perturb_pose(q, i, d[i])
+        from deepfactors_amd import synth
+        R = oracle.so3_exp(d[3:]) @ synth.quat_to_R(q[:4])   # ... the rotation update multiplies from the left
+        q = np.concatenate([synth.R_to_quat(R), q[4:]])
+        assert np.abs(pose_local(p, q) - d).max() < 1e-9
+        assert not pose_equals(p, q, 1e-6) and pose_equals(p, p, 1e-6)
+    # single-coordinate perturbations of the oracle map to unit tangent directions
+    p = rand_pose(rng, oracle)
+    for i in range(6):
+        e = pose_local(p, oracle.perturb_pose(p, i, 1e-4))
+        ref = np.zeros(6); ref[i] = 1e-4
+        assert np.abs(e - ref).max() < 1e-10
