@@ -119,44 +119,45 @@ class PhotometricFactor:
 
 
 def linearize_all(factors, values):
-    """One relinearisation round over many photometric factors in ONE batched launch.
+    """One relinearisation round over many photometric factors: ONE batched launch per pyramid level.
 
-    `values[k] = (pose0, pose1, code0)` for `factors[k]`; all factors must share the aligner, the pyramid level and the image
-    size.  Factors whose values did not move (GetJacobiansIfNeeded's 1e-6 test) keep their cached system; for the others the
-    keyframe depth is updated once per (keyframe, code) and their steps run as one `SfmAligner.RunStepBatch`; every factor's
-    cache is then seeded, so the per-factor `linearize()` calls that follow (iSAM2 asks factor by factor) launch nothing.
-    Returns the list of HessianBlocks."""
+    `values[k] = (pose0, pose1, code0)` for `factors[k]`; all factors must share the aligner.  Factors whose values did not move
+    (GetJacobiansIfNeeded's 1e-6 test) keep their cached system; for the others the keyframe depth is updated once per
+    (keyframe, level) and their steps run as one `SfmAligner.RunStepBatch` per level (a batch needs one image size); every
+    factor's cache is then seeded, so the per-factor `linearize()` calls that follow (iSAM2 asks factor by factor) launch
+    nothing.  Returns the list of HessianBlocks."""
     if not factors:
         return []
     al = factors[0].aligner_
     eps = 1e-6
-    todo = []
+    todo = {}
     for k, (f, (p0, p1, c0)) in enumerate(zip(factors, values)):
-        if f.aligner_ is not al or f.pyrlevel_ != factors[0].pyrlevel_:
-            raise _al.DfxError(-1, "linearize_all: factors must share the aligner and the pyramid level")
+        if f.aligner_ is not al:
+            raise _al.DfxError(-1, "linearize_all: factors must share the aligner")
         c0 = np.asarray(c0, np.float64)
         if (f.first_ or not pose_equals(p0, f.lin_pose0_, eps) or not pose_equals(p1, f.lin_pose1_, eps)
                 or not float(np.linalg.norm(c0 - f.lin_code0_)) < eps):
-            todo.append(k)
-    if todo:
-        lvl = factors[0].pyrlevel_
-        decoded = {}
-        for k in todo:   # UpdateDepthMaps once per keyframe (a keyframe has ONE code, shared by all its factors)
+            todo.setdefault(f.pyrlevel_, []).append(k)
+    decoded = {}
+    for lvl in sorted(todo):
+        idx = todo[lvl]
+        for k in idx:   # UpdateDepthMaps once per (keyframe, level): a keyframe has ONE code, shared by all its factors
             f, c0 = factors[k], np.asarray(values[k][2], np.float32)
-            key = id(f.kf_)
-            if key in decoded:
-                if not np.array_equal(decoded[key], c0):
-                    raise _al.DfxError(-1, "linearize_all: two factors of one keyframe carry different codes")
-                continue
-            f.UpdateDepthMaps(c0)
-            decoded[key] = c0.copy()
+            key = (id(f.kf_), lvl)
+            prev = decoded.get(id(f.kf_))
+            if prev is not None and not np.array_equal(prev, c0):
+                raise _al.DfxError(-1, "linearize_all: two factors of one keyframe carry different codes")
+            decoded[id(f.kf_)] = c0.copy()
+            if key not in decoded:
+                f.UpdateDepthMaps(c0)
+                decoded[key] = True
         pairs = []
-        for k in todo:
+        for k in idx:
             f, (p0, p1, _) = factors[k], values[k]
             pairs.append(dict(pose0=p0, pose1=p1, cam=f.cam_, img0=f.kf_.pyr_img[lvl], img1=f.fr_.pyr_img[lvl], dpt0=f.kf_.pyr_dpt[lvl],
                               prx0_jac=f.kf_.pyr_jac[lvl], grad1=f.fr_.pyr_grad[lvl], valid0=f.kf_.pyr_vld[lvl]))
         items = al.RunStepBatch(al.make_pairs(pairs))
-        for k, item in zip(todo, items):
+        for k, item in zip(idx, items):
             f, (p0, p1, c0) = factors[k], values[k]
             area = float(f.cam_[4]) * float(f.cam_[5])
             item.scaled_residual = (item.residual / item.inliers * area) if item.inliers > 0 else float("inf")

@@ -109,6 +109,19 @@ def test_linearize_all_batches_a_relinearisation_round(dfx):
     vals[2] = (n1["pose0"], p1, n1["code"])
     dfx.linearize_all(batch, vals)
     assert [f.linearizations_ for f in batch] == [1, 1, 2]
+    # factors of several pyramid levels in one call: one batch per level (level 1 of a 2-level keyframe pyramid here)
+    from deepfactors_amd.keyframe import Keyframe
+    kfp, frp = Keyframe(2, w, h, cs, device="cuda"), Frame(2, w, h, device="cuda")
+    kfp.FillPyramids(torch.from_numpy(n0["img0"])); frp.FillPyramids(torch.from_numpy(n0["img1"]))
+    jac3 = n0["prx_jac"].reshape(h, w, cs)
+    kfp.SetDecoderOutputs([n0["prx_orig"], np.ascontiguousarray(n0["prx_orig"][::2, ::2])], [np.zeros((h, w), np.float32), np.zeros((h // 2, w // 2), np.float32)],
+                          [n0["prx_jac"], np.ascontiguousarray(jac3[::2, ::2]).reshape(h // 2, (w // 2) * cs)])
+    cams = synth.camera_pyramid(n0["cam"], 2)
+    two = [dfx.PhotometricFactor(cams[l], kfp, frp, 0, 1, 2, l, al) for l in (0, 1)]
+    v2 = [(n0["pose0"], n0["pose1"], n0["code"])] * 2
+    hb = dfx.linearize_all(two, v2)
+    assert [f.linearizations_ for f in two] == [1, 1] and hb[0].Gs[5].shape == (cs, cs) and np.isfinite(hb[1].f)
+    assert float(np.abs(hb[1].Gs[0]).max()) > 0 and not np.array_equal(hb[0].Gs[0], hb[1].Gs[0])
     # one keyframe, two different codes in one round: refused
     bad = list(vals); bad[1] = (n0["pose0"], n0["pose1"], n0["code"] + 1.0)
     for f in batch:
