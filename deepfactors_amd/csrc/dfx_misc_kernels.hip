@@ -41,12 +41,12 @@ __device__ __forceinline__ Geo geo_from(const SimplePairDev& p) {
 }
 
 // ---- SE3 step: 21 JtJ + 6 Jtr + r^2 + inliers = 29 floats per lane -----------------------------------------
-__global__ __launch_bounds__(kT) void k_se3_step(const SimplePairDev p, const int W, const int H, const float huber_delta,
-                                                 float* __restrict__ partials) {
-  const Geo g = geo_from(p);
+// Per-lane sums of one SE3 Gauss-Newton step over this thread's pixels (lucas_kanade_se3.h:41-77): shared by the blocking
+// operator and by the device-resident tracker.
+__device__ __forceinline__ void se3_accumulate(const Geo& g, const SimplePairDev& p, const int W, const int H, const float huber_delta,
+                                               float (&acc)[29]) {
   const ImgRef I0{ (const char*)p.img0, p.pitch_img0 }, I1{ (const char*)p.img1, p.pitch_img1 };
   const ImgRef D0{ (const char*)p.dpt0, p.pitch_dpt0 }, G1{ (const char*)p.grad1, p.pitch_grad1 };
-  float acc[29];
 #pragma unroll
   for (int q = 0; q < 29; ++q) acc[q] = 0.f;
   const int npx = W * H;
@@ -78,6 +78,13 @@ __global__ __launch_bounds__(kT) void k_se3_step(const SimplePairDev p, const in
       acc[28] += 1.0f;
     }
   }
+}
+
+__global__ __launch_bounds__(kT) void k_se3_step(const SimplePairDev p, const int W, const int H, const float huber_delta,
+                                                 float* __restrict__ partials) {
+  const Geo g = geo_from(p);
+  float acc[29];
+  se3_accumulate(g, p, W, H, huber_delta, acc);
   block_reduce_store<29>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
@@ -102,40 +109,8 @@ __global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev* __rest
 #pragma unroll
   for (int q = 0; q < 9; ++q) g.R[q] = st->Rf[q];
   g.t[0] = st->tf[0]; g.t[1] = st->tf[1]; g.t[2] = st->tf[2];
-  const ImgRef I0{ (const char*)p.img0, p.pitch_img0 }, I1{ (const char*)p.img1, p.pitch_img1 };
-  const ImgRef D0{ (const char*)p.dpt0, p.pitch_dpt0 }, G1{ (const char*)p.grad1, p.pitch_grad1 };
   float acc[29];
-#pragma unroll
-  for (int q = 0; q < 29; ++q) acc[q] = 0.f;
-  const int npx = W * H;
-  for (int i = blockIdx.x * kT + threadIdx.x; i < npx; i += gridDim.x * kT) {
-    const int y = i / W, x = i - y * W;
-    const float d = D0.at(x, y);
-    const float i0 = I0.at(x, y);
-    const Corr c = find_correspondence(g, x, y, d, 1.0f, 0.0f);
-    if (c.valid) {
-      const Taps tp = make_taps(c.u, c.v);
-      float gx, gy;
-      sample_grad(G1, tp, gx, gy);
-      const float samp = sample_img(I1, tp);
-      float J[6], D00, D02, D11, D12;
-      pose_row(g, c, d, gx, gy, J, D00, D02, D11, D12);
-      float r = i0 - samp;
-      const float wgt = huber_weight(r, huber_delta);
-      r *= wgt;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) J[j] *= wgt;
-      int k = 0;
-#pragma unroll
-      for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int b = a; b < 6; ++b) acc[k++] += J[a] * J[b];
-#pragma unroll
-      for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;
-      acc[27] += r * r;
-      acc[28] += 1.0f;
-    }
-  }
+  se3_accumulate(g, p, W, H, huber_delta, acc);
   block_reduce_store<29>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
