@@ -1,0 +1,116 @@
+"""Executable specification of the packed z-space of the SfM step (deepfactors_amd/csrc/dfx_sfm_step.hip): a numpy model of the
+products the kernel accumulates (X, Pm, Dd on 16x16x4 MFMAs, the P P^T tiles on 4x4x1 MFMAs) and of k_sfm_finalize's scatter,
+checked against the direct J^T J / J^T r of the same per-pixel rows.  Runs on the CPU: an index mistake in the layout shows up
+here before any GPU time is spent."""
+import numpy as np
+import pytest
+
+
+def _model_item(gC, wr, inl, s, jac, M, HM, cs):
+    """gC [N][6], wr [N], inl [N], s [N], jac [N][cs]; returns (JtJ dense NPxNP, Jtr, residual, inliers) as the kernels build them."""
+    N = len(wr)
+    ncb = cs // 16
+    NP = 12 + cs
+    P8 = np.concatenate([gC, wr[:, None], inl[:, None]], axis=1)                   # LDS rows 0..7
+    C = [s[:, None] * jac[:, b::ncb] for b in range(ncb)]                          # C_b[i] = s * jac[ncb * i + b]
+    # ---- step kernel: accumulators
+    X = {}
+    for b in range(ncb):
+        for b2 in range(b + 1, ncb):
+            X[(b, b2)] = np.einsum("pi,pj->ij", C[b], C[b2])
+    Pm = [np.einsum("pi,pj->ij", np.concatenate([P8, C[b][:, :8]], axis=1), C[b]) for b in range(ncb)]
+    Dd = []
+    for q in range((ncb + 1) // 2):
+        b0, b1 = 2 * q, min(2 * q + 1, ncb - 1)
+        hi = np.concatenate([C[b0][:, 8:], C[b1][:, 8:]], axis=1)
+        Dd.append(np.einsum("pi,pj->ij", hi, hi))
+    # P P^T tiles on 4x4x1: instruction t handles pixels 5t .. 5t+4; block b < 15 holds tile b % 3 of pixel 5t + b // 3
+    S0 = np.zeros((16, 4, 4))
+    for t in range((N + 4) // 5):
+        for b in range(15):
+            px = 5 * t + b // 3
+            if px >= N:
+                continue
+            typ = b % 3
+            tr, tc = (1 if typ == 2 else 0), (1 if typ != 0 else 0)
+            S0[b] += np.outer(P8[px, 4 * tr:4 * tr + 4], P8[px, 4 * tc:4 * tc + 4])
+
+    # ---- finalize
+    def pp(p, q):
+        typ = 0 if q < 4 else (1 if p < 4 else 2)
+        return sum(S0[b][p & 3, q & 3] for b in range(typ, 15, 3))
+
+    T = np.zeros((12, 6))
+    for n in range(12):
+        j, grp = n % 3, n // 3
+        for i in range(6):
+            if grp == 0:
+                T[n, i] = M[3 * i + j] if i < 3 else 0.0
+            elif grp == 1:
+                T[n, i] = M[3 * (i - 3) + j] if i >= 3 else 0.0
+            elif grp == 2:
+                T[n, i] = -M[3 * i + j] if i < 3 else 0.0
+            else:
+                T[n, i] = -HM[3 * i + j] if i < 3 else -M[3 * (i - 3) + j]
+    H = np.full((NP, NP), np.nan)
+    g = np.full(NP, np.nan)
+
+    def put(a, b, v):
+        lo, hi = min(a, b), max(a, b)
+        assert np.isnan(H[lo, hi]), f"entry ({lo},{hi}) written twice"
+        H[lo, hi] = v
+
+    G = np.array([[pp(min(i, j), max(i, j)) for j in range(6)] for i in range(6)])
+    TG = T @ G @ T.T
+    for n in range(12):
+        for m in range(n, 12):
+            put(n, m, TG[n, m])
+        g[n] = T[n] @ np.array([pp(i, 6) for i in range(6)])
+    residual, inliers = pp(6, 6), pp(7, 7)
+    for (b, b2), S in X.items():
+        for i in range(16):
+            for j in range(16):
+                put(12 + ncb * i + b, 12 + ncb * j + b2, S[i, j])
+    for b, S in enumerate(Pm):
+        for n in range(12):
+            for j in range(16):
+                put(n, 12 + ncb * j + b, T[n] @ S[0:6, j])
+        for j in range(16):
+            assert np.isnan(g[12 + ncb * j + b])
+            g[12 + ncb * j + b] = S[6, j]
+        for i in range(8):
+            for j in range(16):
+                if i <= j:
+                    put(12 + ncb * i + b, 12 + ncb * j + b, S[8 + i, j])
+    for q, S in enumerate(Dd):
+        for r in range(16):
+            for c in range(r, 16):
+                if c < 8:
+                    put(12 + ncb * (8 + r) + 2 * q, 12 + ncb * (8 + c) + 2 * q, S[r, c])
+                elif r >= 8 and 2 * q + 1 < ncb:
+                    put(12 + ncb * r + 2 * q + 1, 12 + ncb * c + 2 * q + 1, S[r, c])
+    assert not np.isnan(H[np.triu_indices(NP)]).any(), "upper triangle not fully covered"
+    assert not np.isnan(g).any()
+    return H, g, residual, inliers
+
+
+@pytest.mark.parametrize("cs", [16, 32, 64])
+def test_packed_zspace_covers_the_item_exactly_once(cs):
+    rng = np.random.default_rng(cs)
+    N = 23   # not a multiple of 5 or 4: exercises the padded pixel of the 4x4 tiles
+    gC, wr, s = rng.normal(size=(N, 6)), rng.normal(size=N), rng.normal(size=N)
+    inl = (rng.random(N) > 0.2).astype(np.float64)
+    gC *= inl[:, None]; wr *= inl; s *= inl          # weights of invalid pixels are zero
+    jac = rng.normal(size=(N, cs))
+    M, HM = rng.normal(size=9), rng.normal(size=9)
+    H, g, residual, inliers = _model_item(gC, wr, inl, s, jac, M, HM, cs)
+    # direct: J = [gC * blkdiag(M, M) | gC * [[-M, -HM], [0, -M]] | s * jac]   (warping.h:119-134, dense_sfm.h:149-200)
+    Mm, HMm = M.reshape(3, 3), HM.reshape(3, 3)
+    J0 = np.concatenate([gC[:, :3] @ Mm, gC[:, 3:] @ Mm], axis=1)
+    J1 = np.concatenate([-(gC[:, :3] @ Mm), -(gC[:, :3] @ HMm) - gC[:, 3:] @ Mm], axis=1)
+    J = np.concatenate([J0, J1, s[:, None] * jac], axis=1)
+    ref = J.T @ J
+    iu = np.triu_indices(12 + cs)
+    assert np.abs(H[iu] - ref[iu]).max() < 1e-9 * np.abs(ref).max()
+    assert np.abs(g - J.T @ wr).max() < 1e-9 * max(1.0, np.abs(J.T @ wr).max())
+    assert abs(residual - float(wr @ wr)) < 1e-9 and inliers == inl.sum()
