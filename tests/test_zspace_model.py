@@ -114,3 +114,45 @@ def test_packed_zspace_covers_the_item_exactly_once(cs):
     assert np.abs(H[iu] - ref[iu]).max() < 1e-9 * np.abs(ref).max()
     assert np.abs(g - J.T @ wr).max() < 1e-9 * max(1.0, np.abs(J.T @ wr).max())
     assert abs(residual - float(wr @ wr)) < 1e-9 and inliers == inl.sum()
+
+
+def _wave_chunks(W, H, total_waves, wid, banded=True):
+    """The chunk sequence of wave `wid` as k_sfm_step computes it (banded map with the interleaved fallback)."""
+    nchunks = (W * H + 63) >> 6
+    vs = (W + 32) >> 6
+    if banded and vs >= 1 and total_waves >= vs:
+        crows = (nchunks + vs - 1) // vs
+        nbands = total_waves // vs
+        per = (crows + nbands - 1) // nbands
+        b, j = wid // vs, wid % vs
+        if b >= nbands:
+            return [], vs
+        cend = min(nchunks, (b * per + per) * vs)
+        return list(range(b * per * vs + j, cend, vs)), vs
+    return list(range(wid, nchunks, total_waves)), total_waves
+
+
+@pytest.mark.parametrize("W,H", [(640, 480), (1280, 960), (320, 240), (100, 77), (101, 67), (17, 9), (64, 1), (8, 8), (12288, 2), (96, 64)])
+def test_chunk_map_visits_every_chunk_once(W, H):
+    """The banded chunk -> wave map (and its fallback for tiny grids) is a partition of the chunks, and the per-lane (x, y)
+    walk (one integer division for the first chunk, then a constant pixel stride with a single wrap test) stays exact."""
+    nchunks = (W * H + 63) >> 6
+    for bpp in (1, 2, 3, 5, 7, 16, 60, 80, 120, 240, 1000):
+        total_waves = 4 * bpp
+        seen = np.zeros(nchunks, np.int32)
+        for wid in range(total_waves):
+            seq, cstride = _wave_chunks(W, H, total_waves, wid)
+            for c in seq:
+                seen[c] += 1
+            if len(seq) > 1:   # advance_xy: x += sdx, y += sdy, one wrap
+                pstride = cstride << 6
+                sdy, sdx = divmod(pstride, W)
+                for lane in (0, 63):
+                    p = seq[0] * 64 + lane
+                    y, x = divmod(p, W)
+                    for c in seq[1:]:
+                        x += sdx; y += sdy
+                        if x >= W:
+                            x -= W; y += 1
+                        assert (y, x) == divmod(c * 64 + lane, W)
+        assert (seen == 1).all(), (W, H, bpp, np.flatnonzero(seen != 1)[:5])
