@@ -218,6 +218,29 @@ class SfmAligner {
     return ReductionItem::FromRaw(raw.data());
   }
 
+  // ---- batched extension (no reference counterpart): one launch over n pairs of one pyramid level.
+  // MakePair packs the RunStep argument list into the C POD; RunStepBatch returns the n items in order.
+  template <typename SE3, typename Cam, typename ImageBuffer, typename GradBuffer>
+  static dfx_sfm_pair MakePair(const SE3& pose0, const SE3& pose1, const Cam& cam, const ImageBuffer& img0, const ImageBuffer& img1,
+                               const ImageBuffer& dpt0, const ImageBuffer& valid0, const ImageBuffer& prx0_jac, const GradBuffer& grad1) {
+    dfx_sfm_pair p;
+    p.pose0 = dfx::detail::to_se3(pose0); p.pose1 = dfx::detail::to_se3(pose1);
+    p.cam = dfx::detail::to_cam(cam);
+    p.img0 = dfx::detail::to_img(img0); p.img1 = dfx::detail::to_img(img1); p.dpt0 = dfx::detail::to_img(dpt0);
+    p.valid0 = dfx::detail::to_img(valid0); p.prx0_jac = dfx::detail::to_img(prx0_jac); p.grad1 = dfx::detail::to_img(grad1);
+    return p;
+  }
+  std::vector<ReductionItem> RunStepBatch(const std::vector<dfx_sfm_pair>& pairs) {
+    const dfx_sfm_params prm = c_params();
+    const std::size_t isz = dfx_item_size(12 + CS);
+    std::vector<unsigned char> raw(isz * pairs.size());
+    dfx::check(dfx_sfm_step_batch(ctx_->get(), CS, &prm, pairs.data(), (int)pairs.size(), raw.data()));
+    std::vector<ReductionItem> out;
+    out.reserve(pairs.size());
+    for (std::size_t k = 0; k < pairs.size(); ++k) out.push_back(ReductionItem::FromRaw(raw.data() + k * isz));
+    return out;
+  }
+
   // cu_sfmaligner.cpp:187-203 (glog CHECK there, exception here)
   void SetEvalThreadsBlocks(int threads, int blocks) {
     if (threads % 64) throw dfx::Error(DFX_E_INVALID, "threads must be a multiple of 64 (CDNA wavefront)");

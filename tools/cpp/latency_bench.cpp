@@ -64,6 +64,13 @@ int main() {
     df::SfmAligner<float, CS> sfm;
     float code[CS] = { 0 };
     timeit("SfmAligner<32>::RunStep 640x480", 300, [&] { (void)sfm.RunStep(p0, p1, code, cam, v0, v1, vd, vd, vv, vj, vg); });
+    {
+      std::vector<dfx_sfm_pair> batch(16, df::SfmAligner<float, CS>::MakePair(p0, p1, cam, v0, v1, vd, vv, vj, vg));
+      const auto items = sfm.RunStepBatch(batch);
+      const auto one = sfm.RunStep(p0, p1, code, cam, v0, v1, vd, vd, vv, vj, vg);
+      if (items.size() != 16 || items[7].inliers != one.inliers) { std::printf("RunStepBatch mismatch\n"); return 1; }
+      timeit("SfmAligner<32>::RunStepBatch, 16 x the same pair", 100, [&] { (void)sfm.RunStepBatch(batch); });
+    }
     timeit("SfmAligner<32>::EvaluateError 640x480", 300, [&] { (void)sfm.EvaluateError(p0, p1, cam, v0, v1, vd, vd, vg); });
     timeit("UpdateDepth<32> 640x480", 300, [&] { df::UpdateDepth<float, CS>(code, vd, vj, 2.0f, vo); });
     timeit("SobelGradients 640x480", 300, [&] { df::SobelGradients(v1, vg); });
