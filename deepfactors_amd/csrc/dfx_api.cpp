@@ -261,11 +261,13 @@ int fill_sfm_pair(dfx_ctx* c, int cs, const dfx_se3* pose0, const dfx_se3* pose1
   return DFX_OK;
 }
 
-// Workgroups per pair for the step kernel, from launch-shape sweeps on MI355X (1 / 4 / 16 / 64
-// pairs of 640x480, 16 x 320x240, 4 x 1280x960 CS 64).  A wave's prologue + epilogue cost about as much as two chunks, so
-// waves should be long; but the batch needs a few thousand waves for the hardware to balance the 2x spread of wave
-// lifetimes.  Chunks per wave: 5 while the batch is small, up to 15 (CS <= 32; a CS 64 chunk carries 2.5x the matrix
-// work) once that still leaves ~3840 waves.  (Sweeps must discard the first ~100 launches of a process: the clocks ramp.)
+// Workgroups per pair for the step kernel, from launch-shape sweeps on MI355X (1 / 4 / 16 / 64 / 128
+// pairs of 640x480, 16 x 320x240, 4 x 1280x960 CS 64).  A wave's prologue + epilogue (descriptor and ray-table loads, cold
+// first loads; the barrier in front of the cross-wave fold) cost about as much as two chunks, so waves should be long; but the
+// batch needs at least ~5 rounds of the 4096 resident waves for the hardware to balance the spread of wave lifetimes (one
+// static round measured 4 % slower than five).  Chunks per wave: 5 while the batch is small, up to 30 (CS <= 32; a CS 64
+// chunk carries 2.5x the matrix work: 10) when that still leaves five rounds.  (Sweeps must discard the first ~100 launches
+// after any idle period: the clocks ramp.)
 int auto_step_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int npairs, int cs) {
   const int nchunks = (int)(((size_t)W * H + 63) / 64);
   int maxb = (nchunks + 3) / 4;   // one chunk per wave at most
@@ -273,8 +275,9 @@ int auto_step_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int npairs, int c
   int b = c->step_blocks;
   if (b <= 0) {
     const long long total_chunks = (long long)nchunks * npairs;
-    int cpw = (int)(total_chunks / 3840);
-    const int cpw_max = cs >= 64 ? 5 : 15;
+    const long long resident_waves = 16LL * c->cu_count;
+    int cpw = (int)(total_chunks / (5 * resident_waves));
+    const int cpw_max = cs >= 64 ? 10 : 30;
     if (cpw < 5) cpw = 5;
     if (cpw > cpw_max) cpw = cpw_max;
     b = (nchunks + 4 * cpw - 1) / (4 * cpw);

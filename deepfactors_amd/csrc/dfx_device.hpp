@@ -41,14 +41,18 @@ constexpr unsigned kOobOffset = 0xF0000000u;   // far beyond any image; API enfo
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
+// AUX = cache policy bits of the instruction (0 default, 2 = nt: streamed once, do not keep in the L2 ahead of reusable lines)
+template <int AUX = 0>
 __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned off, float*) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ f32x2 bload(__amdgpu_buffer_rsrc_t r, unsigned off, f32x2*) {
-  return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0));
+  return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4*) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, AUX));
 }
 
 struct ImgRef {

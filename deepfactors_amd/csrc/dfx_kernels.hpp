@@ -49,8 +49,8 @@ struct SimplePairDev {   // SE3Aligner / EvaluateError / Warp
 };
 
 // z-space size of the SfM step partials: one 256-float block for the 29 (P,P) sums + the packed 16x16 MFMA blocks
-// X(b,b'), Pm(b), Dd(q) (see dfx_sfm_step.hip)
-inline int sfm_nacc(int ncb) { return ncb * (ncb - 1) / 2 + ncb + (ncb + 1) / 2; }
+// X(b,b'), Pm(b) + two 4x4x1 blocks per Dd(q) (see dfx_sfm_step.hip)
+inline int sfm_nacc(int ncb) { return ncb * (ncb - 1) / 2 + ncb + 2 * ((ncb + 1) / 2); }
 inline int sfm_zdim(int ncb) { return (1 + sfm_nacc(ncb)) * 256; }
 
 // All launchers enqueue on `stream` and return the HIP status of the launch.

@@ -15,14 +15,25 @@
 //   Matrix-core time and vector-ALU time ADD on gfx950, so MFMA slots are not wasted on the symmetric halves of the
 //   diagonal blocks: the 16x16 products are PACKED (A and B are arbitrary 16-row selections of z):
 //     X(b,b') : C_b x C_b'  (b < b')                       all 256 sums needed
-//     Pm(b)   : [ P (8) ; C_b rows 0..7 ] x C_b             pose-code, Jtr(code) and the (i < 8, j) part of C_b x C_b
-//     Dd(q)   : [ C_2q rows 8..15 ; C_2q+1 rows 8..15 ]^2   the (i >= 8, j >= 8) parts of two diagonal blocks
-//   4 MFMAs per 4 pixels at CS = 32 (was 6 for the plain upper block-triangle), 12 at CS = 64 (was 15), 2 at CS = 16 (was 3).
+//     Pm(b)   : b even: [ P (8) ; C_b rows 8..15 ] x C_b    pose-code, Jtr(code) and the rows 8..15 of C_b x C_b
+//               b odd : [ C_b rows 0..7 ; P (8) ] x C_b     same with the rows 0..7 of C_b x C_b
+//     Dd(q)   : M = [ C_2q rows 0..7 ; C_2q+1 rows 8..15 ]: the six 4x4 tiles of the two 8x8 diagonal blocks the Pm products
+//               leave open, on TWO v_mfma_f32_4x4x1_16B_f32 (8 cycles each, A = B = M): the operand layout of a 16x16x4 MFMA
+//               (lane = 16 k + row) is also 16 blocks (pixel k, row group rg) of the 4x4x1 form, and its A-broadcast modifier
+//               (CBSZ = 1, ABID = 0: both blocks of a pair use the A rows of the first) yields M0 M0^T, M0 M1^T, M2 M2^T,
+//               M2 M3^T in one instruction; the plain form adds M1 M1^T and M3 M3^T.  16 cycles instead of a 32-cycle 16x16x4
+//               MFMA of which 72 of 256 sums were needed (tools/ubench/mfma4x4_bcast.cpp pins the modifier's semantics).
+//   Matrix-pipe cycles per 4 pixels at CS = 32: 3 x 32 + 16 = 112 (was 128; 192 for the plain upper block-triangle); the 55
+//   needed 4x4 tiles of the 40 x 40 z-space cost 110 at the pipe's rate.
 //   The 29 needed sums of P x P (6x6 upper triangle, 6 Jtr, r^2, inliers; P row 7 = inlier flag) run on
 //   v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 outer products per instruction = the three upper 4x4 tiles of P P^T for
 //   five pixels, 13 instructions (8 cycles each) per chunk, operands straight from the LDS P rows -- 4 accumulator
 //   registers instead of 29 per-lane sums (which cost an occupancy step) and no cross-lane reduction at the end.
-//   Mixed operands are built with one v_mov_b32_dpp each (row_shr:8 / row_shl:8 under a bank mask).
+//   Mixed operands are lane selects (one v_cndmask_b32 each, loop-invariant mask): the P rows are read from LDS by lanes
+//   0..7 AND 8..15 of every 16-lane row (address (lane & 7): a broadcast, no bank conflict), so either half can carry them.
+//   fp32 MFMAs execute on the vector ALU's lanes (tools/ubench/issue_cost.cpp: a co-resident wave's VALU instructions
+//   get no issue slot while fp32 MFMAs run; every VALU instruction adds ~2.2 cycles, a DPP one ~4.4, to the 32 of a
+//   16x16x4), so SIMD time per chunk = 32 x #MFMA16 + 8 x #MFMA4 + 2.2 x #VALU: both terms are kept minimal.
 //
 //   Phase A (lane = pixel): coalesced img0/dpt0 loads, warp, bilinear gathers of img1/grad1, Jacobian row,
 //     Huber weight; the 16-float P row goes to LDS component-major (stride 66 -> conflict-free both ways).
@@ -62,6 +73,12 @@ namespace dfx {
                              // 16 = no P x P fmas, 32 = no ray-table / valid0 reads, 64 = no operand shuffles
 #endif
 
+#ifndef DFX_RING_AUX
+#define DFX_RING_AUX 2       // cache policy of the code-Jacobian stream loads: 2 = nt (read once: do not displace the img1 / grad1 rows
+#endif                       // the bilinear taps of the next chunk row re-use from the L2); -1.6 % kernel time, -3 % read requests with the collapse below
+#ifndef DFX_STREAM_AUX
+#define DFX_STREAM_AUX 0     // cache policy of the coalesced img0 / dpt0 loads (read once per launch)
+#endif
 #ifndef DFX_WAVES
 #define DFX_WAVES 4
 #endif
@@ -82,15 +99,16 @@ template <> __device__ __forceinline__ float jv_get<4>(const f32x4& v, int b) { 
 
 // Byte offset of one code-Jacobian operand vector of the ring inside the [H][W*CS] image: pixel (pbase + 4*gq + lk),
 // codes NCB*li .. NCB*li+NCB-1.  JDENSE (rows back to back) makes the stream linear in the pixel index; the pitched
-// variant pays one integer division per vector.  Offsets of pixels past the image fall outside the buffer resource
-// (dense) or are replaced by kOobOffset (pitched), so the hardware returns 0 without touching memory.
+// variant pays one integer division per vector.  Pixels past the image exist only in the last chunk of an image whose
+// pixel count is not a multiple of 64; that case always takes the pitched variant (launch_t), which clamps them to pixel 0
+// (their weight is 0): no wave-load of the pipelined loop ever has all its lanes out of range (see the note in k_sfm_step).
 template <int NCB, bool JDENSE>
 __device__ __forceinline__ unsigned jv_offset(unsigned pbase, int gq, int li, int lk, unsigned W, unsigned npx, unsigned jac_pitch) {
   constexpr unsigned VB = 4u * NCB;   // bytes per operand vector
   const unsigned p = pbase + 4u * gq + lk;
   if (JDENSE) return (p * 16u + li) * VB;
   const unsigned y = p / W, x = p - y * W;
-  return p < npx ? y * jac_pitch + (x * 16u + li) * VB : kOobOffset;
+  return p < npx ? y * jac_pitch + (x * 16u + li) * VB : (unsigned)li * VB;
 }
 
 // MODE 0: SfmAligner::RunStep.  MODE 1: DepthAligner::RunStep (cu_depthaligner.cpp:32-72) -- same rank-1 GEMM with
@@ -108,8 +126,8 @@ template <int NCB, int MODE, bool JDENSE, bool TABLDS>
 __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_WAVES) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmParamsDev prm,
                                                        const int W, const int H, float* __restrict__ partials, const NeqDev neq) {
   constexpr int NX = NCB * (NCB - 1) / 2, ND = (NCB + 1) / 2;   // X(b,b'), Dd(q); Pm(b): NCB
-  constexpr int NACC = NX + NCB + ND;
-  constexpr int ZDIM = (1 + NACC) * 256;                         // block 0: the 29 P x P sums
+  constexpr int NACC = NX + NCB;                                 // 16x16x4 accumulators
+  constexpr int ZDIM = (1 + NACC + 2 * ND) * 256;                // block 0: the 29 P x P sums; then X, Pm, (Dd broadcast, Dd plain) per q
   constexpr int LDS_FLOATS = kWaves * ((kUFloats > ZDIM) ? kUFloats : ZDIM);   // P rows in the loop, accumulators in the epilogue
   typedef typename JV<NCB>::T jv_t;
   // "No next chunk" is handled by re-reading the wave's current chunk (L2-hot, results never consumed), NOT by
@@ -178,6 +196,9 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   f32x4 acc[NACC];
 #pragma unroll
   for (int a = 0; a < NACC; ++a) acc[a] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+  f32x4 accd[2 * ND];                           // Dd(q): [2q] = A-broadcast form, [2q + 1] = plain form; block (lane >> 2) = (pixel k, row group)
+#pragma unroll
+  for (int a = 0; a < 2 * ND; ++a) accd[a] = f32x4{ 0.f, 0.f, 0.f, 0.f };
   f32x4 accpp = f32x4{ 0.f, 0.f, 0.f, 0.f };   // P x P tiles: block b = lane >> 2 holds tile (b % 3) summed over its pixels
   // 4x4x1 operands: lane (b, i) reads P row 4*tr + i (A) / 4*tc + i (B) of pixel 5*t + b / 3; tiles (tr, tc) = (0,0), (0,1), (1,1);
   // block 15 and pixel 64 read the zero padding column of the LDS rows
@@ -188,13 +209,19 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   const int npx = W * H;
   const int nchunks = (npx + 63) >> 6;
   const int li = lane & 15, lk = lane >> 4;
+  const bool lo8 = li < 8;              // lanes 0..7 of every 16-lane row
+  const int uP_row = (li & 7) * kUStride;   // both halves of a row read P rows 0..7
   const unsigned ring_lane_off = (unsigned)(lk * 16 + li) * (4u * NCB);
   // `lo` is the lane offset made opaque once per chunk (ring_opaque_off): the group offsets then fold into the
   // instructions' 12-bit immediates (+ one v_add per 4 KB step) instead of LICM hoisting sixteen offset VGPRs.
-  auto ring_opaque_off = [&]() { unsigned lo = ring_lane_off; asm volatile("" : "+v"(lo)); return lo; };
-  auto ring_load = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned lo, unsigned pbase, int gq) -> jv_t {
-    if (JDENSE) return bload(rs, lo + (unsigned)gq * (256u * NCB), (jv_t*)nullptr);
-    return bload(jac_rs, jv_offset<NCB, false>(pbase, gq, li, lk, W, npx, jac_pitch), (jv_t*)nullptr);
+  // `real` = false ("no next chunk"): the refill's results are never consumed, but it must stay a load that touches memory (a
+  // wave-load with every lane out of range may retire ahead of older loads and break the counted waits): all lanes then read
+  // the group's first vector of the CURRENT chunk -- one cache line per instruction instead of a second 256*NCB*16-byte
+  // pass over a chunk the stream has long pushed out of the L2 (that pass was 1/15 of all ring traffic).
+  auto ring_opaque_off = [&](bool real) { unsigned lo = real ? ring_lane_off : 0u; asm volatile("" : "+v"(lo)); return lo; };
+  auto ring_load = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned lo, unsigned pbase, int gq, bool real) -> jv_t {
+    if (JDENSE) return bload<DFX_RING_AUX>(rs, lo + (unsigned)gq * (256u * NCB), (jv_t*)nullptr);
+    return bload<DFX_RING_AUX>(jac_rs, jv_offset<NCB, false>(pbase, gq, real ? li : 0, real ? lk : 0, W, npx, jac_pitch), (jv_t*)nullptr);
   };
   // Chunk -> wave map.  Banded (default): a wave walks DOWN the image -- chunk, chunk + one image row, ... -- so the
   // img1 / grad1 rows its bilinear taps share with the chunk below are re-read by the same CU (L2 hit) instead of by a
@@ -247,9 +274,9 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     const unsigned p = pbase + lane;
     const bool inb = p < (unsigned)npx;
     unsigned od = q.y * pitch_d0 + q.x * 4u, oi = q.y * pitch_i0 + q.x * 4u;
-    od = inb ? od : kOobOffset; oi = inb ? oi : kOobOffset;
-    q.d = bload(d0_rs, od, (float*)nullptr);
-    q.i0 = bload(i0_rs, oi, (float*)nullptr);
+    od = inb ? od : 0u; oi = inb ? oi : 0u;   // in range on purpose (weight 0), see the note on all-lanes-out-of-range loads
+    q.d = bload<DFX_STREAM_AUX>(d0_rs, od, (float*)nullptr);
+    q.i0 = bload<DFX_STREAM_AUX>(i0_rs, oi, (float*)nullptr);
     if (DFX_ABLATE & 32) { q.rx = 0.01f * (float)q.x; q.ry = 0.01f * (float)q.y; q.vl = 1.0f; }
     else if (MODE == 0) {   // table rows are padded (kRayTabSlack), so lanes past the last pixel stay inside the allocation
       if (TABLDS) { q.rx = ray_lds[q.x]; q.ry = ray_lds[W + q.y]; }
@@ -262,8 +289,10 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   };
   // A1: warp the pixel and issue its 4 bilinear tap loads.  Branch-free on purpose: a conditional load would make the
   // number of loads younger than the ring path-dependent and force the compiler's vmcnt to the conservative minimum
-  // (i.e. wait for these very gathers at the start of phase B).  Lanes without a correspondence read at kOobOffset:
-  // the buffer unit returns 0 and moves no data.
+  // (i.e. wait for these very gathers at the start of phase B).  Lanes without a correspondence read offset 0 of the image
+  // (their weight is 0 through v_mul_legacy): an out-of-range offset would be cheaper per lane, but a chunk whose 64 pixels
+  // ALL lack a correspondence (image regions that leave the view) would then issue wave-loads that touch no memory, and
+  // those may retire ahead of the older ring loads the counted waits of phase B rely on.
   auto issue_gathers = [&](unsigned pbase, Pix& q) {
     if (MODE == 0) {
       const Corr c = find_correspondence_ray(g, q.rx, q.ry, q.d, prm.border, prm.min_dpt);
@@ -272,8 +301,8 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
       q.c = c; q.ax = tp.ax; q.ay = tp.ay; q.ok = ok;
       unsigned oi = (unsigned)tp.iy * pitch_i1 + (unsigned)tp.ix * 4u, oi2 = oi + pitch_i1;
       unsigned og = (unsigned)tp.iy * pitch_g1 + (unsigned)tp.ix * 8u, og2 = og + pitch_g1;
-      oi = ok ? oi : kOobOffset; oi2 = ok ? oi2 : kOobOffset;
-      og = ok ? og : kOobOffset; og2 = ok ? og2 : kOobOffset;
+      oi = ok ? oi : 0u; oi2 = ok ? oi2 : 0u;
+      og = ok ? og : 0u; og2 = ok ? og2 : 0u;
       q.ia = bload(i1_rs, oi, (f32x2*)nullptr);
       q.ib = bload(i1_rs, oi2, (f32x2*)nullptr);
       q.ga = bload(g1_rs, og, (f32x4*)nullptr);
@@ -307,7 +336,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     __builtin_amdgcn_sched_barrier(0);
     const __amdgpu_buffer_rsrc_t rs0 = ring_rsrc(base);
 #pragma unroll
-    for (int gq = 0; gq < 16; ++gq) jv[gq] = ring_load(rs0, ring_lane_off, base, gq);
+    for (int gq = 0; gq < 16; ++gq) jv[gq] = ring_load(rs0, ring_lane_off, base, gq, true);
     __builtin_amdgcn_sched_barrier(0);
   }
 
@@ -342,7 +371,8 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 #endif
     const int base = chunk << 6;
     const bool has2 = chunk + 2 * cstride < cend;                                                           // wave-uniform
-    const unsigned nbase = (chunk + cstride < cend) ? (unsigned)(chunk + cstride) << 6 : (unsigned)base;    // else: re-read this chunk
+    const bool has1 = chunk + cstride < cend;                                                               // wave-uniform
+    const unsigned nbase = has1 ? (unsigned)(chunk + cstride) << 6 : (unsigned)base;                        // else: re-read this chunk
     const unsigned nnbase = has2 ? (unsigned)(chunk + 2 * cstride) << 6 : nbase;
 
     // ---- A2(c): lane = pixel; taps of this chunk were issued one iteration ago
@@ -415,7 +445,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 #endif
     // ---- phase B: rank-4 updates on the matrix cores; operand ring refilled behind the consumer
     const __amdgpu_buffer_rsrc_t nrs = ring_rsrc(nbase);
-    const unsigned rlo = ring_opaque_off();
+    const unsigned rlo = ring_opaque_off(has1);
 #if !(DFX_ABLATE & 16)
 #pragma unroll
     for (int t = 0; t < 13; ++t)   // P x P: five pixels per instruction
@@ -424,13 +454,13 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 #pragma unroll
     for (int gq = 0; gq < 16; ++gq) {
       const int pp = 4 * gq + lk;
-      const float uP = U[li * kUStride + pp];
+      const float uP = U[uP_row + pp];
       const float s = U[13 * kUStride + pp];
       float sc[NCB];
 #pragma unroll
       for (int b = 0; b < NCB; ++b) sc[b] = mul_zero_wins(s, jv_get<NCB>(jv[gq], b));
 #if !(DFX_ABLATE & 4)
-      jv[gq] = ring_load(nrs, rlo, nbase, gq);
+      jv[gq] = ring_load(nrs, rlo, nbase, gq, has1);
 #endif
 #if DFX_ABLATE & 1
       acc[0][0] += uP;
@@ -444,15 +474,16 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 #pragma unroll
         for (int b2 = b + 1; b2 < NCB; ++b2, ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[b], sc[b2], acc[a], 0, 0, 0);
 #pragma unroll
-      for (int b = 0; b < NCB; ++b, ++a) {   // Pm(b): rows 0..7 = P, rows 8..15 = C_b rows 0..7
-        const float mixed = (DFX_ABLATE & 64) ? uP : dpp_merge<0x118, 0xC>(uP, sc[b]);
+      for (int b = 0; b < NCB; ++b, ++a) {   // Pm(b): even b: rows 0..7 = P, 8..15 = C_b rows 8..15; odd b: rows 0..7 = C_b rows 0..7, 8..15 = P
+        const float mixed = (DFX_ABLATE & 64) ? uP : ((b & 1) ? (lo8 ? sc[b] : uP) : (lo8 ? uP : sc[b]));
         acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(mixed, sc[b], acc[a], 0, 0, 0);
       }
 #pragma unroll
-      for (int q = 0; q < ND; ++q, ++a) {    // Dd(q): rows 0..7 = C_2q rows 8..15, rows 8..15 = C_2q+1 rows 8..15
+      for (int q = 0; q < ND; ++q) {         // Dd(q): M = [C_2q rows 0..7 ; C_2q+1 rows 8..15] (odd NCB, last q: C_2q twice)
         const int b0 = 2 * q, b1 = (2 * q + 1 < NCB) ? 2 * q + 1 : 2 * q;
-        const float hi = (DFX_ABLATE & 64) ? sc[b1] : dpp_merge<0x108, 0x3>(sc[b1], sc[b0]);
-        acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(hi, hi, acc[a], 0, 0, 0);
+        const float M = ((DFX_ABLATE & 64) || b1 == b0) ? sc[b0] : (lo8 ? sc[b0] : sc[b1]);
+        accd[2 * q] = __builtin_amdgcn_mfma_f32_4x4x1f32(M, M, accd[2 * q], 1, 0, 0);           // M0 M0^T, M0 M1^T, M2 M2^T, M2 M3^T per pixel
+        accd[2 * q + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(M, M, accd[2 * q + 1], 0, 0, 0);   // (M0 M0^T), M1 M1^T, (M2 M2^T), M3 M3^T
       }
     }
 #if DFX_TRACE
@@ -479,6 +510,10 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     for (int a = 0; a < NACC; ++a)
 #pragma unroll
       for (int r = 0; r < 4; ++r) mine[(1 + a) * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[a][r];
+#pragma unroll
+    for (int a = 0; a < 2 * ND; ++a)   // 4x4x1 form: [block = 4 k + rg][row r of the A group][column = lane & 3 of the B group]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[(1 + NACC + a) * 256 + ppb * 16 + r * 4 + ppi] = accd[a][r];
   }
   __syncthreads();
   float* out = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ZDIM;
@@ -521,7 +556,7 @@ __device__ __forceinline__ void neq_scatter(float* H0, int a, int b, float v) {
 
 // ---- finalize: sum the workgroup partials of each pair (double, fixed order), map the relative-pose basis onto
 // (pose0, pose1) and scatter the packed z-space blocks into the item layout.
-// grid = (1 + NACC, npairs), 1024 threads: thread = (element of one 256-float block, 1 of 4 partial groups); groups
+// grid = (1 + NACC + 2 ND, npairs), 1024 threads: thread = (element of one 256-float block, 1 of 4 partial groups); groups
 // stride over the pair's `bpp` partials (1 KB coalesced reads, 8 loads in flight) and are folded in fixed order.
 template <int NCB, int NPOSE>
 __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs,
@@ -529,8 +564,8 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
   constexpr int CS = 16 * NCB;
   constexpr int NP = NPOSE + CS;
   constexpr int NX = NCB * (NCB - 1) / 2, ND = (NCB + 1) / 2;
-  constexpr int NACC = NX + NCB + ND;
-  constexpr int ZDIM = (1 + NACC) * 256;
+  constexpr int NACC = NX + NCB;
+  constexpr int ZDIM = (1 + NACC + 2 * ND) * 256;
   constexpr int NT = NP * (NP + 1) / 2;
   __shared__ double red[4][256];
   __shared__ double T[12][6];   // d(pose0, pose1) <- d(relative pose): J = gC * T^T
@@ -635,28 +670,41 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
     { int q = a; for (b = 0; b < NCB; ++b) { const int n = NCB - 1 - b; if (q < n) { b2 = b + 1 + q; break; } q -= n; } }
     if (t < 256) put_code(NCB * (t >> 4) + b, NCB * (t & 15) + b2, (float)S[t]);
   } else if (a < NX + NCB) {
-    // ---- Pm(b): rows 0..5 = gC, row 6 = w r, row 7 unused, rows 8..15 = C_b rows 0..7; columns = C_b
+    // ---- Pm(b): columns = C_b; even b: rows 0..5 = gC, 6 = w r, 7 unused, rows 8..15 = C_b rows 8..15
+    //                            odd b : rows 0..7 = C_b rows 0..7, rows 8..13 = gC, 14 = w r, 15 unused
     const int b = a - NX;
-    if (NPOSE == 12 && t < 192) {          // pose-code: T * S[0..5][j]
+    const int pofs = (b & 1) ? 8 : 0, cofs = 8 - pofs;
+    if (NPOSE == 12 && t < 192) {          // pose-code: T * S[P rows 0..5][j]
       const int n = t >> 4, j = t & 15;
       double v = 0.0;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) v += T[n][i] * S[i * 16 + j];
+      for (int i = 0; i < 6; ++i) v += T[n][i] * S[(pofs + i) * 16 + j];
       put(n, NPOSE + NCB * j + b, (float)v);
     } else if (t >= 192 && t < 208) {      // Jtr (code)
       const int j = t - 192;
-      put_g(NPOSE + NCB * j + b, (float)S[6 * 16 + j]);
-    } else if (t >= 256 && t < 384) {      // C_b[i] * C_b[j], i < 8; (i, j) and (j, i) both exist when j < 8
-      const int i = (t - 256) >> 4, j = t & 15;
-      if (i <= j) put_code(NCB * i + b, NCB * j + b, (float)S[(8 + i) * 16 + j]);
+      put_g(NPOSE + NCB * j + b, (float)S[(pofs + 6) * 16 + j]);
+    } else if (t >= 256 && t < 384) {      // C_b[r] * C_b[c], r in the 8 rows this block carries: upper part, plus (even b) the rows 8..15 x rows 0..7 rectangle
+      const int r = cofs + ((t - 256) >> 4), c = t & 15;
+      if (c >= r || c < cofs) put_code(NCB * r + b, NCB * c + b, (float)S[r * 16 + c]);
     }
-  } else if (t < 256) {
-    // ---- Dd(q): index 0..7 = C_2q rows 8..15, 8..15 = C_2q+1 rows 8..15 (duplicate of the first half when 2q+1 == NCB)
-    const int q = a - NX - NCB;
-    const int r = t >> 4, c = t & 15;
-    if (r <= c) {
-      if (c < 8) put_code(NCB * (8 + r) + 2 * q, NCB * (8 + c) + 2 * q, (float)S[t]);
-      else if (r >= 8 && 2 * q + 1 < NCB) put_code(NCB * r + 2 * q + 1, NCB * c + 2 * q + 1, (float)S[t]);
+  } else {
+    // ---- Dd(q) on 4x4x1: 16 blocks (pixel k, row group rg) of [row i of the A group][column j of the B group]; M = [C_b0 rows 0..7 ;
+    // C_b1 rows 8..15] in groups M0..M3.  form 0 (A broadcast inside block pairs): M0 M0^T, M0 M1^T, M2 M2^T, M2 M3^T; form 1: Mrg Mrg^T.
+    const int d = a - NACC, q = d >> 1, form = d & 1;
+    const int b0 = 2 * q, b1 = 2 * q + 1;   // b1 == NCB (odd NCB, last q): the upper half repeats C_b0 rows 8..15, which Pm(b0) already covers
+    if (t < 64) {
+      const int rg = t >> 4, i = (t >> 2) & 3, j = t & 3;
+      const double v = ((S[rg * 16 + (t & 15)] + S[(4 + rg) * 16 + (t & 15)]) + S[(8 + rg) * 16 + (t & 15)]) + S[(12 + rg) * 16 + (t & 15)];   // the group's 4 pixels
+      const int bb = rg < 2 ? b0 : b1;
+      if (bb < NCB) {
+        const int base = rg < 2 ? 0 : 8;
+        if (form == 0) {
+          if ((rg & 1) == 0) { if (i <= j) put_code(NCB * (base + i) + bb, NCB * (base + j) + bb, (float)v); }
+          else put_code(NCB * (base + i) + bb, NCB * (base + 4 + j) + bb, (float)v);
+        } else if ((rg & 1) == 1) {
+          if (i <= j) put_code(NCB * (base + 4 + i) + bb, NCB * (base + 4 + j) + bb, (float)v);
+        }
+      }
     }
   }
 }
@@ -712,11 +760,12 @@ template <int NCB, int MODE>
 static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm, int bpp,
                            float* partials_dev, void* items_dev, size_t item_stride, hipStream_t stream, bool jac_dense, int prec,
                            hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, const NeqDev& neq = NeqDev{ nullptr, nullptr, 0, 0 }) {
-  constexpr int NACC = NCB * (NCB - 1) / 2 + NCB + (NCB + 1) / 2;
+  constexpr int NACC = NCB * (NCB - 1) / 2 + NCB + 2 * ((NCB + 1) / 2);   // 256-float blocks after block 0 (16x16x4 and 4x4x1 accumulators)
   hipError_t e;
   if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
   const dim3 grid(bpp, npairs), block(kThreads);
   (void)prec;   // one evaluation mode: exact fp32 products on v_mfma_f32_16x16x4_f32
+  if (((long long)W * H) % 64 != 0) jac_dense = false;   // ragged last chunk: the per-vector addressing clamps pixels past the image
   // the ray table rides in dynamic LDS when it fits beside the static arrays (64 KB per workgroup); MODE 1 has no table
   constexpr size_t kStaticLds = sizeof(float) * (size_t)kWaves * ((kUFloats > (1 + NACC) * 256) ? kUFloats : (1 + NACC) * 256);
   const size_t tab_bytes = sizeof(float) * ((size_t)W + H + kRayTabSlack);

@@ -1,0 +1,171 @@
+"""BASELINE.json configurations against the CPU oracle at their real sizes, through the C ABI:
+  configs[4]  1280x960, 64-code (the occupancy-2 kernel variant, 12 MFMAs + 4 tile products per group) and 640x480x64;
+  configs[1]  640x480x32 with PITCHED Jacobian rows (per-vector addressing variant of the step kernel);
+  configs[2]  a 16-keyframe window: 120 pairs per pyramid level in ONE launch, all pairs of a keyframe sharing its
+              prx_jac / dpt0 / valid0 buffers (concurrent 1.0-writes into one valid0 image), levels 0..2;
+  the global-ray-table kernel variant at a realistic height; image regions that leave the view (whole chunks without a
+  correspondence) with bit-determinism over many runs.
+Reference: tests/ut_sfmaligner.cpp:235-327 (GPU vs host evaluation of the same inputs: inliers equal, |dJtJ| <= 1e-1); the
+tolerance here is tests/helpers.py (1e-4 of the block scale against the fp64-accumulating oracle)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_item_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair_dev(w, h, cs, seed, **kw):
+    """Synthetic pair generated on the GPU (seconds at 1280x960x64), plus its host copy for the oracle."""
+    from deepfactors_amd import synth
+    g = synth.make_pair(w, h, cs, seed=seed, device="cuda", **kw)
+    return synth.to_numpy(g), g
+
+
+@pytest.mark.parametrize("w,h,cs", [(1280, 960, 64), (640, 480, 64), (1280, 960, 32)])
+def test_sfm_step_matches_oracle_at_full_size(dfx, oracle, w, h, cs):
+    n, g = _pair_dev(w, h, cs, seed=0xDF05)
+    pose1 = n["pose1"].copy(); pose1[4] += 0.01
+    al = dfx.SfmAligner(code_size=cs)
+    valid_gpu = torch.zeros_like(g["img0"])
+    got = al.RunStep(n["pose0"], pose1, n["code"], n["cam"], g["img0"], g["img1"], g["dpt0"], g["std0"], valid_gpu, g["prx_jac"], g["grad1"])
+    valid_ref = np.zeros_like(n["img0"])
+    ref = oracle.sfm_step(n["pose0"], pose1, n["cam"], n["img0"], n["img1"], n["dpt0"], n["prx_jac"], n["grad1"], valid0=valid_ref, accum_f64=True)
+    assert ref.inliers > 0.8 * w * h
+    assert_item_close(got, ref, w, h, what=f"sfm_step {w}x{h} cs={cs}")
+    assert int((valid_gpu.cpu().numpy() != valid_ref).sum()) <= max(1, int(1e-5 * w * h))
+    # EvaluateError and UpdateDepth at the same size
+    e_got = al.EvaluateError(n["pose0"], pose1, n["cam"], g["img0"], g["img1"], g["dpt0"], None, g["grad1"])
+    e_res, e_inl = oracle.sfm_error(n["pose0"], pose1, n["cam"], n["img0"], n["img1"], n["dpt0"], 0.1)
+    assert abs(int(e_got.inliers) - e_inl) <= max(1, int(1e-5 * w * h))
+    assert abs(e_got.residual - e_res) <= 1e-4 * e_res
+    out = torch.empty_like(g["img0"])
+    dfx.UpdateDepth(n["code"], g["prx_orig"], g["prx_jac"], 2.0, out)
+    d_ref = oracle.update_depth(n["code"], n["prx_orig"], n["prx_jac"], 2.0)
+    assert np.abs(out.cpu().numpy() - d_ref).max() <= 2e-6 * float(((2.0 + d_ref) ** 2 / 2.0).max())
+
+
+def _pitched(t, pad):
+    shape = list(t.shape); shape[1] += pad
+    big = torch.full(shape, float("nan"), dtype=t.dtype, device=t.device)
+    big[:, : t.shape[1]] = t
+    return big[:, : t.shape[1]]
+
+
+@pytest.mark.parametrize("w,h,cs,jpad", [(640, 480, 32, 64), (640, 480, 32, 0), (320, 240, 64, 4 * 64)])
+def test_pitched_jacobian_at_full_size(dfx, oracle, w, h, cs, jpad):
+    """jpad > 0 selects the per-vector addressing variant of the step kernel (JDENSE = false); every other image is pitched too."""
+    n, g = _pair_dev(w, h, cs, seed=0xDF06)
+    al = dfx.SfmAligner(code_size=cs)
+    valid_gpu = _pitched(torch.zeros_like(g["img0"]), 20)
+    valid_gpu.zero_()
+    got = al.RunStep(n["pose0"], n["pose1"], n["code"], n["cam"], _pitched(g["img0"], 28), _pitched(g["img1"], 12), _pitched(g["dpt0"], 4), None,
+                     valid_gpu, _pitched(g["prx_jac"], jpad) if jpad else g["prx_jac"], _pitched(g["grad1"], 6))
+    valid_ref = np.zeros_like(n["img0"])
+    ref = oracle.sfm_step(n["pose0"], n["pose1"], n["cam"], n["img0"], n["img1"], n["dpt0"], n["prx_jac"], n["grad1"], valid0=valid_ref)
+    assert_item_close(got, ref, w, h, what=f"pitched {w}x{h} cs={cs} jpad={jpad}")
+    assert int((valid_gpu.cpu().numpy() != valid_ref).sum()) <= max(1, int(1e-5 * w * h))
+
+
+def test_global_ray_table_variant_at_a_realistic_height(dfx, oracle):
+    """W + H + 80 floats beyond what fits beside the workgroup's static LDS (64 KB): TABLDS = false.  64 rows, 655 k pixels."""
+    w, h, cs = 10240, 64, 16
+    n, g = _pair_dev(w, h, cs, seed=0xDF07)
+    al = dfx.SfmAligner(code_size=cs)
+    got = al.RunStep(n["pose0"], n["pose1"], n["code"], n["cam"], g["img0"], g["img1"], g["dpt0"], None, None, g["prx_jac"], g["grad1"])
+    ref = oracle.sfm_step(n["pose0"], n["pose1"], n["cam"], n["img0"], n["img1"], n["dpt0"], n["prx_jac"], n["grad1"])
+    assert ref.inliers > 0.5 * w * h
+    assert_item_close(got, ref, w, h, what="10240x64 global ray table")
+
+
+def _rand_pose(rng, synth, trs, rot):
+    R = synth.so3_exp(rng.normal(0, rot, 3))
+    return synth.pose_qt(R, rng.normal(0, trs, 3))
+
+
+def test_keyframe_window_120_pairs_share_keyframe_buffers(dfx, oracle):
+    """BASELINE configs[2]: 16 keyframes, every pair i < j (120) per pyramid level in one launch.  All pairs out of keyframe i
+    read ITS prx_jac / dpt0 and write ITS valid0 (15 concurrent writers of 1.0 at most); level-1/-2 cameras are halved
+    (camera_pyramid.h:41-46).  Every item of levels 1 and 2 and every fourth item of level 0 is compared with the oracle;
+    the valid0 images must equal the union of the oracle's masks."""
+    from deepfactors_amd import synth
+    K, cs = 16, 32
+    rng = np.random.default_rng(0xDF03)
+    poses = [_rand_pose(rng, synth, 0.01, 0.006) for _ in range(K)]
+    al = dfx.SfmAligner(code_size=cs)
+    for lvl, (w, h) in enumerate([(640, 480), (320, 240), (160, 120)]):
+        kfs = [_pair_dev(w, h, cs, seed=0x1600 + k) for k in range(K)]   # same seeds at every level: the same scenes, halved cameras
+        valid = [torch.zeros_like(g["img0"]) for _, g in kfs]
+        plist, idx = [], []
+        for i in range(K):
+            for j in range(i + 1, K):
+                ni, gi = kfs[i]; nj, gj = kfs[j]
+                plist.append(dict(pose0=poses[i], pose1=poses[j], cam=ni["cam"], img0=gi["img0"], img1=gj["img0"], dpt0=gi["dpt0"], valid0=valid[i],
+                                  prx0_jac=gi["prx_jac"]))
+                idx.append((i, j))
+        # gradient of the target image: Sobel / 8 of img0 of keyframe j (the Frame::FillPyramids product, frame.h:84-90)
+        grads = []
+        for _, g in kfs:
+            gr = torch.empty((h, w, 2), dtype=torch.float32, device="cuda")
+            dfx.SobelGradients(g["img0"], gr)
+            grads.append(gr)
+        for d, (i, j) in zip(plist, idx):
+            d["grad1"] = grads[j]
+        assert len(plist) == 120
+        items = al.RunStepBatch(al.make_pairs(plist))
+        vref = [np.zeros((h, w), np.float32) for _ in range(K)]
+        step = 4 if lvl == 0 else 1
+        grads_n = [g.cpu().numpy() for g in grads]
+        for q, (i, j) in enumerate(idx):
+            if q % step:
+                continue
+            ni, nj = kfs[i][0], kfs[j][0]
+            ref = oracle.sfm_step(poses[i], poses[j], ni["cam"], ni["img0"], nj["img0"], ni["dpt0"], ni["prx_jac"], grads_n[j], valid0=vref[i])
+            assert ref.inliers > 0.5 * w * h
+            assert_item_close(items[q], ref, w, h, what=f"level {lvl} pair {i}->{j}")
+        if step == 1:
+            for k in range(K - 1):
+                assert int((valid[k].cpu().numpy() != vref[k]).sum()) <= max(1, int(1e-5 * w * h) * (K - 1 - k)), f"valid0 of keyframe {k} level {lvl}"
+        else:   # every pixel some compared pair marked must be marked; nothing is marked outside the image interior rule
+            for k in range(K - 1):
+                v = valid[k].cpu().numpy()
+                assert np.all(v[vref[k] == 1.0] == 1.0) and set(np.unique(v)) <= {0.0, 1.0}
+        assert float(valid[K - 1].abs().max()) == 0.0   # the last keyframe is nobody's keyframe 0
+
+
+def test_regions_out_of_view_are_deterministic_and_match_the_oracle(dfx, oracle):
+    """Large motion + a band of NaN depth: several whole 64-pixel chunks (and whole chunk rows) have no correspondence at all
+    while their neighbours do.  Their tap loads must not disturb the counted waits of the software pipeline: results are
+    bit-identical over 40 runs, alone and inside a batch next to benign pairs, and equal the oracle's."""
+    from deepfactors_amd import synth
+    w, h, cs = 640, 480, 32
+    n, g = _pair_dev(w, h, cs, seed=0xDF08)
+    R = synth.so3_exp(np.array([0.0, 0.35, 0.02]))           # 20 degrees about y: a third of the columns leaves the view
+    pose1 = synth.pose_qt(R.T, -R.T @ np.array([0.4, 0.05, 0.0]))
+    dpt = g["dpt0"].clone()
+    dpt[100:140, :] = float("nan")                            # 40 full rows = 400 chunks without a correspondence
+    dpt[300:330, 200:520] = float("nan")
+    dpt_n = dpt.cpu().numpy()
+    al = dfx.SfmAligner(code_size=cs)
+    ref = oracle.sfm_step(n["pose0"], pose1, n["cam"], n["img0"], n["img1"], dpt_n, n["prx_jac"], n["grad1"])
+    assert 0.2 * w * h < ref.inliers < 0.7 * w * h
+    first = al.RunStep(n["pose0"], pose1, n["code"], n["cam"], g["img0"], g["img1"], dpt, None, None, g["prx_jac"], g["grad1"])
+    assert_item_close(first, ref, w, h, what="out-of-view regions")
+    for _ in range(40):
+        again = al.RunStep(n["pose0"], pose1, n["code"], n["cam"], g["img0"], g["img1"], dpt, None, None, g["prx_jac"], g["grad1"])
+        assert np.array_equal(first.raw, again.raw)
+    n2, g2 = _pair_dev(w, h, cs, seed=0xDF09)
+    bad = dict(pose0=n["pose0"], pose1=pose1, cam=n["cam"], img0=g["img0"], img1=g["img1"], dpt0=dpt, prx0_jac=g["prx_jac"], grad1=g["grad1"])
+    good = dict(pose0=n2["pose0"], pose1=n2["pose1"], cam=n2["cam"], img0=g2["img0"], img1=g2["img1"], dpt0=g2["dpt0"], prx0_jac=g2["prx_jac"], grad1=g2["grad1"])
+    arr = al.make_pairs([good, bad, good, bad, bad, good, bad, good] * 4)
+    ref_good = oracle.sfm_step(n2["pose0"], n2["pose1"], n2["cam"], n2["img0"], n2["img1"], n2["dpt0"], n2["prx_jac"], n2["grad1"])
+    base = None
+    for r in range(10):
+        items = al.RunStepBatch(arr)
+        raw = np.stack([it.raw for it in items])
+        if base is None:
+            base = raw
+            assert_item_close(items[1], ref, w, h, what="batched out-of-view pair")
+            assert_item_close(items[0], ref_good, w, h, what="batched benign pair")
+        assert np.array_equal(raw, base), f"run {r} differs"

@@ -37,7 +37,7 @@ def _gauss_newton(synth, step, update_depth, pose0, pose1, code, cs, iters, lm=1
     return pose1, code, hist
 
 
-@pytest.mark.parametrize("w,h,cs,seed", [(160, 120, 16, 21), (320, 240, 32, 22)])
+@pytest.mark.parametrize("w,h,cs,seed", [(160, 120, 16, 21), (320, 240, 32, 22), (640, 480, 32, 23)])
 def test_sfm_gauss_newton_converges_like_the_oracle(dfx, oracle, w, h, cs, seed):
     from deepfactors_amd import synth
     p = synth.make_pair(w, h, cs, seed=seed, device="cpu")
@@ -67,10 +67,12 @@ def test_sfm_gauss_newton_converges_like_the_oracle(dfx, oracle, w, h, cs, seed)
 
     # both converge (the residual drops by > 10x and settles) ...
     assert hg[-1][0] < 0.1 * hg[0][0] and abs(hg[-1][0] - hg[-2][0]) < 1e-3 * hg[-1][0]
-    # ... to the same estimates: pose within 2e-4 (quaternion / metres), code within 2e-3, residual within 1e-3 relative
-    assert np.abs(pg - pc).max() < 2e-4, (pg, pc)
-    assert np.abs(cg - cc).max() < 2e-3, np.abs(cg - cc).max()
-    assert abs(hg[-1][0] - hc[-1][0]) < 1e-3 * hc[-1][0] and abs(hg[-1][1] - hc[-1][1]) <= max(2, 1e-4 * w * h)
+    # ... to the same estimates, at SURVEY 8c's stated bar: pose within 1e-4 (quaternion / metres) and code within 1e-4 of the
+    # oracle after the same schedule (measured on MI355X: pose 3e-7, code 6e-6 with normal equations of condition 5e6-7e6 -- the
+    # same distance the oracle's own fp32-accumulating mode keeps from its fp64 mode), residual within 1e-4 relative
+    assert np.abs(pg - pc).max() < 1e-4, (pg, pc)
+    assert np.abs(cg - cc).max() < 1e-4, np.abs(cg - cc).max()
+    assert abs(hg[-1][0] - hc[-1][0]) < 1e-4 * hc[-1][0] and abs(hg[-1][1] - hc[-1][1]) <= max(2, 1e-5 * w * h)
     # ... which are the generating ones up to the model error of the synthetic pair (Sobel vs bilinear derivative)
     assert np.abs(pg - n["pose1"]).max() < 2e-3
     assert np.abs(cg - n["code"]).max() < 0.25 * np.abs(code_0 - n["code"]).max()

@@ -1,5 +1,5 @@
-"""Full-size (BASELINE.json configs) checks through size-independent properties -- the CPU oracle would take minutes at
-1280x960x64, so these use invariants of the path instead:
+"""Full-size (BASELINE.json configs) checks through size-independent properties of the path (the direct comparison with the
+CPU oracle at these sizes, incl. 1280x960x64, is tests/test_gpu_configs.py):
   * masking additivity: the sums over a full image equal the sums over its top half plus its bottom half, where "half" is
     selected by making the other half's depth NaN (NaN depth = no correspondence, warping.h:221-224);
   * Cauchy-Schwarz / PSD structure of the normal equations; determinism; batch == single;

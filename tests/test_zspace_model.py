@@ -1,5 +1,5 @@
 """Executable specification of the packed z-space of the SfM step (deepfactors_amd/csrc/dfx_sfm_step.hip): a numpy model of the
-products the kernel accumulates (X, Pm, Dd on 16x16x4 MFMAs, the P P^T tiles on 4x4x1 MFMAs) and of k_sfm_finalize's scatter,
+products the kernel accumulates (X, Pm on 16x16x4 MFMAs, Dd and the P P^T tiles on 4x4x1 MFMAs) and of k_sfm_finalize's scatter,
 checked against the direct J^T J / J^T r of the same per-pixel rows.  Runs on the CPU: an index mistake in the layout shows up
 here before any GPU time is spent."""
 import numpy as np
@@ -18,12 +18,24 @@ def _model_item(gC, wr, inl, s, jac, M, HM, cs):
     for b in range(ncb):
         for b2 in range(b + 1, ncb):
             X[(b, b2)] = np.einsum("pi,pj->ij", C[b], C[b2])
-    Pm = [np.einsum("pi,pj->ij", np.concatenate([P8, C[b][:, :8]], axis=1), C[b]) for b in range(ncb)]
+    # Pm(b): even b: A = [P ; C_b rows 8..15], odd b: A = [C_b rows 0..7 ; P]  (lane selects, no cross-lane moves)
+    Pm = [np.einsum("pi,pj->ij", np.concatenate([P8, C[b][:, 8:]] if b % 2 == 0 else [C[b][:, :8], P8], axis=1), C[b]) for b in range(ncb)]
+    # Dd(q) on 4x4x1: operand M = [C_b0 rows 0..7 ; C_b1 rows 8..15] in the 16x16x4 lane layout = 16 blocks (pixel k, row group rg);
+    # form 0 broadcasts the A rows of the first block of every block pair (CBSZ = 1, ABID = 0), form 1 is the plain product.
+    # Accumulators: [form][block = 4 k + rg][i][j], pixels are grouped by fours as in the kernel (group g, k = pixel % 4).
     Dd = []
     for q in range((ncb + 1) // 2):
         b0, b1 = 2 * q, min(2 * q + 1, ncb - 1)
-        hi = np.concatenate([C[b0][:, 8:], C[b1][:, 8:]], axis=1)
-        Dd.append(np.einsum("pi,pj->ij", hi, hi))
+        Mop = np.concatenate([C[b0][:, :8], C[b1][:, 8:]], axis=1)          # [N][16]
+        acc = np.zeros((2, 16, 4, 4))
+        for px in range(N):
+            k = px % 4
+            for rg in range(4):
+                Bg = Mop[px, 4 * rg:4 * rg + 4]
+                A0 = Mop[px, 4 * (rg & ~1):4 * (rg & ~1) + 4]              # broadcast: block pair (0,1) -> group 0, (2,3) -> group 2
+                acc[0, 4 * k + rg] += np.outer(A0, Bg)
+                acc[1, 4 * k + rg] += np.outer(Bg, Bg)
+        Dd.append(acc)
     # P P^T tiles on 4x4x1: instruction t handles pixels 5t .. 5t+4; block b < 15 holds tile b % 3 of pixel 5t + b // 3
     S0 = np.zeros((16, 4, 4))
     for t in range((N + 4) // 5):
@@ -72,23 +84,34 @@ def _model_item(gC, wr, inl, s, jac, M, HM, cs):
             for j in range(16):
                 put(12 + ncb * i + b, 12 + ncb * j + b2, S[i, j])
     for b, S in enumerate(Pm):
+        pofs = 8 if b % 2 else 0
+        cofs = 8 - pofs
         for n in range(12):
             for j in range(16):
-                put(n, 12 + ncb * j + b, T[n] @ S[0:6, j])
+                put(n, 12 + ncb * j + b, T[n] @ S[pofs:pofs + 6, j])
         for j in range(16):
             assert np.isnan(g[12 + ncb * j + b])
-            g[12 + ncb * j + b] = S[6, j]
-        for i in range(8):
-            for j in range(16):
-                if i <= j:
-                    put(12 + ncb * i + b, 12 + ncb * j + b, S[8 + i, j])
-    for q, S in enumerate(Dd):
-        for r in range(16):
-            for c in range(r, 16):
-                if c < 8:
-                    put(12 + ncb * (8 + r) + 2 * q, 12 + ncb * (8 + c) + 2 * q, S[r, c])
-                elif r >= 8 and 2 * q + 1 < ncb:
-                    put(12 + ncb * r + 2 * q + 1, 12 + ncb * c + 2 * q + 1, S[r, c])
+            g[12 + ncb * j + b] = S[pofs + 6, j]
+        for r in range(cofs, cofs + 8):
+            for c in range(16):
+                if c >= r or c < cofs:
+                    put(12 + ncb * r + b, 12 + ncb * c + b, S[r, c])
+    for q, acc in enumerate(Dd):
+        Tl = acc.reshape(2, 4, 4, 4, 4).sum(axis=1)       # fold the 4 pixels of a group: [form][rg][i][j]
+        for rg in range(4):
+            bb = 2 * q if rg < 2 else 2 * q + 1
+            if bb >= ncb:
+                continue                                   # odd ncb: the upper half repeats rows Pm(b0) already covers
+            base = 0 if rg < 2 else 8
+            for i in range(4):
+                for j in range(4):
+                    if rg % 2 == 0:
+                        if i <= j:
+                            put(12 + ncb * (base + i) + bb, 12 + ncb * (base + j) + bb, Tl[0, rg, i, j])
+                    else:
+                        put(12 + ncb * (base + i) + bb, 12 + ncb * (base + 4 + j) + bb, Tl[0, rg, i, j])
+                        if i <= j:
+                            put(12 + ncb * (base + 4 + i) + bb, 12 + ncb * (base + 4 + j) + bb, Tl[1, rg, i, j])
     assert not np.isnan(H[np.triu_indices(NP)]).any(), "upper triangle not fully covered"
     assert not np.isnan(g).any()
     return H, g, residual, inliers

@@ -22,13 +22,16 @@ def worker(a):
         al = dfx.SfmAligner(dfx.SfmAlignerParams(step_blocks=blocks), code_size=a.cs, ctx=ctx)
         pairs, keep = [], []
         for k in range(a.pairs):
-            t = {n: (v.clone() if isinstance(v, torch.Tensor) else v) for n, v in base.items()}
+            if a.distinct:   # bench.py's workload: every pair its own scene, motion and validity pattern
+                t = synth.make_pair(a.width, a.height, a.cs, seed=0xDF02 + k, device=dev, motion_scale=0.6 + 0.05 * (k % 8))
+            else:
+                t = {n: (v.clone() if isinstance(v, torch.Tensor) else v) for n, v in base.items()}
             keep.append(t)
             pairs.append(dict(pose0=t["pose0"], pose1=t["pose1"], cam=t["cam"], img0=t["img0"], img1=t["img1"], dpt0=t["dpt0"],
-                              prx0_jac=t["prx_jac"], grad1=t["grad1"]))
+                              prx0_jac=t["prx_jac"], grad1=t["grad1"], **(dict(valid0=t["valid0"]) if a.distinct else {})))
         arr = al.make_pairs(pairs)
         items = torch.zeros(a.pairs * dfx.item_size(12 + a.cs), dtype=torch.uint8, device=dev)
-        for _ in range(a.preroll if blocks == int(a.blocks.split(",")[0]) else 5):   # the clocks need ~100 launches after idle
+        for _ in range(a.preroll):   # every configuration: building its inputs idles the GPU, and the clocks need ~50-100 launches after idle
             al.RunStepBatchAsync(arr, items)
         ctx.sync()
         ctx.set_profiling(True)
@@ -54,6 +57,7 @@ def main():
     ap.add_argument("--cs", type=int, default=32)
     ap.add_argument("--mode", type=int, default=0, help="0 = f32 chain MFMA (the only mode since the packed z-space layout)")
     ap.add_argument("--preroll", type=int, default=150, help="untimed launches before the first measurement of a process (clock ramp)")
+    ap.add_argument("--distinct", action="store_true", help="distinct synthetic pairs with a valid0 image, as bench.py builds them")
     ap.add_argument("--worker", action="store_true")
     a = ap.parse_args()
     if a.worker:
@@ -65,6 +69,8 @@ def main():
             env = dict(os.environ, DFX_LIB=os.path.abspath(lib))
             cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--blocks", a.blocks, "--pairs", str(a.pairs), "--steps", str(a.steps),
                    "--width", str(a.width), "--height", str(a.height), "--cs", str(a.cs), "--mode", str(a.mode), "--preroll", str(a.preroll)]
+            if a.distinct:
+                cmd.append("--distinct")
             try:
                 out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=180, stdin=subprocess.DEVNULL)
                 line = [l for l in out.stdout.splitlines() if l.startswith("ABRESULT ")]

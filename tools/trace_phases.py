@@ -7,7 +7,7 @@ import torch
 import deepfactors_amd as dfx
 from deepfactors_amd import synth, _lib
 
-P, W, H, CS = 16, 640, 480, 32
+P, W, H, CS = int(os.environ.get("DFX_TRACE_PAIRS", "16")), 640, 480, 32
 blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 mode = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 dev = torch.device("cuda", 0)
@@ -29,7 +29,7 @@ ctx.set_profiling(False)
 print(f"step kernel {ms_l / n_l * 1e3:.1f} us (HIP events)")
 nb = P * blocks
 ncb = CS // 16
-ZD = (1 + ncb * (ncb - 1) // 2 + ncb + (ncb + 1) // 2) * 256   # z-space partial: block 0 (P x P sums + trace slots) + packed MFMA blocks
+ZD = (1 + ncb * (ncb - 1) // 2 + ncb + 2 * ((ncb + 1) // 2)) * 256   # z-space partial: block 0 (P x P sums + trace slots) + packed MFMA blocks
 buf = np.zeros(nb * ZD, np.float32)
 _lib.check(_lib.lib().dfx_debug_read_partials(ctx.handle, buf.ctypes.data_as(C.c_void_p), buf.nbytes))
 zz = buf.reshape(nb, ZD)
