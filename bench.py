@@ -4,28 +4,37 @@
 One "step" = one pass of the hot path over one batch of synthetic input resident in HBM: a single batched launch of
 SfmAligner::RunStep (reference cu_sfmaligner.cpp:149-185) over `--pairs` independent 640x480, 32-code keyframe->frame
 pairs (BASELINE.json configs[1] geometry, batched; every pair has its own keyframe so the working set,
-pairs x 47 MB = 6 GB, is far beyond the 256 MB Infinity Cache and the sweep is honestly HBM-resident), with the assembly
-of the Gauss-Newton normal-equation blocks fused into its finalize kernel and -- for N > 1 -- their RCCL all-reduce over
-xGMI.  The default, 128 pairs per GPU, is the per-GPU shard of BASELINE configs[3] ("~1k pairs sharded across 8 GPUs"):
-`--gpus 8` IS that configuration, `--gpus 1` is one eighth of it (weak scaling).  `--pairs 16` gives the small-batch figure
-quoted in DESIGN.md section 5.
+pairs x 47 MB = 6 GB, is far beyond the 256 MB Infinity Cache and the sweep is honestly HBM-resident), followed by the
+assembly of the pairs' 44x44 systems into the block-sparse Gauss-Newton normal equations of the keyframe graph
+(dfx_graph_assemble_async) and -- for N > 1 -- their RCCL reduce over xGMI onto the rank that solves.  The default,
+128 pairs per GPU, is the per-GPU shard of BASELINE configs[3] ("~1k pairs sharded across 8 GPUs"); weak scaling.
 
-Multi-GPU: one process per GPU (torch.distributed, backend "nccl" = RCCL); pairs are independent units, sharded
-contiguously across ranks (weak scaling: --pairs per GPU); the only exchange step is the RCCL reduce of the
-block-tridiagonal normal equations onto rank 0, where the solve runs (SURVEY.md section 8e option 2).
+`python bench.py --gpus N` starts its own N ranks (torch.distributed.run, one process per GPU, RCCL); under an external
+torchrun it uses the ranks it is given.
 
-Output: ONE JSON line on rank 0 (see the driver contract in the task statement), including
-  roofline     -- step kernel only: algorithmic bytes (148 B/px x px x pairs per launch) / HIP-event duration
-  cpu_baseline -- the CPU oracle (oracle/, a port of the reference's host path) timed on this box's cores.
+Output: ONE JSON line on rank 0 (the driver contract), with
+  roofline      step kernel only: algorithmic bytes (148 B/px x px x pairs per launch) / HIP-event duration measured inside
+                the library on the launch stream; `traffic` = memory-side bytes of the same kernel from rocprofv3 PMC request
+                counters by size (a counters-only child run of this script; null + reason when rocprofv3 is unavailable)
+  cpu_baseline  the CPU oracle (oracle/, a port of the reference's host path) built -O3 -march=native on this box:
+                median of >= 10 repetitions on all cores (`value`) and on one thread
+  configs       secondary, untimed-by-the-driver measurements of the other BASELINE configs: configs[1] as ONE blocking
+                single-pair call (the reference's per-factor call pattern), configs[4] (1280x960, 64-code) batched, and -- with
+                --window -- configs[3] as a real 64-keyframe / 1024-pair window sharded over the ranks.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -45,40 +54,211 @@ def parse():
     ap.add_argument("--cs", type=int, default=32)
     ap.add_argument("--step-blocks", type=int, default=0, help="workgroups per pair (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child run (roofline.traffic = null)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the secondary configs[1] / configs[4] measurements")
+    ap.add_argument("--window", action="store_true", help="also measure BASELINE configs[3]: 64 keyframes, 1024 pairs over the ranks")
+    ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def cpu_baseline(w, h, cs, seconds):
+# ------------------------------------------------------------------------------------------------------------------------
+def self_spawn(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script on this node."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def cpu_baseline(w, h, cs):
     """The oracle (a port of the reference's host loop over DenseSfm<...,TargetHost>, ut_sfmaligner.cpp:307-315), fp32
-    accumulate, OpenMP over rows on all host cores.  Bounded sample: the same 640x480x32 pair, repeated ~`seconds`."""
+    accumulate, built -O3 -march=native -ffp-contract=off on THIS box.  Median of >= 10 repetitions of the same 640x480x32
+    pair: OpenMP over rows on all host cores (`value`) and one thread (the reference's own host loop is single-threaded)."""
     from deepfactors_amd import synth
     from oracle import dfx_oracle as orc   # cpu_baseline leg only
-    orc.build()
+    orc.build_native()
     n = synth.to_numpy(synth.make_pair(w, h, cs, seed=0xDF02, device="cpu"))
     cores = orc.max_threads()
     args = (n["pose0"], n["pose1"], n["cam"], n["img0"], n["img1"], n["dpt0"], n["prx_jac"], n["grad1"])
-    orc.sfm_step(*args, accum_f64=False, threads=cores)   # warm-up
+
+    def median_rate(threads, reps, budget):
+        for _ in range(2):
+            orc.sfm_step(*args, accum_f64=False, threads=threads)   # warm-up
+        ts, t_start = [], time.perf_counter()
+        while len(ts) < reps or (time.perf_counter() - t_start < budget and len(ts) < 10 * reps):
+            t0 = time.perf_counter()
+            orc.sfm_step(*args, accum_f64=False, threads=threads)
+            ts.append(time.perf_counter() - t0)
+        return 1.0 / float(np.median(ts)), len(ts), time.perf_counter() - t_start
+
+    allc, n_all, t_all = median_rate(cores, 10, 1.5)
+    one, n_one, t_one = median_rate(1, 10, 0.0)
+    return dict(value=allc, unit="pair-evals/s", cores=cores, kind="port", single_thread=one,
+                sample=f"one {w}x{h} cs={cs} SfmAligner::RunStep pair, fp32 accumulate, g++ -O3 -march=native -ffp-contract=off: median of {n_all} "
+                       f"repetitions with OpenMP over rows on {cores} threads ({t_all:.1f} s), median of {n_one} repetitions on 1 thread ({t_one:.1f} s)")
+
+
+def build_pairs(dfx, synth, dev, rank, P, W, H, CS, same=False):
+    pairs, keep = [], []
+    for k in range(P):
+        p = synth.make_pair(W, H, CS, seed=0xDF02 + (0 if same else 1000 * rank + k), device=dev, motion_scale=(1.0 if same else 0.6 + 0.05 * (k % 8)))
+        keep.append(p)
+        pairs.append(dict(pose0=p["pose0"], pose1=p["pose1"], cam=p["cam"], img0=p["img0"], img1=p["img1"], dpt0=p["dpt0"],
+                          prx0_jac=p["prx_jac"], grad1=p["grad1"], valid0=p["valid0"]))
+    return pairs, keep
+
+
+def pmc_traffic(a):
+    """Memory-side traffic of the step kernel from the TCC request counters by size (rocprofv3, counters only, own process so that
+    the timed run above is never profiled).  Returns (bytes per launch or None, detail dict)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, {"source": "unavailable: rocprofv3 not found"}
+    out = tempfile.mkdtemp(prefix="dfx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    worker = [sys.executable, os.path.abspath(__file__), "--pmc-worker", "--pairs", str(a.pairs), "--width", str(a.width), "--height", str(a.height),
+              "--cs", str(a.cs), "--step-blocks", str(a.step_blocks)]
+    passes = {"rd": ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"],
+              "wr": ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"]}
+    vals = {}
+    try:
+        for name, ctrs in passes.items():
+            cmd = [exe, "--pmc"] + ctrs + ["--kernel-include-regex", "k_sfm_step", "--output-format", "csv", "-d", os.path.join(out, name), "-o", "pmc", "--"] + worker
+            r = subprocess.run(cmd, env=env, cwd="/tmp", stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            files = glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, {"source": f"unavailable: rocprofv3 pass '{name}' rc={r.returncode}"}
+            acc, cnt = {}, {}
+            with open(files[0]) as fh:
+                for row in csv.DictReader(fh):
+                    if "k_sfm_step" not in row.get("Kernel_Name", ""):
+                        continue
+                    acc[row["Counter_Name"]] = acc.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                    cnt[row["Counter_Name"]] = cnt.get(row["Counter_Name"], 0) + 1
+            for k in acc:
+                vals[k] = acc[k] / cnt[k]
+        rd = 32 * vals["TCC_EA0_RDREQ_32B_sum"] + 64 * vals["TCC_EA0_RDREQ_64B_sum"] + 128 * vals["TCC_EA0_RDREQ_128B_sum"]
+        other = vals["TCC_EA0_RDREQ_sum"] - vals["TCC_EA0_RDREQ_32B_sum"] - vals["TCC_EA0_RDREQ_64B_sum"] - vals["TCC_EA0_RDREQ_128B_sum"]
+        rd += 64 * max(other, 0.0)
+        wr = 64 * vals["TCC_EA0_WRREQ_64B_sum"] + 32 * max(vals["TCC_EA0_WRREQ_sum"] - vals["TCC_EA0_WRREQ_64B_sum"], 0.0)
+        return rd + wr, {"source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ_{,64B}_sum x request size, averaged over the step-kernel "
+                                   "dispatches of a counters-only child run of this workload (Infinity-Cache hits are included: memory-side requests)",
+                         "read_bytes": rd, "write_bytes": wr}
+    except Exception as e:   # noqa: BLE001 -- measurement is optional, the bench line is not
+        return None, {"source": f"unavailable: {type(e).__name__}: {e}"}
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def secondary_configs(dfx, synth, ctx, dev):
+    """configs[1] as the reference calls it (ONE pair per blocking call, photometric_factor.cpp:267-274) and configs[4]
+    (1280x960, 64-code; 4 pairs per launch, 1.3 GB working set)."""
+    import torch
+    out = {}
+    # ---- configs[1]: single 640x480x32 pair, blocking dfx_sfm_step
+    al = dfx.SfmAligner(code_size=32, ctx=ctx)
+    p = synth.make_pair(640, 480, 32, seed=0xDF02, device=dev)
+    call = lambda: al.RunStep(p["pose0"], p["pose1"], None, p["cam"], p["img0"], p["img1"], p["dpt0"], None, p["valid0"], p["prx_jac"], p["grad1"])  # noqa: E731
+    for _ in range(200):
+        call()
+    ctx.set_profiling(True)
     t0 = time.perf_counter()
-    reps = 0
-    while True:
-        orc.sfm_step(*args, accum_f64=False, threads=cores)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or reps >= 2000:
-            break
-    return dict(value=reps / dt, unit="pair-evals/s", cores=cores, kind="port",
-                sample=f"{reps} repetitions of one {w}x{h} cs={cs} SfmAligner::RunStep pair, OpenMP over rows, fp32 accumulate, {dt:.1f} s")
+    reps = 300
+    for _ in range(reps):
+        call()
+    dt = (time.perf_counter() - t0) / reps
+    n, ms = ctx.profile_read()
+    ctx.set_profiling(False)
+    out["configs1_single_pair_blocking"] = dict(call_us=dt * 1e6, kernel_us=ms / n * 1e3, evals_per_s=1.0 / dt,
+                                                note="one 640x480 cs=32 pair per blocking SfmAligner::RunStep call (46 MB: Infinity-Cache resident, not an HBM figure)")
+    del p
+    # ---- configs[4]: 1280x960, cs = 64
+    W, H, CS, P = 1280, 960, 64, 4
+    al4 = dfx.SfmAligner(code_size=CS, ctx=ctx)
+    pairs, keep = build_pairs(dfx, synth, dev, 7, P, W, H, CS)
+    arr = al4.make_pairs(pairs)
+    items = torch.zeros(P * dfx.item_size(12 + CS), dtype=torch.uint8, device=dev)
+    for _ in range(60):
+        al4.RunStepBatchAsync(arr, items)
+    ctx.sync()
+    ctx.set_profiling(True)
+    for _ in range(20):
+        al4.RunStepBatchAsync(arr, items)
+    n, ms = ctx.profile_read()
+    ctx.set_profiling(False)
+    kern_s = ms / 1e3 / n
+    bpl = (20 + 4 * CS) * W * H * P
+    out["configs4_1280x960_cs64"] = dict(pairs_per_launch=P, kernel_us=kern_s * 1e6, algorithmic_gbs=bpl / kern_s / 1e9, frac=bpl / kern_s / 1e9 / HBM_PEAK_GBS,
+                                         evals_per_s=P / kern_s)
+    return out
+
+
+def window_config(dfx, synth, ctx, dev, dist, rank, world):
+    """BASELINE configs[3]: 64 keyframes (replicated on every rank), each linked to its 16 nearest -> 1024 directed pairs, sharded
+    contiguously (by source keyframe) over the ranks; per step: one batched launch per rank + graph assembly + RCCL reduce."""
+    import torch
+    from deepfactors_amd.dist import NormalEquations, PairGraph, shard_range
+    W, H, CS, K = 640, 480, 32, 64
+    graph = PairGraph.window(K, 16)
+    al = dfx.SfmAligner(code_size=CS, ctx=ctx)
+    rng = np.random.default_rng(0xDF03)
+    kfs = [synth.make_pair(W, H, CS, seed=0x6400 + k, device=dev) for k in range(K)]
+    poses = []
+    for k in range(K):
+        R = synth.so3_exp(rng.normal(0, 0.004, 3))
+        poses.append(synth.pose_qt(R, rng.normal(0, 0.008, 3)))
+    lo, hi = shard_range(graph.n_pairs, rank, world)
+    plist = []
+    for (i, j) in graph.pairs[lo:hi]:
+        a, b = kfs[int(i)], kfs[int(j)]
+        plist.append(dict(pose0=poses[int(i)], pose1=poses[int(j)], cam=a["cam"], img0=a["img0"], img1=b["img0"], dpt0=a["dpt0"], valid0=a["valid0"],
+                          prx0_jac=a["prx_jac"], grad1=b["grad1"]))
+    arr = al.make_pairs(plist)
+    items = torch.zeros((hi - lo) * dfx.item_size(12 + CS), dtype=torch.uint8, device=dev)
+    neq = NormalEquations(graph, CS, dev)
+
+    def step():
+        al.RunStepBatchAssembleAsync(arr, items, neq, lo)
+        if dist is not None:
+            neq.reduce(dist, root=0)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(30):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    steps = 20
+    for _ in range(steps):
+        step()
+    barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = float(el.item())
+    return dict(keyframes=K, pairs=graph.n_pairs, pairs_per_rank=hi - lo, ms_per_step=el / steps * 1e3, evals_per_s=graph.n_pairs * steps / el,
+                system_bytes=int(neq.buf.numel() * 4),
+                note="keyframe pyramids replicated; 16 pairs share each keyframe's 39 MB Jacobian, so this configuration re-reads from L2 / Infinity Cache "
+                     "(not an HBM-roofline figure)")
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ and not a.pmc_worker:
+        self_spawn(a)
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit(f"--gpus {a.gpus} needs torch.distributed.run --nproc-per-node {a.gpus}")
+        sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -92,39 +272,42 @@ def main():
 
     import deepfactors_amd as dfx
     from deepfactors_amd import synth
-    from deepfactors_amd.dist import NormalEquations
+    from deepfactors_amd.dist import NormalEquations, PairGraph
 
     W, H, CS, P = a.width, a.height, a.cs, a.pairs
     ctx = dfx.Context(local)
     al = dfx.SfmAligner(dfx.SfmAlignerParams(step_blocks=a.step_blocks), code_size=CS, ctx=ctx)
 
     # ---- synthetic, device-resident input: P distinct keyframe->frame pairs per rank
-    pairs, keep = [], []
-    for k in range(P):
-        p = synth.make_pair(W, H, CS, seed=0xDF02 + (0 if os.environ.get("DFX_BENCH_SAME") else 1000 * rank + k), device=dev, motion_scale=(1.0 if os.environ.get("DFX_BENCH_SAME") else 0.6 + 0.05 * (k % 8)))
-        keep.append(p)
-        pairs.append(dict(pose0=p["pose0"], pose1=p["pose1"], cam=p["cam"], img0=p["img0"], img1=p["img1"], dpt0=p["dpt0"],
-                          prx0_jac=p["prx_jac"], grad1=p["grad1"], **({} if os.environ.get("DFX_BENCH_NOVALID") else dict(valid0=p["valid0"]))))
+    pairs, keep = build_pairs(dfx, synth, dev, rank, P, W, H, CS, same=bool(os.environ.get("DFX_BENCH_SAME")))
     arr = al.make_pairs(pairs)
     isz = dfx.item_size(12 + CS)
     items = torch.zeros(P * isz, dtype=torch.uint8, device=dev)
-    neq = NormalEquations(world * P + 1, CS, dev)
+
+    if a.pmc_worker:   # counters-only child of pmc_traffic(): a few launches of the same workload, nothing else
+        for _ in range(4):
+            al.RunStepBatchAsync(arr, items)
+        ctx.sync()
+        return
+
+    # the pairs of all ranks form one trajectory: pair p links keyframe node p -> frame node p + 1
+    neq = NormalEquations(PairGraph.chain(world * P), CS, dev)
 
     def step():
-        # hot path: one launch over P pairs; its finalize kernel also scatter-adds the items into the normal-equation
-        # blocks of this rank's pairs (dfx_sfm_step_batch_neq_async = RunStepBatchAsync + assemble_native, fused)
+        # hot path: one launch over P pairs (+ its finalize kernel), then this rank's items are summed into the block-sparse
+        # normal equations of the graph; for N > 1 the ranks' buffers are reduced onto the rank that solves
         al.RunStepBatchAssembleAsync(arr, items, neq, rank * P)
         if dist is not None:
-            neq.reduce(dist, root=0)                           # RCCL reduce over xGMI onto the rank that solves
+            neq.reduce(dist, root=0)                           # RCCL reduce over xGMI
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # setup, untimed and not part of the W warm-up steps: the GPU's clocks take ~100 launches to settle after idle (measured:
-    # the same kernel runs 4 % slower in the first 10 steps of a process than after 60), so ramp them before anything is counted
-    for _ in range(40):
+    # setup, untimed and not part of the W warm-up steps: the GPU's clocks take ~50-100 launches to settle after idle (measured:
+    # the same kernel runs 8 % slower in the first 10 launches after idle), so ramp them before anything is counted
+    for _ in range(60):
         step()
     barrier()
     for _ in range(a.warmup):
@@ -150,30 +333,21 @@ def main():
     assert all(it.inliers > 0.5 * W * H for it in its), [it.inliers for it in its]
     # ... and the exchanged system is the sum of all ranks' pairs: every Jtr entry lands in exactly one slot of g, so the
     # checksum of the reduced g on rank 0 must equal the checksum of all ranks' items (catches stale or double-counted blocks)
-    local = torch.tensor([sum(float(np.sum(it.Jtr.astype(np.float64))) for it in its),
-                          sum(float(np.sum(np.abs(it.Jtr.astype(np.float64)))) for it in its)], dtype=torch.float64, device=dev)
+    chk = torch.tensor([sum(float(np.sum(it.Jtr.astype(np.float64))) for it in its),
+                        sum(float(np.sum(np.abs(it.Jtr.astype(np.float64)))) for it in its)], dtype=torch.float64, device=dev)
     if dist is not None:
-        dist.all_reduce(local)
+        dist.all_reduce(chk)
     if rank == 0:
         got = float(neq.g.double().sum())
-        assert abs(got - float(local[0])) <= 1e-4 * float(local[1]) + 1e-6, (got, local.tolist())
+        assert abs(got - float(chk[0])) <= 1e-4 * float(chk[1]) + 1e-6, (got, chk.tolist())
 
+    out = None
     if rank == 0:
         evals = world * P * a.steps
         bytes_per_launch = (20 + 4 * CS) * W * H * P          # 148 B/px compulsory at CS=32
         kern_s = kern_ms / 1e3 / max(n_launch, 1)
         achieved = bytes_per_launch / kern_s / 1e9
         flops_per_launch = 2.0 * ((12 + CS) * (13 + CS) / 2 + (12 + CS) + 1) * W * H * P   # JtJ + Jtr + r^2 (FMA = 2)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as fh:
-                    tj = json.load(fh)
-                if tj.get("pairs") == P and tj.get("width") == W and tj.get("height") == H and tj.get("cs") == CS:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         out = {
             "metric": "keyframe-pair residual+Jacobian evals/sec (640x480, 32-code)",
             "value": evals / elapsed,
@@ -189,20 +363,41 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1] geometry in the batch size of configs[3] (1k pairs / 8 GPUs): {P} independent {W}x{H} pairs per GPU per step, "
                                    f"CS={CS}, SfmAligner::RunStep (SE3+code Jacobians, JtJ/Jtr) in one launch, level 0; "
-                                   "+ normal-equation block assembly" + (" + RCCL reduce to rank 0" if world > 1 else ""),
+                                   "+ block-sparse normal-equation assembly" + (" + RCCL reduce to rank 0" if world > 1 else ""),
                        "pairs_per_gpu": P, "width": W, "height": H, "code_size": CS,
                        "parallelism": f"pairs sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_sfm_step<2,0>", "kernel_us": kern_s * 1e6, "launches": n_launch,
+                         "traffic": None, "kernel": "k_sfm_step<2,0>", "kernel_us": kern_s * 1e6, "launches": n_launch,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "fp32_tflops": flops_per_launch / kern_s / 1e12},
         }
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(W, H, CS, a.cpu_seconds)
-        print(json.dumps(out), flush=True)
+    configs = {}
+    if world == 1 and not a.no_configs:
+        configs.update(secondary_configs(dfx, synth, ctx, dev))
+    if a.window:
+        del keep, pairs, arr
+        configs["configs3_window64"] = window_config(dfx, synth, ctx, dev, dist, rank, world)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if configs:
+            out["configs"] = configs
+        if world == 1:
+            del ctx
+            torch.cuda.synchronize()
+            if a.no_traffic:
+                out["roofline"]["traffic_source"] = "skipped (--no-traffic)"
+            else:
+                traffic, detail = pmc_traffic(a)
+                out["roofline"]["traffic"] = traffic
+                out["roofline"]["traffic_source"] = detail.pop("source")
+                out["roofline"].update({f"traffic_{k}": v for k, v in detail.items()})
+            if not a.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(W, H, CS)
+        else:
+            out["roofline"]["traffic_source"] = "not collected for N > 1 (per-rank kernels are identical to the N = 1 run)"
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -104,9 +104,10 @@ _PROTOS = {
                                 C.POINTER(CorrItem)]),
     "dfx_sfm_step_batch_async": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SfmParams), C.POINTER(SfmPair), C.c_int, C.c_void_p]),
     "dfx_sfm_step_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SfmParams), C.POINTER(SfmPair), C.c_int, C.c_void_p]),
-    "dfx_neq_assemble_async": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
-    "dfx_sfm_step_batch_neq_async": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SfmParams), C.POINTER(SfmPair), C.c_int, C.c_void_p, C.c_int, C.c_int,
-                                               C.c_void_p, C.c_void_p]),
+    "dfx_graph_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
+    "dfx_graph_destroy": (None, [C.c_void_p]),
+    "dfx_graph_system_floats": (C.c_size_t, [C.c_void_p]),
+    "dfx_graph_assemble_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dfx_update_depth": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(Img), C.POINTER(Img), C.c_float,
                                    C.POINTER(Img)]),
     "dfx_sobel_gradients": (C.c_int, [C.c_void_p, C.POINTER(Img), C.POINTER(Img)]),

@@ -248,18 +248,14 @@ class SfmAligner:
         check(_lib.lib().dfx_sfm_step_batch_async(self.ctx.handle, self.CS, C.byref(p), pair_array, n,
                                                   C.c_void_p(out_items_dev.data_ptr())))
 
-    def RunStepBatchAssembleAsync(self, pair_array, out_items_dev, neq, first_frame):
-        """RunStepBatchAsync + NormalEquations.assemble_native fused into the step's two kernels (dfx_sfm_step_batch_neq_async):
-        `neq` (deepfactors_amd.dist.NormalEquations) receives the blocks of frames [first_frame, first_frame + n]."""
-        n = len(pair_array)
-        isz = item_size(12 + self.CS)
-        if out_items_dev.numel() * out_items_dev.element_size() < n * isz:
-            raise ValueError("output buffer too small")
+    def RunStepBatchAssembleAsync(self, pair_array, out_items_dev, neq, first_pair):
+        """RunStepBatchAsync, then the assembly of this rank's items into the keyframe graph's block-sparse normal equations
+        (deepfactors_amd.dist.NormalEquations over a PairGraph; dfx_graph_assemble_async): `pair_array` holds the graph's pairs
+        [first_pair, first_pair + n).  Both enqueue on the context's stream."""
         if neq.cs != self.CS:
             raise ValueError("normal-equation buffer has a different code size")
-        p = self.params_.sfmparams._c()
-        check(_lib.lib().dfx_sfm_step_batch_neq_async(self.ctx.handle, self.CS, C.byref(p), pair_array, n, C.c_void_p(out_items_dev.data_ptr()),
-                                                      int(first_frame), int(neq.F), C.c_void_p(neq.H.data_ptr()), C.c_void_p(neq.g.data_ptr())))
+        self.RunStepBatchAsync(pair_array, out_items_dev)
+        neq.assemble_native(self.ctx, out_items_dev, int(first_pair), len(pair_array))
 
     def RunStepBatch(self, pair_array):
         n = len(pair_array)

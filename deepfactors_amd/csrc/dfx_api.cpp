@@ -447,27 +447,8 @@ DFX_API int dfx_profile_read(dfx_ctx* c, int* n_launches, double* total_ms) {
 }
 
 // ---- SfmAligner ------------------------------------------------------------------------------------------------
-namespace {
-int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n, void* out_items_dev,
-                        const dfx::NeqDev& neq);
-}
-
 DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
                                      void* out_items_dev) {
-  return sfm_step_batch_impl(c, cs, params, pairs, n, out_items_dev, dfx::NeqDev{ nullptr, nullptr, 0, 0 });
-}
-
-DFX_API int dfx_sfm_step_batch_neq_async(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
-                                         void* out_items_dev, int first_frame, int n_frames, float* H_dev, float* g_dev) {
-  if (!H_dev || !g_dev) return fail(DFX_E_INVALID, "dfx_sfm_step_batch_neq: null normal-equation buffer");
-  if (n <= 0 || first_frame < 0 || first_frame + n + 1 > n_frames)
-    return fail(DFX_E_INVALID, "pairs [%d, %d) do not fit a chain of %d frames", first_frame, first_frame + n, n_frames);
-  return sfm_step_batch_impl(c, cs, params, pairs, n, out_items_dev, dfx::NeqDev{ H_dev, g_dev, first_frame, n_frames });
-}
-
-namespace {
-int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n, void* out_items_dev,
-                        const dfx::NeqDev& neq) {
   if (!c || !params || !pairs || !out_items_dev) return fail(DFX_E_INVALID, "dfx_sfm_step_batch: null argument");
   if (!cs_supported(cs)) return fail(DFX_E_INVALID, "unsupported code size %d (16, 32, 64)", cs);
   if (n <= 0 || n > 65535) return fail(DFX_E_INVALID, "batch size %d out of range [1,65535]", n);
@@ -524,20 +505,72 @@ int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params, const 
   bool jac_dense = true;
   for (int p = 0; p < n; ++p) jac_dense = jac_dense && (hd[p].pitch_jac == W * (uint32_t)cs * 4u);
   DFX_HIP(dfx::launch_sfm_step(cs, dd, n, (int)W, (int)H, prm, bpp, c->partials, out_items_dev, dfx_item_size(12 + cs), c->stream,
-                               jac_dense, c->mfma_mode, eb, ee, neq));
+                               jac_dense, c->mfma_mode, eb, ee));
   return DFX_OK;
 }
-}  // namespace
 
-DFX_API int dfx_neq_assemble_async(dfx_ctx* c, int cs, const void* items_dev, int n_pairs, int first_frame, int n_frames,
-                                   float* H_dev, float* g_dev, int zero_first) {
-  if (!c || !items_dev || !H_dev || !g_dev) return fail(DFX_E_INVALID, "dfx_neq_assemble: null argument");
+// ---- keyframe graph: block-sparse Gauss-Newton normal equations ------------------------------------------------
+struct dfx_graph {
+  int device = 0;
+  int cs = 0, n_nodes = 0, n_pairs = 0;
+  int* dev = nullptr;   // [kf_begin (n_nodes + 1)][fr_begin (n_nodes + 1)][kf_pairs (n_pairs)][fr_pairs (n_pairs)]
+  dfx::GraphDev view{};
+};
+
+DFX_API int dfx_graph_create(dfx_ctx* c, int cs, int n_nodes, int n_pairs, const int32_t* pair_nodes, dfx_graph** out) {
+  if (!c || !pair_nodes || !out) return fail(DFX_E_INVALID, "dfx_graph_create: null argument");
+  *out = nullptr;
   if (!cs_supported(cs)) return fail(DFX_E_INVALID, "unsupported code size %d (16, 32, 64)", cs);
-  if (n_pairs <= 0 || first_frame < 0 || first_frame + n_pairs + 1 > n_frames)
-    return fail(DFX_E_INVALID, "pairs [%d, %d) do not fit a chain of %d frames", first_frame, first_frame + n_pairs, n_frames);
+  if (n_nodes < 2 || n_pairs < 1 || n_nodes > (1 << 20) || n_pairs > (1 << 24)) return fail(DFX_E_INVALID, "graph of %d nodes / %d pairs out of range", n_nodes, n_pairs);
+  for (int p = 0; p < n_pairs; ++p) {
+    const int a = pair_nodes[2 * p], b = pair_nodes[2 * p + 1];
+    if (a < 0 || a >= n_nodes || b < 0 || b >= n_nodes || a == b)
+      return fail(DFX_E_INVALID, "pair %d links nodes (%d, %d): need two distinct nodes in [0, %d)", p, a, b, n_nodes);
+  }
   int rc;
   if ((rc = ensure_device(c))) return rc;
-  DFX_HIP(dfx::launch_neq_assemble(cs, items_dev, dfx_item_size(12 + cs), n_pairs, first_frame, n_frames, H_dev, g_dev, zero_first != 0, c->stream));
+  // CSR by counting sort: pair indices stay ascending inside every node's list (the fixed summation order)
+  const size_t nb = (size_t)n_nodes + 1;
+  std::vector<int> h(2 * nb + 2 * (size_t)n_pairs, 0);
+  int* kf_begin = h.data();
+  int* fr_begin = h.data() + nb;
+  int* kf_pairs = h.data() + 2 * nb;
+  int* fr_pairs = kf_pairs + n_pairs;
+  for (int p = 0; p < n_pairs; ++p) { kf_begin[pair_nodes[2 * p] + 1]++; fr_begin[pair_nodes[2 * p + 1] + 1]++; }
+  for (int n = 0; n < n_nodes; ++n) { kf_begin[n + 1] += kf_begin[n]; fr_begin[n + 1] += fr_begin[n]; }
+  std::vector<int> kc(kf_begin, kf_begin + n_nodes), fc(fr_begin, fr_begin + n_nodes);
+  for (int p = 0; p < n_pairs; ++p) { kf_pairs[kc[pair_nodes[2 * p]]++] = p; fr_pairs[fc[pair_nodes[2 * p + 1]]++] = p; }
+  dfx_graph* g = new dfx_graph();
+  g->device = c->device; g->cs = cs; g->n_nodes = n_nodes; g->n_pairs = n_pairs;
+  hipError_t e = hipMalloc((void**)&g->dev, h.size() * sizeof(int));
+  if (e == hipSuccess) e = hipMemcpy(g->dev, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { if (g->dev) (void)hipFree(g->dev); delete g; return fail(DFX_E_HIP, "dfx_graph_create: %s", hipGetErrorString(e)); }
+  g->view = dfx::GraphDev{ n_nodes, n_pairs, g->dev, g->dev + 2 * nb, g->dev + nb, g->dev + 2 * nb + n_pairs };
+  *out = g;
+  return DFX_OK;
+}
+
+DFX_API void dfx_graph_destroy(dfx_graph* g) {
+  if (!g) return;
+  (void)hipSetDevice(g->device);
+  if (g->dev) (void)hipFree(g->dev);
+  delete g;
+}
+
+DFX_API size_t dfx_graph_system_floats(const dfx_graph* g) {
+  if (!g) return 0;
+  const size_t D = 6 + (size_t)g->cs;
+  return (size_t)g->n_nodes * D * D + (size_t)g->n_pairs * D * 6 + (size_t)g->n_nodes * D;
+}
+
+DFX_API int dfx_graph_assemble_async(dfx_ctx* c, const dfx_graph* g, const void* items_dev, int first_pair, int n_local, float* sys_dev) {
+  if (!c || !g || !items_dev || !sys_dev) return fail(DFX_E_INVALID, "dfx_graph_assemble: null argument");
+  if (g->device != c->device) return fail(DFX_E_INVALID, "graph lives on device %d, context on device %d", g->device, c->device);
+  if (first_pair < 0 || n_local < 0 || first_pair + n_local > g->n_pairs)
+    return fail(DFX_E_INVALID, "pairs [%d, %d) are not inside the graph's %d pairs", first_pair, first_pair + n_local, g->n_pairs);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  DFX_HIP(dfx::launch_graph_assemble(g->cs, g->view, items_dev, dfx_item_size(12 + g->cs), first_pair, n_local, sys_dev, c->stream));
   return DFX_OK;
 }
 

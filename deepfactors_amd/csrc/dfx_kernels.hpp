@@ -27,14 +27,13 @@ struct SfmParamsDev {
   float huber_delta, avg_dpt, min_dpt, border;
 };
 
-// Optional fused normal-equation assembly (dfx_sfm_step_batch_neq_async): the step kernel clears the WHOLE system (all
-// n_frames, like dfx_neq_assemble_async with zero_first), the finalize kernel scatter-adds every item entry as
-// k_neq_assemble would.  H == nullptr: off.
-struct NeqDev {
-  float* H;          // [n_frames][2][D][D]
-  float* g;          // [n_frames][D]
-  int first_frame;   // pair p links frame first_frame + p -> first_frame + p + 1
-  int n_frames;
+// Device-side view of a keyframe graph (dfx_graph): CSR lists of the pairs incident to each node, ascending pair index.
+struct GraphDev {
+  int n_nodes, n_pairs;
+  const int* kf_begin;   // [n_nodes + 1] into kf_pairs: pairs whose KEYFRAME (pose0, code0) is the node
+  const int* kf_pairs;
+  const int* fr_begin;   // [n_nodes + 1] into fr_pairs: pairs whose FRAME (pose1) is the node
+  const int* fr_pairs;
 };
 
 struct SimplePairDev {   // SE3Aligner / EvaluateError / Warp
@@ -57,11 +56,11 @@ inline int sfm_zdim(int ncb) { return (1 + sfm_nacc(ncb)) * 256; }
 // ev_begin/ev_end (optional) bracket the step kernel only.
 hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm,
                            int blocks_per_pair, float* partials_dev, void* items_dev, size_t item_stride,
-                           hipStream_t stream, bool jac_dense, int prec, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr,
-                           const NeqDev& neq = NeqDev{ nullptr, nullptr, 0, 0 });
+                           hipStream_t stream, bool jac_dense, int prec, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair);
-hipError_t launch_neq_assemble(int cs, const void* items_dev, size_t item_stride, int n_pairs, int first_frame, int n_frames,
-                               float* H_dev, float* g_dev, bool zero_first, hipStream_t stream);
+// system layout (floats): Hd [n_nodes][D][D], Ho [n_pairs][D][6], g [n_nodes][D]; contributions of the pairs [first_pair, first_pair + n_local)
+hipError_t launch_graph_assemble(int cs, const GraphDev& G, const void* items_dev, size_t item_stride, int first_pair, int n_local, float* sys_dev,
+                                 hipStream_t stream);
 
 hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
                            void* item_dev, hipStream_t stream);

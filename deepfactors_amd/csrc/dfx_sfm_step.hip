@@ -124,7 +124,7 @@ __device__ __forceinline__ float dpp_merge(float old, float src) {
 
 template <int NCB, int MODE, bool JDENSE, bool TABLDS>
 __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_WAVES) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmParamsDev prm,
-                                                       const int W, const int H, float* __restrict__ partials, const NeqDev neq) {
+                                                       const int W, const int H, float* __restrict__ partials) {
   constexpr int NX = NCB * (NCB - 1) / 2, ND = (NCB + 1) / 2;   // X(b,b'), Dd(q); Pm(b): NCB
   constexpr int NACC = NX + NCB;                                 // 16x16x4 accumulators
   constexpr int ZDIM = (1 + NACC + 2 * ND) * 256;                // block 0: the 29 P x P sums; then X, Pm, (Dd broadcast, Dd plain) per q
@@ -140,19 +140,6 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const SfmPairDev& P = pairs[blockIdx.y];
-
-  if (MODE == 0 && neq.H && blockIdx.x == 0) {
-    // fused assembly: clear the normal-equation system (every frame of the chain, also those other ranks fill: after a
-    // reduce the root's copy holds last step's sums); frame f is cleared by the first workgroup of pair f mod #pairs.
-    // k_sfm_finalize adds into the blocks after this kernel has completed.  Replaces two memsets in front of the launch.
-    constexpr int D = 6 + 16 * NCB;
-    for (int f = blockIdx.y; f < neq.n_frames; f += gridDim.y) {
-      float* Hz = neq.H + (size_t)f * 2 * D * D;
-      float* gz = neq.g + (size_t)f * D;
-      for (int e = threadIdx.x; e < 2 * D * D; e += kThreads) Hz[e] = 0.f;
-      for (int e = threadIdx.x; e < D; e += kThreads) gz[e] = 0.f;
-    }
-  }
 
   Geo g;
 #pragma unroll
@@ -539,28 +526,13 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 #endif
 }
 
-// One entry (a, b) of a pair's (12 + CS)^2 system -> the block-tridiagonal system of the frame chain.  H0 = blocks of the
-// pair's keyframe; parameters 0..5 / 12.. belong to it (pose0, code0), 6..11 to the next frame (pose1).
-template <int CS>
-__device__ __forceinline__ void neq_scatter(float* H0, int a, int b, float v) {
-  constexpr int D = 6 + CS;
-  const int fa = (a >= 6 && a < 12), fb = (b >= 6 && b < 12);
-  const int la = a < 6 ? a : a - 6, lb = b < 6 ? b : b - 6;
-  // A frame's diagonal block receives this pair's (pose0 | code0) x (pose0 | code0) entries and the PREVIOUS pair's
-  // (pose1, pose1) 6x6: only the pose-pose 6x6 has two writers and needs the (commutative) atomic add into zeroed memory.
-  if (fa == fb) {
-    float* dst = H0 + (size_t)fa * 2 * D * D + la * D + lb;
-    if (la < 6 && lb < 6) atomicAdd(dst, v); else *dst = v;
-  } else if (fa == 0) H0[D * D + la * D + lb] = v;   // (frame k rows, frame k+1 cols): single writer
-}
-
 // ---- finalize: sum the workgroup partials of each pair (double, fixed order), map the relative-pose basis onto
 // (pose0, pose1) and scatter the packed z-space blocks into the item layout.
 // grid = (1 + NACC + 2 ND, npairs), 1024 threads: thread = (element of one 256-float block, 1 of 4 partial groups); groups
 // stride over the pair's `bpp` partials (1 KB coalesced reads, 8 loads in flight) and are folded in fixed order.
 template <int NCB, int NPOSE>
 __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs,
-                                                       char* __restrict__ items, const size_t item_stride, const NeqDev neq) {
+                                                       char* __restrict__ items, const size_t item_stride) {
   constexpr int CS = 16 * NCB;
   constexpr int NP = NPOSE + CS;
   constexpr int NX = NCB * (NCB - 1) / 2, ND = (NCB + 1) / 2;
@@ -593,28 +565,12 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
 
   float* item = reinterpret_cast<float*>(items + (size_t)pair * item_stride);
   auto tri = [](int lo, int hi) { return lo * NP - lo * (lo - 1) / 2 + (hi - lo); };
-  // item entry (lo <= hi) -> packed item and, when the fused assembly is on, the frame chain's block system
-  // (same placement as k_neq_assemble: PhotometricFactor::linearize's G11..G33 slices, photometric_factor.cpp:105-161)
-  float* const H0 = (NPOSE == 12 && neq.H) ? neq.H + (size_t)(neq.first_frame + pair) * 2 * (6 + CS) * (6 + CS) : nullptr;
-  auto put = [&](int lo, int hi, float v) {
-    item[tri(lo, hi)] = v;
-    if (NPOSE == 12 && H0) {
-      neq_scatter<CS>(H0, lo, hi, v);
-      if (lo != hi) neq_scatter<CS>(H0, hi, lo, v);
-    }
-  };
+  auto put = [&](int lo, int hi, float v) { item[tri(lo, hi)] = v; };   // item entry (lo <= hi) -> packed upper triangle
   auto put_code = [&](int ca, int cb, float v) {   // code-code entry by code indices
     const int n = NPOSE + ca, m = NPOSE + cb;
     put(n < m ? n : m, n < m ? m : n, v);
   };
-  auto put_g = [&](int n, float v) {
-    item[NT + n] = v;
-    if (NPOSE == 12 && H0) {
-      const int fa = (n >= 6 && n < 12);
-      float* dst = neq.g + (size_t)(neq.first_frame + pair + fa) * (6 + CS) + (n < 6 ? n : n - 6);
-      if (n < 12) atomicAdd(dst, v); else *dst = v;   // pose entries meet the neighbouring pair's, code entries have one writer
-    }
-  };
+  auto put_g = [&](int n, float v) { item[NT + n] = v; };
   // block 0 = 16 4x4 blocks [b][i][j] of the P x P tiles: block b (< 15) holds tile b % 3 ((0,0), (0,1), (1,1) of the 8x8
   // matrix P P^T) summed over its pixels; P = (gC_0..5, w r, inlier flag)
   __shared__ double G8[8][8];   // block 0 only: P P^T (upper triangle), each entry folded over the five 4x4 blocks that hold it
@@ -709,49 +665,6 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
   }
 }
 
-// ---- Gauss-Newton normal-equation assembly over a chain of frames (the exchange buffer of the multi-GPU reduce).
-// Frame k carries (pose 6, code CS); pair p links keyframe (first_frame + p) -> frame (first_frame + p + 1) and adds its
-// 44x44 system exactly as PhotometricFactor::linearize slices it into G11..G33 / g1..g3 (photometric_factor.cpp:105-161):
-//   H[f][0] (D x D) diagonal block of frame f, H[f][1] off-diagonal block (frame f rows, frame f+1 columns), g[f] (D).
-// Only the (pose1, pose1) block of pair p and the (pose0, pose0) block of pair p+1 meet in one destination; two
-// commutative float adds into a zeroed buffer are order-independent, so the result is deterministic.
-template <int CS>
-__global__ __launch_bounds__(256) void k_neq_assemble(const char* __restrict__ items, const size_t item_stride, const int first_frame,
-                                                      float* __restrict__ Hm, float* __restrict__ gv) {
-  constexpr int NP = 12 + CS, D = 6 + CS, NT = NP * (NP + 1) / 2;
-  const int p = blockIdx.x;
-  const float* it = reinterpret_cast<const float*>(items + (size_t)p * item_stride);
-  float* H0 = Hm + (size_t)(first_frame + p) * 2 * D * D;
-  for (int e = threadIdx.x; e < NP * NP; e += 256) {
-    const int a = e / NP, b = e - a * NP;
-    const int lo = a < b ? a : b, hi = a < b ? b : a;
-    neq_scatter<CS>(H0, a, b, it[lo * NP - lo * (lo - 1) / 2 + (hi - lo)]);
-  }
-  for (int a = threadIdx.x; a < NP; a += 256) {
-    const int fa = (a >= 6 && a < 12);
-    const int la = a < 6 ? a : a - 6;
-    float* dst = gv + (size_t)(first_frame + p + fa) * D + la;
-    if (a < 12) atomicAdd(dst, it[NT + a]); else *dst = it[NT + a];
-  }
-}
-
-hipError_t launch_neq_assemble(int cs, const void* items_dev, size_t item_stride, int n_pairs, int first_frame, int n_frames,
-                               float* H_dev, float* g_dev, bool zero_first, hipStream_t stream) {
-  const size_t D = 6 + (size_t)cs;
-  hipError_t e;
-  if (zero_first) {
-    if ((e = hipMemsetAsync(H_dev, 0, (size_t)n_frames * 2 * D * D * sizeof(float), stream)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(g_dev, 0, (size_t)n_frames * D * sizeof(float), stream)) != hipSuccess) return e;
-  }
-  switch (cs) {
-    case 16: hipLaunchKernelGGL(k_neq_assemble<16>, dim3(n_pairs), dim3(256), 0, stream, (const char*)items_dev, item_stride, first_frame, H_dev, g_dev); break;
-    case 32: hipLaunchKernelGGL(k_neq_assemble<32>, dim3(n_pairs), dim3(256), 0, stream, (const char*)items_dev, item_stride, first_frame, H_dev, g_dev); break;
-    case 64: hipLaunchKernelGGL(k_neq_assemble<64>, dim3(n_pairs), dim3(256), 0, stream, (const char*)items_dev, item_stride, first_frame, H_dev, g_dev); break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair) {
   return (size_t)npairs * blocks_per_pair * sfm_zdim(cs / 16) * sizeof(float);
 }
@@ -759,7 +672,7 @@ size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair) {
 template <int NCB, int MODE>
 static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm, int bpp,
                            float* partials_dev, void* items_dev, size_t item_stride, hipStream_t stream, bool jac_dense, int prec,
-                           hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, const NeqDev& neq = NeqDev{ nullptr, nullptr, 0, 0 }) {
+                           hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr) {
   constexpr int NACC = NCB * (NCB - 1) / 2 + NCB + 2 * ((NCB + 1) / 2);   // 256-float blocks after block 0 (16x16x4 and 4x4x1 accumulators)
   hipError_t e;
   if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
@@ -772,27 +685,27 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   const bool tab_lds = MODE == 0 && kStaticLds + tab_bytes + DFX_EXTRA_LDS <= 64 * 1024;
   const size_t dyn = DFX_EXTRA_LDS + (tab_lds ? tab_bytes : 0);
   if (MODE == 0 && tab_lds) {
-    if (jac_dense) hipLaunchKernelGGL((k_sfm_step<NCB, 0, true, true>), grid, block, dyn, stream, pairs_dev, prm, W, H, partials_dev, neq);
-    else hipLaunchKernelGGL((k_sfm_step<NCB, 0, false, true>), grid, block, dyn, stream, pairs_dev, prm, W, H, partials_dev, neq);
+    if (jac_dense) hipLaunchKernelGGL((k_sfm_step<NCB, 0, true, true>), grid, block, dyn, stream, pairs_dev, prm, W, H, partials_dev);
+    else hipLaunchKernelGGL((k_sfm_step<NCB, 0, false, true>), grid, block, dyn, stream, pairs_dev, prm, W, H, partials_dev);
   } else {
-    if (jac_dense) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, true, false>), grid, block, dyn, stream, pairs_dev, prm, W, H, partials_dev, neq);
-    else hipLaunchKernelGGL((k_sfm_step<NCB, MODE, false, false>), grid, block, dyn, stream, pairs_dev, prm, W, H, partials_dev, neq);
+    if (jac_dense) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, true, false>), grid, block, dyn, stream, pairs_dev, prm, W, H, partials_dev);
+    else hipLaunchKernelGGL((k_sfm_step<NCB, MODE, false, false>), grid, block, dyn, stream, pairs_dev, prm, W, H, partials_dev);
   }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
   hipLaunchKernelGGL((k_sfm_finalize<NCB, MODE == 0 ? 12 : 0>), dim3(1 + NACC, npairs), dim3(1024), 0, stream,
-                     (const float*)partials_dev, bpp, pairs_dev, (char*)items_dev, item_stride, neq);
+                     (const float*)partials_dev, bpp, pairs_dev, (char*)items_dev, item_stride);
   return hipGetLastError();
 }
 
 hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm,
                            int blocks_per_pair, float* partials_dev, void* items_dev, size_t item_stride,
-                           hipStream_t stream, bool jac_dense, int prec, hipEvent_t eb, hipEvent_t ee, const NeqDev& neq) {
+                           hipStream_t stream, bool jac_dense, int prec, hipEvent_t eb, hipEvent_t ee) {
   switch (cs) {
-    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, neq);
-    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, neq);
-    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, neq);
+    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee);
+    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee);
+    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee);
     default: return hipErrorInvalidValue;
   }
 }

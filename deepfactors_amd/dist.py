@@ -3,11 +3,20 @@
 
 Keyframe->frame pairs are independent units (PhotometricFactor::RunAlignmentStep takes only that pair's buffers,
 photometric_factor.cpp:267-274), so the pair list is sharded contiguously over ranks with no data-path collective.
-The single exchange step is the reduction of the Gauss-Newton normal-equation blocks: every rank scatter-adds its
-pairs' 44x44 systems into the block-tridiagonal system of the frame chain exactly as PhotometricFactor::linearize
-slices JtJ/Jtr into G11..G33 / g1..g3 (photometric_factor.cpp:105-161), then one all-reduce sums the ranks' partial
-systems (fixed pair->rank map, so the result is independent of the world size up to fp32 summation of at most two
-contributions per block).  The reference itself has no multi-GPU path (single GPU, default stream)."""
+The single exchange step carries the pairs' 44x44 systems to the rank that solves, in one of two forms:
+
+  reduce mode   every rank sums ITS pairs into the block-sparse normal equations of the keyframe graph exactly as
+                PhotometricFactor::linearize slices JtJ/Jtr into G11..G33 / g1..g3 (photometric_factor.cpp:105-161), then ONE
+                RCCL reduce (or all-reduce) adds the ranks' flat buffers;
+  gather mode   the ranks all-gather their items (4152 B per pair at CS = 32: exactly what the reference hands to one
+                gtsam::HessianFactor per pair, photometric_factor.cpp:180) and the system is assembled from all of them in
+                ascending pair order -- bit-identical for every world size; it is also what a host needs to emit the per-pair
+                factors unchanged.
+
+The reference itself has no multi-GPU path (single GPU, default stream) and links arbitrary keyframe -> frame pairs in both
+directions (mapper.cpp:308-311); PairGraph is that structure."""
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -19,81 +28,159 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-class NormalEquations:
-    """Block-tridiagonal normal equations over a chain of F frames; frame k carries (pose 6, code CS).  Pair k links
-    keyframe k -> frame k+1 and contributes at (pose_k, pose_{k+1}, code_k).  Storage: H[F][2][D][D] (diagonal block,
-    upper off-diagonal block to frame k+1) and g[F][D], D = 6 + CS.  assemble() is a gather + index_add on `device`."""
+class PairGraph:
+    """n_nodes keyframes / frames, pairs[p] = (keyframe node, frame node).  Node n owns (pose 6, code CS)."""
 
-    def __init__(self, n_frames, cs, device):
-        D = 6 + cs
-        NP = 12 + cs
-        self.D, self.F, self.NP, self.cs = D, n_frames, NP, cs
-        # one flat exchange buffer (H then g): the multi-GPU reduction is a single collective
-        nH = n_frames * 2 * D * D
-        self.buf = torch.zeros(nH + n_frames * D, dtype=torch.float32, device=device)
-        self.H = self.buf[:nH].view(n_frames, 2, D, D)
-        self.g = self.buf[nH:].view(n_frames, D)
+    def __init__(self, n_nodes, pairs):
+        self.n_nodes = int(n_nodes)
+        self.pairs = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 2))
+        if len(self.pairs) == 0 or self.pairs.min() < 0 or self.pairs.max() >= self.n_nodes or np.any(self.pairs[:, 0] == self.pairs[:, 1]):
+            raise ValueError("pairs must link two distinct nodes in [0, n_nodes)")
+
+    @property
+    def n_pairs(self):
+        return len(self.pairs)
+
+    @staticmethod
+    def chain(n_pairs):
+        """Pair p links keyframe p -> frame p + 1 (a trajectory; block-tridiagonal system)."""
+        return PairGraph(n_pairs + 1, [(p, p + 1) for p in range(n_pairs)])
+
+    @staticmethod
+    def window(n_keyframes, neighbours):
+        """Every keyframe linked (as the pair's keyframe) to its `neighbours` nearest keyframes by index, on both sides: BASELINE
+        configs[3] is window(64, 16) = 1024 directed pairs.  Pairs are ordered by source keyframe, so a contiguous shard of the
+        pair list re-uses its keyframes' Jacobians."""
+        pairs = []
+        for i in range(n_keyframes):
+            cand = sorted((j for j in range(n_keyframes) if j != i), key=lambda j: (abs(j - i), j))[:neighbours]
+            pairs.extend((i, j) for j in sorted(cand))
+        return PairGraph(n_keyframes, pairs)
+
+    @staticmethod
+    def all_pairs(n_keyframes, both_directions=False):
+        """Every pair i < j (BASELINE configs[2]: 16 keyframes -> 120 pairs), optionally also j -> i as the mapper links them
+        (mapper.cpp:308-311)."""
+        pairs = [(i, j) for i in range(n_keyframes) for j in range(n_keyframes) if (i < j or (both_directions and i != j))]
+        return PairGraph(n_keyframes, pairs)
+
+
+class NormalEquations:
+    """Block-sparse Gauss-Newton normal equations over a PairGraph in ONE flat float32 buffer (the unit of the RCCL exchange):
+    Hd [n_nodes][D][D], Ho [n_pairs][D][6], g [n_nodes][D], D = 6 + CS (layout of include/dfx.h, dfx_graph_*).
+    assemble() is the torch formulation (any device; the CPU tests and the reference for the native kernel),
+    assemble_native() the libdfx kernel."""
+
+    def __init__(self, graph, cs, device):
+        self.graph, self.cs = graph, int(cs)
+        D, NP = 6 + self.cs, 12 + self.cs
+        self.D, self.NP = D, NP
+        K, P = graph.n_nodes, graph.n_pairs
+        nd, no = K * D * D, P * D * 6
+        self.buf = torch.zeros(nd + no + K * D, dtype=torch.float32, device=device)
+        self.Hd = self.buf[:nd].view(K, D, D)
+        self.Ho = self.buf[nd:nd + no].view(P, D, 6)
+        self.g = self.buf[nd + no:].view(K, D)
+        self._native = None
         nt = NP * (NP + 1) // 2
+        self.nt = nt
         iu = np.triu_indices(NP)
         packed = np.zeros((NP, NP), np.int64)
         packed[iu] = np.arange(nt)
-        packed = packed + np.triu(packed, 1).T          # full symmetric -> packed upper-triangular index
-        # item parameter n -> (frame offset, local index): pose0 -> (0, 0..5), pose1 -> (1, 0..5), code0 -> (0, 6..)
-        fo = np.array([0] * 6 + [1] * 6 + [0] * cs)
-        li = np.array(list(range(6)) + list(range(6)) + list(range(6, 6 + cs)))
-        src, dst = [], []
-        Hs = 2 * D * D
-        for a in range(NP):
-            for b in range(NP):
-                fa, fb = fo[a], fo[b]
-                if fa == fb:
-                    off = fa * Hs + li[a] * D + li[b]
-                elif fa == 0 and fb == 1:
-                    off = D * D + li[a] * D + li[b]
-                else:
-                    continue   # the lower off-diagonal block is the transpose of the stored one
-                src.append(packed[a, b]); dst.append(off)
-        self.src = torch.tensor(src, dtype=torch.int64, device=device)
-        self.dst = torch.tensor(dst, dtype=torch.int64, device=device)
-        self.gsrc = torch.tensor(nt + np.arange(NP), dtype=torch.int64, device=device)
-        self.gdst = torch.tensor(fo * D + li, dtype=torch.int64, device=device)
-        self.Hs = Hs
+        packed = packed + np.triu(packed, 1).T                       # full symmetric -> packed upper-triangular index
+        kf = np.array(list(range(6)) + list(range(12, 12 + self.cs)))   # node-local index -> item parameter, keyframe role
+        fr = np.arange(6, 12)                                        # frame role: pose1
+        dev = torch.device(device)
+        self._kk = torch.tensor(packed[np.ix_(kf, kf)].reshape(-1), dtype=torch.int64, device=dev)    # D*D
+        self._ff = torch.tensor(packed[np.ix_(fr, fr)].reshape(-1), dtype=torch.int64, device=dev)    # 36
+        self._kf = torch.tensor(packed[np.ix_(kf, fr)].reshape(-1), dtype=torch.int64, device=dev)    # D*6
+        self._gk = torch.tensor(nt + kf, dtype=torch.int64, device=dev)
+        self._gf = torch.tensor(nt + fr, dtype=torch.int64, device=dev)
+        self._pairs = torch.tensor(graph.pairs.astype(np.int64), device=dev)
+        ff_dst = (np.arange(6)[:, None] * D + np.arange(6)[None, :]).reshape(-1)
+        self._ff_dst = torch.tensor(ff_dst, dtype=torch.int64, device=dev)
 
-    def assemble(self, items_u8, first_frame, n_pairs, item_size):
-        """items_u8: uint8 tensor with `n_pairs` JTJJrReductionItem<float,12+CS> records (device memory of this rank)."""
-        f = items_u8.view(torch.float32).view(n_pairs, item_size // 4)
-        base = torch.arange(n_pairs, device=f.device, dtype=torch.int64) + first_frame
-        self.H.zero_()
-        self.g.zero_()
-        self.H.view(-1).index_add_(0, (base[:, None] * self.Hs + self.dst[None, :]).reshape(-1), f[:, self.src].reshape(-1))
-        self.g.view(-1).index_add_(0, (base[:, None] * self.D + self.gdst[None, :]).reshape(-1), f[:, self.gsrc].reshape(-1))
+    # ---- assembly -------------------------------------------------------------------------------------------------------
+    def assemble(self, items_u8, first_pair, n_local, item_size):
+        """items_u8: uint8 tensor with the JTJJrReductionItem<float,12+CS> records of the pairs [first_pair, first_pair + n_local).
+        Overwrites the whole buffer with the contribution of these pairs (accumulated in double, ascending pair order)."""
+        D = self.D
+        f = items_u8.view(torch.float32).view(n_local, item_size // 4).double()
+        pr = self._pairs[first_pair:first_pair + n_local]
+        Hd = torch.zeros(self.graph.n_nodes, D * D, dtype=torch.float64, device=self.buf.device)
+        g = torch.zeros(self.graph.n_nodes, D, dtype=torch.float64, device=self.buf.device)
+        Hd.index_add_(0, pr[:, 0], f[:, self._kk])
+        Hd.view(-1).index_add_(0, (pr[:, 1, None] * (D * D) + self._ff_dst[None, :]).reshape(-1), f[:, self._ff].reshape(-1))
+        g.index_add_(0, pr[:, 0], f[:, self._gk])
+        g.view(-1).index_add_(0, (pr[:, 1, None] * D + torch.arange(6, device=g.device)[None, :]).reshape(-1), f[:, self._gf].reshape(-1))
+        self.Hd.copy_(Hd.view_as(self.Hd).float())
+        self.g.copy_(g.float())
+        self.Ho.zero_()
+        self.Ho[first_pair:first_pair + n_local] = f[:, self._kf].view(n_local, D, 6).float()
 
-    def assemble_native(self, ctx, items_u8, first_frame, n_pairs):
-        """Same as assemble(), as ONE libdfx kernel on the context's stream (dfx_neq_assemble_async); GPU only."""
-        import ctypes as C
+    def native_handle(self, ctx):
+        if self._native is None:
+            from . import _lib
+            h = C.c_void_p()
+            _lib.check(_lib.lib().dfx_graph_create(ctx.handle, self.cs, self.graph.n_nodes, self.graph.n_pairs,
+                                                   self.graph.pairs.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(h)))
+            assert int(_lib.lib().dfx_graph_system_floats(h)) == self.buf.numel()
+            self._native = h
+        return self._native
+
+    def assemble_native(self, ctx, items_u8, first_pair, n_local):
+        """Same result as assemble(), as ONE libdfx kernel on the context's stream (dfx_graph_assemble_async); GPU only."""
         from . import _lib
-        _lib.check(_lib.lib().dfx_neq_assemble_async(ctx.handle, self.cs, C.c_void_p(items_u8.data_ptr()), int(n_pairs), int(first_frame),
-                                                     self.F, C.c_void_p(self.H.data_ptr()), C.c_void_p(self.g.data_ptr()), 1))
+        _lib.check(_lib.lib().dfx_graph_assemble_async(ctx.handle, self.native_handle(ctx), C.c_void_p(items_u8.data_ptr()), int(first_pair),
+                                                       int(n_local), C.c_void_p(self.buf.data_ptr())))
 
+    def __del__(self):
+        try:
+            if self._native is not None:
+                from . import _lib
+                _lib.lib().dfx_graph_destroy(self._native)
+                self._native = None
+        except Exception:
+            pass
+
+    # ---- exchange step --------------------------------------------------------------------------------------------------
     def all_reduce(self, dist):
-        """Exchange step, replicated result: sum the ranks' partial systems on every rank (RCCL all-reduce over xGMI)."""
+        """Reduce mode, replicated result: sum the ranks' partial systems on every rank (RCCL all-reduce over xGMI)."""
         dist.all_reduce(self.buf)
 
     def reduce(self, dist, root=0):
-        """Exchange step, as the solver needs it: sum the ranks' partial systems onto `root`, where the (sequential) solve runs --
+        """Reduce mode as the solver needs it: sum the ranks' partial systems onto `root`, where the (sequential) solve runs --
         half the xGMI traffic of an all-reduce.  The buffers of the other ranks are left as they were (partial)."""
         dist.reduce(self.buf, dst=root)
 
+    @staticmethod
+    def gather_items(dist, items_u8, n_total, item_size, world):
+        """Gather mode: every rank contributes the items of its contiguous shard (shard_range) and receives all n_total items in
+        pair order.  Shards of unequal size are padded to the largest for the collective."""
+        per = -(-n_total // world)
+        pad = torch.zeros(per * item_size, dtype=torch.uint8, device=items_u8.device)
+        pad[: items_u8.numel()] = items_u8.view(-1)
+        out = torch.empty(world * per * item_size, dtype=torch.uint8, device=items_u8.device)
+        dist.all_gather_into_tensor(out, pad)
+        if n_total % world == 0:
+            return out
+        chunks = []
+        for r in range(world):
+            lo, hi = shard_range(n_total, r, world)
+            chunks.append(out[r * per * item_size: r * per * item_size + (hi - lo) * item_size])
+        return torch.cat(chunks)
+
+    # ---- for tests / small systems ----------------------------------------------------------------------------------------
     def dense(self):
-        """Full symmetric (F*D) x (F*D) matrix -- for tests / small systems only."""
-        n = self.F * self.D
-        M = torch.zeros((n, n), dtype=torch.float64)
-        H = self.H.detach().cpu().double()
-        for k in range(self.F):
-            s = slice(k * self.D, (k + 1) * self.D)
-            M[s, s] += H[k, 0]
-            if k + 1 < self.F:
-                s2 = slice((k + 1) * self.D, (k + 2) * self.D)
-                M[s, s2] += H[k, 1]
-                M[s2, s] += H[k, 1].T
+        """Full symmetric (n_nodes * D)^2 matrix and the gradient vector."""
+        D, K = self.D, self.graph.n_nodes
+        M = torch.zeros((K * D, K * D), dtype=torch.float64)
+        Hd, Ho = self.Hd.detach().cpu().double(), self.Ho.detach().cpu().double()
+        for k in range(K):
+            s = slice(k * D, (k + 1) * D)
+            M[s, s] += Hd[k]
+        for p, (a, b) in enumerate(self.graph.pairs):
+            ra, cb = slice(a * D, (a + 1) * D), slice(b * D, b * D + 6)
+            M[ra, cb] += Ho[p]
+            M[cb, ra] += Ho[p].T
         return M

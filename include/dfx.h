@@ -195,19 +195,27 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* ctx, int cs, const dfx_sfm_params*
 DFX_API int dfx_sfm_step_batch(dfx_ctx* ctx, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
                                void* out_items_host);
 
-/* Gauss-Newton normal-equation assembly (new; the reference hands each pair's 44x44 system to its own gtsam::HessianFactor,
- * photometric_factor.cpp:105-180, and lets iSAM2 sum them).  Scatter-adds n_pairs device-resident items into the
- * block-tridiagonal system of a frame chain: pair p links keyframe (first_frame+p) -> frame (first_frame+p+1); frame f
- * owns D = 6+cs unknowns (pose, code).  H_dev = float[n_frames][2][D][D] (diagonal block, upper off-diagonal block),
- * g_dev = float[n_frames][D].  This is the buffer the multi-GPU path all-reduces (RCCL).  Enqueue only. */
-DFX_API int dfx_neq_assemble_async(dfx_ctx* ctx, int cs, const void* items_dev, int n_pairs, int first_frame, int n_frames,
-                                   float* H_dev, float* g_dev, int zero_first);
-
-/* dfx_sfm_step_batch_async + dfx_neq_assemble_async(zero_first = 1) in two kernels instead of five operations: the step
- * kernel clears H/g (all n_frames), the finalize kernel writes the items AND scatter-adds them into the blocks of frames
- * [first_frame, first_frame + n].  Same results as the two separate calls. */
-DFX_API int dfx_sfm_step_batch_neq_async(dfx_ctx* ctx, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
-                                         void* out_items_dev, int first_frame, int n_frames, float* H_dev, float* g_dev);
+/* ---- Gauss-Newton normal equations of a keyframe graph (new: SURVEY section 8e) ---------------------------------------
+ * The reference hands each pair's 44x44 system to its own gtsam::HessianFactor keyed by (pose0, pose1, code0)
+ * (core/gtsam/photometric_factor.cpp:105-180) and lets iSAM2 add the factors; its graph links arbitrary keyframe -> frame
+ * pairs, in both directions (core/mapping/mapper.cpp:308-311).  A dfx_graph fixes that structure once: n_nodes nodes
+ * (keyframes / frames; node n owns D = 6 + cs unknowns: pose, code) and n_pairs pairs, pair p = (keyframe node, frame node) =
+ * pair_nodes[2p], pair_nodes[2p+1] (a HOST array).  The assembled system is ONE flat float buffer -- the unit the multi-GPU
+ * path reduces with RCCL --
+ *     Hd [n_nodes][D][D]   diagonal blocks: G11, G13, G33 of the pairs out of a node, G22 of the pairs into it
+ *     Ho [n_pairs][D][6]   off-diagonal block of pair p: rows = (pose | code) of its keyframe node, columns = pose of its frame
+ *                          node (G12 over G23^T, photometric_factor.cpp:135-161)
+ *     g  [n_nodes][D]      Jtr blocks g1 / g3 and g2 (not negated; the factor negates, photometric_factor.cpp:106)
+ * dfx_graph_assemble_async overwrites the WHOLE buffer with the contribution of the pairs [first_pair, first_pair + n_local)
+ * whose items (JTJJrReductionItem<float,12+cs>, device memory, item l at l * dfx_item_size(12+cs)) this rank holds: every
+ * node's incident pairs are summed in ascending pair order in double and written once (no atomics: bit-reproducible; with
+ * all items on one rank -- gather mode -- independent of the world size).  Enqueue only. */
+typedef struct dfx_graph dfx_graph;
+DFX_API int dfx_graph_create(dfx_ctx* ctx, int cs, int n_nodes, int n_pairs, const int32_t* pair_nodes, dfx_graph** out);
+DFX_API void dfx_graph_destroy(dfx_graph* graph);
+DFX_API size_t dfx_graph_system_floats(const dfx_graph* graph);
+DFX_API int dfx_graph_assemble_async(dfx_ctx* ctx, const dfx_graph* graph, const void* items_dev, int first_pair, int n_local,
+                                     float* sys_dev);
 
 /* ---- image-proc free functions (cuda/cu_image_proc.h:27-46) ---------------------------------- */
 /* UpdateDepth (cu_image_proc.cpp:248-277): dpt = a/(prx_orig + prx_jac . code) - a; code is a HOST array of cs floats. */

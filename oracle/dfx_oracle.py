@@ -26,6 +26,16 @@ def build(force=False):
     return _SO
 
 
+def build_native():
+    """The timed CPU baseline of bench.py: the same source compiled for THIS machine (g++ -O3 -march=native -ffp-contract=off),
+    at run time -- a -march=native object built elsewhere may not run here.  Switches this module to the native library."""
+    global _lib, _SO
+    native = os.path.join(_HERE, "libdfx_oracle_native.so")
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libdfx_oracle_native.so"], stdout=subprocess.DEVNULL)
+    _SO, _lib = native, None
+    return native
+
+
 _lib = None
 
 

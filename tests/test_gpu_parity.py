@@ -121,50 +121,52 @@ def test_sfm_step_batch_mixed_cameras(dfx, oracle):
     assert np.array_equal(first.raw, again.raw)
 
 
-def test_native_normal_equation_assembly_matches_torch(dfx):
-    """dfx_neq_assemble_async == the torch index_add formulation (deepfactors_amd/dist.py), bit for bit."""
-    from deepfactors_amd.dist import NormalEquations
-    w, h, cs, n = 96, 64, 32, 5
-    al = dfx.SfmAligner(code_size=cs)
-    dev = []
-    for k in range(n):
-        p, nn, g = _pair(dfx, w, h, cs, seed=300 + k)
-        dev.append((nn, g))
-    arr = al.make_pairs([dict(pose0=nn["pose0"], pose1=nn["pose1"], cam=nn["cam"], img0=g["img0"], img1=g["img1"], dpt0=g["dpt0"],
-                              prx0_jac=g["prx_jac"], grad1=g["grad1"]) for nn, g in dev])
-    items = torch.zeros(n * dfx.item_size(12 + cs), dtype=torch.uint8, device="cuda")
-    al.RunStepBatchAsync(arr, items)
-    a = NormalEquations(n + 3, cs, "cuda")
-    b = NormalEquations(n + 3, cs, "cuda")
-    a.assemble(items, 1, n, dfx.item_size(12 + cs))
-    b.assemble_native(al.ctx, items, 1, n)
-    al.ctx.sync()
-    assert torch.equal(a.H, b.H) and torch.equal(a.g, b.g)
-    D = a.dense()
-    assert torch.allclose(D, D.T) and float(D.abs().max()) > 0
-    # fused variant (step kernel clears the touched frames, finalize scatter-adds): same bytes, items included; run twice
-    # into a dirty buffer to prove the clearing
-    c = NormalEquations(n + 3, cs, "cuda")
-    c.buf.fill_(123.0)   # e.g. the root's copy after a reduce: other ranks' frames hold last step's sums
-    items2 = torch.zeros_like(items)
-    for _ in range(2):
-        al.RunStepBatchAssembleAsync(arr, items2, c, 1)
-    al.ctx.sync()
-    assert torch.equal(items, items2)
-    assert torch.equal(a.H, c.H) and torch.equal(a.g, c.g)
-    for cs2 in (16, 64):   # the other code sizes against the separate kernel
-        al2 = dfx.SfmAligner(code_size=cs2)
-        p2, nn2, g2 = _pair(dfx, 64, 48, cs2, seed=77)
-        arr2 = al2.make_pairs([dict(pose0=nn2["pose0"], pose1=nn2["pose1"], cam=nn2["cam"], img0=g2["img0"], img1=g2["img1"], dpt0=g2["dpt0"],
-                                    prx0_jac=g2["prx_jac"], grad1=g2["grad1"])] * 3)
-        it_a = torch.zeros(3 * dfx.item_size(12 + cs2), dtype=torch.uint8, device="cuda")
-        it_b = torch.zeros_like(it_a)
-        ea, eb = NormalEquations(4, cs2, "cuda"), NormalEquations(4, cs2, "cuda")
-        al2.RunStepBatchAsync(arr2, it_a)
-        ea.assemble_native(al2.ctx, it_a, 0, 3)
-        al2.RunStepBatchAssembleAsync(arr2, it_b, eb, 0)
-        al2.ctx.sync()
-        assert torch.equal(it_a, it_b) and torch.equal(ea.H, eb.H) and torch.equal(ea.g, eb.g)
+def test_native_graph_assembly_matches_torch(dfx):
+    """dfx_graph_assemble_async == the torch formulation (deepfactors_amd/dist.py) on a general keyframe graph: nodes with many
+    incident pairs in both roles (keyframe of some pairs, frame of others, both directions of one link), a shard of the pair
+    list, dirty target buffers, the three code sizes."""
+    from deepfactors_amd.dist import NormalEquations, PairGraph
+    w, h = 96, 64
+    for cs in (32, 16, 64):
+        al = dfx.SfmAligner(code_size=cs)
+        graph = PairGraph(5, [(0, 1), (0, 2), (1, 0), (1, 2), (2, 4), (3, 2), (0, 4), (4, 3), (2, 1)])
+        n = graph.n_pairs
+        dev = [_pair(dfx, w, h, cs, seed=300 + k)[1:] for k in range(n)]
+        arr = al.make_pairs([dict(pose0=nn["pose0"], pose1=nn["pose1"], cam=nn["cam"], img0=g["img0"], img1=g["img1"], dpt0=g["dpt0"],
+                                  prx0_jac=g["prx_jac"], grad1=g["grad1"]) for nn, g in dev])
+        isz = dfx.item_size(12 + cs)
+        items = torch.zeros(n * isz, dtype=torch.uint8, device="cuda")
+        al.RunStepBatchAsync(arr, items)
+        al.ctx.sync()
+        for first, cnt in ((0, n), (2, 5), (7, 2)):
+            a, b = NormalEquations(graph, cs, "cuda"), NormalEquations(graph, cs, "cuda")
+            b.buf.fill_(123.0)   # e.g. the root's copy after a reduce: every entry must be overwritten
+            a.assemble(items[first * isz:(first + cnt) * isz], first, cnt, isz)
+            for _ in range(2):
+                b.assemble_native(al.ctx, items[first * isz:(first + cnt) * isz], first, cnt)
+            al.ctx.sync()
+            assert torch.equal(a.buf, b.buf), (cs, first, cnt, float((a.buf - b.buf).abs().max()))
+        M = a.dense()
+        assert torch.allclose(M, M.T) and float(M.abs().max()) > 0
+        # step + assembly in one call: same bytes
+        c = NormalEquations(graph, cs, "cuda")
+        items2 = torch.zeros_like(items)
+        al.RunStepBatchAssembleAsync(arr, items2, c, 0)
+        al.ctx.sync()
+        full = NormalEquations(graph, cs, "cuda")
+        full.assemble(items, 0, n, isz)
+        assert torch.equal(items, items2) and torch.equal(full.buf, c.buf)
+        # the dense system equals the sum of the pairs' 44x44 systems placed by hand (PhotometricFactor::linearize's slicing)
+        D, NP = 6 + cs, 12 + cs
+        ref = np.zeros((graph.n_nodes * D, graph.n_nodes * D))
+        gref = np.zeros(graph.n_nodes * D)
+        for p, it in enumerate(al.items_from_bytes(items.cpu().numpy(), cs)):
+            ka, fb = [int(v) for v in graph.pairs[p]]
+            idx = np.array([ka * D + i for i in range(6)] + [fb * D + i for i in range(6)] + [ka * D + 6 + i for i in range(cs)])
+            ref[np.ix_(idx, idx)] += it.toDenseMatrix().astype(np.float64)
+            gref[idx] += it.Jtr.astype(np.float64)
+        assert np.abs(full.dense().numpy() - ref).max() <= 1e-6 * np.abs(ref).max()
+        assert np.abs(full.g.cpu().double().numpy().reshape(-1) - gref).max() <= 1e-6 * np.abs(gref).max()
 
 
 def test_sfm_step_deterministic(dfx):

@@ -1,6 +1,6 @@
 """A keyframe window end to end: F frames in a chain, F - 1 photometric pairs, unknowns (pose_1..pose_{F-1}, code_0..code_{F-2});
-every Gauss-Newton step = UpdateDepth per keyframe + ONE batched RunStep with the normal-equation assembly fused in
-(dfx_sfm_step_batch_neq_async) + a dense solve of the block-tridiagonal system on the host.  Validates the block placement
+every Gauss-Newton step = UpdateDepth per keyframe + ONE batched RunStep + the assembly of the keyframe graph's block-sparse
+normal equations (dfx_graph_assemble_async) + a dense solve of the system on the host.  Validates the block placement
 and signs of the assembled system (PhotometricFactor::linearize's G11..G33 / g1..g3, photometric_factor.cpp:105-161) by the
 only test that matters for a solver: it converges to the generating poses and codes."""
 import numpy as np
@@ -19,7 +19,7 @@ def _R(q):
 
 def test_keyframe_window_gauss_newton(dfx):
     from deepfactors_amd import synth
-    from deepfactors_amd.dist import NormalEquations
+    from deepfactors_amd.dist import NormalEquations, PairGraph
     w, h, cs, F = 160, 120, 16, 4
     D = 6 + cs
     prs = [synth.make_pair(w, h, cs, seed=60 + k, device="cuda", motion_scale=0.6 + 0.2 * k) for k in range(F - 1)]
@@ -37,7 +37,7 @@ def test_keyframe_window_gauss_newton(dfx):
     code = [(0.5 * c).astype(np.float32) for c in truth_code]
 
     al = dfx.SfmAligner(code_size=cs)
-    neq = NormalEquations(F, cs, "cuda")
+    neq = NormalEquations(PairGraph.chain(F - 1), cs, "cuda")
     items = torch.zeros((F - 1) * dfx.item_size(12 + cs), dtype=torch.uint8, device="cuda")
     dpt = [torch.empty_like(p["img0"]) for p in prs]
     hist = []
