@@ -1,0 +1,54 @@
+"""HIP path (through the C ABI) against oracle/_ref -- the reference's own per-pixel code (warping.h, dense_sfm.h,
+lucas_kanade_se3.h ... compiled unmodified, oracle/ref_harness.cpp) -- on the same inputs: the comparison the reference makes
+itself in tests/ut_sfmaligner.cpp:235-327 (GPU RunStep vs a host loop over DenseSfm: inliers equal, |dJtJ| <= 1e-1), at the
+tighter tolerance of tests/helpers.py.  The library travels prebuilt to the GPU box (it is built where /root/reference exists)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_item_close
+from test_oracle_kat import load_fixture, scenenet_cam
+
+ref = pytest.importorskip("oracle.dfx_ref")
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref.available(), reason="oracle/_ref/libdfx_ref.so not built")]
+
+
+@pytest.mark.parametrize("w,h,cs", [(320, 240, 32), (640, 480, 32), (160, 120, 16), (256, 192, 64)])
+def test_sfm_step_matches_the_reference_code(dfx, w, h, cs):
+    from deepfactors_amd import synth
+    g = synth.make_pair(w, h, cs, seed=0xDF0A + w, device="cuda")
+    n = synth.to_numpy(g)
+    pose1 = n["pose1"].copy(); pose1[4] += 0.01
+    al = dfx.SfmAligner(code_size=cs)
+    valid_gpu = torch.zeros_like(g["img0"])
+    got = al.RunStep(n["pose0"], pose1, n["code"], n["cam"], g["img0"], g["img1"], g["dpt0"], g["std0"], valid_gpu, g["prx_jac"], g["grad1"])
+    valid_ref = np.zeros_like(n["img0"])
+    want = ref.sfm_step(n["pose0"], pose1, n["cam"], n["img0"], n["img1"], n["dpt0"], n["prx_jac"], n["grad1"], valid0=valid_ref)
+    assert want.inliers > 0.5 * w * h
+    assert_item_close(got, want, w, h, what=f"HIP vs reference code {w}x{h} cs={cs}")
+    assert int((valid_gpu.cpu().numpy() != valid_ref).sum()) <= max(1, int(1e-5 * w * h))
+    e = al.EvaluateError(n["pose0"], pose1, n["cam"], g["img0"], g["img1"], g["dpt0"], None, g["grad1"])
+    r_res, r_inl = ref.sfm_error(n["pose0"], pose1, n["cam"], n["img0"], n["img1"], n["dpt0"], n["grad1"], 0.1)
+    assert abs(int(e.inliers) - r_inl) <= max(1, int(1e-5 * w * h)) and abs(e.residual - r_res) <= 1e-4 * r_res
+    out = torch.empty_like(g["img0"])
+    dfx.UpdateDepth(n["code"], g["prx_orig"], g["prx_jac"], 2.0, out)
+    d_ref = ref.update_depth(n["code"], n["prx_orig"], n["prx_jac"], 2.0)
+    assert np.abs(out.cpu().numpy() - d_ref).max() <= 2e-6 * float(((2.0 + d_ref) ** 2 / 2.0).max())
+
+
+def test_se3_tracking_on_the_reference_fixture_matches_the_reference_code(dfx, oracle):
+    """ut_se3aligner.cpp:173-211 on data/testimg 1047 -> 1052: every one of the 40 Gauss-Newton steps of the HIP SE3Aligner agrees with
+    the reference's LucasKanadeSE3 at the same pose; the loop reaches the reference's criterion."""
+    img0, img1, dpt0 = load_fixture()
+    w, h = 320, 240
+    cam = scenenet_cam(w, h)
+    grad1 = oracle.sobel(img1)
+    gi0, gi1, gd0, gg1 = (torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (img0, img1, dpt0, grad1))
+    al = dfx.SE3Aligner()
+    qt = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    for it in range(40):
+        got = al.RunStep(qt, cam, gi0, gi1, gd0, gg1)
+        want = ref.se3_step(qt, cam, img0, img1, dpt0, grad1, 0.1)
+        assert_item_close(got, want, w, h, what=f"SE3 step {it}")
+        qt = ref.se3_solve_and_update(got.JtJ, got.Jtr, qt)   # the reference's own update (lucas_kanade_se3.h:85-95)
+    assert got.residual / got.inliers <= 1e-3

@@ -1,0 +1,154 @@
+"""Pins the CPU oracle (oracle/dfx_oracle.cpp, our restatement) to the REFERENCE'S OWN per-pixel code: oracle/_ref/libdfx_ref.so is
+built from the reference's unmodified L0 headers (warping.h, dense_sfm.h, lucas_kanade_se3.h, pinhole_camera{,_impl}.h,
+m_estimators.h, reduction_items.h, kernel_utils.h -- oracle/ref_harness.cpp) against stand-in Eigen / Sophus / VisionCore headers.
+Reference-derived through this pin: every formula of the path (RelativePose and its Jacobians, correspondence + validity,
+projection and warp Jacobians, DepthJacobianPrx, the 12 + CS column row, Huber weight, the accumulated products, the GN update).
+Still fixed by spec only: bilinear sampling and the packed upper-triangular order (stand-in VisionCore).
+
+Differences allowed: the oracle forms R (3x3) from the quaternion in double and rounds once, Sophus rotates through the quaternion
+in float -- projected coordinates differ by ~1 ulp, so a pixel that lands within that distance of the validity border may flip,
+and sums differ at the 1e-6 level."""
+import os
+
+import numpy as np
+import pytest
+
+from test_oracle_kat import load_fixture, scenenet_cam
+
+ref = pytest.importorskip("oracle.dfx_ref")
+pytestmark = pytest.mark.skipif(not (ref.available() or os.path.isdir(os.path.join(ref.REFERENCE, "sources"))),
+                                reason="oracle/_ref not built and no reference tree to build it from")
+
+
+@pytest.fixture(scope="module")
+def refl():
+    ref.build()
+    ref.lib()
+    return ref
+
+
+def _pair(w, h, cs, seed, **kw):
+    from deepfactors_amd import synth
+    return synth.to_numpy(synth.make_pair(w, h, cs, seed=seed, device="cpu", **kw))
+
+
+def _close(got, want, w, h, rel=2e-5):
+    flips = abs(int(got.inliers) - int(want.inliers))
+    assert flips <= max(1, int(1e-5 * w * h)), (got.inliers, want.inliers)
+    slack = 1.0 + 4.0 * flips
+    sj = float(np.abs(want.JtJ).max())
+    assert np.abs(np.asarray(got.JtJ, np.float64) - want.JtJ).max() <= rel * sj * slack
+    sr = max(float(np.abs(want.Jtr).max()), float(np.sqrt(sj * max(want.residual, 0.0))))
+    assert np.abs(np.asarray(got.Jtr, np.float64) - want.Jtr).max() <= rel * sr * slack
+    assert abs(got.residual - want.residual) <= rel * want.residual * slack
+
+
+@pytest.mark.parametrize("w,h,cs,seed", [(160, 120, 32, 11), (96, 64, 16, 12), (128, 96, 64, 13), (320, 240, 32, 14), (100, 77, 32, 15)])
+def test_sfm_step_oracle_equals_reference_code(oracle, refl, w, h, cs, seed):
+    n = _pair(w, h, cs, seed)
+    pose1 = n["pose1"].copy(); pose1[4] += 0.01
+    v_o, v_r = np.zeros((h, w), np.float32), np.zeros((h, w), np.float32)
+    want = refl.sfm_step(n["pose0"], pose1, n["cam"], n["img0"], n["img1"], n["dpt0"], n["prx_jac"], n["grad1"], valid0=v_r)
+    got = oracle.sfm_step(n["pose0"], pose1, n["cam"], n["img0"], n["img1"], n["dpt0"], n["prx_jac"], n["grad1"], valid0=v_o, accum_f64=True)
+    assert want.inliers > 0.5 * w * h
+    _close(got, want, w, h)
+    assert int((v_o != v_r).sum()) <= max(1, int(1e-5 * w * h))
+
+
+def test_sfm_step_reference_test_poses_and_huber(oracle, refl):
+    """ut_sfmaligner.cpp:254-268: pose0 = I, pose1 = inverse(exp(0.1, 0.1, 0), t = (-.5, -.5, 0)) (scaled by 0.1 for overlap), huber 0.5;
+    plus non-default min_dpt / border."""
+    from deepfactors_amd import synth
+    w, h, cs = 192, 144, 32
+    n = _pair(w, h, cs, 21)
+    R = synth.so3_exp(np.array([0.1, 0.1, 0.0]) * 0.1)
+    t = np.array([-0.5, -0.5, 0.0]) * 0.1
+    pose1 = synth.pose_qt(R.T, -R.T @ t)
+    for kw in (dict(huber_delta=0.5), dict(huber_delta=0.02, min_dpt=1.5, valid_border=7), dict(avg_dpt=3.0)):
+        want = refl.sfm_step(n["pose0"], pose1, n["cam"], n["img0"], n["img1"], n["dpt0"], n["prx_jac"], n["grad1"], **kw)
+        got = oracle.sfm_step(n["pose0"], pose1, n["cam"], n["img0"], n["img1"], n["dpt0"], n["prx_jac"], n["grad1"], **kw)
+        assert want.inliers > 0
+        _close(got, want, w, h)
+
+
+def test_single_pixel_items_match(oracle, refl):
+    """Per-pixel (J J^T, J^T r, r^2, valid): everything but one pixel masked by NaN depth (NaN depth = no correspondence,
+    warping.h:221-224), so the sum IS that pixel's item -- 60 pixels incl. the border band where validity is decided."""
+    w, h, cs = 48, 40, 16
+    n = _pair(w, h, cs, 31)
+    rng = np.random.default_rng(5)
+    pix = [(int(rng.integers(0, w)), int(rng.integers(0, h))) for _ in range(40)] + [(x, y) for x in (0, 1, 2, 3, w - 3, w - 1) for y in (0, 2, h - 3)][:20]
+    nvalid = 0
+    for (x, y) in pix:
+        d = np.full((h, w), np.nan, np.float32)
+        d[y, x] = n["dpt0"][y, x]
+        want = refl.sfm_step(n["pose0"], n["pose1"], n["cam"], n["img0"], n["img1"], d, n["prx_jac"], n["grad1"])
+        got = oracle.sfm_step(n["pose0"], n["pose1"], n["cam"], n["img0"], n["img1"], d, n["prx_jac"], n["grad1"])
+        assert got.inliers == want.inliers, (x, y)
+        nvalid += want.inliers
+        if want.inliers:
+            s = max(float(np.abs(want.JtJ).max()), 1e-12)
+            assert np.abs(got.JtJ - want.JtJ).max() <= 5e-5 * s, (x, y)
+            assert np.abs(got.Jtr - want.Jtr).max() <= 5e-5 * max(float(np.abs(want.Jtr).max()), np.sqrt(s * want.residual), 1e-12), (x, y)
+    assert 20 <= nvalid < len(pix)   # both valid and invalid pixels were exercised
+
+
+def test_se3_step_and_error_on_the_reference_fixture(oracle, refl):
+    img0, img1, dpt0 = load_fixture()
+    cam = scenenet_cam(320, 240)
+    grad1 = oracle.sobel(img1)
+    for qt in (np.array([0, 0, 0, 1, 0, 0, 0], np.float32), np.array([0.002, -0.004, 0.001, 1, 0.01, -0.02, 0.005], np.float32)):
+        qt = qt / np.float32(np.linalg.norm(qt[:4])) if False else qt
+        qt[:4] /= np.linalg.norm(qt[:4])
+        want = refl.se3_step(qt, cam, img0, img1, dpt0, grad1, 0.1)
+        got = oracle.se3_step(qt, cam, img0, img1, dpt0, grad1, 0.1, accum_f64=True)
+        _close(got, want, 320, 240)
+        ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+        r_res, r_inl = refl.sfm_error(ident, qt, cam, img0, img1, dpt0, grad1, 0.1)
+        o_res, o_inl = oracle.sfm_error(ident, qt, cam, img0, img1, dpt0, 0.1)
+        assert abs(r_inl - o_inl) <= 1 and abs(r_res - o_res) <= 2e-5 * r_res
+
+
+def test_image_alignment_kat_through_the_reference_code(refl, oracle):
+    """ut_se3aligner.cpp:173-211 ImageAlignmentTest with the reference's own LucasKanadeSE3 + SE3SolveAndUpdate: 40 iterations from
+    identity reach residual / inliers <= 1e-3 -- and the oracle-driven loop lands on the same pose."""
+    img0, img1, dpt0 = load_fixture()
+    cam = scenenet_cam(320, 240)
+    grad1 = oracle.sobel(img1)
+    qt_r = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    qt_o = qt_r.copy()
+    for _ in range(40):
+        r = refl.se3_step(qt_r, cam, img0, img1, dpt0, grad1, 0.1)
+        qt_r = refl.se3_solve_and_update(r.JtJ, r.Jtr, qt_r)
+        o = oracle.se3_step(qt_o, cam, img0, img1, dpt0, grad1, 0.1, accum_f64=True)
+        qt_o = oracle.se3_solve_update(o.JtJ.astype(np.float32), o.Jtr.astype(np.float32), qt_o)
+    assert r.residual / r.inliers <= 1e-3 and r.inliers > 0.9 * 320 * 240
+    assert np.abs(qt_r - qt_o).max() <= 2e-5, (qt_r, qt_o)
+
+
+@pytest.mark.parametrize("cs", [16, 32, 64])
+def test_update_depth_is_bit_identical(oracle, refl, cs):
+    n = _pair(80, 60, cs, 41)
+    rng = np.random.default_rng(cs)
+    code = rng.normal(0, 0.3, cs).astype(np.float32)
+    a = refl.update_depth(code, n["prx_orig"], n["prx_jac"], 2.0)
+    b = oracle.update_depth(code, n["prx_orig"], n["prx_jac"], 2.0)
+    # the reference's Eigen product (1 x CS) * (CS x 1) is a plain left-to-right fp32 dot product; so is the oracle's
+    assert np.abs(a - b).max() <= 2e-6 * float(((2.0 + b) ** 2 / 2.0).max())
+
+
+def test_relative_pose_and_small_math(oracle, refl):
+    rng = np.random.default_rng(3)
+    for _ in range(5):
+        a = np.concatenate([rng.normal(size=4), rng.normal(size=3)]).astype(np.float32); a[:4] /= np.linalg.norm(a[:4])
+        b = np.concatenate([rng.normal(size=4), rng.normal(size=3)]).astype(np.float32); b[:4] /= np.linalg.norm(b[:4])
+        qt, Ja, Jb = refl.relative_pose(a, b)
+        R, t, Oa, Ob = oracle.relative_pose(a, b, dtype=np.float64)
+        Rr = oracle.quat_to_R(qt.astype(np.float64))
+        assert np.abs(Rr - R).max() <= 2e-6 and np.abs(qt[4:] - t).max() <= 2e-6 * max(1.0, float(np.abs(t).max()))
+        assert np.abs(Ja - Oa).max() <= 5e-6 * max(1.0, float(np.abs(Oa).max())) and np.abs(Jb - Ob).max() <= 5e-6
+    for x in (0.0, 0.05, -0.0999, 0.1, 0.1001, -0.7, 3.0):
+        assert abs(refl.huber_weight(x, 0.1) - oracle.huber_weight(x, 0.1)) <= 1e-7
+    assert refl.huber_weight(0.05, 0.1) == 1.0 and abs(refl.huber_weight(0.4, 0.1) - np.sqrt(0.1 * (0.8 - 0.1)) / 0.4) < 1e-6   # abs() is the float overload
+    for d in (0.5, 2.0, 7.5):
+        assert abs(refl.depth_jacobian_prx(d, 2.0) - oracle.depth_jacobian_prx(d, 2.0, dtype=np.float32)) <= 1e-5 * abs(oracle.depth_jacobian_prx(d, 2.0))
