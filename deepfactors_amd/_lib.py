@@ -40,7 +40,7 @@ class Cam(C.Structure):
 
 
 class SfmParams(C.Structure):
-    _fields_ = [("huber_delta", C.c_float), ("avg_dpt", C.c_float), ("min_dpt", C.c_float), ("valid_border", C.c_int32)]
+    _fields_ = [("huber_delta", C.c_float), ("avg_dpt", C.c_float), ("min_dpt", C.c_float), ("valid_border", C.c_int32), ("step_blocks", C.c_int32)]
 
 
 class CorrItem(C.Structure):
@@ -78,6 +78,8 @@ _lib = None
 _PROTOS = {
     "dfx_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "dfx_ctx_destroy": (None, [C.c_void_p]),
+    "dfx_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dfx_ctx_device": (C.c_int, [C.c_void_p]),
     "dfx_last_error": (C.c_char_p, []),
     "dfx_version": (C.c_char_p, []),
     "dfx_sync": (C.c_int, [C.c_void_p]),

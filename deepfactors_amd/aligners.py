@@ -58,8 +58,8 @@ class DenseSfmParams:
     def __init__(self, huber_delta=0.1, avg_dpt=2.0, min_dpt=0.0, valid_border=2):
         self.huber_delta, self.avg_dpt, self.min_dpt, self.valid_border = huber_delta, avg_dpt, min_dpt, valid_border
 
-    def _c(self):
-        return SfmParams(self.huber_delta, self.avg_dpt, self.min_dpt, int(self.valid_border))
+    def _c(self, step_blocks=0):
+        return SfmParams(self.huber_delta, self.avg_dpt, self.min_dpt, int(self.valid_border), int(step_blocks))
 
 
 class SfmAlignerParams:
@@ -108,15 +108,17 @@ def _cam(c):
 
 
 class Context:
-    """One dfx_ctx: device + stream + scratch.  By default it enqueues on PyTorch's current stream of `device`, so
-    ``torch.cuda.Event`` timing and tensor lifetime rules apply unchanged."""
+    """One dfx_ctx: device + stream + scratch.  By default it enqueues on the stream that is PyTorch's current stream of `device`
+    WHEN THE CONTEXT IS CREATED, so ``torch.cuda.Event`` timing and tensor lifetime rules apply unchanged; inside a later
+    ``with torch.cuda.stream(s):`` block call ``use_current_stream()`` (or ``set_stream(s)``) to follow.  `device` None = PyTorch's
+    current device.  Every tensor handed to a call must live on the context's device (checked)."""
 
-    def __init__(self, device=0, stream="torch"):
+    def __init__(self, device=None, stream="torch"):
         self._h = C.c_void_p()
         L = _lib.lib()
         if not torch.cuda.is_available():
             raise DfxError(_lib.DFX_E_NOGPU, "no HIP device visible to PyTorch; libdfx has no CPU fallback")
-        self.device = int(device)
+        self.device = int(torch.cuda.current_device() if device is None else device)
         if stream == "torch":
             sh = torch.cuda.current_stream(self.device).cuda_stream
         elif stream is None:
@@ -131,6 +133,19 @@ class Context:
 
     def sync(self):
         check(_lib.lib().dfx_sync(self._h))
+
+    def set_stream(self, stream):
+        """Re-bind to another stream of the device (a torch.cuda.Stream, a raw hipStream_t integer, or None = default stream)."""
+        sh = stream.cuda_stream if isinstance(stream, torch.cuda.Stream) else stream
+        check(_lib.lib().dfx_ctx_set_stream(self._h, C.c_void_p(int(sh)) if sh else None))
+
+    def use_current_stream(self):
+        self.set_stream(torch.cuda.current_stream(self.device))
+
+    def check_device(self, *tensors):
+        for t in tensors:
+            if isinstance(t, torch.Tensor) and t.is_cuda and t.device.index != self.device:
+                raise DfxError(_lib.DFX_E_INVALID, f"tensor on cuda:{t.device.index} handed to a context of cuda:{self.device}")
 
     def cu_count(self):
         return int(_lib.lib().dfx_device_cu_count(self._h))
@@ -163,11 +178,21 @@ class Context:
 _default_ctx = {}
 
 
-def default_context(device=0):
-    key = int(device)
+def default_context(device=None):
+    """The process-wide context of `device` (None = PyTorch's current device; with one process per GPU that is this rank's GPU)."""
+    key = int(torch.cuda.current_device() if device is None else device) if torch.cuda.is_available() else 0
     if key not in _default_ctx:
         _default_ctx[key] = Context(key)
     return _default_ctx[key]
+
+
+def _ctx_for(ctx, *tensors):
+    """Explicit context, else the default context of the device the first CUDA tensor lives on; all tensors must agree."""
+    if ctx is None:
+        dev = next((t.device.index for t in tensors if isinstance(t, torch.Tensor) and t.is_cuda), None)
+        ctx = default_context(dev)
+    ctx.check_device(*tensors)
+    return ctx
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -182,12 +207,17 @@ class SfmAligner:
         self.ctx = ctx or default_context()
         self.SetStepThreadsBlocks(self.params_.step_threads, self.params_.step_blocks)
 
+    def _p(self):
+        """dfx_sfm_params of this aligner: its own step_blocks travel with every call (two aligners on one context do not alias)."""
+        return self.params_.sfmparams._c(self.params_.step_blocks)
+
     # cu_sfmaligner.cpp:187-203: glog CHECK on bad values -> here an exception
     def SetStepThreadsBlocks(self, threads, blocks):
         if threads % 64:
             raise DfxError(_lib.DFX_E_INVALID, "threads must be a multiple of 64 (the CDNA wavefront)")
-        self.params_.step_threads, self.params_.step_blocks = threads, blocks
-        check(_lib.lib().dfx_sfm_set_step_blocks(self.ctx.handle, int(blocks)))
+        if blocks < 0 or blocks > 65535:
+            raise DfxError(_lib.DFX_E_INVALID, "blocks out of range [0, 65535]")
+        self.params_.step_threads, self.params_.step_blocks = threads, int(blocks)
 
     def SetEvalThreadsBlocks(self, threads, blocks):
         if threads % 64:
@@ -197,9 +227,10 @@ class SfmAligner:
     def RunStep(self, pose0, pose1, code0, cam, img0, img1, dpt0, std0, valid0, prx0_jac, grad1):
         """cu_sfmaligner.cpp:149-185.  `code0` is unused by the kernel (depth is already decoded), as in the reference."""
         del code0
+        self.ctx.check_device(img0, img1, dpt0, std0, valid0, prx0_jac, grad1)
         np_ = 12 + self.CS
         raw = np.zeros(item_size(np_), np.uint8)
-        p = self.params_.sfmparams._c()
+        p = self._p()
         s0, s1, cm = _se3(pose0), _se3(pose1), _cam(cam)
         i0, i1, d0 = _img(img0, "img0"), _img(img1, "img1"), _img(dpt0, "dpt0")
         jc, g1 = _img(prx0_jac, "prx0_jac"), _img(grad1, "grad1", 2)
@@ -213,7 +244,7 @@ class SfmAligner:
     def EvaluateError(self, pose0, pose1, cam, img0, img1, dpt0, std0, grad1):
         """cu_sfmaligner.cpp:120-147."""
         out = CorrItem()
-        p = self.params_.sfmparams._c()
+        p = self._p()
         s0, s1, cm = _se3(pose0), _se3(pose1), _cam(cam)
         i0, i1, d0 = _img(img0, "img0"), _img(img1, "img1"), _img(dpt0, "dpt0")
         sd = _img(std0, "std0") if std0 is not None else None
@@ -228,6 +259,7 @@ class SfmAligner:
         pairs = list(pairs)
         arr = (SfmPair * len(pairs))()
         for k, q in enumerate(pairs):
+            self.ctx.check_device(q["img0"], q["img1"], q["dpt0"], q["prx0_jac"], q["grad1"], q.get("valid0"))
             arr[k].pose0, arr[k].pose1, arr[k].cam = _se3(q["pose0"]), _se3(q["pose1"]), _cam(q["cam"])
             arr[k].img0, arr[k].img1, arr[k].dpt0 = _img(q["img0"], "img0"), _img(q["img1"], "img1"), _img(q["dpt0"], "dpt0")
             arr[k].prx0_jac, arr[k].grad1 = _img(q["prx0_jac"], "prx0_jac"), _img(q["grad1"], "grad1", 2)
@@ -244,7 +276,7 @@ class SfmAligner:
         isz = item_size(12 + self.CS)
         if out_items_dev.numel() * out_items_dev.element_size() < n * isz:
             raise ValueError("output buffer too small")
-        p = self.params_.sfmparams._c()
+        p = self._p()
         check(_lib.lib().dfx_sfm_step_batch_async(self.ctx.handle, self.CS, C.byref(p), pair_array, n,
                                                   C.c_void_p(out_items_dev.data_ptr())))
 
@@ -262,7 +294,7 @@ class SfmAligner:
         np_ = 12 + self.CS
         isz = item_size(np_)
         raw = np.zeros(n * isz, np.uint8)
-        p = self.params_.sfmparams._c()
+        p = self._p()
         check(_lib.lib().dfx_sfm_step_batch(self.ctx.handle, self.CS, C.byref(p), pair_array, n, raw.ctypes.data_as(C.c_void_p)))
         return [JTJJrReductionItem(np_, raw[k * isz:(k + 1) * isz]) for k in range(n)]
 
@@ -329,8 +361,8 @@ class DepthAligner:
 # cu_image_proc.h free functions
 # ------------------------------------------------------------------------------------------------------------
 def UpdateDepth(code, prx_orig, prx_jac, avg_dpt, dpt_out, ctx=None):
-    """``df::UpdateDepth`` (cu_image_proc.cpp:266-277)."""
-    ctx = ctx or default_context()
+    """``df::UpdateDepth`` (cu_image_proc.cpp:266-277).  ctx None = the default context of the tensors' device."""
+    ctx = _ctx_for(ctx, prx_orig, prx_jac, dpt_out)
     cd = np.ascontiguousarray(np.asarray(code, np.float32).reshape(-1))
     po, jc, do = _img(prx_orig, "prx_orig"), _img(prx_jac, "prx_jac"), _img(dpt_out, "dpt_out")
     if jc.w != po.w * len(cd):
@@ -341,21 +373,21 @@ def UpdateDepth(code, prx_orig, prx_jac, avg_dpt, dpt_out, ctx=None):
 
 def SobelGradients(img, grad, ctx=None):
     """``df::SobelGradients`` (cu_image_proc.cpp:94-112)."""
-    ctx = ctx or default_context()
+    ctx = _ctx_for(ctx, img, grad)
     i, g = _img(img, "img"), _img(grad, "grad", 2)
     check(_lib.lib().dfx_sobel_gradients(ctx.handle, C.byref(i), C.byref(g)))
 
 
 def GaussianBlurDown(inp, out, ctx=None):
     """``df::GaussianBlurDown`` (cu_image_proc.cpp:166-186)."""
-    ctx = ctx or default_context()
+    ctx = _ctx_for(ctx, inp, out)
     i, o = _img(inp, "in"), _img(out, "out")
     check(_lib.lib().dfx_gaussian_blur_down(ctx.handle, C.byref(i), C.byref(o)))
 
 
 def SquaredError(buf1, buf2, ctx=None):
     """``df::SquaredError`` (cu_image_proc.cpp:208-240)."""
-    ctx = ctx or default_context()
+    ctx = _ctx_for(ctx, buf1, buf2)
     a, b = _img(buf1, "buf1"), _img(buf2, "buf2")
     out = C.c_float(0)
     check(_lib.lib().dfx_squared_error(ctx.handle, C.byref(a), C.byref(b), C.byref(out)))

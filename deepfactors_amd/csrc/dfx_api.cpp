@@ -200,11 +200,6 @@ void relative_pose(const dfx_se3& p0, const dfx_se3& p1, float* R10, float* t10,
 int ray_table(dfx_ctx* c, const dfx_cam* cam, uint32_t W, uint32_t H, const float** out) {
   for (const auto& t : c->ray_tabs)
     if (t.fx == cam->fx && t.fy == cam->fy && t.u0 == cam->u0 && t.v0 == cam->v0 && t.W == W && t.H == H) { *out = t.dev; return DFX_OK; }
-  if (c->ray_tabs.size() >= 256) {   // a caller cycling through cameras: start over once nothing is in flight
-    DFX_HIP(hipStreamSynchronize(c->stream));
-    for (auto& t : c->ray_tabs) (void)hipFree(t.dev);
-    c->ray_tabs.clear();
-  }
   const size_t n = (size_t)W + H + dfx::kRayTabSlack;
   std::vector<float> h(n, 0.0f);
   volatile float fx = cam->fx, fy = cam->fy, u0 = cam->u0, v0 = cam->v0;   // volatile: no reciprocal / contraction rewrites
@@ -215,6 +210,16 @@ int ray_table(dfx_ctx* c, const dfx_cam* cam, uint32_t W, uint32_t H, const floa
   DFX_HIP(hipMemcpy(dev, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
   c->ray_tabs.push_back({ cam->fx, cam->fy, cam->u0, cam->v0, W, H, dev });
   *out = dev;
+  return DFX_OK;
+}
+
+// A caller cycling through cameras: start over once nothing is in flight.  Called BEFORE the descriptors of a batch are filled,
+// never in between (a descriptor filled earlier in the same batch would keep a pointer to a freed table).
+int ray_table_gc(dfx_ctx* c) {
+  if (c->ray_tabs.size() < 256) return DFX_OK;
+  DFX_HIP(hipStreamSynchronize(c->stream));
+  for (auto& t : c->ray_tabs) (void)hipFree(t.dev);
+  c->ray_tabs.clear();
   return DFX_OK;
 }
 
@@ -268,11 +273,11 @@ int fill_sfm_pair(dfx_ctx* c, int cs, const dfx_se3* pose0, const dfx_se3* pose1
 // static round measured 4 % slower than five).  Chunks per wave: 5 while the batch is small, up to 30 (CS <= 32; a CS 64
 // chunk carries 2.5x the matrix work: 10) when that still leaves five rounds.  (Sweeps must discard the first ~100 launches
 // after any idle period: the clocks ramp.)
-int auto_step_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int npairs, int cs) {
+int auto_step_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int npairs, int cs, int requested = 0) {
   const int nchunks = (int)(((size_t)W * H + 63) / 64);
   int maxb = (nchunks + 3) / 4;   // one chunk per wave at most
   if (maxb < 1) maxb = 1;
-  int b = c->step_blocks;
+  int b = requested > 0 ? requested : c->step_blocks;
   if (b <= 0) {
     const long long total_chunks = (long long)nchunks * npairs;
     const long long resident_waves = 16LL * c->cu_count;
@@ -350,6 +355,7 @@ DFX_API int dfx_ctx_create(int device, void* stream, dfx_ctx** out) {
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) return fail(DFX_E_NOGPU, "no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+  if (device < 0 && (e = hipGetDevice(&device)) != hipSuccess) return fail(DFX_E_HIP, "hipGetDevice failed: %s", hipGetErrorString(e));
   if (device < 0 || device >= ndev) return fail(DFX_E_INVALID, "device %d out of range [0,%d)", device, ndev);
   DFX_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;
@@ -389,6 +395,19 @@ DFX_API void dfx_ctx_destroy(dfx_ctx* c) {
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
+
+DFX_API int dfx_ctx_set_stream(dfx_ctx* c, void* stream) {
+  if (!c) return fail(DFX_E_INVALID, "null context");
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  if ((hipStream_t)stream == c->stream) return DFX_OK;
+  DFX_HIP(hipStreamSynchronize(c->stream));   // staging slots, scratch and result area are ordered on the old stream
+  c->stream = (hipStream_t)stream;
+  for (int i = 0; i < kStageSlots; ++i) c->stage_used[i] = false;
+  return DFX_OK;
+}
+
+DFX_API int dfx_ctx_device(dfx_ctx* c) { return c ? c->device : -1; }
 
 DFX_API int dfx_sync(dfx_ctx* c) {
   if (!c) return fail(DFX_E_INVALID, "null context");
@@ -458,6 +477,7 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
   const uint32_t W = pairs[0].img0.w, H = pairs[0].img0.h;
   if ((size_t)W * H >= (1ull << 31)) return fail(DFX_E_INVALID, "image too large");
 
+  if ((rc = ray_table_gc(c))) return rc;
   int slot;
   char* host;
   const size_t desc_bytes = sizeof(dfx::SfmPairDev) * (size_t)n;
@@ -483,7 +503,8 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
   DFX_HIP(hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, c->stream));
   if ((rc = stage_release(c, slot))) return rc;
 
-  const int bpp = auto_step_blocks(c, W, H, n, cs);
+  if (params->step_blocks < 0 || params->step_blocks > 65535) return fail(DFX_E_INVALID, "step_blocks %d out of range [0,65535]", params->step_blocks);
+  const int bpp = auto_step_blocks(c, W, H, n, cs, params->step_blocks);
   const size_t pbytes = dfx::sfm_step_partials_bytes(cs, n, bpp);
   if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
   if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;

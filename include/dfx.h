@@ -68,6 +68,11 @@ typedef struct dfx_sfm_params {
   float avg_dpt;     /* 2.0 */
   float min_dpt;     /* 0.0 */
   int32_t valid_border; /* 2 */
+  /* SfmAlignerParams::step_blocks (cu_sfmaligner.h:44, SetStepThreadsBlocks cu_sfmaligner.cpp:196-203): workgroups per pair of
+   * the step kernel for THIS call; 0 = the context's value (dfx_sfm_set_step_blocks), which defaults to automatic.  Passed per
+   * call so that two aligners sharing a context cannot change each other's launch shape (the reference's __constant__
+   * sfm_params has exactly that aliasing, cu_sfmaligner.cpp:34,111).  Threads per workgroup are fixed at 256 (4 waves). */
+  int32_t step_blocks;
 } dfx_sfm_params;
 
 /* df::CorrespondenceReductionItem<float> (cuda/reduction_items.h:35-71): 16 bytes */
@@ -77,12 +82,14 @@ typedef struct dfx_corr_item {
   uint64_t inliers;
 } dfx_corr_item;
 
-/* df::JTJJrReductionItem<float,NP> (cuda/reduction_items.h:77-143) is a variable-size POD:
+/* Result item: the MEMBERS of df::JTJJrReductionItem<float,NP> (cuda/reduction_items.h:77-143) in dfx's own packed layout --
  *   float JtJ[NP*(NP+1)/2]   packed upper triangle, row-major ((0,0),(0,1)..(0,NP-1),(1,1)..)
  *   float Jtr[NP]
  *   float residual
  *   (pad to 8)  uint64_t inliers
- * NP = 6 (SE3Aligner, 120 bytes), 12+CS (SfmAligner, 4152 bytes for CS=32), CS (DepthAligner).
+ * NP = 6 (SE3Aligner, 120 bytes), 12+CS (SfmAligner, 4152 bytes for CS=32), CS (DepthAligner).  This is NOT the reference struct's
+ * in-memory layout (Eigen aligns Jtr to 16 bytes there: sizeof is 4160 for NP = 44), so never memcpy an item into the reference
+ * struct: read it through the dfx_item_* accessors below (the C++ shim's FromRaw does).
  * Parameter order for SfmAligner: [pose0 (tx,ty,tz,wx,wy,wz), pose1 (6), code0 (CS)]. */
 static inline size_t dfx_item_jtj_len(int np) { return (size_t)np * (size_t)(np + 1) / 2; }
 static inline size_t dfx_item_inliers_offset(int np) {
@@ -98,16 +105,20 @@ static inline uint64_t dfx_item_inliers(const void* item, int np) {
 
 /* ---- context ------------------------------------------------------------------------------- */
 /* Replaces cuda::Init / per-aligner scratch buffers (cu_sfmaligner.cpp:101-114, cu_se3aligner.cpp:120).
- * `stream` is the hipStream_t every call of this context enqueues on; NULL = the device's default stream (what the
- * reference uses).  The caller's producers of the input images must be ordered with that stream. */
+ * `device` < 0 = the calling thread's current HIP device.  `stream` is the hipStream_t every call of this context enqueues on;
+ * NULL = the device's default stream (what the reference uses).  The caller's producers of the input images must be ordered
+ * with that stream.  Every image handed to a call must live on the context's device. */
 DFX_API int dfx_ctx_create(int device, void* stream, dfx_ctx** out);
+/* Re-binds the context to another stream of its device (waits for the work already enqueued on the old one). */
+DFX_API int dfx_ctx_set_stream(dfx_ctx* ctx, void* stream);
+DFX_API int dfx_ctx_device(dfx_ctx* ctx);
 DFX_API void dfx_ctx_destroy(dfx_ctx* ctx);
 DFX_API const char* dfx_last_error(void);
 DFX_API const char* dfx_version(void);
 /* Waits for everything enqueued on the context's stream. */
 DFX_API int dfx_sync(dfx_ctx* ctx);
-/* SfmAligner::SetStepThreadsBlocks (cu_sfmaligner.cpp:196-203): workgroups per pair for the step
- * kernel; 0 = automatic (sized from the CU count).  Threads per workgroup are fixed at 256 (4 waves). */
+/* Context-wide default of dfx_sfm_params.step_blocks (workgroups per pair of the step kernel); 0 = automatic (sized from the
+ * CU count and the batch).  A non-zero dfx_sfm_params.step_blocks overrides it per call. */
 DFX_API int dfx_sfm_set_step_blocks(dfx_ctx* ctx, int blocks_per_pair);
 DFX_API int dfx_device_cu_count(dfx_ctx* ctx);
 /* How the JtJ/Jtr outer products of the SfM / DepthAligner step are evaluated on the matrix cores (fp32 in, fp32 out):

@@ -12,9 +12,13 @@
 //                  -- or a dfx::pod::SE3f {q[4], t[3]}
 //   Camera-like  : fx() fy() u0() v0() width() height()                                        (df::PinholeCamera<float>)
 //   Image-like   : ptr() pitch() width() height()                                              (vc::Image2DView<T,TargetDeviceCUDA>)
-// so `PhotometricFactor` / `CameraTracker` compile against it unchanged when Sophus/VisionCore are present, and the
-// test program tests/cpp/shim_test.cpp compiles with the POD models when they are not.  INTEGRATION.md shows the
-// CMake lines that swap libdf_cuda for this header + libdfx.so.
+// When <Eigen/Core> is on the include path (it always is in the reference's build) the result items carry Eigen types exactly as
+// the reference's do -- `JtJ.toDenseMatrix()` returns Eigen::Matrix<float,NP,NP>, `Jtr` is Eigen::Matrix<float,NP,1> -- so the two
+// consumers that matter compile unchanged: `sys.JtJ.toDenseMatrix().template cast<double>()` / `-sys.Jtr.template cast<double>()`
+// (core/gtsam/photometric_factor.cpp:105-106) and `-result.JtJ.toDenseMatrix().ldlt().solve(result.Jtr)`
+// (core/system/camera_tracker.cpp:59).  Without Eigen the same members are std::array (row-major dense).  tests/cpp/shim_test.cpp
+// reproduces those call sites against Sophus / Eigen / VisionCore-shaped types and runs them on the GPU.  INTEGRATION.md shows
+// the CMake lines that swap libdf_cuda for this header + libdfx.so.
 //
 // Errors: every non-zero C-ABI status becomes a dfx::Error (std::runtime_error), mirroring vc::CUDAException thrown by
 // CudaCheckLastError (sources/cuda/launch_utils.h:26-32); "no overlap" stays in-band as inliers == 0.
@@ -29,6 +33,13 @@
 #include <vector>
 
 #include "dfx.h"
+
+#if defined(__has_include)
+#if __has_include(<Eigen/Core>)
+#include <Eigen/Core>
+#define DFX_SHIM_HAS_EIGEN 1
+#endif
+#endif
 
 namespace dfx {
 
@@ -96,15 +107,27 @@ inline dfx_img to_img(const Img& im) {
 // One context per host thread (the reference is single-threaded under slam_mutex_).
 class Context {
  public:
-  explicit Context(int device = 0, void* stream = nullptr) { check(dfx_ctx_create(device, stream, &ctx_)); }
+  // device < 0: the calling thread's current HIP device; stream: a hipStream_t, nullptr = the default stream (the reference's)
+  explicit Context(int device = -1, void* stream = nullptr) { check(dfx_ctx_create(device, stream, &ctx_)); }
   ~Context() { dfx_ctx_destroy(ctx_); }
   Context(const Context&) = delete;
   Context& operator=(const Context&) = delete;
   dfx_ctx* get() const { return ctx_; }
-  static std::shared_ptr<Context> Default() {
-    static thread_local std::shared_ptr<Context> c = std::make_shared<Context>(0, nullptr);
+  int device() const { return dfx_ctx_device(ctx_); }
+  void SetStream(void* stream) { check(dfx_ctx_set_stream(ctx_, stream)); }
+  // The thread's default context: created on first use on the thread's CURRENT device (one process per GPU: this rank's GPU),
+  // default stream.  SetDefault installs another one (other device / stream) for the aligners and free functions constructed or
+  // called afterwards on this thread.
+  static std::shared_ptr<Context>& DefaultSlot() {
+    static thread_local std::shared_ptr<Context> c;
     return c;
   }
+  static std::shared_ptr<Context> Default() {
+    std::shared_ptr<Context>& c = DefaultSlot();
+    if (!c) c = std::make_shared<Context>(-1, nullptr);
+    return c;
+  }
+  static void SetDefault(std::shared_ptr<Context> c) { DefaultSlot() = std::move(c); }
 
  private:
   dfx_ctx* ctx_ = nullptr;
@@ -125,29 +148,47 @@ struct CorrespondenceReductionItem {
 template <typename Scalar, int NP>
 struct JTJJrReductionItem {
   static_assert(std::is_same<Scalar, float>::value, "the gfx950 kernels are fp32 (the reference instantiates float only)");
+#ifdef DFX_SHIM_HAS_EIGEN
+  typedef Eigen::Matrix<Scalar, NP, 1> JacobianType;
+#else
+  typedef std::array<Scalar, NP> JacobianType;
+#endif
   struct HessianType {
+#ifdef DFX_SHIM_HAS_EIGEN
+    typedef Eigen::Matrix<Scalar, NP, NP> DenseMatrixType;
+#else
+    typedef std::array<Scalar, NP * NP> DenseMatrixType;   // row-major
+#endif
     std::array<Scalar, NP*(NP + 1) / 2> coeff_{};
     const std::array<Scalar, NP*(NP + 1) / 2>& coeff() const { return coeff_; }
     Scalar operator()(int r, int c) const {
       if (r > c) std::swap(r, c);
       return coeff_[(std::size_t)r * NP - (std::size_t)r * (r - 1) / 2 + (c - r)];
     }
-    // row-major dense NP x NP (Eigen users: Eigen::Map<Eigen::Matrix<float,NP,NP,Eigen::RowMajor>>(v.data()))
-    std::array<Scalar, NP * NP> toDenseMatrix() const {
-      std::array<Scalar, NP * NP> M{};
+    DenseMatrixType toDenseMatrix() const {
+      DenseMatrixType M;
+#ifdef DFX_SHIM_HAS_EIGEN
+      for (int r = 0; r < NP; ++r) for (int c = 0; c < NP; ++c) M(r, c) = (*this)(r, c);
+#else
       for (int r = 0; r < NP; ++r) for (int c = 0; c < NP; ++c) M[(std::size_t)r * NP + c] = (*this)(r, c);
+#endif
       return M;
     }
   };
   HessianType JtJ;
-  std::array<Scalar, NP> Jtr{};
+  JacobianType Jtr{};
   Scalar residual = 0;
   std::size_t inliers = 0;
 
   static JTJJrReductionItem FromRaw(const void* raw) {
     JTJJrReductionItem it;
     std::memcpy(it.JtJ.coeff_.data(), dfx_item_jtj(raw), sizeof(Scalar) * it.JtJ.coeff_.size());
-    std::memcpy(it.Jtr.data(), dfx_item_jtr(raw, NP), sizeof(Scalar) * NP);
+    const float* g = dfx_item_jtr(raw, NP);
+#ifdef DFX_SHIM_HAS_EIGEN
+    for (int i = 0; i < NP; ++i) it.Jtr(i) = g[i];
+#else
+    for (int i = 0; i < NP; ++i) it.Jtr[i] = g[i];
+#endif
     it.residual = dfx_item_residual(raw, NP);
     it.inliers = (std::size_t)dfx_item_inliers(raw, NP);
     return it;
@@ -187,9 +228,11 @@ class SfmAligner {
   virtual ~SfmAligner() {}
 
   // cu_sfmaligner.cpp:120-147
-  template <typename SE3, typename Cam, typename ImageBuffer, typename GradBuffer>
-  ErrorReductionItem EvaluateError(const SE3& pose0, const SE3& pose1, const Cam& cam, const ImageBuffer& img0,
-                                   const ImageBuffer& img1, const ImageBuffer& dpt0, const ImageBuffer& std0,
+  // Every image argument is its own deduced type: the reference's callers mix vc::Image2DView values, references and
+  // Image2DManaged buffers (which convert to views there) in one call.
+  template <typename SE3, typename Cam, typename Img0, typename Img1, typename Dpt0, typename Std0, typename GradBuffer>
+  ErrorReductionItem EvaluateError(const SE3& pose0, const SE3& pose1, const Cam& cam, const Img0& img0,
+                                   const Img1& img1, const Dpt0& dpt0, const Std0& std0,
                                    const GradBuffer& grad1) {
     const dfx_se3 p0 = dfx::detail::to_se3(pose0), p1 = dfx::detail::to_se3(pose1);
     const dfx_cam c = dfx::detail::to_cam(cam);
@@ -202,10 +245,11 @@ class SfmAligner {
   }
 
   // cu_sfmaligner.cpp:149-185.  code0 is unused by the kernel (depth is already decoded), as in the reference.
-  template <typename SE3, typename CodeT, typename Cam, typename ImageBuffer, typename GradBuffer>
-  ReductionItem RunStep(const SE3& pose0, const SE3& pose1, const CodeT& /*code0*/, const Cam& cam, const ImageBuffer& img0,
-                        const ImageBuffer& img1, const ImageBuffer& dpt0, const ImageBuffer& std0, ImageBuffer& valid0,
-                        const ImageBuffer& prx0_jac, const GradBuffer& grad1) {
+  template <typename SE3, typename CodeT, typename Cam, typename Img0, typename Img1, typename Dpt0, typename Std0, typename Vld0, typename Jac0,
+            typename GradBuffer>
+  ReductionItem RunStep(const SE3& pose0, const SE3& pose1, const CodeT& /*code0*/, const Cam& cam, const Img0& img0,
+                        const Img1& img1, const Dpt0& dpt0, const Std0& std0, Vld0& valid0,
+                        const Jac0& prx0_jac, const GradBuffer& grad1) {
     const dfx_se3 p0 = dfx::detail::to_se3(pose0), p1 = dfx::detail::to_se3(pose1);
     const dfx_cam c = dfx::detail::to_cam(cam);
     const dfx_sfm_params prm = c_params();
@@ -220,9 +264,9 @@ class SfmAligner {
 
   // ---- batched extension (no reference counterpart): one launch over n pairs of one pyramid level.
   // MakePair packs the RunStep argument list into the C POD; RunStepBatch returns the n items in order.
-  template <typename SE3, typename Cam, typename ImageBuffer, typename GradBuffer>
-  static dfx_sfm_pair MakePair(const SE3& pose0, const SE3& pose1, const Cam& cam, const ImageBuffer& img0, const ImageBuffer& img1,
-                               const ImageBuffer& dpt0, const ImageBuffer& valid0, const ImageBuffer& prx0_jac, const GradBuffer& grad1) {
+  template <typename SE3, typename Cam, typename Img0, typename Img1, typename Dpt0, typename Vld0, typename Jac0, typename GradBuffer>
+  static dfx_sfm_pair MakePair(const SE3& pose0, const SE3& pose1, const Cam& cam, const Img0& img0, const Img1& img1,
+                               const Dpt0& dpt0, const Vld0& valid0, const Jac0& prx0_jac, const GradBuffer& grad1) {
     dfx_sfm_pair p;
     p.pose0 = dfx::detail::to_se3(pose0); p.pose1 = dfx::detail::to_se3(pose1);
     p.cam = dfx::detail::to_cam(cam);
@@ -248,13 +292,14 @@ class SfmAligner {
   }
   void SetStepThreadsBlocks(int threads, int blocks) {
     if (threads % 64) throw dfx::Error(DFX_E_INVALID, "threads must be a multiple of 64 (CDNA wavefront)");
-    params_.step_threads = threads; params_.step_blocks = blocks;
-    dfx::check(dfx_sfm_set_step_blocks(ctx_->get(), blocks));
+    if (blocks < 0 || blocks > 65535) throw dfx::Error(DFX_E_INVALID, "blocks out of range [0, 65535]");
+    params_.step_threads = threads; params_.step_blocks = blocks;   // travels with every call of THIS aligner (dfx_sfm_params.step_blocks)
   }
 
  private:
   dfx_sfm_params c_params() const {
-    return dfx_sfm_params{ params_.sfmparams.huber_delta, params_.sfmparams.avg_dpt, params_.sfmparams.min_dpt, params_.sfmparams.valid_border };
+    return dfx_sfm_params{ params_.sfmparams.huber_delta, params_.sfmparams.avg_dpt, params_.sfmparams.min_dpt, params_.sfmparams.valid_border,
+                           params_.step_blocks };
   }
   SfmAlignerParams params_;
   std::shared_ptr<dfx::Context> ctx_;
@@ -271,9 +316,9 @@ class SE3Aligner {
   virtual ~SE3Aligner() {}
 
   // cu_se3aligner.cpp:125-151: renders img1 into frame 0 (img2)
-  template <typename SE3, typename Cam, typename ImageBuffer>
-  CorrespondenceItem Warp(const SE3& se3, const Cam& cam, const ImageBuffer& img0, const ImageBuffer& img1, const ImageBuffer& dpt0,
-                          ImageBuffer& img2) {
+  template <typename SE3, typename Cam, typename Img0, typename Img1, typename Dpt0, typename Img2>
+  CorrespondenceItem Warp(const SE3& se3, const Cam& cam, const Img0& img0, const Img1& img1, const Dpt0& dpt0,
+                          Img2& img2) {
     const dfx_se3 p = dfx::detail::to_se3(se3);
     const dfx_cam c = dfx::detail::to_cam(cam);
     const dfx_img i0 = dfx::detail::to_img(img0), i1 = dfx::detail::to_img(img1), d0 = dfx::detail::to_img(dpt0), i2 = dfx::detail::to_img(img2);
@@ -283,8 +328,8 @@ class SE3Aligner {
   }
 
   // cu_se3aligner.cpp:153-176
-  template <typename SE3, typename Cam, typename ImageBuffer, typename GradBuffer>
-  ReductionItem RunStep(const SE3& se3, const Cam& cam, const ImageBuffer& img0, const ImageBuffer& img1, const ImageBuffer& dpt0,
+  template <typename SE3, typename Cam, typename Img0, typename Img1, typename Dpt0, typename GradBuffer>
+  ReductionItem RunStep(const SE3& se3, const Cam& cam, const Img0& img0, const Img1& img1, const Dpt0& dpt0,
                         const GradBuffer& grad1) {
     const dfx_se3 p = dfx::detail::to_se3(se3);
     const dfx_cam c = dfx::detail::to_cam(cam);
@@ -308,8 +353,8 @@ class DepthAligner {
   explicit DepthAligner(std::shared_ptr<dfx::Context> ctx = dfx::Context::Default()) : ctx_(std::move(ctx)) {}
 
   // cu_depthaligner.cpp:78-110 (avg_dpt hard-coded to 2 there)
-  template <typename CodeT, typename ImageBuffer>
-  ReductionItem RunStep(const CodeT& code, const ImageBuffer& target_dpt, const ImageBuffer& prx_orig, const ImageBuffer& prx_jac) {
+  template <typename CodeT, typename Tgt, typename Prx, typename Jac>
+  ReductionItem RunStep(const CodeT& code, const Tgt& target_dpt, const Prx& prx_orig, const Jac& prx_jac) {
     const dfx_img tg = dfx::detail::to_img(target_dpt), po = dfx::detail::to_img(prx_orig), jc = dfx::detail::to_img(prx_jac);
     if (jc.w / tg.w != (uint32_t)CS) throw dfx::Error(DFX_E_INVALID, "DepthAligner used with a different code size than it was compiled for");
     float cd[CS];
@@ -324,28 +369,31 @@ class DepthAligner {
 };
 
 // ---- cu_image_proc.h:27-46 -------------------------------------------------------------------------------------------
-template <typename T, int CS, typename ImageBuf, typename CodeT>
-void UpdateDepth(const CodeT& code, const ImageBuf& prx_orig, const ImageBuf& prx_jac, T avg_dpt, ImageBuf& dpt_out) {
+// The reference's signatures, plus an optional trailing context (default: the thread's default context, i.e. the current
+// device -- dfx::Context::SetDefault to use another device or stream).
+template <typename T, int CS, typename ImageBuf, typename CodeT, typename PrxBuf, typename JacBuf>
+void UpdateDepth(const CodeT& code, const PrxBuf& prx_orig, const JacBuf& prx_jac, T avg_dpt, ImageBuf& dpt_out,
+                 const std::shared_ptr<dfx::Context>& ctx = dfx::Context::Default()) {
   float cd[CS];
   for (int i = 0; i < CS; ++i) cd[i] = (float)code[i];
   const dfx_img po = dfx::detail::to_img(prx_orig), jc = dfx::detail::to_img(prx_jac), out = dfx::detail::to_img(dpt_out);
-  dfx::check(dfx_update_depth(dfx::Context::Default()->get(), CS, cd, &po, &jc, (float)avg_dpt, &out));
+  dfx::check(dfx_update_depth(ctx->get(), CS, cd, &po, &jc, (float)avg_dpt, &out));
 }
 template <typename ImgBuf, typename GradBuf>
-void SobelGradients(const ImgBuf& img, GradBuf& grad) {
+void SobelGradients(const ImgBuf& img, GradBuf& grad, const std::shared_ptr<dfx::Context>& ctx = dfx::Context::Default()) {
   const dfx_img i = dfx::detail::to_img(img), g = dfx::detail::to_img(grad);
-  dfx::check(dfx_sobel_gradients(dfx::Context::Default()->get(), &i, &g));
+  dfx::check(dfx_sobel_gradients(ctx->get(), &i, &g));
 }
-template <typename ImgBuf>
-void GaussianBlurDown(const ImgBuf& in, ImgBuf& out) {
+template <typename InBuf, typename OutBuf>
+void GaussianBlurDown(const InBuf& in, OutBuf& out, const std::shared_ptr<dfx::Context>& ctx = dfx::Context::Default()) {
   const dfx_img i = dfx::detail::to_img(in), o = dfx::detail::to_img(out);
-  dfx::check(dfx_gaussian_blur_down(dfx::Context::Default()->get(), &i, &o));
+  dfx::check(dfx_gaussian_blur_down(ctx->get(), &i, &o));
 }
-template <typename ImgBuf>
-float SquaredError(const ImgBuf& buf1, const ImgBuf& buf2) {
+template <typename Buf1, typename Buf2>
+float SquaredError(const Buf1& buf1, const Buf2& buf2, const std::shared_ptr<dfx::Context>& ctx = dfx::Context::Default()) {
   const dfx_img a = dfx::detail::to_img(buf1), b = dfx::detail::to_img(buf2);
   float out = 0;
-  dfx::check(dfx_squared_error(dfx::Context::Default()->get(), &a, &b, &out));
+  dfx::check(dfx_squared_error(ctx->get(), &a, &b, &out));
   return out;
 }
 

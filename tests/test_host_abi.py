@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     from deepfactors_amd import _lib
     assert C.sizeof(_lib.Img) == 24 and C.sizeof(_lib.SE3) == 28 and C.sizeof(_lib.Cam) == 24
-    assert C.sizeof(_lib.SfmParams) == 16 and C.sizeof(_lib.CorrItem) == 16
+    assert C.sizeof(_lib.SfmParams) == 20 and _lib.SfmParams.step_blocks.offset == 16 and C.sizeof(_lib.CorrItem) == 16
     assert _lib.CorrItem.inliers.offset == 8
     # JTJJrReductionItem<float,NP> sizes quoted in SURVEY.md (reduction_items.h:139-142): 120 B (NP=6), 4152 B (NP=44)
     assert _lib.item_size(6) == 120 and _lib.item_size(44) == 4152 and _lib.item_inliers_offset(44) == 4144
