@@ -112,6 +112,11 @@ _PROTOS = {
     "dfx_graph_assemble_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dfx_update_depth": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(Img), C.POINTER(Img), C.c_float,
                                    C.POINTER(Img)]),
+    "dfx_update_depth_batch_async": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(Img), C.POINTER(Img), C.c_float, C.POINTER(Img)]),
+    "dfx_sfm_linearize_batch_async": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SfmParams), C.POINTER(SfmPair), C.POINTER(Img), C.POINTER(C.c_float), C.c_int,
+                                                C.c_void_p]),
+    "dfx_sfm_linearize_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SfmParams), C.POINTER(SfmPair), C.POINTER(Img), C.POINTER(C.c_float), C.c_int,
+                                          C.c_void_p]),
     "dfx_sobel_gradients": (C.c_int, [C.c_void_p, C.POINTER(Img), C.POINTER(Img)]),
     "dfx_gaussian_blur_down": (C.c_int, [C.c_void_p, C.POINTER(Img), C.POINTER(Img)]),
     "dfx_squared_error": (C.c_int, [C.c_void_p, C.POINTER(Img), C.POINTER(Img), C.POINTER(C.c_float)]),

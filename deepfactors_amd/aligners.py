@@ -289,6 +289,25 @@ class SfmAligner:
         self.RunStepBatchAsync(pair_array, out_items_dev)
         neq.assemble_native(self.ctx, out_items_dev, int(first_pair), len(pair_array))
 
+    def LinearizeBatch(self, pair_array, prx0_orig, codes0, out_items_dev=None):
+        """PhotometricFactor::RunAlignmentStep over a batch (photometric_factor.cpp:225-293): UpdateDepthMaps once per distinct keyframe
+        depth map of the batch, then ONE batched RunStep (dfx_sfm_linearize_batch[_async]).  `prx0_orig`: one tensor per pair,
+        `codes0`: [n][CS] array.  With `out_items_dev` (uint8 CUDA tensor) it only enqueues; otherwise it returns the items."""
+        n = len(pair_array)
+        codes = np.ascontiguousarray(np.asarray(codes0, np.float32).reshape(n, self.CS))
+        imgs = (Img * n)(*[_img(t, "prx0_orig") for t in prx0_orig])
+        self.ctx.check_device(*prx0_orig)
+        p = self._p()
+        cp = codes.ctypes.data_as(C.POINTER(C.c_float))
+        if out_items_dev is not None:
+            check(_lib.lib().dfx_sfm_linearize_batch_async(self.ctx.handle, self.CS, C.byref(p), pair_array, imgs, cp, n, C.c_void_p(out_items_dev.data_ptr())))
+            return None
+        np_ = 12 + self.CS
+        isz = item_size(np_)
+        raw = np.zeros(n * isz, np.uint8)
+        check(_lib.lib().dfx_sfm_linearize_batch(self.ctx.handle, self.CS, C.byref(p), pair_array, imgs, cp, n, raw.ctypes.data_as(C.c_void_p)))
+        return [JTJJrReductionItem(np_, raw[k * isz:(k + 1) * isz]) for k in range(n)]
+
     def RunStepBatch(self, pair_array):
         n = len(pair_array)
         np_ = 12 + self.CS
@@ -369,6 +388,19 @@ def UpdateDepth(code, prx_orig, prx_jac, avg_dpt, dpt_out, ctx=None):
         raise DfxError(_lib.DFX_E_INVALID, f"prx_jac row length {jc.w} != W*CS = {po.w}*{len(cd)}")
     check(_lib.lib().dfx_update_depth(ctx.handle, len(cd), cd.ctypes.data_as(C.POINTER(C.c_float)), C.byref(po), C.byref(jc),
                                       float(avg_dpt), C.byref(do)))
+
+
+def UpdateDepthBatch(codes, prx_origs, prx_jacs, avg_dpt, dpt_outs, ctx=None):
+    """n ``df::UpdateDepth`` of one image size in one launch (dfx_update_depth_batch_async; Mapper::UpdateMap, mapper.cpp:860-888).
+    Enqueues only."""
+    ctx = _ctx_for(ctx, *prx_origs, *prx_jacs, *dpt_outs)
+    n = len(prx_origs)
+    cd = np.ascontiguousarray(np.asarray(codes, np.float32).reshape(n, -1))
+    cs = cd.shape[1]
+    po = (Img * n)(*[_img(t, "prx_orig") for t in prx_origs])
+    jc = (Img * n)(*[_img(t, "prx_jac") for t in prx_jacs])
+    do = (Img * n)(*[_img(t, "dpt_out") for t in dpt_outs])
+    check(_lib.lib().dfx_update_depth_batch_async(ctx.handle, cs, n, cd.ctypes.data_as(C.POINTER(C.c_float)), po, jc, float(avg_dpt), do))
 
 
 def SobelGradients(img, grad, ctx=None):

@@ -57,6 +57,8 @@ struct dfx_ctx {
   float* code_dev = nullptr;   // 64 floats per stage slot
   float* depth_scratch = nullptr;
   size_t depth_scratch_bytes = 0;
+  dfx::DepthJobDev* jobs_dev = nullptr;   // batched UpdateDepth descriptors, one region per stage slot
+  size_t jobs_cap = 0;
 
   // pinned host staging ring (descriptors / codes going up) and a result area coming down
   char* stage_host = nullptr;
@@ -385,6 +387,7 @@ DFX_API void dfx_ctx_destroy(dfx_ctx* c) {
   if (c->pairs_dev) (void)hipFree(c->pairs_dev);
   if (c->code_dev) (void)hipFree(c->code_dev);
   if (c->depth_scratch) (void)hipFree(c->depth_scratch);
+  if (c->jobs_dev) (void)hipFree(c->jobs_dev);
   if (c->track_state_dev) (void)hipFree(c->track_state_dev);
   if (c->sg_dev) (void)hipFree(c->sg_dev);
   for (auto& t : c->ray_tabs) (void)hipFree(t.dev);
@@ -874,6 +877,123 @@ DFX_API int dfx_update_depth(dfx_ctx* c, int cs, const float* code, const dfx_im
   DFX_HIP(hipStreamSynchronize(c->stream));
   return DFX_OK;
 }
+
+// ---- batched decoder + the reference's real hot entry -----------------------------------------------------------------------
+namespace {
+// jobs: host-side list of decode jobs of one image size; uploads the descriptors through the staging ring and enqueues ONE launch
+int update_depth_jobs(dfx_ctx* c, int cs, const std::vector<dfx::DepthJobDev>& jobs, float avg_dpt, uint32_t W, uint32_t H) {
+  const int n = (int)jobs.size();
+  if (n == 0) return DFX_OK;
+  int rc, slot;
+  char* host;
+  const size_t bytes = sizeof(dfx::DepthJobDev) * (size_t)n;
+  if ((rc = stage_acquire(c, bytes, &slot, &host))) return rc;
+  std::memcpy(host, jobs.data(), bytes);
+  if (c->jobs_cap < (size_t)n) {
+    DFX_HIP(hipStreamSynchronize(c->stream));
+    if (c->jobs_dev) DFX_HIP(hipFree(c->jobs_dev));
+    c->jobs_dev = nullptr;
+    const size_t cap = (size_t)n * 2;
+    DFX_HIP(hipMalloc((void**)&c->jobs_dev, sizeof(dfx::DepthJobDev) * cap * kStageSlots));
+    c->jobs_cap = cap;
+  }
+  dfx::DepthJobDev* dd = c->jobs_dev + (size_t)slot * c->jobs_cap;
+  DFX_HIP(hipMemcpyAsync(dd, host, bytes, hipMemcpyHostToDevice, c->stream));
+  if ((rc = stage_release(c, slot))) return rc;
+  DFX_HIP(dfx::launch_update_depth_batch(cs, dd, n, avg_dpt, (int)W, (int)H, c->stream));
+  return DFX_OK;
+}
+
+int fill_depth_job(int cs, const float* code, const dfx_img* prx_orig, const dfx_img* prx_jac, const dfx_img* dpt_out, uint32_t W, uint32_t H,
+                   dfx::DepthJobDev* j) {
+  int rc;
+  if (!code) return fail(DFX_E_INVALID, "null code");
+  if ((rc = check_img(prx_orig, "prx_orig", W, H, 4))) return rc;
+  if ((rc = check_img(dpt_out, "dpt_out", W, H, 4))) return rc;
+  if ((rc = check_img(prx_jac, "prx_jac", W * (uint32_t)cs, H, 4))) return rc;
+  if (((uintptr_t)prx_jac->ptr | prx_jac->pitch_bytes) & 15) return fail(DFX_E_INVALID, "prx_jac: pointer/pitch must be 16-byte aligned");
+  std::memset(j->code, 0, sizeof(j->code));
+  std::memcpy(j->code, code, sizeof(float) * (size_t)cs);
+  j->prx = (const float*)prx_orig->ptr; j->jac = (const float*)prx_jac->ptr; j->out = (float*)dpt_out->ptr;
+  j->pitch_prx = (uint32_t)prx_orig->pitch_bytes; j->pitch_jac = (uint32_t)prx_jac->pitch_bytes; j->pitch_out = (uint32_t)dpt_out->pitch_bytes;
+  j->_pad = 0;
+  return DFX_OK;
+}
+}  // namespace
+
+DFX_API int dfx_update_depth_batch_async(dfx_ctx* c, int cs, int n, const float* codes, const dfx_img* prx_orig, const dfx_img* prx_jac, float avg_dpt,
+                                         const dfx_img* dpt_out) {
+  if (!c || !codes || !prx_orig || !prx_jac || !dpt_out) return fail(DFX_E_INVALID, "dfx_update_depth_batch: null argument");
+  if (!cs_supported(cs)) return fail(DFX_E_INVALID, "unsupported code size %d (16, 32, 64)", cs);
+  if (n <= 0 || n > 65535) return fail(DFX_E_INVALID, "batch size %d out of range [1,65535]", n);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  if (!img_ok(&prx_orig[0])) return fail(DFX_E_INVALID, "job 0: prx_orig null or empty");
+  const uint32_t W = prx_orig[0].w, H = prx_orig[0].h;
+  std::vector<dfx::DepthJobDev> jobs((size_t)n);
+  for (int k = 0; k < n; ++k)
+    if ((rc = fill_depth_job(cs, codes + (size_t)k * cs, &prx_orig[k], &prx_jac[k], &dpt_out[k], W, H, &jobs[k]))) {
+      g_last_error = "job " + std::to_string(k) + ": " + g_last_error;
+      return rc;
+    }
+  return update_depth_jobs(c, cs, jobs, avg_dpt, W, H);
+}
+
+DFX_API int dfx_sfm_linearize_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, const dfx_img* prx0_orig,
+                                          const float* codes0, int n, void* out_items_dev) {
+  if (!c || !params || !pairs || !prx0_orig || !codes0 || !out_items_dev) return fail(DFX_E_INVALID, "dfx_sfm_linearize_batch: null argument");
+  if (!cs_supported(cs)) return fail(DFX_E_INVALID, "unsupported code size %d (16, 32, 64)", cs);
+  if (n <= 0 || n > 65535) return fail(DFX_E_INVALID, "batch size %d out of range [1,65535]", n);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  if (!img_ok(&pairs[0].img0)) return fail(DFX_E_INVALID, "pair 0: img0 null or empty");
+  const uint32_t W = pairs[0].img0.w, H = pairs[0].img0.h;
+  // UpdateDepthMaps once per DISTINCT keyframe depth map of the batch (the reference decodes it again for every factor that
+  // shares the keyframe, photometric_factor.cpp:229,332-341): pairs that share dpt0 must agree on code, prx_orig and prx_jac.
+  std::vector<dfx::DepthJobDev> jobs;
+  std::vector<const void*> seen;
+  std::vector<int> first;
+  for (int p = 0; p < n; ++p) {
+    const void* key = pairs[p].dpt0.ptr;
+    size_t k = 0;
+    while (k < seen.size() && seen[k] != key) ++k;
+    if (k == seen.size()) {
+      dfx::DepthJobDev j;
+      if ((rc = fill_depth_job(cs, codes0 + (size_t)p * cs, &prx0_orig[p], &pairs[p].prx0_jac, &pairs[p].dpt0, W, H, &j))) {
+        g_last_error = "pair " + std::to_string(p) + ": " + g_last_error;
+        return rc;
+      }
+      seen.push_back(key); first.push_back(p); jobs.push_back(j);
+    } else {
+      const int q = first[k];
+      if (std::memcmp(codes0 + (size_t)p * cs, codes0 + (size_t)q * cs, sizeof(float) * (size_t)cs) != 0 || prx0_orig[p].ptr != prx0_orig[q].ptr ||
+          pairs[p].prx0_jac.ptr != pairs[q].prx0_jac.ptr)
+        return fail(DFX_E_INVALID, "pairs %d and %d write the same depth map from different codes / decoder images", q, p);
+    }
+  }
+  if ((rc = update_depth_jobs(c, cs, jobs, params->avg_dpt, W, H))) return rc;
+  return dfx_sfm_step_batch_async(c, cs, params, pairs, n, out_items_dev);
+}
+
+DFX_API int dfx_sfm_linearize_batch(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, const dfx_img* prx0_orig,
+                                    const float* codes0, int n, void* out_items_host) {
+  if (!c || !out_items_host) return fail(DFX_E_INVALID, "dfx_sfm_linearize_batch: null argument");
+  if (n <= 0) return fail(DFX_E_INVALID, "batch size %d", n);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  const size_t bytes = dfx_item_size(12 + cs) * (size_t)n;
+  if (bytes <= kDirectResultMax) {
+    void* tgt;
+    if ((rc = result_target(c, bytes, &tgt))) return rc;
+    if ((rc = dfx_sfm_linearize_batch_async(c, cs, params, pairs, prx0_orig, codes0, n, tgt))) return rc;
+    return finish_result(c, out_items_host, bytes);
+  }
+  if (c->items_bytes < bytes) DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, bytes, c->stream))) return rc;
+  if ((rc = dfx_sfm_linearize_batch_async(c, cs, params, pairs, prx0_orig, codes0, n, c->items_dev))) return rc;
+  return fetch_result(c, c->items_dev, out_items_host, bytes);
+}
+
 
 DFX_API int dfx_sobel_gradients(dfx_ctx* c, const dfx_img* img, const dfx_img* grad_out) {
   if (!c) return fail(DFX_E_INVALID, "null context");

@@ -36,6 +36,14 @@ struct GraphDev {
   const int* fr_pairs;
 };
 
+struct DepthJobDev {   // one UpdateDepth of a batch (k_update_depth_batch): dpt = a / (prx + jac . code) - a
+  float code[64];
+  const float* prx;
+  const float* jac;
+  float* out;
+  uint32_t pitch_prx, pitch_jac, pitch_out, _pad;
+};
+
 struct SimplePairDev {   // SE3Aligner / EvaluateError / Warp
   float R[9], t[3];
   float fx, fy, u0, v0, w, h;
@@ -71,6 +79,7 @@ hipError_t launch_se3_warp(const SimplePairDev& p, int W, int H, int blocks, flo
 hipError_t launch_update_depth(int cs, const float* code_dev, const float* prx_orig, uint32_t pitch_prx, const float* jac,
                                uint32_t pitch_jac, float avg_dpt, float* dpt_out, uint32_t pitch_out, int W, int H,
                                hipStream_t stream);
+hipError_t launch_update_depth_batch(int cs, const DepthJobDev* jobs_dev, int njobs, float avg_dpt, int W, int H, hipStream_t stream);
 hipError_t launch_sobel(const float* img, uint32_t pitch, float* grad, uint32_t gpitch, int W, int H, hipStream_t stream);
 hipError_t launch_blur_down(const float* in, uint32_t pitch, int W, int H, float* out, uint32_t opitch, int OW, int OH,
                             hipStream_t stream);

@@ -394,10 +394,10 @@ __global__ __launch_bounds__(1024) void k_finalize_rows(const float* __restrict_
 // LPP = CS/4 lanes share one pixel (float4 each -> every wave-load is 1 KiB contiguous); 64 pixels per wave step so
 // that the prx read and the depth write are single coalesced 256-byte accesses.
 template <int CS>
-__global__ __launch_bounds__(kT) void k_update_depth(const float* __restrict__ code, const float* __restrict__ prx,
-                                                     const uint32_t pitch_prx, const float* __restrict__ jac,
-                                                     const uint32_t pitch_jac, const float avg_dpt, float* __restrict__ out,
-                                                     const uint32_t pitch_out, const int W, const int H) {
+__device__ __forceinline__ void update_depth_body(const float* __restrict__ code, const float* __restrict__ prx,
+                                                  const uint32_t pitch_prx, const float* __restrict__ jac,
+                                                  const uint32_t pitch_jac, const float avg_dpt, float* __restrict__ out,
+                                                  const uint32_t pitch_out, const int W, const int H) {
   constexpr int LPP = CS / 4;        // lanes per pixel
   constexpr int PPL = 64 / LPP;      // pixels per wave-load
   constexpr int NSUB = 64 / PPL;     // wave-loads per 64-pixel chunk (== LPP)
@@ -437,6 +437,22 @@ __global__ __launch_bounds__(kT) void k_update_depth(const float* __restrict__ c
       reinterpret_cast<float*>((char*)out + (size_t)y * pitch_out)[x] = avg_dpt / pr - avg_dpt;
     }
   }
+}
+
+template <int CS>
+__global__ __launch_bounds__(kT) void k_update_depth(const float* __restrict__ code, const float* __restrict__ prx,
+                                                     const uint32_t pitch_prx, const float* __restrict__ jac,
+                                                     const uint32_t pitch_jac, const float avg_dpt, float* __restrict__ out,
+                                                     const uint32_t pitch_out, const int W, const int H) {
+  update_depth_body<CS>(code, prx, pitch_prx, jac, pitch_jac, avg_dpt, out, pitch_out, W, H);
+}
+
+// n decode jobs of one image size in ONE launch (grid.y = job): Mapper::UpdateMap re-decodes every changed keyframe per level
+// (core/mapping/mapper.cpp:860-888), dfx_sfm_linearize_batch decodes every distinct keyframe of a batch of pairs.
+template <int CS>
+__global__ __launch_bounds__(kT) void k_update_depth_batch(const DepthJobDev* __restrict__ jobs, const float avg_dpt, const int W, const int H) {
+  const DepthJobDev& j = jobs[blockIdx.y];
+  update_depth_body<CS>(j.code, j.prx, j.pitch_prx, j.jac, j.pitch_jac, avg_dpt, j.out, j.pitch_out, W, H);
 }
 
 // ---- Sobel / 8 with clamped borders (cu_image_proc.cpp:57-92) ---------------------------------------------------
@@ -537,6 +553,22 @@ hipError_t launch_update_depth(int cs, const float* code_dev, const float* prx_o
     case 16: hipLaunchKernelGGL(k_update_depth<16>, dim3(blocks), dim3(kT), 0, stream, code_dev, prx_orig, pitch_prx, jac, pitch_jac, avg_dpt, dpt_out, pitch_out, W, H); break;
     case 32: hipLaunchKernelGGL(k_update_depth<32>, dim3(blocks), dim3(kT), 0, stream, code_dev, prx_orig, pitch_prx, jac, pitch_jac, avg_dpt, dpt_out, pitch_out, W, H); break;
     case 64: hipLaunchKernelGGL(k_update_depth<64>, dim3(blocks), dim3(kT), 0, stream, code_dev, prx_orig, pitch_prx, jac, pitch_jac, avg_dpt, dpt_out, pitch_out, W, H); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_update_depth_batch(int cs, const DepthJobDev* jobs_dev, int njobs, float avg_dpt, int W, int H, hipStream_t stream) {
+  const int nchunks = (W * H + 63) / 64;
+  int blocks = (nchunks + 3) / 4;
+  const int cap = (8192 + njobs - 1) / njobs;   // ~8 workgroups per CU over the whole batch
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  const dim3 grid(blocks, njobs);
+  switch (cs) {
+    case 16: hipLaunchKernelGGL(k_update_depth_batch<16>, grid, dim3(kT), 0, stream, jobs_dev, avg_dpt, W, H); break;
+    case 32: hipLaunchKernelGGL(k_update_depth_batch<32>, grid, dim3(kT), 0, stream, jobs_dev, avg_dpt, W, H); break;
+    case 64: hipLaunchKernelGGL(k_update_depth_batch<64>, grid, dim3(kT), 0, stream, jobs_dev, avg_dpt, W, H); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -128,7 +128,8 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   constexpr int NX = NCB * (NCB - 1) / 2, ND = (NCB + 1) / 2;   // X(b,b'), Dd(q); Pm(b): NCB
   constexpr int NACC = NX + NCB;                                 // 16x16x4 accumulators
   constexpr int ZDIM = (1 + NACC + 2 * ND) * 256;                // block 0: the 29 P x P sums; then X, Pm, (Dd broadcast, Dd plain) per q
-  constexpr int LDS_FLOATS = kWaves * ((kUFloats > ZDIM) ? kUFloats : ZDIM);   // P rows in the loop, accumulators in the epilogue
+  constexpr int SLOT = (kUFloats > ZDIM) ? kUFloats : ZDIM;   // per wave: its P rows in the loop, its accumulators in the epilogue (same place)
+  constexpr int LDS_FLOATS = kWaves * SLOT;
   typedef typename JV<NCB>::T jv_t;
   // "No next chunk" is handled by re-reading the wave's current chunk (L2-hot, results never consumed), NOT by
   // out-of-range offsets: a wave-load whose lanes are all out of range completes without touching memory and may
@@ -175,9 +176,9 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     // the busiest shared resource: 28 vector-memory instructions per chunk), two LDS reads cost nothing measurable.
     const int ntab = W + H + kRayTabSlack;
     for (int e = threadIdx.x; e < ntab; e += kThreads) ray_lds[e] = gload<float>(ray_tab + (unsigned)e * 4u);
-    __syncthreads();
   }
-  float* U = lds + wave * kUFloats;
+  if (MODE == 0 && TABLDS) __syncthreads();
+  float* U = lds + wave * SLOT;
   if (lane < 16) U[(lane >> 1) * kUStride + 64 + (lane & 1)] = 0.f;   // padding columns 64, 65 of P rows 0..7 (read as zeros by the 4x4 tiles)
 
   f32x4 acc[NACC];
@@ -488,9 +489,12 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   // Every wave parks its accumulators in its own LDS region, ONE barrier, then all threads sum and store (the earlier
   // wave-after-wave read-modify-write needed four barriers with three waves idle each time; same sums, same order).
   // C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
-  __syncthreads();   // everybody is done with the P rows
+  // (Tried: no barrier at all -- every wave parks its set in its own slot, draws a ticket from an LDS counter, and the last one to
+  // arrive folds while the others retire at once.  Waves idle ~10 % of their lifetime at this barrier, yet the kernel time did not
+  // move (1059 vs 1058 us at 128 pairs): the kernel is bound by HBM traffic, not by resident waves; 3 instead of 4 workgroups per
+  // CU cost 1.3 %.)
   {
-    float* mine = lds + wave * ZDIM;
+    float* mine = lds + wave * SLOT;
 #pragma unroll
     for (int r = 0; r < 4; ++r) mine[ppb * 16 + r * 4 + ppi] = accpp[r];   // block 0: [4x4 block b][row r][column = lane & 3]
 #pragma unroll
@@ -502,12 +506,12 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 #pragma unroll
       for (int r = 0; r < 4; ++r) mine[(1 + NACC + a) * 256 + ppb * 16 + r * 4 + ppi] = accd[a][r];
   }
-  __syncthreads();
   float* out = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ZDIM;
+  __syncthreads();
   for (int e = threadIdx.x; e < ZDIM; e += kThreads) {
     float v = lds[e];
 #pragma unroll
-    for (int wv = 1; wv < kWaves; ++wv) v += lds[wv * ZDIM + e];
+    for (int wv = 1; wv < kWaves; ++wv) v += lds[wv * SLOT + e];
     out[e] = v;
   }
 #if DFX_TRACE

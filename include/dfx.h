@@ -206,6 +206,17 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* ctx, int cs, const dfx_sfm_params*
 DFX_API int dfx_sfm_step_batch(dfx_ctx* ctx, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
                                void* out_items_host);
 
+/* PhotometricFactor::RunAlignmentStep (core/gtsam/photometric_factor.cpp:225-293) over a batch: UpdateDepthMaps (:332-341: dpt0 =
+ * decode(code0) with the keyframe's prx_orig / prx_jac) followed by SfmAligner::RunStep, for n pairs in two launches and no host
+ * round trip in between.  pairs[p].dpt0 is the keyframe's depth map (written, then read); prx0_orig[p] its zero-code proximity;
+ * codes0[p*cs ..) (HOST) its code; params->avg_dpt the decoder's scale.  Every DISTINCT depth map of the batch is decoded once
+ * -- the reference decodes it again for every factor that shares the keyframe -- so pairs sharing dpt0 must carry the same code
+ * and decoder images (checked).  Why the decode is not folded into the step kernel itself is in DESIGN.md section 3.3. */
+DFX_API int dfx_sfm_linearize_batch_async(dfx_ctx* ctx, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs,
+                                          const dfx_img* prx0_orig, const float* codes0, int n, void* out_items_dev);
+DFX_API int dfx_sfm_linearize_batch(dfx_ctx* ctx, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs,
+                                    const dfx_img* prx0_orig, const float* codes0, int n, void* out_items_host);
+
 /* ---- Gauss-Newton normal equations of a keyframe graph (new: SURVEY section 8e) ---------------------------------------
  * The reference hands each pair's 44x44 system to its own gtsam::HessianFactor keyed by (pose0, pose1, code0)
  * (core/gtsam/photometric_factor.cpp:105-180) and lets iSAM2 add the factors; its graph links arbitrary keyframe -> frame
@@ -232,6 +243,10 @@ DFX_API int dfx_graph_assemble_async(dfx_ctx* ctx, const dfx_graph* graph, const
 /* UpdateDepth (cu_image_proc.cpp:248-277): dpt = a/(prx_orig + prx_jac . code) - a; code is a HOST array of cs floats. */
 DFX_API int dfx_update_depth(dfx_ctx* ctx, int cs, const float* code, const dfx_img* prx_orig, const dfx_img* prx_jac,
                              float avg_dpt, const dfx_img* dpt_out);
+/* n independent UpdateDepth jobs of one image size in ONE launch (new; Mapper::UpdateMap re-decodes every changed keyframe level by
+ * level, core/mapping/mapper.cpp:860-888): job k uses codes[k*cs .. k*cs+cs) (HOST), prx_orig[k], prx_jac[k], dpt_out[k].  Enqueue only. */
+DFX_API int dfx_update_depth_batch_async(dfx_ctx* ctx, int cs, int n, const float* codes, const dfx_img* prx_orig, const dfx_img* prx_jac,
+                                         float avg_dpt, const dfx_img* dpt_out);
 /* SobelGradients (cu_image_proc.cpp:57-112): grad = (gx, gy)/8 with clamped borders. */
 DFX_API int dfx_sobel_gradients(dfx_ctx* ctx, const dfx_img* img, const dfx_img* grad_out);
 /* GaussianBlurDown (cu_image_proc.cpp:134-186): 5x5 binomial + decimate by 2; out is (w/2, h/2). */

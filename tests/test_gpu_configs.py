@@ -169,3 +169,43 @@ def test_regions_out_of_view_are_deterministic_and_match_the_oracle(dfx, oracle)
             assert_item_close(items[1], ref, w, h, what="batched out-of-view pair")
             assert_item_close(items[0], ref_good, w, h, what="batched benign pair")
         assert np.array_equal(raw, base), f"run {r} differs"
+
+
+def test_linearize_batch_is_update_depth_then_step(dfx, oracle):
+    """dfx_sfm_linearize_batch = PhotometricFactor::RunAlignmentStep over a batch (photometric_factor.cpp:225-293): UpdateDepthMaps once
+    per distinct keyframe, then RunStep.  Against the oracle's update_depth o sfm_step, for pairs that share keyframes (decoded
+    once) and pairs that do not; the keyframes' depth maps end up decoded; conflicting codes for one depth map are refused."""
+    from deepfactors_amd import synth
+    w, h, cs, K = 160, 120, 32, 3
+    rng = np.random.default_rng(8)
+    kfs = [_pair_dev(w, h, cs, seed=0x2200 + k) for k in range(K)]
+    codes = [rng.normal(0, 0.3, cs).astype(np.float32) for _ in range(K)]
+    poses = [_rand_pose(rng, synth, 0.01, 0.006) for _ in range(K)]
+    dpt = [torch.full_like(g["img0"], float("nan")) for _, g in kfs]      # stale depth maps: must be overwritten before they are read
+    idx = [(0, 1), (0, 2), (1, 2), (2, 0), (1, 0)]
+    al = dfx.SfmAligner(code_size=cs)
+    arr = al.make_pairs([dict(pose0=poses[i], pose1=poses[j], cam=kfs[i][0]["cam"], img0=kfs[i][1]["img0"], img1=kfs[j][1]["img0"], dpt0=dpt[i],
+                              prx0_jac=kfs[i][1]["prx_jac"], grad1=kfs[j][1]["grad1"]) for i, j in idx])
+    items = al.LinearizeBatch(arr, [kfs[i][1]["prx_orig"] for i, _ in idx], [codes[i] for i, _ in idx])
+    for q, (i, j) in enumerate(idx):
+        ni, nj = kfs[i][0], kfs[j][0]
+        d_ref = oracle.update_depth(codes[i], ni["prx_orig"], ni["prx_jac"], 2.0)
+        assert np.abs(dpt[i].cpu().numpy() - d_ref).max() <= 2e-6 * float(((2.0 + d_ref) ** 2 / 2.0).max())
+        ref = oracle.sfm_step(poses[i], poses[j], ni["cam"], ni["img0"], nj["img0"], dpt[i].cpu().numpy(), ni["prx_jac"], nj["grad1"])
+        assert ref.inliers > 0.5 * w * h
+        assert_item_close(items[q], ref, w, h, what=f"linearize pair {i}->{j}")
+    # async form into device memory gives the same bytes
+    out = torch.zeros(len(idx) * dfx.item_size(12 + cs), dtype=torch.uint8, device="cuda")
+    al.LinearizeBatch(arr, [kfs[i][1]["prx_orig"] for i, _ in idx], [codes[i] for i, _ in idx], out)
+    al.ctx.sync()
+    for a, b in zip(items, al.items_from_bytes(out.cpu().numpy(), cs)):
+        assert np.array_equal(a.raw, b.raw)
+    with pytest.raises(dfx.DfxError):   # two pairs of keyframe 0 with different codes
+        al.LinearizeBatch(arr, [kfs[i][1]["prx_orig"] for i, _ in idx], [codes[i] if q != 1 else codes[1] for q, (i, _) in enumerate(idx)])
+    # batched decoder alone == the single-image operator, bit for bit
+    outs_b = [torch.empty_like(g["img0"]) for _, g in kfs]
+    dfx.UpdateDepthBatch(codes, [g["prx_orig"] for _, g in kfs], [g["prx_jac"] for _, g in kfs], 2.0, outs_b)
+    for k, (_, g) in enumerate(kfs):
+        one = torch.empty_like(g["img0"])
+        dfx.UpdateDepth(codes[k], g["prx_orig"], g["prx_jac"], 2.0, one)
+        assert torch.equal(one, outs_b[k])
