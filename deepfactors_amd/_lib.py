@@ -89,6 +89,11 @@ _PROTOS = {
     "dfx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "dfx_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "dfx_debug_read_partials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dfx_img_alloc": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t, C.POINTER(Img)]),
+    "dfx_img_free": (C.c_int, [C.c_void_p, C.POINTER(Img)]),
+    "dfx_img_upload": (C.c_int, [C.c_void_p, C.POINTER(Img), C.c_void_p, C.c_size_t, C.c_size_t]),
+    "dfx_img_download": (C.c_int, [C.c_void_p, C.POINTER(Img), C.c_void_p, C.c_size_t, C.c_size_t]),
+    "dfx_img_fill_f32": (C.c_int, [C.c_void_p, C.POINTER(Img), C.c_float]),
     "dfx_se3_step": (C.c_int, [C.c_void_p, C.POINTER(SE3), C.POINTER(Cam), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img),
                                C.POINTER(Img), C.c_float, C.c_void_p]),
     "dfx_se3_warp": (C.c_int, [C.c_void_p, C.POINTER(SE3), C.POINTER(Cam), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img),

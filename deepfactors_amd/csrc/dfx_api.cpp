@@ -468,6 +468,66 @@ DFX_API int dfx_profile_read(dfx_ctx* c, int* n_launches, double* total_ms) {
   return DFX_OK;
 }
 
+// ---- library-owned device images -------------------------------------------------------------------------------
+DFX_API int dfx_img_alloc(dfx_ctx* c, uint32_t w, uint32_t h, size_t elem_bytes, dfx_img* out) {
+  if (!c || !out) return fail(DFX_E_INVALID, "dfx_img_alloc: null argument");
+  if (w == 0 || h == 0 || (elem_bytes != 4 && elem_bytes != 8)) return fail(DFX_E_INVALID, "dfx_img_alloc: %ux%u elements of %zu bytes", w, h, elem_bytes);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  const size_t pitch = ((size_t)w * elem_bytes + 15) & ~(size_t)15;
+  if (pitch * (size_t)h >= 0x70000000ull) return fail(DFX_E_INVALID, "image of %zu bytes exceeds the 0x70000000-byte buffer-resource limit", pitch * (size_t)h);
+  void* p = nullptr;
+  DFX_HIP(hipMalloc(&p, pitch * (size_t)h));
+  DFX_HIP(hipMemsetAsync(p, 0, pitch * (size_t)h, c->stream));
+  *out = dfx_img{ p, pitch, w, h };
+  return DFX_OK;
+}
+
+DFX_API int dfx_img_free(dfx_ctx* c, dfx_img* img) {
+  if (!c || !img) return fail(DFX_E_INVALID, "dfx_img_free: null argument");
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  if (img->ptr) {
+    DFX_HIP(hipStreamSynchronize(c->stream));
+    DFX_HIP(hipFree(img->ptr));
+  }
+  *img = dfx_img{ nullptr, 0, 0, 0 };
+  return DFX_OK;
+}
+
+DFX_API int dfx_img_upload(dfx_ctx* c, const dfx_img* dst, const void* host, size_t host_pitch, size_t elem_bytes) {
+  if (!c || !img_ok(dst) || !host) return fail(DFX_E_INVALID, "dfx_img_upload: null argument");
+  const size_t row = (size_t)dst->w * elem_bytes;
+  if (host_pitch < row || dst->pitch_bytes < row) return fail(DFX_E_INVALID, "dfx_img_upload: pitch smaller than a row of %zu bytes", row);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  DFX_HIP(hipMemcpy2DAsync(dst->ptr, dst->pitch_bytes, host, host_pitch, row, dst->h, hipMemcpyHostToDevice, c->stream));
+  DFX_HIP(hipStreamSynchronize(c->stream));
+  return DFX_OK;
+}
+
+DFX_API int dfx_img_download(dfx_ctx* c, const dfx_img* src, void* host, size_t host_pitch, size_t elem_bytes) {
+  if (!c || !img_ok(src) || !host) return fail(DFX_E_INVALID, "dfx_img_download: null argument");
+  const size_t row = (size_t)src->w * elem_bytes;
+  if (host_pitch < row || src->pitch_bytes < row) return fail(DFX_E_INVALID, "dfx_img_download: pitch smaller than a row of %zu bytes", row);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  DFX_HIP(hipMemcpy2DAsync(host, host_pitch, src->ptr, src->pitch_bytes, row, src->h, hipMemcpyDeviceToHost, c->stream));
+  DFX_HIP(hipStreamSynchronize(c->stream));
+  return DFX_OK;
+}
+
+DFX_API int dfx_img_fill_f32(dfx_ctx* c, const dfx_img* dst, float value) {
+  if (!c || !img_ok(dst)) return fail(DFX_E_INVALID, "dfx_img_fill_f32: null argument");
+  if (dst->pitch_bytes & 3) return fail(DFX_E_INVALID, "dfx_img_fill_f32: pitch not a multiple of 4");
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  int bits;
+  std::memcpy(&bits, &value, 4);
+  DFX_HIP(hipMemsetD32Async((hipDeviceptr_t)dst->ptr, bits, dst->pitch_bytes / 4 * (size_t)dst->h, c->stream));   // row padding included
+  return DFX_OK;
+}
+
 // ---- SfmAligner ------------------------------------------------------------------------------------------------
 DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
                                      void* out_items_dev) {

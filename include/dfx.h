@@ -139,6 +139,16 @@ DFX_API int dfx_profile_read(dfx_ctx* ctx, int* n_launches, double* total_ms);
 /* Debug: copies the first `bytes` of the workgroup-partials scratch of the last launch to the host. */
 DFX_API int dfx_debug_read_partials(dfx_ctx* ctx, void* host, size_t bytes);
 
+/* ---- device images owned through the library (what include/dfx_host.hpp's keyframe store is made of; replaces the device side of
+ * cuda/synced_pyramid.h:30-217 / vc::Image2DManaged).  elem_bytes = 4 (float images; prx_jac has w = W*CS) or 8 (gradients).  Rows
+ * are 16-byte aligned and otherwise unpadded, so a Jacobian allocated here takes the dense-stream kernel variant.  upload /
+ * download block like the reference's copyFrom; fill only enqueues. */
+DFX_API int dfx_img_alloc(dfx_ctx* ctx, uint32_t w, uint32_t h, size_t elem_bytes, dfx_img* out);
+DFX_API int dfx_img_free(dfx_ctx* ctx, dfx_img* img);
+DFX_API int dfx_img_upload(dfx_ctx* ctx, const dfx_img* dst, const void* host, size_t host_pitch_bytes, size_t elem_bytes);
+DFX_API int dfx_img_download(dfx_ctx* ctx, const dfx_img* src, void* host, size_t host_pitch_bytes, size_t elem_bytes);
+DFX_API int dfx_img_fill_f32(dfx_ctx* ctx, const dfx_img* dst, float value);
+
 /* ---- SE3Aligner<float> (cuda/cu_se3aligner.h:52-72) ----------------------------------------- */
 /* RunStep (cu_se3aligner.cpp:153-176): out_item = JTJJrReductionItem<float,6> on the HOST (120 bytes). */
 DFX_API int dfx_se3_step(dfx_ctx* ctx, const dfx_se3* pose_10, const dfx_cam* cam, const dfx_img* img0,

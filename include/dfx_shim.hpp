@@ -285,6 +285,10 @@ class SfmAligner {
     return out;
   }
 
+  // for host layers built on the C ABI (include/dfx_host.hpp): this aligner's dfx_sfm_params and its context
+  dfx_sfm_params Params() const { return c_params(); }
+  dfx_ctx* ContextHandle() const { return ctx_->get(); }
+
   // cu_sfmaligner.cpp:187-203 (glog CHECK there, exception here)
   void SetEvalThreadsBlocks(int threads, int blocks) {
     if (threads % 64) throw dfx::Error(DFX_E_INVALID, "threads must be a multiple of 64 (CDNA wavefront)");

@@ -15,3 +15,13 @@ def test_cpp_shim_tracker():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120, stdin=subprocess.DEVNULL)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "shim_test OK" in out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_host_layer():
+    """include/dfx_host.hpp (C++17 keyframe store + LinearizeAll over the C ABI): tests/cpp/host_test.cpp, compiled with plain g++."""
+    exe = os.path.join(ROOT, "tests", "cpp", "host_test")
+    assert os.path.exists(exe), "tests/cpp/host_test not built: run __graft_entry__.build()"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300, stdin=subprocess.DEVNULL)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "host_test OK" in out.stdout
