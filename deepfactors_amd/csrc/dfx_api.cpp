@@ -541,11 +541,18 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
   if ((size_t)W * H >= (1ull << 31)) return fail(DFX_E_INVALID, "image too large");
 
   if ((rc = ray_table_gc(c))) return rc;
-  int slot;
-  char* host;
+  // n == 1 (the reference's call pattern: one pair per blocking call): the descriptor travels in the kernel arguments -- no
+  // staging slot, no host-to-device copy in front of the launch.  n > 1: descriptor array in device memory.
+  dfx::SfmPairDev one;
+  dfx::SfmPairDev* hd = &one;
+  dfx::SfmPairDev* dd = nullptr;
+  int slot = -1;
   const size_t desc_bytes = sizeof(dfx::SfmPairDev) * (size_t)n;
-  if ((rc = stage_acquire(c, desc_bytes, &slot, &host))) return rc;
-  dfx::SfmPairDev* hd = reinterpret_cast<dfx::SfmPairDev*>(host);
+  if (n > 1) {
+    char* host;
+    if ((rc = stage_acquire(c, desc_bytes, &slot, &host))) return rc;
+    hd = reinterpret_cast<dfx::SfmPairDev*>(host);
+  }
   for (int p = 0; p < n; ++p) {
     const dfx_sfm_pair& q = pairs[p];
     if ((rc = fill_sfm_pair(c, cs, &q.pose0, &q.pose1, &q.cam, &q.img0, &q.img1, &q.dpt0, &q.valid0, &q.prx0_jac, &q.grad1, W, H, &hd[p]))) {
@@ -553,18 +560,20 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
       return rc;
     }
   }
-  // device descriptor array: one region per stage slot so that in-flight launches keep their own copy
-  if (c->pairs_cap < (size_t)n) {
-    DFX_HIP(hipStreamSynchronize(c->stream));
-    if (c->pairs_dev) DFX_HIP(hipFree(c->pairs_dev));
-    c->pairs_dev = nullptr;
-    const size_t cap = (size_t)n * 2;
-    DFX_HIP(hipMalloc((void**)&c->pairs_dev, sizeof(dfx::SfmPairDev) * cap * kStageSlots));
-    c->pairs_cap = cap;
+  if (n > 1) {
+    // device descriptor array: one region per stage slot so that in-flight launches keep their own copy
+    if (c->pairs_cap < (size_t)n) {
+      DFX_HIP(hipStreamSynchronize(c->stream));
+      if (c->pairs_dev) DFX_HIP(hipFree(c->pairs_dev));
+      c->pairs_dev = nullptr;
+      const size_t cap = (size_t)n * 2;
+      DFX_HIP(hipMalloc((void**)&c->pairs_dev, sizeof(dfx::SfmPairDev) * cap * kStageSlots));
+      c->pairs_cap = cap;
+    }
+    dd = c->pairs_dev + (size_t)slot * c->pairs_cap;
+    DFX_HIP(hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, c->stream));
+    if ((rc = stage_release(c, slot))) return rc;
   }
-  dfx::SfmPairDev* dd = c->pairs_dev + (size_t)slot * c->pairs_cap;
-  DFX_HIP(hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, c->stream));
-  if ((rc = stage_release(c, slot))) return rc;
 
   if (params->step_blocks < 0 || params->step_blocks > 65535) return fail(DFX_E_INVALID, "step_blocks %d out of range [0,65535]", params->step_blocks);
   const int bpp = auto_step_blocks(c, W, H, n, cs, params->step_blocks);
@@ -589,7 +598,7 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
   bool jac_dense = true;
   for (int p = 0; p < n; ++p) jac_dense = jac_dense && (hd[p].pitch_jac == W * (uint32_t)cs * 4u);
   DFX_HIP(dfx::launch_sfm_step(cs, dd, n, (int)W, (int)H, prm, bpp, c->partials, out_items_dev, dfx_item_size(12 + cs), c->stream,
-                               jac_dense, c->mfma_mode, eb, ee));
+                               jac_dense, c->mfma_mode, eb, ee, n == 1 ? &one : nullptr));
   return DFX_OK;
 }
 
@@ -1121,23 +1130,14 @@ DFX_API int dfx_depth_aligner_step(dfx_ctx* c, int cs, const float* code, const 
   DFX_HIP(dfx::launch_update_depth(cs, code_dev, (const float*)prx_orig->ptr, (uint32_t)prx_orig->pitch_bytes,
                                    (const float*)prx_jac->ptr, (uint32_t)prx_jac->pitch_bytes, avg_dpt, c->depth_scratch, W * 4,
                                    (int)W, (int)H, c->stream));
-  // pseudo-pair descriptor
-  int slot;
-  char* host;
-  if ((rc = stage_acquire(c, sizeof(dfx::SfmPairDev), &slot, &host))) return rc;
-  dfx::SfmPairDev* hd = reinterpret_cast<dfx::SfmPairDev*>(host);
+  // pseudo-pair descriptor: travels in the kernel arguments
+  dfx::SfmPairDev hd_;
+  dfx::SfmPairDev* hd = &hd_;
   std::memset(hd, 0, sizeof(*hd));
   hd->fx = hd->fy = 1.f;
   hd->img0 = (const float*)target_dpt->ptr; hd->pitch_img0 = (uint32_t)target_dpt->pitch_bytes;
   hd->dpt0 = c->depth_scratch; hd->pitch_dpt0 = W * 4;
   hd->jac = (const float*)prx_jac->ptr; hd->pitch_jac = (uint32_t)prx_jac->pitch_bytes;
-  if (c->pairs_cap < 1) {
-    DFX_HIP(hipMalloc((void**)&c->pairs_dev, sizeof(dfx::SfmPairDev) * 2 * kStageSlots));
-    c->pairs_cap = 2;
-  }
-  dfx::SfmPairDev* dd = c->pairs_dev + (size_t)slot * c->pairs_cap;
-  DFX_HIP(hipMemcpyAsync(dd, hd, sizeof(*hd), hipMemcpyHostToDevice, c->stream));
-  if ((rc = stage_release(c, slot))) return rc;
   const int bpp = auto_step_blocks(c, W, H, 1, cs);
   const size_t pbytes = dfx::sfm_step_partials_bytes(cs, 1, bpp);
   if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
@@ -1145,7 +1145,7 @@ DFX_API int dfx_depth_aligner_step(dfx_ctx* c, int cs, const float* code, const 
   const size_t ibytes = dfx_item_size(cs);
   void* tgt;
   if ((rc = result_target(c, ibytes, &tgt))) return rc;
-  DFX_HIP(dfx::launch_depth_aligner_step(cs, dd, (int)W, (int)H, avg_dpt, bpp, c->partials, tgt, c->stream,
+  DFX_HIP(dfx::launch_depth_aligner_step(cs, hd, (int)W, (int)H, avg_dpt, bpp, c->partials, tgt, c->stream,
                                          prx_jac->pitch_bytes == (size_t)W * cs * 4, c->mfma_mode));
   return finish_result(c, out_item, ibytes);
 }

@@ -64,7 +64,8 @@ inline int sfm_zdim(int ncb) { return (1 + sfm_nacc(ncb)) * 256; }
 // ev_begin/ev_end (optional) bracket the step kernel only.
 hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm,
                            int blocks_per_pair, float* partials_dev, void* items_dev, size_t item_stride,
-                           hipStream_t stream, bool jac_dense, int prec, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
+                           hipStream_t stream, bool jac_dense, int prec, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr,
+                           const SfmPairDev* one_host = nullptr);   // one_host (npairs == 1): the descriptor travels in the kernel arguments
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair);
 // system layout (floats): Hd [n_nodes][D][D], Ho [n_pairs][D][6], g [n_nodes][D]; contributions of the pairs [first_pair, first_pair + n_local)
 hipError_t launch_graph_assemble(int cs, const GraphDev& G, const void* items_dev, size_t item_stride, int first_pair, int n_local, float* sys_dev,
@@ -85,7 +86,7 @@ hipError_t launch_blur_down(const float* in, uint32_t pitch, int W, int H, float
                             hipStream_t stream);
 hipError_t launch_squared_error(const float* a, uint32_t pitch_a, const float* b, uint32_t pitch_b, int W, int H, int blocks,
                                 float* partials_dev, float* out_dev, hipStream_t stream);
-hipError_t launch_depth_aligner_step(int cs, const SfmPairDev* pair_dev, int W, int H, float avg_dpt, int blocks,
+hipError_t launch_depth_aligner_step(int cs, const SfmPairDev* pair_host, int W, int H, float avg_dpt, int blocks,
                                      float* partials_dev, void* item_dev, hipStream_t stream, bool jac_dense, int prec);
 
 // device-resident tracker

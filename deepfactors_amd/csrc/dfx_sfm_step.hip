@@ -122,8 +122,10 @@ __device__ __forceinline__ float dpp_merge(float old, float src) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, 0xF, BANKS, false));
 }
 
-template <int NCB, int MODE, bool JDENSE, bool TABLDS>
-__global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_WAVES) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmParamsDev prm,
+// BYVAL: a single pair travels in the kernel arguments (`one`) instead of a descriptor array in device memory -- the reference's call
+// pattern is one pair per blocking call, and the staged host-to-device copy of a 200-byte descriptor cost more than the launch.
+template <int NCB, int MODE, bool JDENSE, bool TABLDS, bool BYVAL>
+__global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_WAVES) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmPairDev one, const SfmParamsDev prm,
                                                        const int W, const int H, float* __restrict__ partials) {
   constexpr int NX = NCB * (NCB - 1) / 2, ND = (NCB + 1) / 2;   // X(b,b'), Dd(q); Pm(b): NCB
   constexpr int NACC = NX + NCB;                                 // 16x16x4 accumulators
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const SfmPairDev& P = pairs[blockIdx.y];
+  const SfmPairDev& P = BYVAL ? one : pairs[blockIdx.y];
 
   Geo g;
 #pragma unroll
@@ -534,8 +536,8 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 // (pose0, pose1) and scatter the packed z-space blocks into the item layout.
 // grid = (1 + NACC + 2 ND, npairs), 1024 threads: thread = (element of one 256-float block, 1 of 4 partial groups); groups
 // stride over the pair's `bpp` partials (1 KB coalesced reads, 8 loads in flight) and are folded in fixed order.
-template <int NCB, int NPOSE>
-__global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs,
+template <int NCB, int NPOSE, bool BYVAL>
+__global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs, const SfmPairDev one,
                                                        char* __restrict__ items, const size_t item_stride) {
   constexpr int CS = 16 * NCB;
   constexpr int NP = NPOSE + CS;
@@ -552,8 +554,8 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
   red[rg][el] = strided_sum_f64<4>(src, rg, bpp, ZDIM);
   if (NPOSE == 12 && threadIdx.x < 72) {
     const int n = threadIdx.x / 6, i = threadIdx.x - n * 6;
-    const float* M = pairs[pair].M;
-    const float* HM = pairs[pair].HM;
+    const float* M = BYVAL ? one.M : pairs[pair].M;
+    const float* HM = BYVAL ? one.HM : pairs[pair].HM;
     const int j = n % 3, grp = n / 3;   // grp 0: pose0 trs, 1: pose0 rot, 2: pose1 trs, 3: pose1 rot
     double v = 0.0;
     if (grp == 0) v = i < 3 ? (double)M[3 * i + j] : 0.0;
@@ -676,7 +678,7 @@ size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair) {
 template <int NCB, int MODE>
 static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm, int bpp,
                            float* partials_dev, void* items_dev, size_t item_stride, hipStream_t stream, bool jac_dense, int prec,
-                           hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr) {
+                           hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, const SfmPairDev* one_host = nullptr) {
   constexpr int NACC = NCB * (NCB - 1) / 2 + NCB + 2 * ((NCB + 1) / 2);   // 256-float blocks after block 0 (16x16x4 and 4x4x1 accumulators)
   hipError_t e;
   if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
@@ -688,40 +690,48 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   const size_t tab_bytes = sizeof(float) * ((size_t)W + H + kRayTabSlack);
   const bool tab_lds = MODE == 0 && kStaticLds + tab_bytes + DFX_EXTRA_LDS <= 64 * 1024;
   const size_t dyn = DFX_EXTRA_LDS + (tab_lds ? tab_bytes : 0);
+  const bool byval = one_host != nullptr && npairs == 1;
+  const SfmPairDev one = byval ? *one_host : SfmPairDev{};
+#define DFX_LAUNCH_STEP(M_, JD_, TL_)                                                                                                              \
+  do {                                                                                                                                             \
+    if (byval) hipLaunchKernelGGL((k_sfm_step<NCB, M_, JD_, TL_, true>), grid, block, dyn, stream, (const SfmPairDev*)nullptr, one, prm, W, H, partials_dev); \
+    else hipLaunchKernelGGL((k_sfm_step<NCB, M_, JD_, TL_, false>), grid, block, dyn, stream, pairs_dev, one, prm, W, H, partials_dev);              \
+  } while (0)
   if (MODE == 0 && tab_lds) {
-    if (jac_dense) hipLaunchKernelGGL((k_sfm_step<NCB, 0, true, true>), grid, block, dyn, stream, pairs_dev, prm, W, H, partials_dev);
-    else hipLaunchKernelGGL((k_sfm_step<NCB, 0, false, true>), grid, block, dyn, stream, pairs_dev, prm, W, H, partials_dev);
+    if (jac_dense) DFX_LAUNCH_STEP(0, true, true); else DFX_LAUNCH_STEP(0, false, true);
   } else {
-    if (jac_dense) hipLaunchKernelGGL((k_sfm_step<NCB, MODE, true, false>), grid, block, dyn, stream, pairs_dev, prm, W, H, partials_dev);
-    else hipLaunchKernelGGL((k_sfm_step<NCB, MODE, false, false>), grid, block, dyn, stream, pairs_dev, prm, W, H, partials_dev);
+    if (jac_dense) DFX_LAUNCH_STEP(MODE, true, false); else DFX_LAUNCH_STEP(MODE, false, false);
   }
+#undef DFX_LAUNCH_STEP
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL((k_sfm_finalize<NCB, MODE == 0 ? 12 : 0>), dim3(1 + NACC, npairs), dim3(1024), 0, stream,
-                     (const float*)partials_dev, bpp, pairs_dev, (char*)items_dev, item_stride);
+  if (byval) hipLaunchKernelGGL((k_sfm_finalize<NCB, MODE == 0 ? 12 : 0, true>), dim3(1 + NACC, npairs), dim3(1024), 0, stream,
+                                (const float*)partials_dev, bpp, (const SfmPairDev*)nullptr, one, (char*)items_dev, item_stride);
+  else hipLaunchKernelGGL((k_sfm_finalize<NCB, MODE == 0 ? 12 : 0, false>), dim3(1 + NACC, npairs), dim3(1024), 0, stream,
+                          (const float*)partials_dev, bpp, pairs_dev, one, (char*)items_dev, item_stride);
   return hipGetLastError();
 }
 
 hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm,
                            int blocks_per_pair, float* partials_dev, void* items_dev, size_t item_stride,
-                           hipStream_t stream, bool jac_dense, int prec, hipEvent_t eb, hipEvent_t ee) {
+                           hipStream_t stream, bool jac_dense, int prec, hipEvent_t eb, hipEvent_t ee, const SfmPairDev* one_host) {
   switch (cs) {
-    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee);
-    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee);
-    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee);
+    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host);
+    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host);
+    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host);
     default: return hipErrorInvalidValue;
   }
 }
 
-// DepthAligner::RunStep: `pair_dev` describes ONE pseudo-pair with img0 = target depth, dpt0 = current depth, jac.
-hipError_t launch_depth_aligner_step(int cs, const SfmPairDev* pair_dev, int W, int H, float avg_dpt, int blocks,
+// DepthAligner::RunStep: `pair_host` describes ONE pseudo-pair with img0 = target depth, dpt0 = current depth, jac (passed by value).
+hipError_t launch_depth_aligner_step(int cs, const SfmPairDev* pair_host, int W, int H, float avg_dpt, int blocks,
                                      float* partials_dev, void* item_dev, hipStream_t stream, bool jac_dense, int prec) {
   SfmParamsDev prm{ 0.f, avg_dpt, 0.f, 0.f };
   switch (cs) {
-    case 16: return launch_t<1, 1>(pair_dev, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec);
-    case 32: return launch_t<2, 1>(pair_dev, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec);
-    case 64: return launch_t<4, 1>(pair_dev, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec);
+    case 16: return launch_t<1, 1>(nullptr, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec, nullptr, nullptr, pair_host);
+    case 32: return launch_t<2, 1>(nullptr, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec, nullptr, nullptr, pair_host);
+    case 64: return launch_t<4, 1>(nullptr, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec, nullptr, nullptr, pair_host);
     default: return hipErrorInvalidValue;
   }
 }
