@@ -44,6 +44,9 @@ struct dfx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t copy_stream = nullptr;          // descriptor uploads of batched launches run beside the previous launch's kernels
+  hipEvent_t slot_done[kStageSlots] = {};     // recorded on `stream` behind the kernels that read a slot's device copy
+  bool slot_busy[kStageSlots] = {};
   int cu_count = 0;
   int step_blocks = 0;   // 0 = auto
   int mfma_mode = DFX_MFMA_F32_CHAIN;
@@ -109,6 +112,7 @@ int stage_acquire(dfx_ctx* c, size_t bytes, int* slot, char** host) {
   if (bytes > c->stage_slot_bytes) {
     // drain and regrow
     DFX_HIP(hipStreamSynchronize(c->stream));
+    if (c->copy_stream) DFX_HIP(hipStreamSynchronize(c->copy_stream));
     if (c->stage_host) DFX_HIP(hipHostFree(c->stage_host));
     c->stage_host = nullptr;
     size_t n = bytes * 2;
@@ -372,8 +376,11 @@ DFX_API int dfx_ctx_create(int device, void* stream, dfx_ctx** out) {
   c->stream = (hipStream_t)stream;
   for (int i = 0; i < kStageSlots; ++i) {
     e = hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->slot_done[i], hipEventDisableTiming);
     if (e != hipSuccess) { delete c; return fail(DFX_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(e)); }
   }
+  e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return fail(DFX_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
   *out = c;
   return DFX_OK;
 }
@@ -393,7 +400,9 @@ DFX_API void dfx_ctx_destroy(dfx_ctx* c) {
   for (auto& t : c->ray_tabs) (void)hipFree(t.dev);
   if (c->stage_host) (void)hipHostFree(c->stage_host);
   if (c->result_host) (void)hipHostFree(c->result_host);
+  if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   for (int i = 0; i < kStageSlots; ++i) if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
+  for (int i = 0; i < kStageSlots; ++i) if (c->slot_done[i]) (void)hipEventDestroy(c->slot_done[i]);
   for (auto& pr : c->prof_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -405,8 +414,9 @@ DFX_API int dfx_ctx_set_stream(dfx_ctx* c, void* stream) {
   if ((rc = ensure_device(c))) return rc;
   if ((hipStream_t)stream == c->stream) return DFX_OK;
   DFX_HIP(hipStreamSynchronize(c->stream));   // staging slots, scratch and result area are ordered on the old stream
+  DFX_HIP(hipStreamSynchronize(c->copy_stream));
   c->stream = (hipStream_t)stream;
-  for (int i = 0; i < kStageSlots; ++i) c->stage_used[i] = false;
+  for (int i = 0; i < kStageSlots; ++i) { c->stage_used[i] = false; c->slot_busy[i] = false; }
   return DFX_OK;
 }
 
@@ -561,18 +571,25 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
     }
   }
   if (n > 1) {
-    // device descriptor array: one region per stage slot so that in-flight launches keep their own copy
+    // device descriptor array: one region per stage slot so that in-flight launches keep their own copy.  The upload runs on
+    // the context's copy stream, beside the kernels of the previous launches (it used to sit between them on the launch stream:
+    // ~10 us per step); the launch stream waits for it, and the copy stream waits for the last kernels that read this slot.
     if (c->pairs_cap < (size_t)n) {
       DFX_HIP(hipStreamSynchronize(c->stream));
+      DFX_HIP(hipStreamSynchronize(c->copy_stream));
       if (c->pairs_dev) DFX_HIP(hipFree(c->pairs_dev));
       c->pairs_dev = nullptr;
       const size_t cap = (size_t)n * 2;
       DFX_HIP(hipMalloc((void**)&c->pairs_dev, sizeof(dfx::SfmPairDev) * cap * kStageSlots));
       c->pairs_cap = cap;
+      for (int i = 0; i < kStageSlots; ++i) c->slot_busy[i] = false;
     }
     dd = c->pairs_dev + (size_t)slot * c->pairs_cap;
-    DFX_HIP(hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, c->stream));
-    if ((rc = stage_release(c, slot))) return rc;
+    if (c->slot_busy[slot]) DFX_HIP(hipStreamWaitEvent(c->copy_stream, c->slot_done[slot], 0));
+    DFX_HIP(hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, c->copy_stream));
+    DFX_HIP(hipEventRecord(c->stage_ev[slot], c->copy_stream));
+    c->stage_used[slot] = true;
+    DFX_HIP(hipStreamWaitEvent(c->stream, c->stage_ev[slot], 0));
   }
 
   if (params->step_blocks < 0 || params->step_blocks > 65535) return fail(DFX_E_INVALID, "step_blocks %d out of range [0,65535]", params->step_blocks);
@@ -599,6 +616,10 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
   for (int p = 0; p < n; ++p) jac_dense = jac_dense && (hd[p].pitch_jac == W * (uint32_t)cs * 4u);
   DFX_HIP(dfx::launch_sfm_step(cs, dd, n, (int)W, (int)H, prm, bpp, c->partials, out_items_dev, dfx_item_size(12 + cs), c->stream,
                                jac_dense, c->mfma_mode, eb, ee, n == 1 ? &one : nullptr));
+  if (n > 1) {
+    DFX_HIP(hipEventRecord(c->slot_done[slot], c->stream));
+    c->slot_busy[slot] = true;
+  }
   return DFX_OK;
 }
 

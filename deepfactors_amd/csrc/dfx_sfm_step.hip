@@ -70,7 +70,7 @@ namespace dfx {
 #endif
 #ifndef DFX_ABLATE
 #define DFX_ABLATE 0         // diagnosis only (wrong results): 1 = no MFMAs, 2 = no phase-A math/gathers, 4 = no ring loads,
-                             // 16 = no P x P fmas, 32 = no ray-table / valid0 reads, 64 = no operand shuffles
+                             // 16 = no P x P fmas, 32 = no ray-table / valid0 reads, 64 = no operand shuffles, 128 = no tap gathers
 #endif
 
 #ifndef DFX_RING_AUX
@@ -269,12 +269,20 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     q.i0 = bload<DFX_STREAM_AUX>(i0_rs, oi, (float*)nullptr);
     if (DFX_ABLATE & 32) { q.rx = 0.01f * (float)q.x; q.ry = 0.01f * (float)q.y; q.vl = 1.0f; }
     else if (MODE == 0) {   // table rows are padded (kRayTabSlack), so lanes past the last pixel stay inside the allocation
+#if DFX_ABLATE & 512
+      q.rx = ((float)q.x - g.u0) * (1.0f / g.fx); q.ry = ((float)q.y - g.v0) * (1.0f / g.fy);
+#else
       if (TABLDS) { q.rx = ray_lds[q.x]; q.ry = ray_lds[W + q.y]; }
       else { q.rx = gload<float>(ray_tab + (unsigned)q.x * 4u); q.ry = gload<float>(ray_tab + (unsigned)(W + q.y) * 4u); }
+#endif
       // valid0 is all ones from BuildKeyframe on (mapper.cpp:937) and only ever set: reading it (4 B/px, coalesced) and
       // skipping pixels that already hold 1.0 makes the steady state write-free; HBM writes cost about twice their bytes.
       // Always issued (keeps the load count static): without a valid0 image the read goes to the depth image instead.
+#if DFX_ABLATE & 256
+      q.vl = 1.0f;
+#else
       q.vl = gload<float>(vld_base + (inb ? (unsigned)q.y * vld_pitch + (unsigned)q.x * 4u : 0u));
+#endif
     }
   };
   // A1: warp the pixel and issue its 4 bilinear tap loads.  Branch-free on purpose: a conditional load would make the
@@ -293,10 +301,15 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
       unsigned og = (unsigned)tp.iy * pitch_g1 + (unsigned)tp.ix * 8u, og2 = og + pitch_g1;
       oi = ok ? oi : 0u; oi2 = ok ? oi2 : 0u;
       og = ok ? og : 0u; og2 = ok ? og2 : 0u;
+#if DFX_ABLATE & 128
+      q.ia = f32x2{ c.u, c.v }; q.ib = f32x2{ c.qx, c.qy }; q.ga = f32x4{ c.vx, c.vy, c.vz, c.iz }; q.gb = q.ga;
+      (void)oi; (void)oi2; (void)og; (void)og2;
+#else
       q.ia = bload(i1_rs, oi, (f32x2*)nullptr);
       q.ib = bload(i1_rs, oi2, (f32x2*)nullptr);
       q.ga = bload(g1_rs, og, (f32x4*)nullptr);
       q.gb = bload(g1_rs, og2, (f32x4*)nullptr);
+#endif
     } else {
       q.ia = f32x2{ 0.f, 0.f }; q.ib = q.ia;
       q.ga = f32x4{ 0.f, 0.f, 0.f, 0.f }; q.gb = q.ga;
@@ -419,6 +432,8 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
       if (++vk == 32) flush_valid();
     }
     // ---- A1(c+1) and the depth prefetch of c+2: issued BEFORE the ring refills of phase B
+    // (Tried: A1 + prefetch inside phase B, after MFMA group 1 / 4 / 8, so that their VALU chains fill the issue gaps of the MFMA
+    // stream of the same wave: 139 VGPRs -> 3 waves per SIMD, +2.7 % kernel time.  The overlap comes from the co-resident waves.)
     cur.x = nxt.x; cur.y = nxt.y; cur.d = nxt.d; cur.i0 = nxt.i0; cur.rx = nxt.rx; cur.ry = nxt.ry; cur.vl = nxt.vl;
 #if !(DFX_ABLATE & 2)
     issue_gathers(nbase, cur);
