@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child run (roofline.traffic = null)")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary configs[1] / configs[4] measurements")
     ap.add_argument("--window", action="store_true", help="also measure BASELINE configs[3]: 64 keyframes, 1024 pairs over the ranks")
+    ap.add_argument("--schedule", choices=["auto", "static"], default="auto",
+                    help="auto: dynamic item queues for large batches (default of the library); static: the bit-reproducible static partition")
     ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -121,7 +123,7 @@ def pmc_traffic(a):
     out = tempfile.mkdtemp(prefix="dfx_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     worker = [sys.executable, os.path.abspath(__file__), "--pmc-worker", "--pairs", str(a.pairs), "--width", str(a.width), "--height", str(a.height),
-              "--cs", str(a.cs), "--step-blocks", str(a.step_blocks)]
+              "--cs", str(a.cs), "--step-blocks", str(a.step_blocks), "--schedule", a.schedule]
     passes = {"rd": ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"],
               "wr": ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"]}
     vals = {}
@@ -276,6 +278,9 @@ def main():
 
     W, H, CS, P = a.width, a.height, a.cs, a.pairs
     ctx = dfx.Context(local)
+    if a.schedule == "static":
+        from deepfactors_amd import _lib as _dl
+        ctx.set_schedule(_dl.DFX_SCHEDULE_STATIC)
     al = dfx.SfmAligner(dfx.SfmAlignerParams(step_blocks=a.step_blocks), code_size=CS, ctx=ctx)
 
     # ---- synthetic, device-resident input: P distinct keyframe->frame pairs per rank

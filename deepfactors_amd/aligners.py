@@ -154,6 +154,11 @@ class Context:
         """_lib.DFX_MFMA_F32_CHAIN (bitwise fp32 fmaf chain) is the only mode; DFX_MFMA_BF16X3 is rejected (see include/dfx.h)."""
         check(_lib.lib().dfx_set_mfma_mode(self._h, int(mode)))
 
+    def set_schedule(self, mode):
+        """_lib.DFX_SCHEDULE_AUTO (dynamic item queues for large batches) or _lib.DFX_SCHEDULE_STATIC (always the static,
+        bit-reproducible partition); see include/dfx.h."""
+        check(_lib.lib().dfx_set_schedule(self._h, int(mode)))
+
     def set_profiling(self, enable):
         check(_lib.lib().dfx_set_profiling(self._h, int(bool(enable))))
 

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -50,6 +51,9 @@ struct dfx_ctx {
   int cu_count = 0;
   int step_blocks = 0;   // 0 = auto
   int mfma_mode = DFX_MFMA_F32_CHAIN;
+  int schedule = DFX_SCHEDULE_AUTO;
+  unsigned* qhead = nullptr;   // dynamic schedule: one item-queue head per pair of a batch (rewound by the finalize kernel)
+  size_t qhead_cap = 0;
 
   float* partials = nullptr;   // device scratch for workgroup partials
   size_t partials_bytes = 0;
@@ -395,6 +399,7 @@ DFX_API void dfx_ctx_destroy(dfx_ctx* c) {
   if (c->code_dev) (void)hipFree(c->code_dev);
   if (c->depth_scratch) (void)hipFree(c->depth_scratch);
   if (c->jobs_dev) (void)hipFree(c->jobs_dev);
+  if (c->qhead) (void)hipFree(c->qhead);
   if (c->track_state_dev) (void)hipFree(c->track_state_dev);
   if (c->sg_dev) (void)hipFree(c->sg_dev);
   for (auto& t : c->ray_tabs) (void)hipFree(t.dev);
@@ -444,6 +449,13 @@ DFX_API int dfx_set_mfma_mode(dfx_ctx* c, int mode) {
                                "(DESIGN.md section 5) and was dropped with the packed z-space layout");
   if (mode != DFX_MFMA_F32_CHAIN) return fail(DFX_E_INVALID, "unknown MFMA mode %d", mode);
   c->mfma_mode = mode;
+  return DFX_OK;
+}
+
+DFX_API int dfx_set_schedule(dfx_ctx* c, int mode) {
+  if (!c) return fail(DFX_E_INVALID, "null context");
+  if (mode != DFX_SCHEDULE_AUTO && mode != DFX_SCHEDULE_STATIC) return fail(DFX_E_INVALID, "unknown schedule %d", mode);
+  c->schedule = mode;
   return DFX_OK;
 }
 
@@ -593,7 +605,44 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
   }
 
   if (params->step_blocks < 0 || params->step_blocks > 65535) return fail(DFX_E_INVALID, "step_blocks %d out of range [0,65535]", params->step_blocks);
-  const int bpp = auto_step_blocks(c, W, H, n, cs, params->step_blocks);
+  // the dense-stream variant needs every pair's Jacobian rows back to back; one pitched pair selects the general kernel
+  bool jac_dense = true;
+  for (int p = 0; p < n; ++p) jac_dense = jac_dense && (hd[p].pitch_jac == W * (uint32_t)cs * 4u);
+  // Dynamic schedule (k_sfm_step<..., DYN>): resident wave-workers popping items from per-pair queues.  It pays once the batch
+  // keeps every slot busy for many items (>= 16 pairs); it needs 64-pixel columns (W % 64 == 0), dense Jacobian rows and the
+  // per-wave ray tables beside the P rows in LDS.  An explicit launch shape (step_blocks) or DFX_SCHEDULE_STATIC keeps the
+  // static, bit-reproducible launch.
+  dfx::DynDev dyn{ nullptr, 0, 0, 0, 0, 0u };
+  int dyn_grid = 0;
+  {
+    const int resident_wgs = 4 * c->cu_count;
+    const int team = n > 0 ? (4 * resident_wgs) / n : 0;
+    const size_t dyn_lds = sizeof(float) * 4 * ((size_t)W + H + dfx::kRayTabSlack + 16 * 66);
+    if (c->schedule == DFX_SCHEDULE_AUTO && params->step_blocks == 0 && c->step_blocks == 0 && n >= 16 && team >= 1 && team <= 1024 && jac_dense && W % 64 == 0 &&
+        W / 64 <= 64 && dyn_lds <= 40 * 1024 && (size_t)W * H < (1u << 26)) {
+      const int vs = (int)(W / 64);
+      int R = (int)(((long long)H * vs) / ((long long)team * 24));
+      if (const char* ev = std::getenv("DFX_DYN_ROWS")) R = std::atoi(ev);   // tuning aid
+      if (R < 2) R = 2;
+      if (R > 32) R = 32;
+      dyn.items_per_pair = vs * (int)((H + R - 1) / R);
+      dyn.rows_per_item = R;
+      dyn.npairs = n;
+      dyn.team = team;
+      dyn.vs_magic = (unsigned)((1ull << 32) / (unsigned)vs + 1ull);
+      dyn_grid = resident_wgs;
+      if (c->qhead_cap < (size_t)n) {
+        DFX_HIP(hipStreamSynchronize(c->stream));
+        if (c->qhead) DFX_HIP(hipFree(c->qhead));
+        c->qhead = nullptr;
+        DFX_HIP(hipMalloc((void**)&c->qhead, sizeof(unsigned) * (size_t)n * 2));
+        DFX_HIP(hipMemsetAsync(c->qhead, 0, sizeof(unsigned) * (size_t)n * 2, c->stream));
+        c->qhead_cap = (size_t)n * 2;
+      }
+      dyn.qhead = c->qhead;
+    }
+  }
+  const int bpp = dyn.qhead ? dyn.team : auto_step_blocks(c, W, H, n, cs, params->step_blocks);
   const size_t pbytes = dfx::sfm_step_partials_bytes(cs, n, bpp);
   if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
   if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
@@ -611,11 +660,8 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
     ee = c->prof_pool[c->prof_used].second;
     c->prof_used++;
   }
-  // the dense-stream variant needs every pair's Jacobian rows back to back; one pitched pair selects the general kernel
-  bool jac_dense = true;
-  for (int p = 0; p < n; ++p) jac_dense = jac_dense && (hd[p].pitch_jac == W * (uint32_t)cs * 4u);
   DFX_HIP(dfx::launch_sfm_step(cs, dd, n, (int)W, (int)H, prm, bpp, c->partials, out_items_dev, dfx_item_size(12 + cs), c->stream,
-                               jac_dense, c->mfma_mode, eb, ee, n == 1 ? &one : nullptr));
+                               jac_dense, c->mfma_mode, eb, ee, n == 1 ? &one : nullptr, dyn.qhead ? &dyn : nullptr, dyn_grid));
   if (n > 1) {
     DFX_HIP(hipEventRecord(c->slot_done[slot], c->stream));
     c->slot_busy[slot] = true;

@@ -36,6 +36,16 @@ struct GraphDev {
   const int* fr_pairs;
 };
 
+// Dynamic schedule of the batched SfM step (k_sfm_step<..., DYN>): per-pair item queues popped by wave-workers
+struct DynDev {
+  unsigned* qhead;      // [npairs] next item of each pair; rewound by k_sfm_finalize
+  int items_per_pair;   // columns (W / 64) x row bands
+  int rows_per_item;    // image rows per item (<= 32)
+  int npairs;
+  int team;             // waves per pair = partials per pair
+  unsigned vs_magic;    // 2^32 / (W / 64) + 1: chunk id -> image row by one multiply-high
+};
+
 struct DepthJobDev {   // one UpdateDepth of a batch (k_update_depth_batch): dpt = a / (prx + jac . code) - a
   float code[64];
   const float* prx;
@@ -65,7 +75,8 @@ inline int sfm_zdim(int ncb) { return (1 + sfm_nacc(ncb)) * 256; }
 hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm,
                            int blocks_per_pair, float* partials_dev, void* items_dev, size_t item_stride,
                            hipStream_t stream, bool jac_dense, int prec, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr,
-                           const SfmPairDev* one_host = nullptr);   // one_host (npairs == 1): the descriptor travels in the kernel arguments
+                           const SfmPairDev* one_host = nullptr,   // one_host (npairs == 1): the descriptor travels in the kernel arguments
+                           const DynDev* dyn = nullptr, int dyn_grid = 0);   // dyn: the dynamic schedule (workgroups = dyn_grid, partials = [pair][team])
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair);
 // system layout (floats): Hd [n_nodes][D][D], Ho [n_pairs][D][6], g [n_nodes][D]; contributions of the pairs [first_pair, first_pair + n_local)
 hipError_t launch_graph_assemble(int cs, const GraphDev& G, const void* items_dev, size_t item_stride, int first_pair, int n_local, float* sys_dev,

@@ -124,14 +124,26 @@ __device__ __forceinline__ float dpp_merge(float old, float src) {
 
 // BYVAL: a single pair travels in the kernel arguments (`one`) instead of a descriptor array in device memory -- the reference's call
 // pattern is one pair per blocking call, and the staged host-to-device copy of a 200-byte descriptor cost more than the launch.
-template <int NCB, int MODE, bool JDENSE, bool TABLDS, bool BYVAL>
+//
+// DYN (large batches, W % 64 == 0, dense Jacobian rows): the waves are independent workers.  The grid is sized to be resident at once;
+// wave g serves pair g mod #pairs as member g / #pairs of that pair's team and pops ITEMS (one 64-pixel column x `rows_per_item`
+// image rows, walked downwards) from the pair's queue with a scalar atomic until the queue is empty; its accumulators live in
+// registers across all its items and are written ONCE, straight to global memory (no cross-wave fold, no barrier anywhere).
+// Why: the four waves of a SIMD progress at very different rates (oldest-first arbitration: the same 150 chunks take one wave
+// 520 us and another 1080 us), so any static split leaves slots idle -- a static single round measured 30 % idle slot-time, the
+// multi-round launch 19 % (dispatch gaps, prologues, the barrier in front of the fold).  With the queue every slot streams until
+// the pair's work is gone.  The price: which items a wave sums is decided at run time, so results are reproducible to fp32
+// re-association (1e-7 relative), not bit for bit; dfx_set_schedule(ctx, DFX_SCHEDULE_STATIC) restores the static, bit-reproducible
+// launch.  Teams mix the dispatch ages (members g, g + #pairs, ...), so no pair is served by only old or only young waves.
+template <int NCB, int MODE, bool JDENSE, bool TABLDS, bool BYVAL, bool DYN>
 __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_WAVES) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmPairDev one, const SfmParamsDev prm,
-                                                       const int W, const int H, float* __restrict__ partials) {
+                                                       const int W, const int H, float* __restrict__ partials, const DynDev dyn) {
+  static_assert(!DYN || (MODE == 0 && JDENSE && TABLDS && !BYVAL), "the dynamic schedule exists for the batched dense SfM step");
   constexpr int NX = NCB * (NCB - 1) / 2, ND = (NCB + 1) / 2;   // X(b,b'), Dd(q); Pm(b): NCB
   constexpr int NACC = NX + NCB;                                 // 16x16x4 accumulators
   constexpr int ZDIM = (1 + NACC + 2 * ND) * 256;                // block 0: the 29 P x P sums; then X, Pm, (Dd broadcast, Dd plain) per q
   constexpr int SLOT = (kUFloats > ZDIM) ? kUFloats : ZDIM;   // per wave: its P rows in the loop, its accumulators in the epilogue (same place)
-  constexpr int LDS_FLOATS = kWaves * SLOT;
+  constexpr int LDS_FLOATS = kWaves * (DYN ? kUFloats : SLOT);   // DYN: no epilogue fold, only the P rows
   typedef typename JV<NCB>::T jv_t;
   // "No next chunk" is handled by re-reading the wave's current chunk (L2-hot, results never consumed), NOT by
   // out-of-range offsets: a wave-load whose lanes are all out of range completes without touching memory and may
@@ -142,7 +154,12 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const SfmPairDev& P = BYVAL ? one : pairs[blockIdx.y];
+  // DYN: wave -> (pair, team member); surplus waves (team * #pairs < waves of the grid) retire at once
+  const int dyn_gid = DYN ? (int)blockIdx.x * kWaves + wave : 0;
+  const int dyn_pair = DYN ? dyn_gid % dyn.npairs : 0;
+  const int dyn_member = DYN ? dyn_gid / dyn.npairs : 0;
+  if (DYN && dyn_member >= dyn.team) return;
+  const SfmPairDev& P = BYVAL ? one : pairs[DYN ? dyn_pair : (int)blockIdx.y];
 
   Geo g;
 #pragma unroll
@@ -173,14 +190,16 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   const char* const vld_base = valid0 ? reinterpret_cast<const char*>(valid0) : reinterpret_cast<const char*>(P.dpt0);
   const uint32_t vld_pitch = valid0 ? pitch_v0 : pitch_d0;
 
+  const int ntab = W + H + kRayTabSlack;
+  float* const ray_w = DYN ? ray_lds + wave * ntab : ray_lds;   // DYN: the four waves of a workgroup serve four pairs (possibly four cameras)
   if (MODE == 0 && TABLDS) {
     // Stage the ray table in LDS: two global loads per chunk for it cost 9 % of the kernel (the L1 / address unit of a CU is
     // the busiest shared resource: 28 vector-memory instructions per chunk), two LDS reads cost nothing measurable.
-    const int ntab = W + H + kRayTabSlack;
-    for (int e = threadIdx.x; e < ntab; e += kThreads) ray_lds[e] = gload<float>(ray_tab + (unsigned)e * 4u);
+    if (DYN) { for (int e = lane; e < ntab; e += 64) ray_w[e] = gload<float>(ray_tab + (unsigned)e * 4u); }
+    else { for (int e = threadIdx.x; e < ntab; e += kThreads) ray_lds[e] = gload<float>(ray_tab + (unsigned)e * 4u); }
   }
-  if (MODE == 0 && TABLDS) __syncthreads();
-  float* U = lds + wave * SLOT;
+  if (MODE == 0 && TABLDS && !DYN) __syncthreads();
+  float* U = lds + wave * (DYN ? kUFloats : SLOT);
   if (lane < 16) U[(lane >> 1) * kUStride + 64 + (lane & 1)] = 0.f;   // padding columns 64, 65 of P rows 0..7 (read as zeros by the 4x4 tiles)
 
   f32x4 acc[NACC];
@@ -221,7 +240,38 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   const int wid = blockIdx.x * kWaves + wave;
   const int vs = (W + 32) >> 6;   // chunk stride of one image row (exact when W % 64 == 0)
   int chunk, cstride, cend;
-  if (DFX_BANDED && vs >= 1 && total_waves >= vs) {
+  // DYN: item t of a pair = column t % vs, image rows [t / vs * R, + R): chunks row * vs + column, one image row apart
+  int gen_next = -1, gen_end = 0;   // generator: next chunk of the item being handed out, its end (wave-uniform)
+  bool gen_dry = false;
+  auto dyn_pop = [&]() -> unsigned {   // SMEM atomic: returns through lgkmcnt, so the counted vmcnt waits of the pipeline never see it
+    unsigned t = 1u;
+    asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t) : "s"(dyn.qhead + dyn_pair) : "memory");
+    return t;
+  };
+  // chunk id -> image row (chunks per row = vs <= 64, ids < 2^20: the multiply-high by dyn.vs_magic = 2^32 / vs + 1 is exact)
+  auto dyn_row = [&](int c) -> int { return (int)__builtin_amdgcn_readfirstlane((int)__umulhi((unsigned)c, dyn.vs_magic)); };
+  auto dyn_gen = [&]() -> int {        // next chunk id of this wave's sequence, -1 once the pair's queue is empty
+    if (gen_next >= 0 && gen_next < gen_end) { const int c = gen_next; gen_next += vs; return c; }
+    if (!gen_dry) {
+      const unsigned t = dyn_pop();
+      if (t < (unsigned)dyn.items_per_pair) {
+        const int band = dyn_row((int)t);          // item t: column t % vs, row band t / vs
+        const int row0 = band * dyn.rows_per_item;
+        const int c = row0 * vs + ((int)t - band * vs);
+        gen_end = min((row0 + dyn.rows_per_item) * vs, nchunks);
+        gen_next = c + vs;
+        return c;
+      }
+      gen_dry = true;
+    }
+    gen_next = -1;
+    return -1;
+  };
+  int q0 = -1, q1 = -1, q2 = -1;   // DYN: the chunk being processed and the two the pipeline looks ahead to
+  if (DYN) {
+    q0 = dyn_gen(); q1 = dyn_gen(); q2 = dyn_gen();
+    chunk = q0 < 0 ? nchunks : q0; cstride = vs; cend = nchunks;
+  } else if (DFX_BANDED && vs >= 1 && total_waves >= vs) {
     const int crows = (nchunks + vs - 1) / vs;
     const int nbands = total_waves / vs;
     const int per = (crows + nbands - 1) / nbands;   // chunk rows per band = chunks per wave
@@ -272,7 +322,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 #if DFX_ABLATE & 512
       q.rx = ((float)q.x - g.u0) * (1.0f / g.fx); q.ry = ((float)q.y - g.v0) * (1.0f / g.fy);
 #else
-      if (TABLDS) { q.rx = ray_lds[q.x]; q.ry = ray_lds[W + q.y]; }
+      if (TABLDS) { q.rx = ray_w[q.x]; q.ry = ray_w[W + q.y]; }
       else { q.rx = gload<float>(ray_tab + (unsigned)q.x * 4u); q.ry = gload<float>(ray_tab + (unsigned)(W + q.y) * 4u); }
 #endif
       // valid0 is all ones from BuildKeyframe on (mapper.cpp:937) and only ever set: reading it (4 B/px, coalesced) and
@@ -322,16 +372,17 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   Pix cur, nxt;
   {
     const unsigned base = (chunk < cend) ? (unsigned)chunk << 6 : 0u;   // idle wave: harmless loads of chunk 0
-    {
+    if (DYN) { const int c = q0 < 0 ? 0 : q0, r = dyn_row(c); cur.x = (c - r * vs) * 64 + lane; cur.y = r; }
+    else {
       const unsigned p = base + lane;   // the only integer division: first chunk of the wave
       cur.y = p / (unsigned)W;
       cur.x = p - cur.y * W;
     }
     prefetch_di0(base, cur);
-    const bool has1 = chunk + cstride < cend;
-    const unsigned nb0 = has1 ? (unsigned)(chunk + cstride) << 6 : base;
+    const bool has1 = DYN ? (q0 >= 0 && q1 >= 0) : (chunk + cstride < cend);
+    const unsigned nb0 = has1 ? (unsigned)(DYN ? q1 : chunk + cstride) << 6 : base;
     nxt.x = cur.x; nxt.y = cur.y;
-    if (has1) advance_xy(nxt.x, nxt.y);
+    if (has1) { if (DYN) { const int r = dyn_row(q1); nxt.x = (q1 - r * vs) * 64 + lane; nxt.y = r; } else advance_xy(nxt.x, nxt.y); }
     prefetch_di0(nb0, nxt);
     issue_gathers(base, cur);
     // Keep the issue order of the loop body (gathers, depth prefetch, THEN ring): the waitcnt bookkeeping at the loop
@@ -354,7 +405,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
       int fx = vx0, fy = vy0;
       for (int k = 0; k < vk; ++k) {
         if ((vmask >> k) & 1u) gstore<float>((char*)valid0 + (size_t)fy * pitch_v0 + (size_t)fx * 4, 1.0f);
-        advance_xy(fx, fy);
+        if (DYN) fy += 1; else advance_xy(fx, fy);   // DYN: the recorded chunks are one item's, one image row apart
       }
       vx0 = fx; vy0 = fy;
     }
@@ -366,17 +417,17 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   const unsigned long long trStart = __builtin_amdgcn_s_memtime();
   const unsigned long long trRealStart = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz
 #endif
-  for (; chunk < cend; chunk += cstride) {
+  for (; chunk < cend; chunk = DYN ? (q0 < 0 ? nchunks : q0) : chunk + cstride) {
 #if DFX_TRACE
     __builtin_amdgcn_sched_barrier(0);
     const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_sched_barrier(0);
 #endif
     const int base = chunk << 6;
-    const bool has2 = chunk + 2 * cstride < cend;                                                           // wave-uniform
-    const bool has1 = chunk + cstride < cend;                                                               // wave-uniform
-    const unsigned nbase = has1 ? (unsigned)(chunk + cstride) << 6 : (unsigned)base;                        // else: re-read this chunk
-    const unsigned nnbase = has2 ? (unsigned)(chunk + 2 * cstride) << 6 : nbase;
+    const bool has2 = DYN ? (q1 >= 0 && q2 >= 0) : (chunk + 2 * cstride < cend);                             // wave-uniform
+    const bool has1 = DYN ? (q1 >= 0) : (chunk + cstride < cend);                                            // wave-uniform
+    const unsigned nbase = has1 ? (unsigned)(DYN ? q1 : chunk + cstride) << 6 : (unsigned)base;             // else: re-read this chunk
+    const unsigned nnbase = has2 ? (unsigned)(DYN ? q2 : chunk + 2 * cstride) << 6 : nbase;
 
     // ---- A2(c): lane = pixel; taps of this chunk were issued one iteration ago
     {
@@ -429,7 +480,10 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
       for (int q = 0; q < 7; ++q) U[q * kUStride + lane] = u16[q];
       U[7 * kUStride + lane] = u16[14];    // inlier flag: its square sums to the inlier count
       U[13 * kUStride + lane] = u16[13];
-      if (++vk == 32) flush_valid();
+      if (++vk == 32 || (DYN && (int)nbase != base + (vs << 6))) {   // DYN: the item ends with this chunk -- its bits form one burst
+        flush_valid();
+        if (DYN) { const int c1 = (int)(nbase >> 6), r = dyn_row(c1); vx0 = (c1 - r * vs) * 64 + lane; vy0 = r; }
+      }
     }
     // ---- A1(c+1) and the depth prefetch of c+2: issued BEFORE the ring refills of phase B
     // (Tried: A1 + prefetch inside phase B, after MFMA group 1 / 4 / 8, so that their VALU chains fill the issue gaps of the MFMA
@@ -438,7 +492,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 #if !(DFX_ABLATE & 2)
     issue_gathers(nbase, cur);
 #endif
-    if (has2) advance_xy(nxt.x, nxt.y);   // otherwise nxt keeps pointing at the last real chunk
+    if (has2) { if (DYN) { const int r = dyn_row(q2); nxt.x = (q2 - r * vs) * 64 + lane; nxt.y = r; } else advance_xy(nxt.x, nxt.y); }   // otherwise nxt keeps pointing at the last real chunk
     prefetch_di0(nnbase, nxt);
     __builtin_amdgcn_wave_barrier();   // LDS hand-over inside one wave: program order is enough for the hardware
 
@@ -498,6 +552,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     __builtin_amdgcn_sched_barrier(0);
 #endif
     __builtin_amdgcn_wave_barrier();
+    if (DYN) { q0 = q1; q1 = q2; q2 = dyn_gen(); }
   }
 
   flush_valid();
@@ -510,6 +565,20 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   // arrive folds while the others retire at once.  Waves idle ~10 % of their lifetime at this barrier, yet the kernel time did not
   // move (1059 vs 1058 us at 128 pairs): the kernel is bound by HBM traffic, not by resident waves; 3 instead of 4 workgroups per
   // CU cost 1.3 %.)
+  if (DYN) {   // one partial per wave = per team member, same z-space layout; nothing to fold
+    float* mine = partials + ((size_t)dyn_pair * dyn.team + dyn_member) * ZDIM;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mine[ppb * 16 + r * 4 + ppi] = accpp[r];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[(1 + a) * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[a][r];
+#pragma unroll
+    for (int a = 0; a < 2 * ND; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[(1 + NACC + a) * 256 + ppb * 16 + r * 4 + ppi] = accd[a][r];
+    return;
+  }
   {
     float* mine = lds + wave * SLOT;
 #pragma unroll
@@ -553,7 +622,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 // stride over the pair's `bpp` partials (1 KB coalesced reads, 8 loads in flight) and are folded in fixed order.
 template <int NCB, int NPOSE, bool BYVAL>
 __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs, const SfmPairDev one,
-                                                       char* __restrict__ items, const size_t item_stride) {
+                                                       char* __restrict__ items, const size_t item_stride, unsigned* __restrict__ qhead) {
   constexpr int CS = 16 * NCB;
   constexpr int NP = NPOSE + CS;
   constexpr int NX = NCB * (NCB - 1) / 2, ND = (NCB + 1) / 2;
@@ -565,6 +634,7 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
 
   const int blk = blockIdx.x, pair = blockIdx.y;
   const int el = threadIdx.x & 255, rg = threadIdx.x >> 8;
+  if (qhead && blk == 0 && threadIdx.x == 0) qhead[pair] = 0u;   // dynamic schedule: the pair's item queue is rewound for the next launch
   const float* src = partials + (size_t)pair * bpp * ZDIM + blk * 256 + el;
   red[rg][el] = strided_sum_f64<4>(src, rg, bpp, ZDIM);
   if (NPOSE == 12 && threadIdx.x < 72) {
@@ -693,7 +763,8 @@ size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair) {
 template <int NCB, int MODE>
 static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm, int bpp,
                            float* partials_dev, void* items_dev, size_t item_stride, hipStream_t stream, bool jac_dense, int prec,
-                           hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, const SfmPairDev* one_host = nullptr) {
+                           hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, const SfmPairDev* one_host = nullptr,
+                           const DynDev* dyn = nullptr, int dyn_grid = 0) {
   constexpr int NACC = NCB * (NCB - 1) / 2 + NCB + 2 * ((NCB + 1) / 2);   // 256-float blocks after block 0 (16x16x4 and 4x4x1 accumulators)
   hipError_t e;
   if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
@@ -704,13 +775,27 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   constexpr size_t kStaticLds = sizeof(float) * (size_t)kWaves * ((kUFloats > (1 + NACC) * 256) ? kUFloats : (1 + NACC) * 256);
   const size_t tab_bytes = sizeof(float) * ((size_t)W + H + kRayTabSlack);
   const bool tab_lds = MODE == 0 && kStaticLds + tab_bytes + DFX_EXTRA_LDS <= 64 * 1024;
-  const size_t dyn = DFX_EXTRA_LDS + (tab_lds ? tab_bytes : 0);
+  const size_t dyn_lds = DFX_EXTRA_LDS + (tab_lds ? tab_bytes : 0);
   const bool byval = one_host != nullptr && npairs == 1;
   const SfmPairDev one = byval ? *one_host : SfmPairDev{};
+  const DynDev nodyn{ nullptr, 0, 0, 0, 0, 0u };
+  if (dyn && dyn->qhead) {
+    // dynamic schedule: a resident grid of wave-workers (see k_sfm_step); partials = [pair][team member]
+    if constexpr (MODE == 0) {
+      const size_t dlds = sizeof(float) * (size_t)kWaves * ((size_t)W + H + kRayTabSlack);
+      hipLaunchKernelGGL((k_sfm_step<NCB, 0, true, true, false, true>), dim3(dyn_grid), block, dlds, stream, pairs_dev, one, prm, W, H, partials_dev, *dyn);
+      e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
+      hipLaunchKernelGGL((k_sfm_finalize<NCB, 12, false>), dim3(1 + NACC, npairs), dim3(1024), 0, stream,
+                         (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead);
+      return hipGetLastError();
+    }
+  }
 #define DFX_LAUNCH_STEP(M_, JD_, TL_)                                                                                                              \
   do {                                                                                                                                             \
-    if (byval) hipLaunchKernelGGL((k_sfm_step<NCB, M_, JD_, TL_, true>), grid, block, dyn, stream, (const SfmPairDev*)nullptr, one, prm, W, H, partials_dev); \
-    else hipLaunchKernelGGL((k_sfm_step<NCB, M_, JD_, TL_, false>), grid, block, dyn, stream, pairs_dev, one, prm, W, H, partials_dev);              \
+    if (byval) hipLaunchKernelGGL((k_sfm_step<NCB, M_, JD_, TL_, true, false>), grid, block, dyn_lds, stream, (const SfmPairDev*)nullptr, one, prm, W, H, partials_dev, nodyn); \
+    else hipLaunchKernelGGL((k_sfm_step<NCB, M_, JD_, TL_, false, false>), grid, block, dyn_lds, stream, pairs_dev, one, prm, W, H, partials_dev, nodyn);              \
   } while (0)
   if (MODE == 0 && tab_lds) {
     if (jac_dense) DFX_LAUNCH_STEP(0, true, true); else DFX_LAUNCH_STEP(0, false, true);
@@ -722,19 +807,20 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   if (e != hipSuccess) return e;
   if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
   if (byval) hipLaunchKernelGGL((k_sfm_finalize<NCB, MODE == 0 ? 12 : 0, true>), dim3(1 + NACC, npairs), dim3(1024), 0, stream,
-                                (const float*)partials_dev, bpp, (const SfmPairDev*)nullptr, one, (char*)items_dev, item_stride);
+                                (const float*)partials_dev, bpp, (const SfmPairDev*)nullptr, one, (char*)items_dev, item_stride, (unsigned*)nullptr);
   else hipLaunchKernelGGL((k_sfm_finalize<NCB, MODE == 0 ? 12 : 0, false>), dim3(1 + NACC, npairs), dim3(1024), 0, stream,
-                          (const float*)partials_dev, bpp, pairs_dev, one, (char*)items_dev, item_stride);
+                          (const float*)partials_dev, bpp, pairs_dev, one, (char*)items_dev, item_stride, (unsigned*)nullptr);
   return hipGetLastError();
 }
 
 hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm,
                            int blocks_per_pair, float* partials_dev, void* items_dev, size_t item_stride,
-                           hipStream_t stream, bool jac_dense, int prec, hipEvent_t eb, hipEvent_t ee, const SfmPairDev* one_host) {
+                           hipStream_t stream, bool jac_dense, int prec, hipEvent_t eb, hipEvent_t ee, const SfmPairDev* one_host,
+                           const DynDev* dyn, int dyn_grid) {
   switch (cs) {
-    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host);
-    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host);
-    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host);
+    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid);
+    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid);
+    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid);
     default: return hipErrorInvalidValue;
   }
 }

@@ -147,7 +147,10 @@ def test_regions_out_of_view_are_deterministic_and_match_the_oracle(dfx, oracle)
     dpt[100:140, :] = float("nan")                            # 40 full rows = 400 chunks without a correspondence
     dpt[300:330, 200:520] = float("nan")
     dpt_n = dpt.cpu().numpy()
-    al = dfx.SfmAligner(code_size=cs)
+    from deepfactors_amd import _lib
+    ctx = dfx.Context()
+    ctx.set_schedule(_lib.DFX_SCHEDULE_STATIC)   # bit-reproducibility is the static schedule's contract (the dynamic one: test below)
+    al = dfx.SfmAligner(code_size=cs, ctx=ctx)
     ref = oracle.sfm_step(n["pose0"], pose1, n["cam"], n["img0"], n["img1"], dpt_n, n["prx_jac"], n["grad1"])
     assert 0.2 * w * h < ref.inliers < 0.7 * w * h
     first = al.RunStep(n["pose0"], pose1, n["code"], n["cam"], g["img0"], g["img1"], dpt, None, None, g["prx_jac"], g["grad1"])
@@ -209,3 +212,50 @@ def test_linearize_batch_is_update_depth_then_step(dfx, oracle):
         one = torch.empty_like(g["img0"])
         dfx.UpdateDepth(codes[k], g["prx_orig"], g["prx_jac"], 2.0, one)
         assert torch.equal(one, outs_b[k])
+
+
+def test_dynamic_schedule_matches_the_oracle_and_the_static_schedule(dfx, oracle):
+    """Batches of >= 16 pairs run on resident wave-workers popping items from per-pair queues (DFX_SCHEDULE_AUTO): every item still
+    equals the oracle at the stated tolerance and the static schedule to fp32 re-association; valid0 images are written alike;
+    repeated launches (the queues are rewound by the finalize kernel) stay correct; pairs with regions out of view and mixed
+    cameras included."""
+    from deepfactors_amd import _lib, synth
+    w, h, cs, n = 640, 480, 32, 20
+    rng = np.random.default_rng(12)
+    host, dev = [], []
+    for k in range(6):
+        nk, gk = _pair_dev(w, h, cs, seed=0x3300 + k, motion_scale=0.5 + 0.2 * k)
+        if k == 3:   # another camera for one keyframe
+            nk["cam"] = nk["cam"].copy(); nk["cam"][0] *= 1.05; nk["cam"][2] += 2.0
+        if k == 4:   # a band without correspondences
+            gk["dpt0"][200:260, :] = float("nan"); nk["dpt0"] = gk["dpt0"].cpu().numpy()
+        host.append(nk); dev.append(gk)
+    idx = [(int(rng.integers(0, 6)), int(rng.integers(0, 6))) for _ in range(n)]
+    plist, valid_dyn, valid_sta = [], [torch.zeros_like(g["img0"]) for g in dev], [torch.zeros_like(g["img0"]) for g in dev]
+    def pairs(valid):
+        out = []
+        for (i, j) in idx:
+            pose1 = host[j]["pose1"].copy(); pose1[4] += 0.004 * j
+            out.append(dict(pose0=host[i]["pose0"], pose1=pose1, cam=host[i]["cam"], img0=dev[i]["img0"], img1=dev[j]["img1"], dpt0=dev[i]["dpt0"], valid0=valid[i],
+                            prx0_jac=dev[i]["prx_jac"], grad1=dev[j]["grad1"]))
+        return out
+    ctx_d, ctx_s = dfx.Context(), dfx.Context()
+    ctx_s.set_schedule(_lib.DFX_SCHEDULE_STATIC)
+    al_d, al_s = dfx.SfmAligner(code_size=cs, ctx=ctx_d), dfx.SfmAligner(code_size=cs, ctx=ctx_s)
+    arr_d, arr_s = al_d.make_pairs(pairs(valid_dyn)), al_s.make_pairs(pairs(valid_sta))
+    it_s = al_s.RunStepBatch(arr_s)
+    for rep in range(3):
+        it_d = al_d.RunStepBatch(arr_d)
+        for q, (i, j) in enumerate(idx):
+            assert it_d[q].inliers == it_s[q].inliers
+            sc = float(np.abs(it_s[q].JtJ).max())
+            assert np.abs(it_d[q].JtJ.astype(np.float64) - it_s[q].JtJ).max() <= 3e-6 * sc, (rep, q)
+            assert abs(it_d[q].residual - it_s[q].residual) <= 1e-5 * it_s[q].residual
+    for q in range(0, n, 3):
+        i, j = idx[q]
+        pose1 = host[j]["pose1"].copy(); pose1[4] += 0.004 * j
+        ref = oracle.sfm_step(host[i]["pose0"], pose1, host[i]["cam"], host[i]["img0"], host[j]["img1"], host[i]["dpt0"], host[i]["prx_jac"], host[j]["grad1"])
+        assert_item_close(it_d[q], ref, w, h, what=f"dynamic schedule pair {q}")
+    for a, b in zip(valid_dyn, valid_sta):
+        assert torch.equal(a, b)
+    assert any(float(v.max()) == 1.0 for v in valid_dyn)
