@@ -196,6 +196,37 @@ def secondary_configs(dfx, synth, ctx, dev):
     bpl = (20 + 4 * CS) * W * H * P
     out["configs4_1280x960_cs64"] = dict(pairs_per_launch=P, kernel_us=kern_s * 1e6, algorithmic_gbs=bpl / kern_s / 1e9, frac=bpl / kern_s / 1e9 / HBM_PEAK_GBS,
                                          evals_per_s=P / kern_s)
+    del pairs, keep, arr, items
+    # ---- configs[2] as the reference's relinearisation round (PhotometricFactor::RunAlignmentStep, photometric_factor.cpp:225-293, for every
+    # factor of a 16-keyframe window): UpdateDepth once per keyframe whose code moved + one batched RunStep over the 120 pairs
+    from deepfactors_amd.dist import PairGraph
+    W, H, CS, K = 640, 480, 32, 16
+    graph = PairGraph.all_pairs(K, both_directions=False)
+    al2 = dfx.SfmAligner(code_size=CS, ctx=ctx)
+    kfs = [synth.make_pair(W, H, CS, seed=0x1600 + k, device=dev) for k in range(K)]
+    plist, prx, codes = [], [], []
+    for (i, j) in graph.pairs:
+        a, b = kfs[int(i)], kfs[int(j)]
+        plist.append(dict(pose0=a["pose0"], pose1=b["pose1"], cam=a["cam"], img0=a["img0"], img1=b["img0"], dpt0=a["dpt0"], valid0=a["valid0"],
+                          prx0_jac=a["prx_jac"], grad1=b["grad1"]))
+        prx.append(a["prx_orig"])
+        codes.append(np.asarray(a["code"].cpu() if hasattr(a["code"], "cpu") else a["code"], np.float32))
+    arr = al2.make_pairs(plist)
+    items = torch.zeros(len(plist) * dfx.item_size(12 + CS), dtype=torch.uint8, device=dev)
+    codes = np.stack(codes)
+    for _ in range(40):
+        al2.LinearizeBatch(arr, prx, codes, items)
+    ctx.sync()
+    reps = 40
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        al2.LinearizeBatch(arr, prx, codes, items)
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / reps
+    byts = ((8 + 4 * CS) * K + (20 + 4 * CS) * len(plist)) * W * H
+    out["configs2_linearize_16kf_120pairs"] = dict(round_us=dt * 1e6, evals_per_s=len(plist) / dt, algorithmic_gbs=byts / dt / 1e9, frac=byts / dt / 1e9 / HBM_PEAK_GBS,
+                                                   note="UpdateDepth of the 16 keyframes (136 B/px each) + one batched RunStep of the 120 pairs (148 B/px each) per round, wall clock "
+                                                        "of enqueue-to-completion; the 16 Jacobian images (630 MB) are shared by the pairs, so part of the stream is Infinity-Cache/L2 traffic")
     return out
 
 
@@ -374,7 +405,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "k_sfm_step<2,0>", "kernel_us": kern_s * 1e6, "launches": n_launch,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "fp32_tflops": flops_per_launch / kern_s / 1e12},
+                         "fp32_tflops": flops_per_launch / kern_s / 1e12,
+                         "schedule": "dynamic item queues (results reproducible to fp32 re-association)" if ctx.last_schedule_dynamic()
+                                     else "static partition (bit-reproducible)"},
         }
     configs = {}
     if world == 1 and not a.no_configs:

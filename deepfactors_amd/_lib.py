@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DFX_LIB") or os.path.join(_HERE, "libdfx.so")   # DFX_LIB: tuning variants (tools/ab_variants.sh)
 
 DFX_OK = 0
-DFX_SCHEDULE_AUTO, DFX_SCHEDULE_STATIC = 0, 1
+DFX_SCHEDULE_AUTO, DFX_SCHEDULE_STATIC, DFX_SCHEDULE_DYNAMIC = 0, 1, 2
 DFX_E_INVALID = -1
 DFX_E_HIP = -2
 DFX_E_NOGPU = -3
@@ -88,6 +88,7 @@ _PROTOS = {
     "dfx_device_cu_count": (C.c_int, [C.c_void_p]),
     "dfx_set_mfma_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "dfx_set_schedule": (C.c_int, [C.c_void_p, C.c_int]),
+    "dfx_last_schedule": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "dfx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "dfx_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "dfx_debug_read_partials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -159,6 +159,12 @@ class Context:
         bit-reproducible partition); see include/dfx.h."""
         check(_lib.lib().dfx_set_schedule(self._h, int(mode)))
 
+    def last_schedule_dynamic(self):
+        """True when the last batched SfM step of this context ran on the dynamic item queues."""
+        d = C.c_int(0)
+        check(_lib.lib().dfx_last_schedule(self._h, C.byref(d)))
+        return bool(d.value)
+
     def set_profiling(self, enable):
         check(_lib.lib().dfx_set_profiling(self._h, int(bool(enable))))
 

@@ -52,6 +52,7 @@ struct dfx_ctx {
   int step_blocks = 0;   // 0 = auto
   int mfma_mode = DFX_MFMA_F32_CHAIN;
   int schedule = DFX_SCHEDULE_AUTO;
+  int last_dynamic = 0;        // 1 when the last batched SfM step ran the dynamic schedule
   unsigned* qhead = nullptr;   // dynamic schedule: one item-queue head per pair of a batch (rewound by the finalize kernel)
   size_t qhead_cap = 0;
 
@@ -375,6 +376,7 @@ DFX_API int dfx_ctx_create(int device, void* stream, dfx_ctx** out) {
   dfx_ctx* c = new dfx_ctx();
   c->device = device;
   c->cu_count = prop.multiProcessorCount;
+  if (const char* ev = std::getenv("DFX_SCHEDULE")) c->schedule = std::strcmp(ev, "static") == 0 ? DFX_SCHEDULE_STATIC : std::strcmp(ev, "dynamic") == 0 ? DFX_SCHEDULE_DYNAMIC : DFX_SCHEDULE_AUTO;   // tuning aid (tools/ab_bench.py)
   // NULL = the device's default stream, on which the reference runs everything (cuda/launch_utils.h:26-32): work is
   // then ordered with any other default-stream producer of the images (e.g. PyTorch ops on its default stream).
   c->stream = (hipStream_t)stream;
@@ -454,8 +456,14 @@ DFX_API int dfx_set_mfma_mode(dfx_ctx* c, int mode) {
 
 DFX_API int dfx_set_schedule(dfx_ctx* c, int mode) {
   if (!c) return fail(DFX_E_INVALID, "null context");
-  if (mode != DFX_SCHEDULE_AUTO && mode != DFX_SCHEDULE_STATIC) return fail(DFX_E_INVALID, "unknown schedule %d", mode);
+  if (mode != DFX_SCHEDULE_AUTO && mode != DFX_SCHEDULE_STATIC && mode != DFX_SCHEDULE_DYNAMIC) return fail(DFX_E_INVALID, "unknown schedule %d", mode);
   c->schedule = mode;
+  return DFX_OK;
+}
+
+DFX_API int dfx_last_schedule(dfx_ctx* c, int* dynamic) {
+  if (!c || !dynamic) return fail(DFX_E_INVALID, "null argument");
+  *dynamic = c->last_dynamic;
   return DFX_OK;
 }
 
@@ -608,17 +616,20 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
   // the dense-stream variant needs every pair's Jacobian rows back to back; one pitched pair selects the general kernel
   bool jac_dense = true;
   for (int p = 0; p < n; ++p) jac_dense = jac_dense && (hd[p].pitch_jac == W * (uint32_t)cs * 4u);
-  // Dynamic schedule (k_sfm_step<..., DYN>): resident wave-workers popping items from per-pair queues.  It pays once the batch
-  // keeps every slot busy for many items (>= 16 pairs); it needs 64-pixel columns (W % 64 == 0), dense Jacobian rows and the
-  // per-wave ray tables beside the P rows in LDS.  An explicit launch shape (step_blocks) or DFX_SCHEDULE_STATIC keeps the
-  // static, bit-reproducible launch.
+  // Dynamic schedule (k_sfm_step<..., DYN>): resident wave-workers popping items from per-pair queues.  It needs 64-pixel columns
+  // (W % 64 == 0), dense Jacobian rows and the per-wave ray tables beside the P rows in LDS, and it pays only when a pair's team is
+  // small: the queue heads are device-scope atomics (served memory-side, across the 8 XCDs' L2s: ~0.2 us each, serialised per
+  // word), so a 256-wave team on 16 pairs spends its time queueing for pops (measured 515 vs 151 us; 64 pairs 647 vs 558 us),
+  // a 32-wave team on 128 pairs does not (1106 vs 1122 us).  Hence teams of at most 32 waves, i.e. >= 16 * CUs / 32 pairs.  An
+  // explicit launch shape (step_blocks) or DFX_SCHEDULE_STATIC keeps the static, bit-reproducible launch.
   dfx::DynDev dyn{ nullptr, 0, 0, 0, 0, 0u };
   int dyn_grid = 0;
   {
     const int resident_wgs = 4 * c->cu_count;
     const int team = n > 0 ? (4 * resident_wgs) / n : 0;
     const size_t dyn_lds = sizeof(float) * 4 * ((size_t)W + H + dfx::kRayTabSlack + 16 * 66);
-    if (c->schedule == DFX_SCHEDULE_AUTO && params->step_blocks == 0 && c->step_blocks == 0 && n >= 16 && team >= 1 && team <= 1024 && jac_dense && W % 64 == 0 &&
+    const bool team_ok = c->schedule == DFX_SCHEDULE_DYNAMIC ? (team >= 1 && team <= 1024) : (team >= 1 && team <= 32);
+    if (c->schedule != DFX_SCHEDULE_STATIC && params->step_blocks == 0 && c->step_blocks == 0 && team_ok && jac_dense && W % 64 == 0 &&
         W / 64 <= 64 && dyn_lds <= 40 * 1024 && (size_t)W * H < (1u << 26)) {
       const int vs = (int)(W / 64);
       int R = (int)(((long long)H * vs) / ((long long)team * 24));
@@ -642,6 +653,7 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
       dyn.qhead = c->qhead;
     }
   }
+  c->last_dynamic = dyn.qhead ? 1 : 0;
   const int bpp = dyn.qhead ? dyn.team : auto_step_blocks(c, W, H, n, cs, params->step_blocks);
   const size_t pbytes = dfx::sfm_step_partials_bytes(cs, n, bpp);
   if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));

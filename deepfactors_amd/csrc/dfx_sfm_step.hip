@@ -577,6 +577,16 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     for (int a = 0; a < 2 * ND; ++a)
 #pragma unroll
       for (int r = 0; r < 4; ++r) mine[(1 + NACC + a) * 256 + ppb * 16 + r * 4 + ppi] = accd[a][r];
+#if DFX_TRACE
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {   // trace builds only: {phase A cycles, phase B cycles, loop start (100 MHz ticks mod 2^24), loop lifetime in ticks}, chunks
+      mine[15 * 16 + 0] = (float)trA;
+      mine[15 * 16 + 1] = (float)trB;
+      mine[15 * 16 + 2] = (float)(trRealStart & 0xFFFFFFull);
+      mine[15 * 16 + 3] = (float)(__builtin_amdgcn_s_memrealtime() - trRealStart);
+      mine[11 * 16 + 2] = (float)trN;
+    }
+#endif
     return;
   }
   {

@@ -129,16 +129,21 @@ DFX_API int dfx_device_cu_count(dfx_ctx* ctx);
 #define DFX_MFMA_F32_CHAIN 0
 #define DFX_MFMA_BF16X3 1
 DFX_API int dfx_set_mfma_mode(dfx_ctx* ctx, int mode);
-/* Launch schedule of the batched SfM step.
- *  DFX_SCHEDULE_AUTO    (default) large batches (>= 16 pairs, W % 64 == 0, unpadded Jacobian rows, no explicit step_blocks) run on
- *                       resident wave-workers that pop work items from per-pair queues: no idle slots behind the hardware's uneven
- *                       wave progress (+5 % throughput at 128 pairs).  Which items a wave sums is decided at run time, so results
- *                       are reproducible to fp32 re-association (~1e-7 relative), not bit for bit.  Everything else (single pairs,
- *                       small batches) takes the static launch.
- *  DFX_SCHEDULE_STATIC  always the static partition: bit-reproducible for a given launch shape, like the reference's fixed grid. */
+/* Launch schedule of the batched SfM step (no reference counterpart: the reference has one fixed 11 x 32 grid, cu_sfmaligner.cpp:60).
+ *  DFX_SCHEDULE_AUTO     (default) batches large enough that a pair is served by at most 32 waves (>= 16 * CUs / 32 = 128 pairs on an
+ *                        MI355X; W % 64 == 0, unpadded Jacobian rows, no explicit step_blocks) run on resident wave-workers that pop
+ *                        work items from per-pair queues: no slots idle behind the hardware's uneven wave progress (+1.5 % at 128
+ *                        pairs).  Which items a wave sums is decided at run time, so results are reproducible to fp32
+ *                        re-association (~1e-7 relative), not bit for bit.  Everything else takes the static launch.
+ *  DFX_SCHEDULE_STATIC   always the static partition: bit-reproducible for a given launch shape, like the reference's fixed grid.
+ *  DFX_SCHEDULE_DYNAMIC  the queues whenever the launch is structurally able to (any team size): for tests and tuning; with few
+ *                        pairs the queue heads are contended and it is up to 3x SLOWER than the static launch.
+ * dfx_last_schedule: *dynamic = 1 when the context's last batched SfM step ran on the queues. */
 #define DFX_SCHEDULE_AUTO 0
 #define DFX_SCHEDULE_STATIC 1
+#define DFX_SCHEDULE_DYNAMIC 2
 DFX_API int dfx_set_schedule(dfx_ctx* ctx, int mode);
+DFX_API int dfx_last_schedule(dfx_ctx* ctx, int* dynamic);
 /* Measurement hook (no reference counterpart; the reference times with std::clock around blocking calls,
  * tools/kernel_benchmark.cpp:145-180): when enabled, every SfM step launch is bracketed by HIP events on the
  * context's stream -- around the step kernel only, excluding the finalize kernel and copies.
