@@ -165,7 +165,7 @@ def secondary_configs(dfx, synth, ctx, dev):
     al = dfx.SfmAligner(code_size=32, ctx=ctx)
     p = synth.make_pair(640, 480, 32, seed=0xDF02, device=dev)
     call = lambda: al.RunStep(p["pose0"], p["pose1"], None, p["cam"], p["img0"], p["img1"], p["dpt0"], None, p["valid0"], p["prx_jac"], p["grad1"])  # noqa: E731
-    for _ in range(200):
+    for _ in range(2000):
         call()
     ctx.set_profiling(True)
     t0 = time.perf_counter()
@@ -184,7 +184,7 @@ def secondary_configs(dfx, synth, ctx, dev):
     pairs, keep = build_pairs(dfx, synth, dev, 7, P, W, H, CS)
     arr = al4.make_pairs(pairs)
     items = torch.zeros(P * dfx.item_size(12 + CS), dtype=torch.uint8, device=dev)
-    for _ in range(60):
+    for _ in range(600):
         al4.RunStepBatchAsync(arr, items)
     ctx.sync()
     ctx.set_profiling(True)
@@ -214,7 +214,7 @@ def secondary_configs(dfx, synth, ctx, dev):
     arr = al2.make_pairs(plist)
     items = torch.zeros(len(plist) * dfx.item_size(12 + CS), dtype=torch.uint8, device=dev)
     codes = np.stack(codes)
-    for _ in range(40):
+    for _ in range(200):
         al2.LinearizeBatch(arr, prx, codes, items)
     ctx.sync()
     reps = 40
@@ -341,9 +341,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # setup, untimed and not part of the W warm-up steps: the GPU's clocks take ~50-100 launches to settle after idle (measured:
-    # the same kernel runs 8 % slower in the first 10 launches after idle), so ramp them before anything is counted
-    for _ in range(60):
+    # setup, untimed and not part of the W warm-up steps: after idle the GPU needs ~0.15 s of sustained work to reach its steady clocks
+    # (tools/clock_series.py, 128-pair steps: launches 0-49 average 1287 us, 50-99 1144 us, from 100 on 1065 +- 5 us for thousands
+    # of launches), so ~0.45 s of the same steps run before anything is counted; the count is fixed so that all ranks agree
+    ramp_steps = max(100, 51200 // max(P, 1))
+    for _ in range(ramp_steps):
         step()
     barrier()
     for _ in range(a.warmup):
@@ -391,6 +393,7 @@ def main():
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
+            "ramp_steps": ramp_steps,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",

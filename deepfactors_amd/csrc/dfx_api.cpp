@@ -627,7 +627,7 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
   {
     const int resident_wgs = 4 * c->cu_count;
     const int team = n > 0 ? (4 * resident_wgs) / n : 0;
-    const size_t dyn_lds = sizeof(float) * 4 * ((size_t)W + H + dfx::kRayTabSlack + 16 * 66);
+    const size_t dyn_lds = sizeof(float) * 4 * ((size_t)W + H + dfx::kRayTabSlack + 16 * 68);
     const bool team_ok = c->schedule == DFX_SCHEDULE_DYNAMIC ? (team >= 1 && team <= 1024) : (team >= 1 && team <= 32);
     if (c->schedule != DFX_SCHEDULE_STATIC && params->step_blocks == 0 && c->step_blocks == 0 && team_ok && jac_dense && W % 64 == 0 &&
         W / 64 <= 64 && dyn_lds <= 40 * 1024 && (size_t)W * H < (1u << 26)) {

@@ -36,7 +36,7 @@
 //   16x16x4), so SIMD time per chunk = 32 x #MFMA16 + 8 x #MFMA4 + 2.2 x #VALU: both terms are kept minimal.
 //
 //   Phase A (lane = pixel): coalesced img0/dpt0 loads, warp, bilinear gathers of img1/grad1, Jacobian row,
-//     Huber weight; the 16-float P row goes to LDS component-major (stride 66 -> conflict-free both ways).
+//     Huber weight; the P row goes to LDS component-major (row stride 68 floats).
 //   Phase B (lane = (i = lane&15, k = lane>>4)): the code Jacobian is loaded from HBM directly in MFMA operand
 //     layout -- lane (i,k) reads NCB consecutive floats of pixel 4g+k, i.e. every wave-load is one fully
 //     contiguous 256*NCB-byte run of the [H][W*CS] stream (86 % of all bytes).  The 16 operand registers are a
@@ -77,14 +77,20 @@ namespace dfx {
 #define DFX_RING_AUX 2       // cache policy of the code-Jacobian stream loads: 2 = nt (read once: do not displace the img1 / grad1 rows
 #endif                       // the bilinear taps of the next chunk row re-use from the L2); -1.6 % kernel time, -3 % read requests with the collapse below
 #ifndef DFX_STREAM_AUX
-#define DFX_STREAM_AUX 0     // cache policy of the coalesced img0 / dpt0 loads (read once per launch)
+#define DFX_STREAM_AUX 1     // cache policy of the coalesced img0 / dpt0 loads (read once per launch): 1 = sc0, they bypass the CU's L1 and leave
+                             // it to the bilinear taps; -1 % (1055-1059 vs 1067 us, 4 interleaved runs each); nt (2) and sc0+nt (3) are no better
 #endif
 #ifndef DFX_WAVES
 #define DFX_WAVES 4
 #endif
 constexpr int kWaves = DFX_WAVES;         // waves per workgroup
 constexpr int kThreads = kWaves * 64;
-constexpr int kUStride = 66;              // floats; 16 rows x 66: bank = (2*i + p) % 32 -> conflict-free
+#ifndef DFX_USTRIDE
+#define DFX_USTRIDE 68       // floats between the P rows of a wave in LDS: bank = (4 * row + pixel) % 32 keeps the 16x16 operand reads (8 rows x 4
+#endif                       // pixels) and the 4x4 tile reads (8 rows x 3 pixels per half wave) apart.  66 had twice the bank conflicts (32 M vs
+                             // 16 M per 128-pair launch), 65 five times -- and all of 65 .. 80 measure the same kernel time within 0.5 %
+                             // (tools/lds_ab.sh): the LDS is 22 % busy and never the limiter.
+constexpr int kUStride = DFX_USTRIDE;
 constexpr int kUFloats = 16 * kUStride;   // per wave
 
 template <int NCB> struct JV;
