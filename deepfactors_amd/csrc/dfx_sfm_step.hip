@@ -570,7 +570,8 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   // (Tried: no barrier at all -- every wave parks its set in its own slot, draws a ticket from an LDS counter, and the last one to
   // arrive folds while the others retire at once.  Waves idle ~10 % of their lifetime at this barrier, yet the kernel time did not
   // move (1059 vs 1058 us at 128 pairs): the kernel is bound by HBM traffic, not by resident waves; 3 instead of 4 workgroups per
-  // CU cost 1.3 %.)
+  // CU cost 1.3 %.  Also without effect, 3 interleaved runs each at 128 pairs (1071-1089 us all): the valid0 read through a buffer
+  // resource with the sc0 policy of the other streams; the four waves of a workgroup serving ONE pair in the dynamic schedule.)
   if (DYN) {   // one partial per wave = per team member, same z-space layout; nothing to fold
     float* mine = partials + ((size_t)dyn_pair * dyn.team + dyn_member) * ZDIM;
 #pragma unroll
