@@ -22,6 +22,8 @@ timeout 60 gpurun_build/mfma4x4_bcast > $OUT/ubench_mfma4x4_bcast.txt 2>&1 < /de
 timeout 60 gpurun_build/scalar_atomic > $OUT/ubench_scalar_atomic.txt 2>&1 < /dev/null
 DFX_LIB=$PWD/gpurun_build/libdfx_trace.so timeout 200 python tools/trace_dyn.py > $OUT/dyn_wave_end_times.txt 2>&1 < /dev/null
 timeout 120 tests/cpp/latency_bench > $OUT/latency_cpp.txt 2>&1 < /dev/null
+timeout 200 python tools/clock_series.py --n 2000 --win 50 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/clock_series.txt
+timeout 300 python tools/run_configs.py > $OUT/configs.json 2> $OUT/configs.err < /dev/null
 timeout 120 gpurun_build/read_bw >> $OUT/ubench_read_bw.txt 2>&1 < /dev/null
 find $OUT -name "*.csv" -size +200k -delete
 find $OUT -name "*.db" -delete
