@@ -407,13 +407,14 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   int vk = 0;                       // wave-uniform: chunks recorded in vmask
   int vx0 = cur.x, vy0 = cur.y;     // pixel of bit 0
   auto flush_valid = [&]() {
-    if (MODE == 0 && valid0) {
+    // wave-uniform early-out: in the steady state (the map already holds 1.0 wherever a pixel is an inlier) no bit is set and the
+    // burst loop -- ~10 VALU instructions per recorded chunk even when nothing is stored -- is skipped altogether
+    if (MODE == 0 && valid0 && __builtin_amdgcn_ballot_w64(vmask != 0u) != 0ull) {
       int fx = vx0, fy = vy0;
       for (int k = 0; k < vk; ++k) {
         if ((vmask >> k) & 1u) gstore<float>((char*)valid0 + (size_t)fy * pitch_v0 + (size_t)fx * 4, 1.0f);
         if (DYN) fy += 1; else advance_xy(fx, fy);   // DYN: the recorded chunks are one item's, one image row apart
       }
-      vx0 = fx; vy0 = fy;
     }
     vmask = 0; vk = 0;
   };
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
       U[13 * kUStride + lane] = u16[13];
       if (++vk == 32 || (DYN && (int)nbase != base + (vs << 6))) {   // DYN: the item ends with this chunk -- its bits form one burst
         flush_valid();
-        if (DYN) { const int c1 = (int)(nbase >> 6), r = dyn_row(c1); vx0 = (c1 - r * vs) * 64 + lane; vy0 = r; }
+        vx0 = nxt.x; vy0 = nxt.y;   // bit 0 of the next burst = this lane's pixel of chunk c+1 (what nxt holds until A1 below)
       }
     }
     // ---- A1(c+1) and the depth prefetch of c+2: issued BEFORE the ring refills of phase B
