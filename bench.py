@@ -158,7 +158,7 @@ def pmc_traffic(a):
 
 def secondary_configs(dfx, synth, ctx, dev):
     """configs[1] as the reference calls it (ONE pair per blocking call, photometric_factor.cpp:267-274) and configs[4]
-    (1280x960, 64-code; 4 pairs per launch, 1.3 GB working set)."""
+    (1280x960, 64-code; 16 pairs per launch, 5.5 GB working set)."""
     import torch
     out = {}
     # ---- configs[1]: single 640x480x32 pair, blocking dfx_sfm_step
@@ -179,12 +179,12 @@ def secondary_configs(dfx, synth, ctx, dev):
                                                 note="one 640x480 cs=32 pair per blocking SfmAligner::RunStep call (46 MB: Infinity-Cache resident, not an HBM figure)")
     del p
     # ---- configs[4]: 1280x960, cs = 64
-    W, H, CS, P = 1280, 960, 64, 4
+    W, H, CS, P = 1280, 960, 64, 16
     al4 = dfx.SfmAligner(code_size=CS, ctx=ctx)
     pairs, keep = build_pairs(dfx, synth, dev, 7, P, W, H, CS)
     arr = al4.make_pairs(pairs)
     items = torch.zeros(P * dfx.item_size(12 + CS), dtype=torch.uint8, device=dev)
-    for _ in range(600):
+    for _ in range(250):
         al4.RunStepBatchAsync(arr, items)
     ctx.sync()
     ctx.set_profiling(True)
