@@ -277,12 +277,12 @@ int fill_sfm_pair(dfx_ctx* c, int cs, const dfx_se3* pose0, const dfx_se3* pose1
   return DFX_OK;
 }
 
-// Workgroups per pair for the step kernel, from launch-shape sweeps on MI355X (1 / 4 / 16 / 64 / 128
-// pairs of 640x480, 16 x 320x240, 4 x 1280x960 CS 64).  A wave's prologue + epilogue (descriptor and ray-table loads, cold
-// first loads; the barrier in front of the cross-wave fold) cost about as much as two chunks, so waves should be long; but the
-// batch needs at least ~5 rounds of the 4096 resident waves for the hardware to balance the spread of wave lifetimes (one
-// static round measured 4 % slower than five).  Chunks per wave: 5 while the batch is small, up to 30 when that still leaves five rounds (CS 64: 2.5 rounds, see below).  (Sweeps must discard the first ~100 launches
-// after any idle period: the clocks ramp.)
+// Workgroups per pair for the step kernel, from launch-shape sweeps on MI355X at steady clocks (tools/ab_bench.py --blocks, 3000
+// launches of preroll; round 1's sweeps were taken inside the clock ramp and favoured twice as many, shorter workgroups).  A wave's
+// prologue + epilogue (descriptor and ray-table loads, cold first loads, the barrier in front of the cross-wave fold) cost about as
+// much as two chunks, so waves should be long: 5 chunks per wave while the batch is small (1 / 2 / 4 pairs of 640x480: 240
+// workgroups per pair is best), then as many as leave ~1.25 rounds of the 16 * CUs resident waves, up to 30:
+//   8 pairs 78 -> 74 us, 16 pairs 148 -> 138 us, 32 pairs 294 -> 258 us, 64 pairs 550 -> 533 us against the old five-round rule.
 int auto_step_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int npairs, int cs, int requested = 0) {
   const int nchunks = (int)(((size_t)W * H + 63) / 64);
   int maxb = (nchunks + 3) / 4;   // one chunk per wave at most
@@ -293,7 +293,7 @@ int auto_step_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int npairs, int c
     // CS 64 runs two waves per SIMD (215 VGPRs) and its chunks carry 3x the matrix work: 2.5 rounds of its 8 * CUs resident waves
     // measured best (4 pairs 1280x960: 309 us at 15 chunks per wave vs 330 at 5; 16 pairs: 1204 us at 30 vs 1245 at 10)
     const long long resident_waves = (cs >= 64 ? 8LL : 16LL) * c->cu_count;
-    int cpw = cs >= 64 ? (int)(2 * total_chunks / (5 * resident_waves)) : (int)(total_chunks / (5 * resident_waves));
+    int cpw = cs >= 64 ? (int)(2 * total_chunks / (5 * resident_waves)) : (int)(4 * total_chunks / (5 * resident_waves));
     const int cpw_max = 30;
     if (cpw < 5) cpw = 5;
     if (cpw > cpw_max) cpw = cpw_max;

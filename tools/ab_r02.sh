@@ -1,7 +1,6 @@
-A="--width 1280 --height 960 --cs 64 --distinct --steps 40 --preroll 600"
-timeout 600 python tools/ab_bench.py --worker --pairs 4 $A --blocks 0,640,480,384,320,256,192,160,128,96 2>&1 | grep ABRESULT | python -c "
+A="--distinct --steps 100 --preroll 3000"
+for spec in "32 0,172,40,0,172" "64 0,80,40,0,80" "16 0,240,80,0,240"; do set -- $spec
+DFX_SCHEDULE=static timeout 600 python tools/ab_bench.py --worker --pairs $1 $A --blocks $2 2>&1 | grep ABRESULT | python -c "
 import sys,json
-d=json.loads(sys.stdin.read().split('ABRESULT ')[1]); print('4 pairs', {k: round(v['kernel_us'],1) for k,v in d.items()})"
-timeout 600 python tools/ab_bench.py --worker --pairs 16 $A --blocks 0,480,320,240,160,120,96,64 2>&1 | grep ABRESULT | python -c "
-import sys,json
-d=json.loads(sys.stdin.read().split('ABRESULT ')[1]); print('16 pairs', {k: round(v['kernel_us'],1) for k,v in d.items()})"
+d=json.loads(sys.stdin.read().split('ABRESULT ')[1]); print('$1 pairs', {k: round(v['kernel_us'],1) for k,v in d.items()})"
+done
