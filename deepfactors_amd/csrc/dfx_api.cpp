@@ -55,6 +55,7 @@ struct dfx_ctx {
   int last_dynamic = 0;        // 1 when the last batched SfM step ran the dynamic schedule
   unsigned* qhead = nullptr;   // dynamic schedule: one item-queue head per pair of a batch (rewound by the finalize kernel)
   size_t qhead_cap = 0;
+  bool qhead_dirty = false;    // a dynamic launch failed between its step and its finalize kernel: the heads were not rewound
 
   float* partials = nullptr;   // device scratch for workgroup partials
   size_t partials_bytes = 0;
@@ -673,8 +674,13 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
     ee = c->prof_pool[c->prof_used].second;
     c->prof_used++;
   }
+  if (dyn.qhead) {
+    if (c->qhead_dirty) DFX_HIP(hipMemsetAsync(c->qhead, 0, sizeof(unsigned) * c->qhead_cap, c->stream));
+    c->qhead_dirty = true;
+  }
   DFX_HIP(dfx::launch_sfm_step(cs, dd, n, (int)W, (int)H, prm, bpp, c->partials, out_items_dev, dfx_item_size(12 + cs), c->stream,
                                jac_dense, c->mfma_mode, eb, ee, n == 1 ? &one : nullptr, dyn.qhead ? &dyn : nullptr, dyn_grid));
+  c->qhead_dirty = false;   // both kernels are enqueued: the finalize kernel rewinds the heads
   if (n > 1) {
     DFX_HIP(hipEventRecord(c->slot_done[slot], c->stream));
     c->slot_busy[slot] = true;
