@@ -184,6 +184,23 @@ __device__ __forceinline__ double strided_sum_f64(const float* __restrict__ src,
   return s;
 }
 
+// Same sum, same order, for n <= STEP * MAXQ: every load of the thread is in flight at once (ONE L2 round trip instead of one per
+// batch of 8 plus one per leftover row).  Rows past n contribute +0.0, which leaves the running double sum unchanged bit for bit.
+template <int STEP, int MAXQ>
+__device__ __forceinline__ double strided_sum_f64_wide(const float* __restrict__ src, int first, int n, size_t stride) {
+  float v[MAXQ];
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) {
+    const int b = first + q * STEP;
+    const float t = src[(size_t)(b < n ? b : 0) * stride];   // unconditional load of an existing row (a conditional one is a branch + wait each)
+    v[q] = b < n ? t : 0.0f;
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) s += (double)v[q];
+  return s;
+}
+
 // 64-lane sum via shuffles (wave = 64 on gfx950)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

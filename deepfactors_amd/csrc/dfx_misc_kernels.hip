@@ -120,60 +120,97 @@ __global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__
   __shared__ double red[32][kSimpleRow];
   __shared__ double sum[kSimpleRow];
   const int e = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  double s = strided_sum_f64<32>(partials + e, rg, nblocks, kSimpleRow);
+  double s = strided_sum_f64_wide<32, 32>(partials + e, rg, nblocks, kSimpleRow);
   red[rg][e] = s;
   __syncthreads();
   if (rg == 0) {
     s = 0.0;
+#pragma unroll
     for (int q = 0; q < 32; ++q) s += red[q][e];
     sum[e] = s;
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
-  // Thread 0's small matrices live in LDS: as private arrays they are indexed dynamically, land in scratch memory and
-  // made this kernel as slow as the step kernel itself (10.5 us; rocprofv3 kernel trace of the tracker).
-  __shared__ double ws[128];
+  // Thread 0 solves.  Every loop below is fully unrolled so that the small matrices are REGISTERS (as dynamically indexed private
+  // arrays they landed in scratch memory and made this kernel as slow as the step kernel itself; as LDS arrays every dependent
+  // access paid an LDS round trip: 8.3 us for the kernel, most of a tracker iteration).
   // reference precision: the item is fp32 (JTJJrReductionItem<float,6>) before the solve (camera_tracker.cpp:59)
-  double* A = ws; double* bvec = ws + 36;
-  int k = 0;
-  for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { const double v = (double)(float)sum[k++]; A[a * 6 + b] = v; A[b * 6 + a] = v; }
-  for (int a = 0; a < 6; ++a) bvec[a] = (double)(float)sum[21 + a];
+  double A[6][6], bvec[6];
+  {
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = a; b < 6; ++b) { const double v = (double)(float)sum[k++]; A[a][b] = v; A[b][a] = v; }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) bvec[a] = (double)(float)sum[21 + a];
+  }
   st->last_residual = (float)sum[27];
   st->last_inliers = (float)sum[28];
   st->iterations_done += 1;
-  // LDL^T
-  double* L = ws + 42; double* D = ws + 78; double* yv = ws + 84; double* x = ws + 90;
+  // LDL^T (no pivoting), forward / diagonal / backward substitution
+  double L[6][6], D[6], yv[6], x[6];
   bool ok = sum[28] > 0.0;
-  for (int i = 0; i < 36; ++i) L[i] = 0.0;
-  for (int j = 0; j < 6 && ok; ++j) {
-    double d = A[j * 6 + j];
-    for (int q = 0; q < j; ++q) d -= L[j * 6 + q] * L[j * 6 + q] * D[q];
-    if (!(fabs(d) > 0.0)) { ok = false; break; }
-    D[j] = d; L[j * 6 + j] = 1.0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double d = A[j][j];
+#pragma unroll
+    for (int q = 0; q < j; ++q) d -= L[j][q] * L[j][q] * D[q];
+    ok = ok && (fabs(d) > 0.0);
+    D[j] = d;
+#pragma unroll
     for (int i = j + 1; i < 6; ++i) {
-      double v = A[i * 6 + j];
-      for (int q = 0; q < j; ++q) v -= L[i * 6 + q] * L[j * 6 + q] * D[q];
-      L[i * 6 + j] = v / d;
+      double v = A[i][j];
+#pragma unroll
+      for (int q = 0; q < j; ++q) v -= L[i][q] * L[j][q] * D[q];
+      L[i][j] = v / d;
     }
   }
   if (!ok) { st->solver_failures += 1; return; }
-  for (int i = 0; i < 6; ++i) { double v = bvec[i]; for (int q = 0; q < i; ++q) v -= L[i * 6 + q] * yv[q]; yv[i] = v; }
-  for (int i = 5; i >= 0; --i) { double v = yv[i] / D[i]; for (int q = i + 1; q < 6; ++q) v -= L[q * 6 + i] * x[q]; x[i] = v; }
-  // update = -x ; t += update[0:3] ; R = exp(update[3:6]) * R
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double v = bvec[i];
+#pragma unroll
+    for (int q = 0; q < i; ++q) v -= L[i][q] * yv[q];
+    yv[i] = v;
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double v = yv[i] / D[i];
+#pragma unroll
+    for (int q = i + 1; q < 6; ++q) v -= L[q][i] * x[q];
+    x[i] = v;
+  }
+  // update = -x ; t += update[0:3] ; R = exp(update[3:6]) * R   (lucas_kanade_se3.h:85-95)
   const double w0 = -x[3], w1 = -x[4], w2 = -x[5];
   const double th2 = w0 * w0 + w1 * w1 + w2 * w2, th = sqrt(th2);
   const double Ac = th < 1e-9 ? 1.0 - th2 / 6.0 : sin(th) / th, Bc = th < 1e-9 ? 0.5 - th2 / 24.0 : (1.0 - cos(th)) / th2;
-  double* K = ws + 96; double* E = ws + 105; double* Rn = ws + 114;
-  K[0] = 0; K[1] = -w2; K[2] = w1; K[3] = w2; K[4] = 0; K[5] = -w0; K[6] = -w1; K[7] = w0; K[8] = 0;
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
-    double k2 = 0; for (int q = 0; q < 3; ++q) k2 += K[i * 3 + q] * K[q * 3 + j];
-    E[i * 3 + j] = (i == j ? 1.0 : 0.0) + Ac * K[i * 3 + j] + Bc * k2;
-  }
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
-    double v = 0; for (int q = 0; q < 3; ++q) v += E[i * 3 + q] * st->R[q * 3 + j];
-    Rn[i * 3 + j] = v;
-  }
-  for (int i = 0; i < 9; ++i) { st->R[i] = Rn[i]; st->Rf[i] = (float)Rn[i]; }
+  const double K[3][3] = { { 0, -w2, w1 }, { w2, 0, -w0 }, { -w1, w0, 0 } };
+  double E[3][3], Rn[3][3], Ro[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      Ro[i][j] = st->R[i * 3 + j];
+      double k2 = 0;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) k2 += K[i][q] * K[q][j];
+      E[i][j] = (i == j ? 1.0 : 0.0) + Ac * K[i][j] + Bc * k2;
+    }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double v = 0;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) v += E[i][q] * Ro[q][j];
+      Rn[i][j] = v;
+    }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { st->R[i * 3 + j] = Rn[i][j]; st->Rf[i * 3 + j] = (float)Rn[i][j]; }
+#pragma unroll
   for (int i = 0; i < 3; ++i) { st->t[i] -= x[i]; st->tf[i] = (float)st->t[i]; }
 }
 
@@ -372,7 +409,8 @@ __global__ __launch_bounds__(1024) void k_finalize_rows(const float* __restrict_
                                                         char* __restrict__ out) {
   __shared__ double red[32][kSimpleRow];
   const int e = threadIdx.x & 31, rg = threadIdx.x >> 5;   // 32 row groups
-  double s = strided_sum_f64<32>(partials + e, rg, nblocks, kSimpleRow);
+  static_assert(kMaxSimpleBlocks <= 32 * 32, "one load per row group and thread");
+  double s = strided_sum_f64_wide<32, 32>(partials + e, rg, nblocks, kSimpleRow);
   red[rg][e] = s;
   __syncthreads();
   if (rg != 0) return;
