@@ -167,20 +167,30 @@ __device__ __forceinline__ void pose_row(const Geo& g, const Corr& c, float d, f
 extern "C" __device__ float dfx_llvm_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");
 __device__ __forceinline__ float mul_zero_wins(float a, float b) { return dfx_llvm_fmul_legacy(a, b); }
 
-// sum_{b = first, first+STEP, ... < n} src[b * stride] in double, in that fixed order, with 8 loads in flight (a plain loop
+// sum_{b = first, first+STEP, ... < n} src[b * stride] in double, in that fixed order, with DEPTH loads in flight (a plain loop
 // pays one L2 round trip per element: 9.7 us for 1024 partial rows).
-template <int STEP>
+template <int STEP, int DEPTH = 8>
 __device__ __forceinline__ double strided_sum_f64(const float* __restrict__ src, int first, int n, size_t stride) {
   double s = 0.0;
   int b = first;
-  for (; b + 7 * STEP < n; b += 8 * STEP) {
-    float v[8];
+  for (; b + (DEPTH - 1) * STEP < n; b += DEPTH * STEP) {
+    float v[DEPTH];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = src[(size_t)(b + q * STEP) * stride];
+    for (int q = 0; q < DEPTH; ++q) v[q] = src[(size_t)(b + q * STEP) * stride];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) s += (double)v[q];
+    for (int q = 0; q < DEPTH; ++q) s += (double)v[q];
   }
-  for (; b < n; b += STEP) s += (double)src[(size_t)b * stride];
+  if (b < n) {   // leftover rows: again all in flight (unconditional loads of existing rows, +0.0 for the rows past n)
+    float v[DEPTH];
+#pragma unroll
+    for (int q = 0; q < DEPTH; ++q) {
+      const int r = b + q * STEP;
+      const float t = src[(size_t)(r < n ? r : b) * stride];
+      v[q] = r < n ? t : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < DEPTH; ++q) s += (double)v[q];
+  }
   return s;
 }
 

@@ -654,7 +654,7 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
   const int el = threadIdx.x & 255, rg = threadIdx.x >> 8;
   if (qhead && blk == 0 && threadIdx.x == 0) qhead[pair] = 0u;   // dynamic schedule: the pair's item queue is rewound for the next launch
   const float* src = partials + (size_t)pair * bpp * ZDIM + blk * 256 + el;
-  red[rg][el] = strided_sum_f64<4>(src, rg, bpp, ZDIM);
+  red[rg][el] = strided_sum_f64<4, 16>(src, rg, bpp, ZDIM);   // a single pair has 240 partials: 60 rows per group = 4 round trips
   if (NPOSE == 12 && threadIdx.x < 72) {
     const int n = threadIdx.x / 6, i = threadIdx.x - n * 6;
     const float* M = BYVAL ? one.M : pairs[pair].M;
