@@ -157,7 +157,7 @@ def pmc_traffic(a):
 
 
 def secondary_configs(dfx, synth, ctx, dev):
-    """configs[1] as the reference calls it (ONE pair per blocking call, photometric_factor.cpp:267-274) and configs[4]
+    """configs[1] as the reference calls it (ONE pair per blocking call, photometric_factor.cpp:267-274), its 3-level pyramid variant, configs[4]
     (1280x960, 64-code; 16 pairs per launch, 5.5 GB working set)."""
     import torch
     out = {}
@@ -178,6 +178,25 @@ def secondary_configs(dfx, synth, ctx, dev):
     out["configs1_single_pair_blocking"] = dict(call_us=dt * 1e6, kernel_us=ms / n * 1e3, evals_per_s=1.0 / dt,
                                                 note="one 640x480 cs=32 pair per blocking SfmAligner::RunStep call (46 MB: Infinity-Cache resident, not an HBM figure)")
     del p
+    # ---- SURVEY 8d "all pyramid levels" variant: the 128-pair batch at levels 0, 1, 2 (640x480, 320x240, 160x120), one launch per level
+    lv_us = []
+    for (w, h) in ((640, 480), (320, 240), (160, 120)):
+        pairs, keep = build_pairs(dfx, synth, dev, 3, 128, w, h, 32)
+        arr = al.make_pairs(pairs)
+        items = torch.zeros(128 * dfx.item_size(12 + 32), dtype=torch.uint8, device=dev)
+        for _ in range(300 if w == 640 else 1500):
+            al.RunStepBatchAsync(arr, items)
+        ctx.sync()
+        ctx.set_profiling(True)
+        for _ in range(30):
+            al.RunStepBatchAsync(arr, items)
+        n, ms = ctx.profile_read()
+        ctx.set_profiling(False)
+        lv_us.append(ms / n * 1e3)
+        del pairs, keep, arr, items
+    tot = sum(lv_us) * 1e-6
+    out["configs1_pyramid3_128pairs"] = dict(level_kernel_us=lv_us, evals_per_s=128 / tot, algorithmic_gbs=148 * (640 * 480 + 320 * 240 + 160 * 120) * 128 / tot / 1e9,
+                                             note="SfmAligner::RunStep over levels 0-2 of 128 pairs (one launch per level, step kernels only): one 'evaluation' = all three levels")
     # ---- configs[4]: 1280x960, cs = 64
     W, H, CS, P = 1280, 960, 64, 16
     al4 = dfx.SfmAligner(code_size=CS, ctx=ctx)
@@ -343,11 +362,25 @@ def main():
 
     # setup, untimed and not part of the W warm-up steps: after idle the GPU needs ~0.15 s of sustained work to reach its steady clocks
     # (tools/clock_series.py, 128-pair steps: launches 0-49 average 1287 us, 50-99 1144 us, from 100 on 1065 +- 5 us for thousands
-    # of launches), so ~0.45 s of the same steps run before anything is counted; the count is fixed so that all ranks agree
-    ramp_steps = max(100, 51200 // max(P, 1))
-    for _ in range(ramp_steps):
-        step()
-    barrier()
+    # of launches) and some boxes take longer, so the same steps run in windows until the step kernel's time has settled: three
+    # consecutive windows within 1 %, at least 6 windows (~0.35 s), at most 40 (~2.3 s).  All ranks leave the loop together.
+    win = max(25, 6400 // max(P, 1))
+    ramp_steps, hist = 0, []
+    ctx.set_profiling(True)
+    for w_i in range(40):
+        for _ in range(win):
+            step()
+        barrier()
+        n_w, ms_w = ctx.profile_read()
+        hist.append(ms_w / max(n_w, 1))
+        ramp_steps += win
+        settled = w_i >= 5 and max(hist[-3:]) <= 1.01 * min(hist[-3:])
+        go_on = torch.tensor([0 if settled else 1], dtype=torch.int32, device=dev)
+        if dist is not None:
+            dist.all_reduce(go_on, op=dist.ReduceOp.MAX)
+        if int(go_on.item()) == 0:
+            break
+    ctx.set_profiling(False)
     for _ in range(a.warmup):
         step()
     barrier()
@@ -394,6 +427,7 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ramp_steps": ramp_steps,
+            "ramp_kernel_us": [round(h * 1e3, 1) for h in hist],
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
