@@ -57,8 +57,8 @@ def parse():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child run (roofline.traffic = null)")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary configs[1] / configs[4] measurements")
     ap.add_argument("--window", action="store_true", help="also measure BASELINE configs[3]: 64 keyframes, 1024 pairs over the ranks")
-    ap.add_argument("--schedule", choices=["auto", "static"], default="auto",
-                    help="auto: dynamic item queues for large batches (default of the library); static: the bit-reproducible static partition")
+    ap.add_argument("--schedule", choices=["auto", "static", "dynamic"], default="auto",
+                    help="auto / static: the library's default, the bit-reproducible static partition; dynamic: per-pair item queues (opt-in)")
     ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -328,9 +328,9 @@ def main():
 
     W, H, CS, P = a.width, a.height, a.cs, a.pairs
     ctx = dfx.Context(local)
-    if a.schedule == "static":
+    if a.schedule != "auto":
         from deepfactors_amd import _lib as _dl
-        ctx.set_schedule(_dl.DFX_SCHEDULE_STATIC)
+        ctx.set_schedule(_dl.DFX_SCHEDULE_STATIC if a.schedule == "static" else _dl.DFX_SCHEDULE_DYNAMIC)
     al = dfx.SfmAligner(dfx.SfmAlignerParams(step_blocks=a.step_blocks), code_size=CS, ctx=ctx)
 
     # ---- synthetic, device-resident input: P distinct keyframe->frame pairs per rank

@@ -155,8 +155,8 @@ class Context:
         check(_lib.lib().dfx_set_mfma_mode(self._h, int(mode)))
 
     def set_schedule(self, mode):
-        """_lib.DFX_SCHEDULE_AUTO (dynamic item queues for large batches) or _lib.DFX_SCHEDULE_STATIC (always the static,
-        bit-reproducible partition); see include/dfx.h."""
+        """_lib.DFX_SCHEDULE_AUTO / DFX_SCHEDULE_STATIC (the static, bit-reproducible partition; the default) or
+        DFX_SCHEDULE_DYNAMIC (opt-in per-pair item queues for batches of >= 128 pairs); see include/dfx.h."""
         check(_lib.lib().dfx_set_schedule(self._h, int(mode)))
 
     def last_schedule_dynamic(self):

@@ -618,20 +618,20 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
   // the dense-stream variant needs every pair's Jacobian rows back to back; one pitched pair selects the general kernel
   bool jac_dense = true;
   for (int p = 0; p < n; ++p) jac_dense = jac_dense && (hd[p].pitch_jac == W * (uint32_t)cs * 4u);
-  // Dynamic schedule (k_sfm_step<..., DYN>): resident wave-workers popping items from per-pair queues.  It needs 64-pixel columns
-  // (W % 64 == 0), dense Jacobian rows and the per-wave ray tables beside the P rows in LDS, and it pays only when a pair's team is
-  // small: the queue heads are device-scope atomics (served memory-side, across the 8 XCDs' L2s: ~0.2 us each, serialised per
-  // word), so a 256-wave team on 16 pairs spends its time queueing for pops (measured 515 vs 151 us; 64 pairs 647 vs 558 us),
-  // a 32-wave team on 128 pairs does not (1106 vs 1122 us).  Hence teams of at most 32 waves, i.e. >= 16 * CUs / 32 pairs.  An
-  // explicit launch shape (step_blocks) or DFX_SCHEDULE_STATIC keeps the static, bit-reproducible launch.
+  // Dynamic schedule (k_sfm_step<..., DYN>, opt-in: DFX_SCHEDULE_DYNAMIC): resident wave-workers popping items from per-pair queues.
+  // It needs 64-pixel columns (W % 64 == 0), dense Jacobian rows and the per-wave ray tables beside the P rows in LDS.  Measured
+  // against the static launch on the same box, 128 pairs: -1.2 ... -1.5 % on four boxes, +-0 on one, +4.5 % on two -- its gain
+  // depends on the box, so it is not the default.  The queue heads are device-scope atomics (served memory-side, across the 8 XCDs'
+  // L2s: ~0.2 us each, serialised per word): teams of more than 32 waves (fewer than 128 pairs) spend their time queueing for pops
+  // (16 pairs: 515 vs 151 us; 64 pairs: 647 vs 558 us).
   dfx::DynDev dyn{ nullptr, 0, 0, 0, 0, 0u };
   int dyn_grid = 0;
   {
     const int resident_wgs = 4 * c->cu_count;
     const int team = n > 0 ? (4 * resident_wgs) / n : 0;
     const size_t dyn_lds = sizeof(float) * 4 * ((size_t)W + H + dfx::kRayTabSlack + 16 * 68);
-    const bool team_ok = c->schedule == DFX_SCHEDULE_DYNAMIC ? (team >= 1 && team <= 1024) : (team >= 1 && team <= 32);
-    if (c->schedule != DFX_SCHEDULE_STATIC && params->step_blocks == 0 && c->step_blocks == 0 && team_ok && jac_dense && W % 64 == 0 &&
+    const bool team_ok = team >= 1 && team <= 1024;
+    if (c->schedule == DFX_SCHEDULE_DYNAMIC && params->step_blocks == 0 && c->step_blocks == 0 && team_ok && jac_dense && W % 64 == 0 &&
         W / 64 <= 64 && dyn_lds <= 40 * 1024 && (size_t)W * H < (1u << 26)) {
       const int vs = (int)(W / 64);
       int R = (int)(((long long)H * vs) / ((long long)team * 24));

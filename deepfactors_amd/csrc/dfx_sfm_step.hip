@@ -162,8 +162,10 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // DYN: wave -> (pair, team member); surplus waves (team * #pairs < waves of the grid) retire at once
   const int dyn_gid = DYN ? (int)blockIdx.x * kWaves + wave : 0;
-  const int dyn_pair = DYN ? dyn_gid % dyn.npairs : 0;
+  // member row m = gid / #pairs serves the pairs rotated by 4 m: workgroup b runs on XCD b mod 8, and without the rotation all
+  // members of a pair (b = const mod 32 at 128 pairs) would sit on ONE XCD -- nothing would balance the XCDs against each other
   const int dyn_member = DYN ? dyn_gid / dyn.npairs : 0;
+  const int dyn_pair = DYN ? (dyn_gid - dyn_member * dyn.npairs + 4 * dyn_member) % dyn.npairs : 0;
   if (DYN && dyn_member >= dyn.team) return;
   const SfmPairDev& P = BYVAL ? one : pairs[DYN ? dyn_pair : (int)blockIdx.y];
 

@@ -130,14 +130,14 @@ DFX_API int dfx_device_cu_count(dfx_ctx* ctx);
 #define DFX_MFMA_BF16X3 1
 DFX_API int dfx_set_mfma_mode(dfx_ctx* ctx, int mode);
 /* Launch schedule of the batched SfM step (no reference counterpart: the reference has one fixed 11 x 32 grid, cu_sfmaligner.cpp:60).
- *  DFX_SCHEDULE_AUTO     (default) batches large enough that a pair is served by at most 32 waves (>= 16 * CUs / 32 = 128 pairs on an
- *                        MI355X; W % 64 == 0, unpadded Jacobian rows, no explicit step_blocks) run on resident wave-workers that pop
- *                        work items from per-pair queues: no slots idle behind the hardware's uneven wave progress (+1.5 % at 128
- *                        pairs).  Which items a wave sums is decided at run time, so results are reproducible to fp32
- *                        re-association (~1e-7 relative), not bit for bit.  Everything else takes the static launch.
- *  DFX_SCHEDULE_STATIC   always the static partition: bit-reproducible for a given launch shape, like the reference's fixed grid.
- *  DFX_SCHEDULE_DYNAMIC  the queues whenever the launch is structurally able to (any team size): for tests and tuning; with few
- *                        pairs the queue heads are contended and it is up to 3x SLOWER than the static launch.
+ *  DFX_SCHEDULE_AUTO     (default) the library's choice -- today always the static partition.
+ *  DFX_SCHEDULE_STATIC   the static partition: bit-reproducible for a given launch shape, like the reference's fixed grid.
+ *  DFX_SCHEDULE_DYNAMIC  opt-in: whenever the launch is structurally able to (W % 64 == 0, unpadded Jacobian rows, no explicit
+ *                        step_blocks) the batch runs on resident wave-workers that pop work items from per-pair queues, so no slot
+ *                        idles behind the hardware's uneven wave progress.  Which items a wave sums is decided at run time: results
+ *                        are reproducible to fp32 re-association (~1e-7 relative), not bit for bit.  Worth trying for >= 128 pairs
+ *                        (a pair's team is then <= 32 waves): -1.5 % to +4.5 % kernel time depending on the box; with fewer pairs the
+ *                        queue heads are contended and it is up to 3x SLOWER than the static launch.
  * dfx_last_schedule: *dynamic = 1 when the context's last batched SfM step ran on the queues. */
 #define DFX_SCHEDULE_AUTO 0
 #define DFX_SCHEDULE_STATIC 1
