@@ -131,16 +131,17 @@ __device__ __forceinline__ float dpp_merge(float old, float src) {
 // BYVAL: a single pair travels in the kernel arguments (`one`) instead of a descriptor array in device memory -- the reference's call
 // pattern is one pair per blocking call, and the staged host-to-device copy of a 200-byte descriptor cost more than the launch.
 //
-// DYN (large batches, W % 64 == 0, dense Jacobian rows): the waves are independent workers.  The grid is sized to be resident at once;
-// wave g serves pair g mod #pairs as member g / #pairs of that pair's team and pops ITEMS (one 64-pixel column x `rows_per_item`
-// image rows, walked downwards) from the pair's queue with a scalar atomic until the queue is empty; its accumulators live in
-// registers across all its items and are written ONCE, straight to global memory (no cross-wave fold, no barrier anywhere).
+// DYN (opt-in, dfx_set_schedule(ctx, DFX_SCHEDULE_DYNAMIC); W % 64 == 0, dense Jacobian rows): the waves are independent workers.  The
+// grid is sized to be resident at once; wave g is member g / #pairs of one pair's team and pops ITEMS (one 64-pixel column x
+// `rows_per_item` image rows, walked downwards) from the pair's queue with a scalar atomic until the queue is empty; its accumulators
+// live in registers across all its items and are written ONCE, straight to global memory (no cross-wave fold, no barrier anywhere).
 // Why: the four waves of a SIMD progress at very different rates (oldest-first arbitration: the same 150 chunks take one wave
 // 520 us and another 1080 us), so any static split leaves slots idle -- a static single round measured 30 % idle slot-time, the
 // multi-round launch 19 % (dispatch gaps, prologues, the barrier in front of the fold).  With the queue every slot streams until
-// the pair's work is gone.  The price: which items a wave sums is decided at run time, so results are reproducible to fp32
-// re-association (1e-7 relative), not bit for bit; dfx_set_schedule(ctx, DFX_SCHEDULE_STATIC) restores the static, bit-reproducible
-// launch.  Teams mix the dispatch ages (members g, g + #pairs, ...), so no pair is served by only old or only young waves.
+// the pair's work is gone (3.5 - 7 % idle).  What it buys is small, though -- HBM and the issue pipe are the limiters, not the slots:
+// -1.5 % kernel time on most boxes, +4.5 % on some, which is why the static launch is the default.  The
+// price: which items a wave sums is decided at run time, so results are reproducible to fp32 re-association (1e-7 relative), not
+// bit for bit.  Teams mix the dispatch ages (members g, g + #pairs, ...) and are rotated across the XCDs.
 template <int NCB, int MODE, bool JDENSE, bool TABLDS, bool BYVAL, bool DYN>
 __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_WAVES) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmPairDev one, const SfmParamsDev prm,
                                                        const int W, const int H, float* __restrict__ partials, const DynDev dyn) {
