@@ -133,6 +133,12 @@ def relative_pose(a_qt, b_qt):
     return out, ja.reshape(6, 6), jb.reshape(6, 6)
 
 
+def camera_pyramid(cam, levels):
+    out = np.zeros(levels * 6, np.float32)
+    lib().ref_camera_pyramid_f32(_p(_f32(cam)), int(levels), _p(out))
+    return out.reshape(levels, 6)
+
+
 def huber_weight(x, delta):
     return float(lib().ref_huber_weight_f32(x, delta))
 

@@ -23,6 +23,8 @@
 
 #include "dense_sfm.h"
 #include "lucas_kanade_se3.h"
+#include <ostream>
+#include "camera_pyramid.h"
 
 #define REF_API extern "C" __attribute__((visibility("default")))
 
@@ -189,8 +191,18 @@ REF_API void ref_relative_pose_f32(const float* a_qt, const float* b_qt, float* 
   for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { jac_a36[r * 6 + c] = Ja(r, c); jac_b36[r * 6 + c] = Jb(r, c); }
 }
 
+// CameraPyramid (camera_pyramid.h:35-48): out = levels x (fx, fy, u0, v0, w, h)
+REF_API void ref_camera_pyramid_f32(const float* cam6, int levels, float* out) {
+  const df::PinholeCamera<float> cam(cam6[0], cam6[1], cam6[2], cam6[3], cam6[4], cam6[5]);
+  const df::CameraPyramid<float> pyr(cam, (std::size_t)levels);
+  for (int i = 0; i < levels; ++i) {
+    out[i * 6 + 0] = pyr[i].fx(); out[i * 6 + 1] = pyr[i].fy(); out[i * 6 + 2] = pyr[i].u0(); out[i * 6 + 3] = pyr[i].v0();
+    out[i * 6 + 4] = pyr[i].width(); out[i * 6 + 5] = pyr[i].height();
+  }
+}
+
 REF_API float ref_huber_weight_f32(float x, float delta) { return df::HuberWeight(x, delta); }
 REF_API float ref_depth_jacobian_prx_f32(float d, float a) { return df::DepthJacobianPrx(d, a); }
 REF_API const char* ref_sources() {
-  return "sources/common/algorithm/{warping,dense_sfm,lucas_kanade_se3,pinhole_camera,pinhole_camera_impl,m_estimators}.h + sources/cuda/{reduction_items,kernel_utils}.h, unmodified";
+  return "sources/common/algorithm/{warping,dense_sfm,lucas_kanade_se3,pinhole_camera,pinhole_camera_impl,m_estimators,camera_pyramid}.h + sources/cuda/{reduction_items,kernel_utils}.h, unmodified";
 }

@@ -152,3 +152,19 @@ def test_relative_pose_and_small_math(oracle, refl):
     assert refl.huber_weight(0.05, 0.1) == 1.0 and abs(refl.huber_weight(0.4, 0.1) - np.sqrt(0.1 * (0.8 - 0.1)) / 0.4) < 1e-6   # abs() is the float overload
     for d in (0.5, 2.0, 7.5):
         assert abs(refl.depth_jacobian_prx(d, 2.0) - oracle.depth_jacobian_prx(d, 2.0, dtype=np.float32)) <= 1e-5 * abs(oracle.depth_jacobian_prx(d, 2.0))
+
+
+def test_camera_pyramid_matches_the_reference_code():
+    """CameraPyramid (camera_pyramid.h:35-48: every level is the ORIGINAL camera resized to the integer-halved size of the level above)
+    against synth.camera_pyramid (level by level): identical for even sizes (the ratios are powers of two), within one float ulp of the
+    intrinsics for sizes that halve with a remainder."""
+    from deepfactors_amd import synth
+    for cam, levels in ((synth.scenenet_cam(640, 480), 4), (synth.scenenet_cam(1280, 960), 4), (synth.scenenet_cam(320, 240), 3)):
+        want = ref.camera_pyramid(cam, levels)
+        got = np.stack(synth.camera_pyramid(cam, levels))
+        assert np.array_equal(got, want), (got, want)
+    odd = np.array([100.0, 98.5, 50.5, 37.25, 101, 75], np.float32)
+    want = ref.camera_pyramid(odd, 3)
+    got = np.stack(synth.camera_pyramid(odd, 3))
+    assert np.array_equal(got[:, 4:], want[:, 4:]) and list(want[:, 4]) == [101, 50, 25] and list(want[:, 5]) == [75, 37, 18]
+    assert np.allclose(got[:, :4], want[:, :4], rtol=2.5e-7, atol=0)
