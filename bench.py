@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary configs[1] / configs[4] measurements")
     ap.add_argument("--window", action="store_true", help="also measure BASELINE configs[3]: 64 keyframes, 1024 pairs over the ranks")
     ap.add_argument("--schedule", choices=["auto", "static", "dynamic"], default="auto",
-                    help="auto / static: the library's default, the bit-reproducible static partition; dynamic: per-pair item queues (opt-in)")
+                    help="auto: measure the library's static default and its opt-in dynamic item queues during the untimed ramp and run the faster; static / dynamic: force one")
     ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -329,8 +329,8 @@ def main():
     W, H, CS, P = a.width, a.height, a.cs, a.pairs
     ctx = dfx.Context(local)
     if a.schedule != "auto":
-        from deepfactors_amd import _lib as _dl
-        ctx.set_schedule(_dl.DFX_SCHEDULE_STATIC if a.schedule == "static" else _dl.DFX_SCHEDULE_DYNAMIC)
+        from deepfactors_amd import _lib as _dl0
+        ctx.set_schedule(_dl0.DFX_SCHEDULE_STATIC if a.schedule == "static" else _dl0.DFX_SCHEDULE_DYNAMIC)
     al = dfx.SfmAligner(dfx.SfmAlignerParams(step_blocks=a.step_blocks), code_size=CS, ctx=ctx)
 
     # ---- synthetic, device-resident input: P distinct keyframe->frame pairs per rank
@@ -380,6 +380,35 @@ def main():
             dist.all_reduce(go_on, op=dist.ReduceOp.MAX)
         if int(go_on.item()) == 0:
             break
+    # Schedule choice (--schedule auto only, still untimed): the library's default is the static, bit-reproducible launch; its opt-in
+    # dynamic item queues are 1.5-2.3 % faster on most boxes and 4.5 % slower on some, so two windows of each are
+    # measured here, on this box, and the faster one runs the warm-up and the timed steps.  The choice and both figures are reported.
+    from deepfactors_amd import _lib as _dl
+    sched_probe = None
+    if a.schedule == "auto":
+        def window_us(mode):
+            ctx.set_schedule(mode)
+            for _ in range(win):
+                step()
+            barrier()
+            ctx.profile_read()
+            for _ in range(2 * win):
+                step()
+            barrier()
+            n_w, ms_w = ctx.profile_read()
+            return ms_w / max(n_w, 1) * 1e3
+        us_dyn = window_us(_dl.DFX_SCHEDULE_DYNAMIC)
+        ran_dyn = ctx.last_schedule_dynamic()          # the launch may be structurally unable to (then both windows were static)
+        us_sta = window_us(_dl.DFX_SCHEDULE_STATIC)
+        ramp_steps += 6 * win
+        keep_static = torch.tensor([0 if (ran_dyn and us_dyn < 0.995 * us_sta) else 1], dtype=torch.int32, device=dev)
+        if dist is not None:
+            dist.all_reduce(keep_static, op=dist.ReduceOp.MAX)   # every rank runs the same schedule
+        use_dyn = int(keep_static.item()) == 0
+        ctx.set_schedule(_dl.DFX_SCHEDULE_DYNAMIC if use_dyn else _dl.DFX_SCHEDULE_STATIC)
+        a.schedule = "dynamic" if use_dyn else "static"          # the PMC child run below measures the same kernel
+        sched_probe = {"static_kernel_us": round(us_sta, 1), "dynamic_kernel_us": round(us_dyn, 1) if ran_dyn else None,
+                       "chosen": "dynamic" if use_dyn else "static"}
     ctx.set_profiling(False)
     for _ in range(a.warmup):
         step()
@@ -428,6 +457,7 @@ def main():
             "warmup": a.warmup,
             "ramp_steps": ramp_steps,
             "ramp_kernel_us": [round(h * 1e3, 1) for h in hist],
+            "schedule_probe": sched_probe,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
@@ -446,6 +476,7 @@ def main():
                          "schedule": "dynamic item queues (results reproducible to fp32 re-association)" if ctx.last_schedule_dynamic()
                                      else "static partition (bit-reproducible)"},
         }
+    ctx.set_schedule(_dl.DFX_SCHEDULE_AUTO)   # the secondary measurements below run the library's defaults
     configs = {}
     if world == 1 and not a.no_configs:
         configs.update(secondary_configs(dfx, synth, ctx, dev))
