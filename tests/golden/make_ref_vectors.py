@@ -1,0 +1,68 @@
+"""Generates tests/golden/ref_vectors.npz: inputs AND the outputs of the REFERENCE'S OWN per-pixel code on them.
+
+Run in the build container only (needs /root/reference to build oracle/_ref):
+    python tests/golden/make_ref_vectors.py
+
+The outputs come from oracle/_ref/libdfx_ref.so, i.e. the reference's unmodified headers
+    sources/common/algorithm/{warping,dense_sfm,lucas_kanade_se3,pinhole_camera_impl,m_estimators}.h
+driven by oracle/ref_harness.cpp the way tests/ut_sfmaligner.cpp:299-315 (host loop over DenseSfm) and
+tests/ut_se3aligner.cpp:173-211 drive them.  They are the committed known-answer vectors for
+    SfmAligner::RunStep   (cu_sfmaligner.cpp:149-185)    -> sfm_{JtJ,Jtr,residual,inliers,valid0}
+    SfmAligner::EvaluateError (cu_sfmaligner.cpp:120-147) -> err_{residual,inliers}
+    SE3Aligner::RunStep   (cu_se3aligner.cpp:153-176)     -> se3_{JtJ,Jtr,residual,inliers}
+    UpdateDepth           (cu_image_proc.cpp:248-277)     -> dpt
+    RelativePose          (warping.h:98-137)              -> rel_{pose,J_a,J_b}
+so that the oracle (CPU tests) and the HIP path (GPU tests) stay pinned to reference-derived numbers even where the
+prebuilt oracle/_ref library is absent (it is git-ignored; /root/reference does not exist on the GPU box).
+
+The inputs are stored too (float32, small sizes): deepfactors_amd.synth evaluates its fields with torch, whose
+transcendental functions may differ in the last bit between builds, and a known-answer test must not depend on that.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(HERE, "ref_vectors.npz")
+
+# (name, w, h, cs, seed, huber_delta, motion_scale): two code sizes (NCB = 2 and 4 of the step kernel), odd huber / motion on the second
+CASES = [("a", 64, 40, 32, 0x601D, 0.1, 1.0),
+         ("b", 64, 24, 64, 0x601E, 0.05, 0.6)]
+
+
+def main():
+    from deepfactors_amd import synth
+    from oracle import dfx_ref as ref
+    if not os.path.isdir(os.path.join(ref.REFERENCE, "sources")):
+        sys.exit("reference tree not present; the vectors can only be regenerated in the build container")
+    ref.build()
+    out = {"sources": np.frombuffer(ref.lib().ref_sources(), dtype=np.uint8)}
+    for name, w, h, cs, seed, huber, motion in CASES:
+        n = synth.to_numpy(synth.make_pair(w, h, cs, seed=seed, device="cpu", motion_scale=motion))
+        pose1 = n["pose1"].copy()
+        pose1[4] += 0.01                     # off the minimum, so Jtr is not ~0
+        valid0 = np.zeros((h, w), np.float32)
+        s = ref.sfm_step(n["pose0"], pose1, n["cam"], n["img0"], n["img1"], n["dpt0"], n["prx_jac"], n["grad1"], huber_delta=huber, valid0=valid0)
+        e_res, e_inl = ref.sfm_error(n["pose0"], pose1, n["cam"], n["img0"], n["img1"], n["dpt0"], n["grad1"], huber)
+        rel, ja, jb = ref.relative_pose(pose1, n["pose0"])
+        k = ref.se3_step(rel, n["cam"], n["img0"], n["img1"], n["dpt0"], n["grad1"], huber)
+        dpt = ref.update_depth(n["code"], n["prx_orig"], n["prx_jac"], 2.0)
+        assert s.inliers > 0.5 * w * h and k.inliers > 0.5 * w * h
+        for key in ("cam", "pose0", "code", "img0", "img1", "dpt0", "grad1", "prx_orig", "prx_jac"):
+            out[f"{name}_{key}"] = np.asarray(n[key], np.float32)
+        out.update({f"{name}_pose1": pose1.astype(np.float32), f"{name}_huber": np.float32(huber), f"{name}_cs": np.int32(cs),
+                    f"{name}_sfm_JtJ": s.JtJ, f"{name}_sfm_Jtr": s.Jtr, f"{name}_sfm_residual": np.float64(s.residual), f"{name}_sfm_inliers": np.int64(s.inliers),
+                    f"{name}_sfm_valid0": valid0.astype(np.uint8),
+                    f"{name}_err_residual": np.float64(e_res), f"{name}_err_inliers": np.int64(e_inl),
+                    f"{name}_rel_pose": rel, f"{name}_rel_Ja": ja, f"{name}_rel_Jb": jb,
+                    f"{name}_se3_JtJ": k.JtJ, f"{name}_se3_Jtr": k.Jtr, f"{name}_se3_residual": np.float64(k.residual), f"{name}_se3_inliers": np.int64(k.inliers),
+                    f"{name}_dpt": dpt})
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,82 @@
+"""Known-answer vectors produced by the REFERENCE'S OWN code (tests/golden/ref_vectors.npz, made by tests/golden/make_ref_vectors.py
+from oracle/_ref = the reference's unmodified warping.h / dense_sfm.h / lucas_kanade_se3.h / pinhole_camera_impl.h / m_estimators.h):
+inputs and outputs are both in the file, so these tests need neither /root/reference nor the prebuilt oracle/_ref library.
+
+CPU (not gpu): the oracle reproduces them (the oracle's pin).  GPU: the HIP path through the C ABI reproduces them, at the
+stated tolerance of tests/helpers.py (1e-4 of max|JtJ|; the reference's own GPU-vs-CPU bar is 1e-1 absolute, ut_sfmaligner.cpp:320-326)."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+from helpers import assert_item_close
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_vectors.npz")
+CASES = ["a", "b"]
+
+
+@pytest.fixture(scope="module")
+def gold():
+    z = np.load(GOLD)
+    return {k: z[k] for k in z.files}
+
+
+def _case(gold, name):
+    g = {k[len(name) + 1:]: v for k, v in gold.items() if k.startswith(name + "_")}
+    h, w = g["img0"].shape
+    return g, w, h, int(g["cs"]), float(g["huber"])
+
+
+def _item(g, prefix):
+    return types.SimpleNamespace(JtJ=g[prefix + "_JtJ"], Jtr=g[prefix + "_Jtr"], residual=float(g[prefix + "_residual"]), inliers=int(g[prefix + "_inliers"]))
+
+
+def test_vectors_come_from_the_reference_headers(gold):
+    src = bytes(gold["sources"]).decode()
+    assert "dense_sfm" in src and "lucas_kanade_se3" in src and "warping" in src and "unmodified" in src
+    for name in CASES:
+        g, w, h, cs, _ = _case(gold, name)
+        assert g["prx_jac"].shape == (h, w * cs) and g["sfm_JtJ"].shape == ((12 + cs) * (13 + cs) // 2,)
+        assert g["sfm_inliers"] > 0.5 * w * h and g["sfm_valid0"].sum() == g["sfm_inliers"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_the_reference_vectors(oracle, gold, name):
+    g, w, h, cs, huber = _case(gold, name)
+    v = np.zeros((h, w), np.float32)
+    got = oracle.sfm_step(g["pose0"], g["pose1"], g["cam"], g["img0"], g["img1"], g["dpt0"], g["prx_jac"], g["grad1"], huber_delta=huber, valid0=v,
+                          accum_f64=True)
+    assert_item_close(got, _item(g, "sfm"), w, h, rel=2e-5, what=f"oracle sfm_step vs reference vectors ({name})")
+    assert got.inliers == int(g["sfm_inliers"]) and np.array_equal(v.astype(np.uint8), g["sfm_valid0"])
+    e_res, e_inl = oracle.sfm_error(g["pose0"], g["pose1"], g["cam"], g["img0"], g["img1"], g["dpt0"], huber_delta=huber)
+    assert e_inl == int(g["err_inliers"]) and abs(e_res - float(g["err_residual"])) <= 2e-5 * float(g["err_residual"])
+    R, t, ja, jb = oracle.relative_pose(g["pose1"], g["pose0"])          # RelativePose(pose1, pose0, J1, J0), cu_sfmaligner.cpp:166
+    assert np.abs(R - oracle.quat_to_R(g["rel_pose"][:4])).max() <= 1e-6 and np.abs(t - g["rel_pose"][4:]).max() <= 1e-6
+    assert np.abs(ja - g["rel_Ja"]).max() <= 1e-6 and np.abs(jb - g["rel_Jb"]).max() <= 1e-6
+    k = oracle.se3_step(g["rel_pose"], g["cam"], g["img0"], g["img1"], g["dpt0"], g["grad1"], huber)
+    assert_item_close(k, _item(g, "se3"), w, h, rel=2e-5, what=f"oracle se3_step vs reference vectors ({name})")
+    d = oracle.update_depth(g["code"], g["prx_orig"], g["prx_jac"], 2.0)
+    assert np.abs(d - g["dpt"]).max() <= 2e-6 * float(((2.0 + g["dpt"]) ** 2 / 2.0).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_path_reproduces_the_reference_vectors(dfx, gold, name):
+    import torch
+    g, w, h, cs, huber = _case(gold, name)
+    dev = {k: torch.from_numpy(np.ascontiguousarray(g[k])).cuda() for k in ("img0", "img1", "dpt0", "grad1", "prx_orig", "prx_jac")}
+    al = dfx.SfmAligner(dfx.SfmAlignerParams(dfx.DenseSfmParams(huber_delta=huber)), code_size=cs)
+    valid = torch.zeros((h, w), dtype=torch.float32, device="cuda")
+    got = al.RunStep(g["pose0"], g["pose1"], g["code"], g["cam"], dev["img0"], dev["img1"], dev["dpt0"], None, valid, dev["prx_jac"], dev["grad1"])
+    assert_item_close(got, _item(g, "sfm"), w, h, what=f"HIP sfm_step vs reference vectors ({name})")
+    assert int((valid.cpu().numpy().astype(np.uint8) != g["sfm_valid0"]).sum()) <= 1
+    e = al.EvaluateError(g["pose0"], g["pose1"], g["cam"], dev["img0"], dev["img1"], dev["dpt0"], None, dev["grad1"])
+    assert abs(int(e.inliers) - int(g["err_inliers"])) <= 1 and abs(e.residual - float(g["err_residual"])) <= 1e-4 * float(g["err_residual"])
+    se3 = dfx.SE3Aligner()
+    se3.SetHuberDelta(huber)
+    k = se3.RunStep(g["rel_pose"], g["cam"], dev["img0"], dev["img1"], dev["dpt0"], dev["grad1"])
+    assert_item_close(k, _item(g, "se3"), w, h, what=f"HIP se3_step vs reference vectors ({name})")
+    out = torch.empty((h, w), dtype=torch.float32, device="cuda")
+    dfx.UpdateDepth(g["code"], dev["prx_orig"], dev["prx_jac"], 2.0, out)
+    assert np.abs(out.cpu().numpy() - g["dpt"]).max() <= 2e-6 * float(((2.0 + g["dpt"]) ** 2 / 2.0).max())
