@@ -378,6 +378,7 @@ DFX_API int dfx_ctx_create(int device, void* stream, dfx_ctx** out) {
   dfx_ctx* c = new dfx_ctx();
   c->device = device;
   c->cu_count = prop.multiProcessorCount;
+  if (const char* ev = std::getenv("DFX_MFMA")) c->mfma_mode = std::strcmp(ev, "bf16x3") == 0 ? DFX_MFMA_BF16X3 : DFX_MFMA_F32_CHAIN;   // tuning aid (tools/ab_bench.py)
   if (const char* ev = std::getenv("DFX_SCHEDULE")) c->schedule = std::strcmp(ev, "static") == 0 ? DFX_SCHEDULE_STATIC : std::strcmp(ev, "dynamic") == 0 ? DFX_SCHEDULE_DYNAMIC : DFX_SCHEDULE_AUTO;   // tuning aid (tools/ab_bench.py)
   // NULL = the device's default stream, on which the reference runs everything (cuda/launch_utils.h:26-32): work is
   // then ordered with any other default-stream producer of the images (e.g. PyTorch ops on its default stream).
@@ -448,10 +449,7 @@ DFX_API int dfx_device_cu_count(dfx_ctx* c) { return c ? c->cu_count : 0; }
 
 DFX_API int dfx_set_mfma_mode(dfx_ctx* c, int mode) {
   if (!c) return fail(DFX_E_INVALID, "null context");
-  if (mode == DFX_MFMA_BF16X3)
-    return fail(DFX_E_INVALID, "DFX_MFMA_BF16X3 is not available: the exact bf16x3 split was measured slower than the fp32 chain "
-                               "(DESIGN.md section 5) and was dropped with the packed z-space layout");
-  if (mode != DFX_MFMA_F32_CHAIN) return fail(DFX_E_INVALID, "unknown MFMA mode %d", mode);
+  if (mode != DFX_MFMA_F32_CHAIN && mode != DFX_MFMA_BF16X3) return fail(DFX_E_INVALID, "unknown MFMA mode %d", mode);
   c->mfma_mode = mode;
   return DFX_OK;
 }

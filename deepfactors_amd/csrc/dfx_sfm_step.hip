@@ -117,6 +117,28 @@ __device__ __forceinline__ unsigned jv_offset(unsigned pbase, int gq, int li, in
   return p < npx ? y * jac_pitch + (x * 16u + li) * VB : (unsigned)li * VB;
 }
 
+// ---- DFX_MFMA_BF16X3 helpers -----------------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));   // operand type of __builtin_amdgcn_mfma_f32_16x16x32_bf16 (8 bf16 = 4 VGPRs)
+constexpr int b3_tiles(int ncb) { return 1 + ncb + ncb * (ncb + 1) / 2; }
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {   // {RNE_bf16(lo) in bits 0..15, RNE_bf16(hi) in bits 16..31}
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// Exact three-way split of two fp32 values into packed bf16 pieces (tools/ubench/bf16x3_probe.cpp: 2^20 inputs reconstructed exactly
+// on the hardware).  The subtractions are exact (Sterbenz-like: each remainder fits the fp32 mantissa).
+__device__ __forceinline__ void split3_bf16(float x0, float x1, unsigned& ph, unsigned& pm, unsigned& pl) {
+  ph = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(ph << 16), r1 = x1 - __uint_as_float(ph & 0xffff0000u);
+  pm = cvt_pk_bf16(r0, r1);
+  const float s0 = r0 - __uint_as_float(pm << 16), s1 = r1 - __uint_as_float(pm & 0xffff0000u);
+  pl = cvt_pk_bf16(s0, s1);
+}
+__device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 // MODE 0: SfmAligner::RunStep.  MODE 1: DepthAligner::RunStep (cu_depthaligner.cpp:32-72) -- same rank-1 GEMM with
 // z = [0 (6), diff, 0 | s * jac], s = -2 |diff| * dDepth/dPrx; `img0` carries the target depth and `dpt0`
 // the current depth (already decoded by k_update_depth); every pixel is an inlier.
@@ -142,13 +164,15 @@ __device__ __forceinline__ float dpp_merge(float old, float src) {
 // -1.5 % kernel time on most boxes, +4.5 % on some, which is why the static launch is the default.  The
 // price: which items a wave sums is decided at run time, so results are reproducible to fp32 re-association (1e-7 relative), not
 // bit for bit.  Teams mix the dispatch ages (members g, g + #pairs, ...) and are rotated across the XCDs.
-template <int NCB, int MODE, bool JDENSE, bool TABLDS, bool BYVAL, bool DYN>
+template <int NCB, int MODE, bool JDENSE, bool TABLDS, bool BYVAL, bool DYN, bool B3>
 __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_WAVES) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmPairDev one, const SfmParamsDev prm,
                                                        const int W, const int H, float* __restrict__ partials, const DynDev dyn) {
   static_assert(!DYN || (MODE == 0 && JDENSE && TABLDS && !BYVAL), "the dynamic schedule exists for the batched dense SfM step");
+  static_assert(!B3 || DFX_ABLATE == 0, "the ablation switches exist for the fp32 chain only");
   constexpr int NX = NCB * (NCB - 1) / 2, ND = (NCB + 1) / 2;   // X(b,b'), Dd(q); Pm(b): NCB
   constexpr int NACC = NX + NCB;                                 // 16x16x4 accumulators
-  constexpr int ZDIM = (1 + NACC + 2 * ND) * 256;                // block 0: the 29 P x P sums; then X, Pm, (Dd broadcast, Dd plain) per q
+  constexpr int NT3 = b3_tiles(NCB);                             // B3: plain 16x16 tiles (P,P), (P,C_b), (C_b,C_b') b <= b'
+  constexpr int ZDIM = B3 ? NT3 * 256 : (1 + NACC + 2 * ND) * 256;   // block 0: the 29 P x P sums; then X, Pm, (Dd broadcast, Dd plain) per q
   constexpr int SLOT = (kUFloats > ZDIM) ? kUFloats : ZDIM;   // per wave: its P rows in the loop, its accumulators in the epilogue (same place)
   constexpr int LDS_FLOATS = kWaves * (DYN ? kUFloats : SLOT);   // DYN: no epilogue fold, only the P rows
   typedef typename JV<NCB>::T jv_t;
@@ -210,6 +234,10 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   if (MODE == 0 && TABLDS && !DYN) __syncthreads();
   float* U = lds + wave * (DYN ? kUFloats : SLOT);
   if (lane < 16) U[(lane >> 1) * kUStride + 64 + (lane & 1)] = 0.f;   // padding columns 64, 65 of P rows 0..7 (read as zeros by the 4x4 tiles)
+  if (B3) U[15 * kUStride + lane] = 0.f;   // B3: the P block's rows 8..15 are zeros -- lanes 8..15 of every 16-lane row read this LDS row instead
+  f32x4 acc3[B3 ? NT3 : 1];                // B3: one accumulator per tile
+#pragma unroll
+  for (int a = 0; a < (B3 ? NT3 : 1); ++a) acc3[a] = f32x4{ 0.f, 0.f, 0.f, 0.f };
 
   f32x4 acc[NACC];
 #pragma unroll
@@ -515,6 +543,54 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     // ---- phase B: rank-4 updates on the matrix cores; operand ring refilled behind the consumer
     const __amdgpu_buffer_rsrc_t nrs = ring_rsrc(nbase);
     const unsigned rlo = ring_opaque_off(has1);
+    if constexpr (B3) {
+      // ---- phase B, exact bf16 split (DFX_MFMA_BF16X3): every fp32 entry of z is split into three bf16 pieces, x = h + m + l EXACTLY
+      // (h = RNE_bf16(x), m = RNE_bf16(x - h), l = x - h - m: 8 + 8 + 8 significant bits and a sign each), and z z^T is summed as
+      // hh + hm + mh + hl + lh + mm on v_mfma_f32_16x16x32_bf16 (fp32 accumulate; the dropped ml + lm + ll terms are below 2^-26 of
+      // the product, i.e. below the rounding of an fp32 multiply).  A bf16 MFMA covers 32 pixels: half a chunk; lane (li, lk), slot j
+      // of a half h holds pixel 4 (8 h + j) + lk -- the ring registers jv[8 h + j] as they are.  A and B use the same
+      // pixel -> (lane group, slot) assignment, which is all the sum over k needs.  z blocks: 0 = P (rows 0..7; 8..15 zero), 1 + b = C_b.
+      const int prow = lo8 ? li * kUStride : 15 * kUStride;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        u32x4 oh[1 + NCB], om[1 + NCB], ol[1 + NCB];   // packed bf16 pairs (slots 2 jp, 2 jp + 1) of the three pieces of every block
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+          float x[1 + NCB][2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int gq = 8 * h + 2 * jp + e;
+            const int pp = 4 * gq + lk;
+            const float s = U[13 * kUStride + pp];
+            x[0][e] = U[prow + pp];
+#pragma unroll
+            for (int b = 0; b < NCB; ++b) x[1 + b][e] = mul_zero_wins(s, jv_get<NCB>(jv[gq], b));
+#if !(DFX_ABLATE & 4)
+            jv[gq] = ring_load(nrs, rlo, nbase, gq, has1);
+#endif
+          }
+#pragma unroll
+          for (int k = 0; k < 1 + NCB; ++k) {
+            unsigned ph, pm, pl;
+            split3_bf16(x[k][0], x[k][1], ph, pm, pl);
+            oh[k][jp] = ph; om[k][jp] = pm; ol[k][jp] = pl;
+          }
+        }
+        // tiles: t = 0 (P,P); 1 + b (P,C_b); then (C_b,C_b') for b <= b' in row-major order.  Product-major issue order: consecutive
+        // MFMAs write different accumulators; small terms first.
+        auto tiles = [&](const u32x4 (&A)[1 + NCB], const u32x4 (&Bv)[1 + NCB]) {
+          int t = 0;
+          acc3[t] = mfma_bf16(A[0], Bv[0], acc3[t]); ++t;
+#pragma unroll
+          for (int b = 0; b < NCB; ++b, ++t) acc3[t] = mfma_bf16(A[0], Bv[1 + b], acc3[t]);
+#pragma unroll
+          for (int b = 0; b < NCB; ++b)
+#pragma unroll
+            for (int b2 = b; b2 < NCB; ++b2, ++t) acc3[t] = mfma_bf16(A[1 + b], Bv[1 + b2], acc3[t]);
+        };
+        tiles(om, om); tiles(oh, ol); tiles(ol, oh); tiles(oh, om); tiles(om, oh); tiles(oh, oh);
+      }
+    } else {
 #if !(DFX_ABLATE & 16)
 #pragma unroll
     for (int t = 0; t < 13; ++t)   // P x P: five pixels per instruction
@@ -555,6 +631,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
         accd[2 * q + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(M, M, accd[2 * q + 1], 0, 0, 0);   // (M0 M0^T), M1 M1^T, (M2 M2^T), M3 M3^T
       }
     }
+    }   // !B3
 #if DFX_TRACE
     __builtin_amdgcn_sched_barrier(0);
     const unsigned long long tr2 = __builtin_amdgcn_s_memtime();
@@ -578,6 +655,12 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   // resource with the sc0 policy of the other streams; the four waves of a workgroup serving ONE pair in the dynamic schedule.)
   if (DYN) {   // one partial per wave = per team member, same z-space layout; nothing to fold
     float* mine = partials + ((size_t)dyn_pair * dyn.team + dyn_member) * ZDIM;
+    if constexpr (B3) {
+#pragma unroll
+      for (int a = 0; a < NT3; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[a * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc3[a][r];
+    } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r) mine[ppb * 16 + r * 4 + ppi] = accpp[r];
 #pragma unroll
@@ -588,6 +671,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     for (int a = 0; a < 2 * ND; ++a)
 #pragma unroll
       for (int r = 0; r < 4; ++r) mine[(1 + NACC + a) * 256 + ppb * 16 + r * 4 + ppi] = accd[a][r];
+    }
 #if DFX_TRACE
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {   // trace builds only: {phase A cycles, phase B cycles, loop start (100 MHz ticks mod 2^24), loop lifetime in ticks}, chunks
@@ -602,6 +686,12 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   }
   {
     float* mine = lds + wave * SLOT;
+    if constexpr (B3) {   // every tile in the C/D layout of a 16x16 MFMA: [row = 4 (lane >> 4) + r][col = lane & 15]
+#pragma unroll
+      for (int a = 0; a < NT3; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[a * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc3[a][r];
+    } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r) mine[ppb * 16 + r * 4 + ppi] = accpp[r];   // block 0: [4x4 block b][row r][column = lane & 3]
 #pragma unroll
@@ -612,6 +702,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     for (int a = 0; a < 2 * ND; ++a)   // 4x4x1 form: [block = 4 k + rg][row r of the A group][column = lane & 3 of the B group]
 #pragma unroll
       for (int r = 0; r < 4; ++r) mine[(1 + NACC + a) * 256 + ppb * 16 + r * 4 + ppi] = accd[a][r];
+    }
   }
   float* out = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ZDIM;
   __syncthreads();
@@ -777,6 +868,105 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
   }
 }
 
+// ---- finalize of the DFX_MFMA_BF16X3 step: the partials are plain 16x16 tiles S[row][col] (tile 0: P x P; 1 + b: P x C_b; then
+// C_b x C_b', b <= b', row-major), entry i of C_b = code NCB * i + b.  Same reduction (double, fixed order), same T map, same item.
+template <int NCB, int NPOSE, bool BYVAL>
+__global__ __launch_bounds__(1024) void k_sfm_finalize_b3(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs, const SfmPairDev one,
+                                                          char* __restrict__ items, const size_t item_stride, unsigned* __restrict__ qhead) {
+  constexpr int CS = 16 * NCB;
+  constexpr int NP = NPOSE + CS;
+  constexpr int ZDIM = b3_tiles(NCB) * 256;
+  constexpr int NT = NP * (NP + 1) / 2;
+  __shared__ double red[4][256];
+  __shared__ double T[12][6];   // d(pose0, pose1) <- d(relative pose): J = gC * T^T
+
+  const int blk = blockIdx.x, pair = blockIdx.y;
+  const int el = threadIdx.x & 255, rg = threadIdx.x >> 8;
+  if (qhead && blk == 0 && threadIdx.x == 0) qhead[pair] = 0u;
+  const float* src = partials + (size_t)pair * bpp * ZDIM + blk * 256 + el;
+  red[rg][el] = strided_sum_f64<4, 16>(src, rg, bpp, ZDIM);
+  if (NPOSE == 12 && threadIdx.x < 72) {
+    const int n = threadIdx.x / 6, i = threadIdx.x - n * 6;
+    const float* M = BYVAL ? one.M : pairs[pair].M;
+    const float* HM = BYVAL ? one.HM : pairs[pair].HM;
+    const int j = n % 3, grp = n / 3;   // grp 0: pose0 trs, 1: pose0 rot, 2: pose1 trs, 3: pose1 rot
+    double v = 0.0;
+    if (grp == 0) v = i < 3 ? (double)M[3 * i + j] : 0.0;
+    else if (grp == 1) v = i >= 3 ? (double)M[3 * (i - 3) + j] : 0.0;
+    else if (grp == 2) v = i < 3 ? -(double)M[3 * i + j] : 0.0;
+    else v = i < 3 ? -(double)HM[3 * i + j] : -(double)M[3 * (i - 3) + j];
+    T[n][i] = v;
+  }
+  __syncthreads();
+  if (rg == 0) red[0][el] = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
+  __syncthreads();
+  const double* S = red[0];   // S[row * 16 + col]
+
+  float* item = reinterpret_cast<float*>(items + (size_t)pair * item_stride);
+  auto tri = [](int lo, int hi) { return lo * NP - lo * (lo - 1) / 2 + (hi - lo); };
+  auto put = [&](int lo, int hi, float v) { item[tri(lo, hi)] = v; };
+  auto put_code = [&](int ca, int cb, float v) {
+    const int n = NPOSE + ca, m = NPOSE + cb;
+    put(n < m ? n : m, n < m ? m : n, v);
+  };
+  auto put_g = [&](int n, float v) { item[NT + n] = v; };
+  const int t = threadIdx.x;
+  if (blk == 0) {
+    // P = (gC_0..5, w r, inlier flag); the tile holds both triangles of P P^T, the upper one is used
+    auto pp = [&](int p, int q) { return S[p * 16 + q]; };
+    if (NPOSE == 12) {
+      if (t < 144) {                       // pose-pose: T G T^T
+        const int n = t / 12, m = t - n * 12;
+        if (n <= m) {
+          double v = 0.0;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            double r = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) r += (i <= j ? pp(i, j) : pp(j, i)) * T[m][j];
+            v += T[n][i] * r;
+          }
+          put(n, m, (float)v);
+        }
+      } else if (t < 156) {                // Jtr (pose): T * (gC . wr)
+        const int n = t - 144;
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v += T[n][i] * pp(i, 6);
+        put_g(n, (float)v);
+      }
+    }
+    if (t == 160) item[NT + NP] = (float)pp(6, 6);          // residual = sum (w r)^2
+    if (t == 161) {
+      const size_t off = (((size_t)(NT + NP + 1)) * 4 + 7) & ~(size_t)7;
+      *reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(item) + off) = (unsigned long long)(pp(7, 7) + 0.5);
+    }
+    return;
+  }
+  if (blk <= NCB) {
+    // ---- (P, C_b): rows 0..5 = gC, row 6 = w r; column j = code NCB * j + b
+    const int b = blk - 1;
+    if (NPOSE == 12 && t < 192) {          // pose-code: T * S[P rows 0..5][j]
+      const int n = t >> 4, j = t & 15;
+      double v = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) v += T[n][i] * S[i * 16 + j];
+      put(n, NPOSE + NCB * j + b, (float)v);
+    } else if (t >= 192 && t < 208) {      // Jtr (code)
+      const int j = t - 192;
+      put_g(NPOSE + NCB * j + b, (float)S[6 * 16 + j]);
+    }
+    return;
+  }
+  // ---- (C_b, C_b'), b <= b': S[i][j] = C_b[i] * C_b'[j]; the diagonal tiles carry both triangles, i <= j is used
+  int b = 0, b2 = 0;
+  { int q = blk - 1 - NCB; for (b = 0; b < NCB; ++b) { const int n = NCB - b; if (q < n) { b2 = b + q; break; } q -= n; } }
+  if (t < 256) {
+    const int i = t >> 4, j = t & 15;
+    if (b != b2 || i <= j) put_code(NCB * i + b, NCB * j + b2, (float)S[t]);
+  }
+}
+
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair) {
   return (size_t)npairs * blocks_per_pair * sfm_zdim(cs / 16) * sizeof(float);
 }
@@ -790,7 +980,7 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   hipError_t e;
   if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
   const dim3 grid(bpp, npairs), block(kThreads);
-  (void)prec;   // one evaluation mode: exact fp32 products on v_mfma_f32_16x16x4_f32
+  const bool b3 = prec == 1;   // DFX_MFMA_BF16X3 (include/dfx.h): exact three-way bf16 split on v_mfma_f32_16x16x32_bf16; 0: the fp32 chain
   if (((long long)W * H) % 64 != 0) jac_dense = false;   // ragged last chunk: the per-vector addressing clamps pixels past the image
   // the ray table rides in dynamic LDS when it fits beside the static arrays (64 KB per workgroup); MODE 1 has no table
   constexpr size_t kStaticLds = sizeof(float) * (size_t)kWaves * ((kUFloats > (1 + NACC) * 256) ? kUFloats : (1 + NACC) * 256);
@@ -804,33 +994,47 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
     // dynamic schedule: a resident grid of wave-workers (see k_sfm_step); partials = [pair][team member]
     if constexpr (MODE == 0) {
       const size_t dlds = sizeof(float) * (size_t)kWaves * ((size_t)W + H + kRayTabSlack);
-      hipLaunchKernelGGL((k_sfm_step<NCB, 0, true, true, false, true>), dim3(dyn_grid), block, dlds, stream, pairs_dev, one, prm, W, H, partials_dev, *dyn);
+      if (b3) hipLaunchKernelGGL((k_sfm_step<NCB, 0, true, true, false, true, true>), dim3(dyn_grid), block, dlds, stream, pairs_dev, one, prm, W, H, partials_dev, *dyn);
+      else hipLaunchKernelGGL((k_sfm_step<NCB, 0, true, true, false, true, false>), dim3(dyn_grid), block, dlds, stream, pairs_dev, one, prm, W, H, partials_dev, *dyn);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
       if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
-      hipLaunchKernelGGL((k_sfm_finalize<NCB, 12, false>), dim3(1 + NACC, npairs), dim3(1024), 0, stream,
-                         (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead);
+      if (b3) hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, 12, false>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, stream,
+                                 (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead);
+      else hipLaunchKernelGGL((k_sfm_finalize<NCB, 12, false>), dim3(1 + NACC, npairs), dim3(1024), 0, stream,
+                              (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead);
       return hipGetLastError();
     }
   }
-#define DFX_LAUNCH_STEP(M_, JD_, TL_)                                                                                                              \
+#define DFX_LAUNCH_STEP_(M_, JD_, TL_, B3_)                                                                                                        \
   do {                                                                                                                                             \
-    if (byval) hipLaunchKernelGGL((k_sfm_step<NCB, M_, JD_, TL_, true, false>), grid, block, dyn_lds, stream, (const SfmPairDev*)nullptr, one, prm, W, H, partials_dev, nodyn); \
-    else hipLaunchKernelGGL((k_sfm_step<NCB, M_, JD_, TL_, false, false>), grid, block, dyn_lds, stream, pairs_dev, one, prm, W, H, partials_dev, nodyn);              \
+    if (byval) hipLaunchKernelGGL((k_sfm_step<NCB, M_, JD_, TL_, true, false, B3_>), grid, block, dyn_lds, stream, (const SfmPairDev*)nullptr, one, prm, W, H, partials_dev, nodyn); \
+    else hipLaunchKernelGGL((k_sfm_step<NCB, M_, JD_, TL_, false, false, B3_>), grid, block, dyn_lds, stream, pairs_dev, one, prm, W, H, partials_dev, nodyn);              \
   } while (0)
+#define DFX_LAUNCH_STEP(M_, JD_, TL_) do { if (b3) DFX_LAUNCH_STEP_(M_, JD_, TL_, true); else DFX_LAUNCH_STEP_(M_, JD_, TL_, false); } while (0)
   if (MODE == 0 && tab_lds) {
     if (jac_dense) DFX_LAUNCH_STEP(0, true, true); else DFX_LAUNCH_STEP(0, false, true);
   } else {
     if (jac_dense) DFX_LAUNCH_STEP(MODE, true, false); else DFX_LAUNCH_STEP(MODE, false, false);
   }
 #undef DFX_LAUNCH_STEP
+#undef DFX_LAUNCH_STEP_
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
-  if (byval) hipLaunchKernelGGL((k_sfm_finalize<NCB, MODE == 0 ? 12 : 0, true>), dim3(1 + NACC, npairs), dim3(1024), 0, stream,
-                                (const float*)partials_dev, bpp, (const SfmPairDev*)nullptr, one, (char*)items_dev, item_stride, (unsigned*)nullptr);
-  else hipLaunchKernelGGL((k_sfm_finalize<NCB, MODE == 0 ? 12 : 0, false>), dim3(1 + NACC, npairs), dim3(1024), 0, stream,
-                          (const float*)partials_dev, bpp, pairs_dev, one, (char*)items_dev, item_stride, (unsigned*)nullptr);
+  constexpr int NPOSE = MODE == 0 ? 12 : 0;
+  const SfmPairDev* fpairs = byval ? (const SfmPairDev*)nullptr : pairs_dev;
+  if (b3) {
+    if (byval) hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, true>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, stream,
+                                  (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr);
+    else hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, false>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, stream,
+                            (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr);
+  } else {
+    if (byval) hipLaunchKernelGGL((k_sfm_finalize<NCB, NPOSE, true>), dim3(1 + NACC, npairs), dim3(1024), 0, stream,
+                                  (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr);
+    else hipLaunchKernelGGL((k_sfm_finalize<NCB, NPOSE, false>), dim3(1 + NACC, npairs), dim3(1024), 0, stream,
+                            (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr);
+  }
   return hipGetLastError();
 }
 

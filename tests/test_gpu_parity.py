@@ -53,9 +53,10 @@ def test_sfm_step_reference_test_poses(dfx, oracle):
     assert np.abs(got.toDenseMatrix() - ref.dense()).max() <= 1e-1 or np.abs(ref.JtJ).max() > 1e3
 
 
-def test_fp32_chain_is_tight_and_bf16x3_is_rejected(dfx, oracle):
+def test_fp32_chain_is_tight_and_unknown_modes_are_rejected(dfx, oracle):
     """The fp32 MFMA chain against the fp64-accumulated oracle: error below 5e-6 of the block scale (the stated tolerance is
-    1e-4).  The removed bf16x3 mode must be refused loudly, not silently mapped to something else."""
+    1e-4).  An unknown evaluation mode must be refused loudly, not silently mapped to something else (the exact bf16 split,
+    DFX_MFMA_BF16X3, has its own tests: tests/test_gpu_bf16x3.py)."""
     from deepfactors_amd import _lib
     w, h, cs = 320, 240, 32
     p, n, g = _pair(dfx, w, h, cs, seed=77)
@@ -68,7 +69,7 @@ def test_fp32_chain_is_tight_and_bf16x3_is_rejected(dfx, oracle):
     err = float(np.abs(np.asarray(got.JtJ, np.float64) - np.asarray(ref.JtJ, np.float64)).max() / np.abs(ref.JtJ).max())
     assert err < 5e-6, err
     with pytest.raises(dfx.DfxError):
-        ctx.set_mfma_mode(_lib.DFX_MFMA_BF16X3)
+        ctx.set_mfma_mode(7)
 
 
 def test_sfm_step_batch(dfx, oracle):

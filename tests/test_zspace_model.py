@@ -179,3 +179,132 @@ def test_chunk_map_visits_every_chunk_once(W, H):
                             x -= W; y += 1
                         assert (y, x) == divmod(c * 64 + lane, W)
         assert (seen == 1).all(), (W, H, bpp, np.flatnonzero(seen != 1)[:5])
+
+
+# ---- DFX_MFMA_BF16X3: exact three-way bf16 split, plain 16x16 tiles (k_sfm_step<..., B3 = true>, k_sfm_finalize_b3) -----------------
+def _rne_bf16(x):
+    """float32 -> nearest-even bfloat16, returned as float32 (what v_cvt_pk_bf16_f32 does, tools/ubench/bf16x3_probe.cpp)."""
+    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def _split3(x):
+    x = np.asarray(x, np.float32)
+    h = _rne_bf16(x)
+    r = (x - h).astype(np.float32)
+    m = _rne_bf16(r)
+    l = (r - m).astype(np.float32)
+    return h, m, l
+
+
+def test_three_way_bf16_split_is_exact():
+    rng = np.random.default_rng(3)
+    x = (rng.uniform(1, 2, 200000) * 2.0 ** rng.integers(-40, 41, 200000) * rng.choice([-1, 1], 200000)).astype(np.float32)
+    h, m, l = _split3(x)
+    assert np.array_equal(h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64), x.astype(np.float64))
+    for p in (h, m, l):                                   # every piece is a bf16 (low 16 bits clear), the last one without rounding
+        assert not (p.view(np.uint32) & 0xFFFF).any()
+
+
+def _model_item_b3(gC, wr, inl, s, jac, M, HM, cs):
+    """The bf16x3 step + k_sfm_finalize_b3 in numpy: z blocks 0 = P (8 rows + 8 zero rows), 1 + b = C_b; tile t: 0 (P,P), 1 + b (P,C_b),
+    then (C_b,C_b') for b <= b' row-major; every tile = hh + hm + mh + hl + lh + mm of the split operands (fp32 accumulate on the
+    hardware, float64 here)."""
+    ncb = cs // 16
+    NP = 12 + cs
+    N = len(wr)
+    P16 = np.concatenate([gC, wr[:, None], inl[:, None], np.zeros((N, 8))], axis=1).astype(np.float32)
+    blocks = [P16] + [(s[:, None].astype(np.float32) * jac[:, b::ncb].astype(np.float32)).astype(np.float32) for b in range(ncb)]
+    pieces = [_split3(b) for b in blocks]
+
+    def tile(ka, kb):
+        (ha, ma, la), (hb, mb, lb) = pieces[ka], pieces[kb]
+        acc = np.zeros((16, 16))
+        for A, B in ((ma, mb), (ha, lb), (la, hb), (ha, mb), (ma, hb), (ha, hb)):
+            acc += np.einsum("pi,pj->ij", A.astype(np.float64), B.astype(np.float64))
+        return acc
+
+    tiles = [tile(0, 0)] + [tile(0, 1 + b) for b in range(ncb)] + [tile(1 + b, 1 + b2) for b in range(ncb) for b2 in range(b, ncb)]
+    assert len(tiles) == 1 + ncb + ncb * (ncb + 1) // 2
+
+    T = np.zeros((12, 6))
+    for n in range(12):
+        j, grp = n % 3, n // 3
+        for i in range(6):
+            if grp == 0:
+                T[n, i] = M[3 * i + j] if i < 3 else 0.0
+            elif grp == 1:
+                T[n, i] = M[3 * (i - 3) + j] if i >= 3 else 0.0
+            elif grp == 2:
+                T[n, i] = -M[3 * i + j] if i < 3 else 0.0
+            else:
+                T[n, i] = -HM[3 * i + j] if i < 3 else -M[3 * (i - 3) + j]
+    H = np.full((NP, NP), np.nan)
+    g = np.full(NP, np.nan)
+
+    def put(a, b, v):
+        lo, hi = min(a, b), max(a, b)
+        assert np.isnan(H[lo, hi]), f"entry ({lo},{hi}) written twice"
+        H[lo, hi] = v
+
+    # blk 0
+    S = tiles[0]
+    pp = lambda p, q: S[p, q]
+    G = np.array([[pp(min(i, j), max(i, j)) for j in range(6)] for i in range(6)])
+    TG = T @ G @ T.T
+    for n in range(12):
+        for m in range(n, 12):
+            put(n, m, TG[n, m])
+        g[n] = T[n] @ np.array([pp(i, 6) for i in range(6)])
+    residual, inliers = pp(6, 6), pp(7, 7)
+    # blk 1 + b
+    for b in range(ncb):
+        S = tiles[1 + b]
+        for n in range(12):
+            for j in range(16):
+                put(n, 12 + ncb * j + b, T[n] @ S[0:6, j])
+        for j in range(16):
+            assert np.isnan(g[12 + ncb * j + b])
+            g[12 + ncb * j + b] = S[6, j]
+    # code-code tiles: index -> (b, b2) exactly as k_sfm_finalize_b3 decodes blockIdx.x
+    for blk in range(1 + ncb, len(tiles)):
+        q = blk - 1 - ncb
+        for b in range(ncb):
+            n = ncb - b
+            if q < n:
+                b2 = b + q
+                break
+            q -= n
+        S = tiles[blk]
+        for i in range(16):
+            for j in range(16):
+                if b != b2 or i <= j:
+                    put(12 + ncb * i + b, 12 + ncb * j + b2, S[i, j])
+    assert not np.isnan(H[np.triu_indices(NP)]).any(), "upper triangle not fully covered"
+    assert not np.isnan(g).any()
+    return H, g, residual, inliers
+
+
+@pytest.mark.parametrize("cs", [16, 32, 64])
+def test_bf16x3_tiles_cover_the_item_exactly_once_at_fp32_accuracy(cs):
+    rng = np.random.default_rng(100 + cs)
+    N = 64
+    gC, wr, s = rng.normal(size=(N, 6)), rng.normal(size=N), rng.normal(size=N)
+    inl = (rng.random(N) > 0.2).astype(np.float64)
+    gC *= inl[:, None]; wr *= inl; s *= inl
+    jac = rng.normal(size=(N, cs))
+    gC, wr, s, jac = (a.astype(np.float32).astype(np.float64) for a in (gC, wr, s, jac))
+    M, HM = rng.normal(size=9), rng.normal(size=9)
+    H, g, residual, inliers = _model_item_b3(gC, wr, inl, s, jac, M, HM, cs)
+    Mm, HMm = M.reshape(3, 3), HM.reshape(3, 3)
+    C = (s[:, None].astype(np.float32) * jac.astype(np.float32)).astype(np.float64)      # the kernel's fp32 product s * jac
+    J0 = np.concatenate([gC[:, :3] @ Mm, gC[:, 3:] @ Mm], axis=1)
+    J1 = np.concatenate([-(gC[:, :3] @ Mm), -(gC[:, :3] @ HMm) - gC[:, 3:] @ Mm], axis=1)
+    J = np.concatenate([J0, J1, C], axis=1)
+    ref = J.T @ J
+    iu = np.triu_indices(12 + cs)
+    # the dropped ml + lm + ll terms are < 2^-26 of a product
+    assert np.abs(H[iu] - ref[iu]).max() < 3e-8 * np.abs(ref).max()
+    assert np.abs(g - J.T @ wr).max() < 3e-8 * max(1.0, np.abs(J.T @ wr).max())
+    assert abs(residual - float(wr @ wr)) < 3e-8 * float(wr @ wr) and abs(inliers - inl.sum()) < 1e-6
