@@ -156,6 +156,33 @@ def pmc_traffic(a):
         shutil.rmtree(out, ignore_errors=True)
 
 
+def mode_kernel_us(ctx, launch, bytes_per_launch, warm, steps):
+    """Step-kernel time of `launch` with the context switched to DFX_MFMA_BF16X3 (the opt-in exact three-way bf16 split); the context
+    is switched back whatever happens, and a failure is reported instead of raised (this is a secondary figure of the bench line)."""
+    from deepfactors_amd import _lib
+    try:
+        ctx.set_mfma_mode(_lib.DFX_MFMA_BF16X3)
+        for _ in range(warm):
+            launch()
+        ctx.sync()
+        ctx.set_profiling(True)
+        for _ in range(steps):
+            launch()
+        n, ms = ctx.profile_read()
+        ctx.set_profiling(False)
+        ks = ms / 1e3 / max(n, 1)
+        return dict(kernel_us=ks * 1e6, algorithmic_gbs=bytes_per_launch / ks / 1e9, frac=bytes_per_launch / ks / 1e9 / HBM_PEAK_GBS,
+                    mfma="exact three-way bf16 split on v_mfma_f32_16x16x32_bf16, fp32 accumulate (opt-in DFX_MFMA_BF16X3; fp32-accurate, tests/test_gpu_bf16x3.py)")
+    except Exception as e:   # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        try:
+            ctx.set_profiling(False)
+            ctx.set_mfma_mode(_lib.DFX_MFMA_F32_CHAIN)
+        except Exception:   # noqa: BLE001
+            pass
+
+
 def secondary_configs(dfx, synth, ctx, dev):
     """configs[1] as the reference calls it (ONE pair per blocking call, photometric_factor.cpp:267-274), its 3-level pyramid variant, configs[4]
     (1280x960, 64-code; 16 pairs per launch, 5.5 GB working set)."""
@@ -214,7 +241,9 @@ def secondary_configs(dfx, synth, ctx, dev):
     kern_s = ms / 1e3 / n
     bpl = (20 + 4 * CS) * W * H * P
     out["configs4_1280x960_cs64"] = dict(pairs_per_launch=P, kernel_us=kern_s * 1e6, algorithmic_gbs=bpl / kern_s / 1e9, frac=bpl / kern_s / 1e9 / HBM_PEAK_GBS,
-                                         evals_per_s=P / kern_s)
+                                         evals_per_s=P / kern_s, mfma="fp32 chain (library default)")
+    # the same batch on the opt-in exact three-way bf16 split (DFX_MFMA_BF16X3): CS = 64 is matrix-bound on the fp32 chain
+    out["configs4_1280x960_cs64"]["bf16x3"] = mode_kernel_us(ctx, lambda: al4.RunStepBatchAsync(arr, items), bpl, warm=150, steps=20)
     del pairs, keep, arr, items
     # ---- configs[2] as the reference's relinearisation round (PhotometricFactor::RunAlignmentStep, photometric_factor.cpp:225-293, for every
     # factor of a 16-keyframe window): UpdateDepth once per keyframe whose code moved + one batched RunStep over the 120 pairs
@@ -479,6 +508,8 @@ def main():
     ctx.set_schedule(_dl.DFX_SCHEDULE_AUTO)   # the secondary measurements below run the library's defaults
     configs = {}
     if world == 1 and not a.no_configs:
+        # the timed workload once more on the opt-in exact bf16 split (static schedule; the line's `value` and `roofline` above are the fp32 chain's)
+        configs["headline_workload_bf16x3"] = mode_kernel_us(ctx, lambda: al.RunStepBatchAsync(arr, items), (20 + 4 * CS) * W * H * P, warm=150, steps=30)
         configs.update(secondary_configs(dfx, synth, ctx, dev))
     if a.window:
         del keep, pairs, arr
