@@ -151,7 +151,8 @@ class Context:
         return int(_lib.lib().dfx_device_cu_count(self._h))
 
     def set_mfma_mode(self, mode):
-        """_lib.DFX_MFMA_F32_CHAIN (bitwise fp32 fmaf chain) is the only mode; DFX_MFMA_BF16X3 is rejected (see include/dfx.h)."""
+        """_lib.DFX_MFMA_F32_CHAIN (default: bitwise an fp32 fmaf chain) or _lib.DFX_MFMA_BF16X3 (opt-in: exact three-way bf16 split on the
+        bf16 matrix cores, fp32-accurate, faster for code size 64; see include/dfx.h)."""
         check(_lib.lib().dfx_set_mfma_mode(self._h, int(mode)))
 
     def set_schedule(self, mode):

@@ -122,10 +122,16 @@ DFX_API int dfx_sync(dfx_ctx* ctx);
 DFX_API int dfx_sfm_set_step_blocks(dfx_ctx* ctx, int blocks_per_pair);
 DFX_API int dfx_device_cu_count(dfx_ctx* ctx);
 /* How the JtJ/Jtr outer products of the SfM / DepthAligner step are evaluated on the matrix cores (fp32 in, fp32 out):
- *  DFX_MFMA_F32_CHAIN  the only mode: v_mfma_f32_16x16x4_f32 -- bitwise an fp32 fmaf chain over the pixels of a wave.
- *  DFX_MFMA_BF16X3     (rejected with DFX_E_INVALID) an exact three-way bf16 split of every fp32 operand on the bf16
- *                      matrix cores; it was fp32-accurate but 6 % slower than the chain (the splits cost more vector-ALU
- *                      time than the faster MFMAs save) and is no longer built. */
+ *  DFX_MFMA_F32_CHAIN  (default) v_mfma_f32_16x16x4_f32 -- bitwise an fp32 fmaf chain over the pixels of a wave.
+ *  DFX_MFMA_BF16X3     opt-in: every fp32 entry is split EXACTLY into three bf16 pieces (x = h + m + l, round-to-nearest-even
+ *                      through v_cvt_pk_bf16_f32) and the products are summed as hh + hm + mh + hl + lh + mm on
+ *                      v_mfma_f32_16x16x32_bf16 with fp32 accumulation; the dropped terms are below 2^-26 of a product, i.e.
+ *                      below the rounding of an fp32 multiply -- measured error against the fp64 oracle equals the chain's
+ *                      (tests/test_gpu_bf16x3.py).  Same inlier sets, same valid0 writes, bit-reproducible for a launch shape
+ *                      like the chain, but its bits differ from the chain's.  MI355X, same box: code size 64 at 1280x960
+ *                      1200 -> 997 us per 16 pairs (the fp32 chain is matrix-bound there), code size 32 at 640x480 1055 -> 1041 us
+ *                      per 128 pairs.  The round-1 implementation of this idea was slower than the chain
+ *                      and had been removed; this one costs 11 vector-ALU instructions per pair of values. */
 #define DFX_MFMA_F32_CHAIN 0
 #define DFX_MFMA_BF16X3 1
 DFX_API int dfx_set_mfma_mode(dfx_ctx* ctx, int mode);
