@@ -73,6 +73,12 @@ namespace dfx {
                              // 16 = no P x P fmas, 32 = no ray-table / valid0 reads, 64 = no operand shuffles, 128 = no tap gathers
 #endif
 
+#ifndef DFX_B3_PSPLIT
+#define DFX_B3_PSPLIT 0      // DFX_MFMA_BF16X3 only, NOT YET MEASURED (written without GPU time left in round 2): 1 = the P block is split once per
+#endif                       // pixel in phase A and handed to phase B as packed bf16 pieces through LDS (ds_write_b16 / ds_read_b128): -44 VALU per chunk
+#ifndef DFX_B3_DIAG4
+#define DFX_B3_DIAG4 0       // DFX_MFMA_BF16X3 only, NOT YET MEASURED: 1 = (CS <= 32) the diagonal tiles take four products instead of six:
+#endif                       // S = hh + mm and N = hm + hl in two accumulators, Z = S + N + N^T in the finalize kernel (-12 of 72 MFMAs at CS = 32)
 #ifndef DFX_RING_AUX
 #define DFX_RING_AUX 2       // cache policy of the code-Jacobian stream loads: 2 = nt (read once: do not displace the img1 / grad1 rows
 #endif                       // the bilinear taps of the next chunk row re-use from the L2); -1.6 % kernel time, -3 % read requests with the collapse below
@@ -121,6 +127,8 @@ __device__ __forceinline__ unsigned jv_offset(unsigned pbase, int gq, int li, in
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));   // operand type of __builtin_amdgcn_mfma_f32_16x16x32_bf16 (8 bf16 = 4 VGPRs)
 constexpr int b3_tiles(int ncb) { return 1 + ncb + ncb * (ncb + 1) / 2; }
+constexpr bool b3_diag4(int ncb) { return DFX_B3_DIAG4 != 0 && ncb <= 2; }                          // two accumulators per diagonal tile: registers allow it up to CS = 32
+constexpr int b3_blocks(int ncb) { return b3_tiles(ncb) + (b3_diag4(ncb) ? 1 + ncb : 0); }      // 256-float blocks of a partial: the tiles, then N of (P,P), (C_b,C_b)
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {   // {RNE_bf16(lo) in bits 0..15, RNE_bf16(hi) in bits 16..31}
   unsigned r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
@@ -172,7 +180,8 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   constexpr int NX = NCB * (NCB - 1) / 2, ND = (NCB + 1) / 2;   // X(b,b'), Dd(q); Pm(b): NCB
   constexpr int NACC = NX + NCB;                                 // 16x16x4 accumulators
   constexpr int NT3 = b3_tiles(NCB);                             // B3: plain 16x16 tiles (P,P), (P,C_b), (C_b,C_b') b <= b'
-  constexpr int ZDIM = B3 ? NT3 * 256 : (1 + NACC + 2 * ND) * 256;   // block 0: the 29 P x P sums; then X, Pm, (Dd broadcast, Dd plain) per q
+  constexpr int NB3 = b3_blocks(NCB);                            // B3: accumulators = blocks of the partial
+  constexpr int ZDIM = B3 ? NB3 * 256 : (1 + NACC + 2 * ND) * 256;   // block 0: the 29 P x P sums; then X, Pm, (Dd broadcast, Dd plain) per q
   constexpr int SLOT = (kUFloats > ZDIM) ? kUFloats : ZDIM;   // per wave: its P rows in the loop, its accumulators in the epilogue (same place)
   constexpr int LDS_FLOATS = kWaves * (DYN ? kUFloats : SLOT);   // DYN: no epilogue fold, only the P rows
   typedef typename JV<NCB>::T jv_t;
@@ -235,9 +244,10 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   float* U = lds + wave * (DYN ? kUFloats : SLOT);
   if (lane < 16) U[(lane >> 1) * kUStride + 64 + (lane & 1)] = 0.f;   // padding columns 64, 65 of P rows 0..7 (read as zeros by the 4x4 tiles)
   if (B3) U[15 * kUStride + lane] = 0.f;   // B3: the P block's rows 8..15 are zeros -- lanes 8..15 of every 16-lane row read this LDS row instead
-  f32x4 acc3[B3 ? NT3 : 1];                // B3: one accumulator per tile
+  f32x4 acc3[B3 ? NB3 : 1];                // B3: one accumulator per tile (+ the N parts of the diagonal tiles with DFX_B3_DIAG4)
 #pragma unroll
-  for (int a = 0; a < (B3 ? NT3 : 1); ++a) acc3[a] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+  for (int a = 0; a < (B3 ? NB3 : 1); ++a) acc3[a] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+  const int psl = 32 * (lane >> 5) + 8 * (lane & 3) + ((lane >> 2) & 7);   // DFX_B3_PSPLIT: 16-bit slot of pixel `lane` = 32 h + 4 j + k inside a (piece, row) line: [h][k][j]
 
   f32x4 acc[NACC];
 #pragma unroll
@@ -514,10 +524,25 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
         u16[14] = ok ? 1.0f : 0.0f;
         vmask |= ((ok && cur.vl != 1.0f) ? 1u : 0u) << vk;   // valid0(x, y) = 1 (dense_sfm.h:161), written in bursts: flush_valid
       }
+      if constexpr (B3 && DFX_B3_PSPLIT != 0) {
+        // the P block leaves phase A already split: 16-bit element ((piece * 8 + row) * 64 + [h][k][j]) of the wave's LDS region, so that lane
+        // (row, k) of phase B finds the eight slots of a half-chunk as ONE 16-byte vector per piece (rows 0..11 of U; s stays fp32 in row 13)
+        unsigned short* const UH = reinterpret_cast<unsigned short*>(U);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          unsigned ph, pm, pl;
+          split3_bf16(u16[2 * r], r == 3 ? u16[14] : u16[2 * r + 1], ph, pm, pl);   // row 7 = inlier flag
+          UH[(0 * 8 + 2 * r) * 64 + psl] = (unsigned short)ph; UH[(0 * 8 + 2 * r + 1) * 64 + psl] = (unsigned short)(ph >> 16);
+          UH[(1 * 8 + 2 * r) * 64 + psl] = (unsigned short)pm; UH[(1 * 8 + 2 * r + 1) * 64 + psl] = (unsigned short)(pm >> 16);
+          UH[(2 * 8 + 2 * r) * 64 + psl] = (unsigned short)pl; UH[(2 * 8 + 2 * r + 1) * 64 + psl] = (unsigned short)(pl >> 16);
+        }
+        U[13 * kUStride + lane] = u16[13];
+      } else {
 #pragma unroll
       for (int q = 0; q < 7; ++q) U[q * kUStride + lane] = u16[q];
       U[7 * kUStride + lane] = u16[14];    // inlier flag: its square sums to the inlier count
       U[13 * kUStride + lane] = u16[13];
+      }
       if (++vk == 32 || (DYN && (int)nbase != base + (vs << 6))) {   // DYN: the item ends with this chunk -- its bits form one burst
         flush_valid();
         vx0 = nxt.x; vy0 = nxt.y;   // bit 0 of the next burst = this lane's pixel of chunk c+1 (what nxt holds until A1 below)
@@ -551,9 +576,17 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
       // of a half h holds pixel 4 (8 h + j) + lk -- the ring registers jv[8 h + j] as they are.  A and B use the same
       // pixel -> (lane group, slot) assignment, which is all the sum over k needs.  z blocks: 0 = P (rows 0..7; 8..15 zero), 1 + b = C_b.
       const int prow = lo8 ? li * kUStride : 15 * kUStride;
+      // DFX_B3_PSPLIT: lanes 8..15 of a row read the pieces of P rows 0..7 again -- rows / columns 8..15 of the P tiles are never read
+      // by the finalize kernel, so any finite content will do and no zero row is needed
+      const char* const pbytes = reinterpret_cast<const char*>(U) + (li & 7) * 128 + lk * 16;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         u32x4 oh[1 + NCB], om[1 + NCB], ol[1 + NCB];   // packed bf16 pairs (slots 2 jp, 2 jp + 1) of the three pieces of every block
+        if constexpr (DFX_B3_PSPLIT != 0) {
+          oh[0] = *reinterpret_cast<const u32x4*>(pbytes + 0 * 1024 + h * 64);
+          om[0] = *reinterpret_cast<const u32x4*>(pbytes + 1 * 1024 + h * 64);
+          ol[0] = *reinterpret_cast<const u32x4*>(pbytes + 2 * 1024 + h * 64);
+        }
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
           float x[1 + NCB][2];
@@ -562,7 +595,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
             const int gq = 8 * h + 2 * jp + e;
             const int pp = 4 * gq + lk;
             const float s = U[13 * kUStride + pp];
-            x[0][e] = U[prow + pp];
+            x[0][e] = DFX_B3_PSPLIT != 0 ? 0.f : U[prow + pp];
 #pragma unroll
             for (int b = 0; b < NCB; ++b) x[1 + b][e] = mul_zero_wins(s, jv_get<NCB>(jv[gq], b));
 #if !(DFX_ABLATE & 4)
@@ -570,7 +603,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 #endif
           }
 #pragma unroll
-          for (int k = 0; k < 1 + NCB; ++k) {
+          for (int k = (DFX_B3_PSPLIT != 0 ? 1 : 0); k < 1 + NCB; ++k) {
             unsigned ph, pm, pl;
             split3_bf16(x[k][0], x[k][1], ph, pm, pl);
             oh[k][jp] = ph; om[k][jp] = pm; ol[k][jp] = pl;
@@ -588,7 +621,32 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 #pragma unroll
             for (int b2 = b; b2 < NCB; ++b2, ++t) acc3[t] = mfma_bf16(A[1 + b], Bv[1 + b2], acc3[t]);
         };
+        if constexpr (b3_diag4(NCB)) {
+          // off-diagonal tiles: all six products; diagonal tiles d = 0 (P,P), 1 + b (C_b,C_b): S = mm + hh in their tile, N = hl + hm in acc3[NT3 + d]
+          auto offd = [&](const u32x4 (&A)[1 + NCB], const u32x4 (&Bv)[1 + NCB]) {
+#pragma unroll
+            for (int b = 0; b < NCB; ++b) acc3[1 + b] = mfma_bf16(A[0], Bv[1 + b], acc3[1 + b]);
+            int t = 1 + NCB;
+#pragma unroll
+            for (int b = 0; b < NCB; ++b)
+#pragma unroll
+              for (int b2 = b; b2 < NCB; ++b2, ++t) if (b2 != b) acc3[t] = mfma_bf16(A[1 + b], Bv[1 + b2], acc3[t]);
+          };
+          auto diag = [&](const u32x4 (&A)[1 + NCB], const u32x4 (&Bv)[1 + NCB], bool npart) {
+            acc3[npart ? NT3 : 0] = mfma_bf16(A[0], Bv[0], acc3[npart ? NT3 : 0]);
+            int t = 1 + NCB;
+#pragma unroll
+            for (int b = 0; b < NCB; ++b) {
+              const int td = npart ? NT3 + 1 + b : t;
+              acc3[td] = mfma_bf16(A[1 + b], Bv[1 + b], acc3[td]);
+              t += NCB - b;
+            }
+          };
+          offd(om, om); diag(om, om, false); offd(oh, ol); diag(oh, ol, true); offd(ol, oh); offd(oh, om); diag(oh, om, true); offd(om, oh);
+          offd(oh, oh); diag(oh, oh, false);
+        } else {
         tiles(om, om); tiles(oh, ol); tiles(ol, oh); tiles(oh, om); tiles(om, oh); tiles(oh, oh);
+        }
       }
     } else {
 #if !(DFX_ABLATE & 16)
@@ -657,7 +715,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     float* mine = partials + ((size_t)dyn_pair * dyn.team + dyn_member) * ZDIM;
     if constexpr (B3) {
 #pragma unroll
-      for (int a = 0; a < NT3; ++a)
+      for (int a = 0; a < NB3; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mine[a * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc3[a][r];
     } else {
@@ -688,7 +746,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     float* mine = lds + wave * SLOT;
     if constexpr (B3) {   // every tile in the C/D layout of a 16x16 MFMA: [row = 4 (lane >> 4) + r][col = lane & 15]
 #pragma unroll
-      for (int a = 0; a < NT3; ++a)
+      for (int a = 0; a < NB3; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mine[a * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc3[a][r];
     } else {
@@ -875,9 +933,11 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize_b3(const float* __restric
                                                           char* __restrict__ items, const size_t item_stride, unsigned* __restrict__ qhead) {
   constexpr int CS = 16 * NCB;
   constexpr int NP = NPOSE + CS;
-  constexpr int ZDIM = b3_tiles(NCB) * 256;
+  constexpr int NT3 = b3_tiles(NCB);
+  constexpr int ZDIM = b3_blocks(NCB) * 256;
   constexpr int NT = NP * (NP + 1) / 2;
   __shared__ double red[4][256];
+  __shared__ double redn[b3_diag4(NCB) ? 4 : 1][256];   // DFX_B3_DIAG4: the N part of a diagonal tile
   __shared__ double T[12][6];   // d(pose0, pose1) <- d(relative pose): J = gC * T^T
 
   const int blk = blockIdx.x, pair = blockIdx.y;
@@ -885,6 +945,13 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize_b3(const float* __restric
   if (qhead && blk == 0 && threadIdx.x == 0) qhead[pair] = 0u;
   const float* src = partials + (size_t)pair * bpp * ZDIM + blk * 256 + el;
   red[rg][el] = strided_sum_f64<4, 16>(src, rg, bpp, ZDIM);
+  // DFX_B3_DIAG4: diagonal tile d = 0 (P,P) / 1 + b (C_b,C_b) keeps S = hh + mm in its own block and N = hm + hl in block NT3 + d
+  int dtile = -1;
+  if (b3_diag4(NCB)) {
+    if (blk == 0) dtile = 0;
+    else if (blk > NCB) { int q = blk - 1 - NCB; for (int b = 0; b < NCB; ++b) { if (q == 0) { dtile = 1 + b; break; } q -= NCB - b; if (q < 0) break; } }
+    if (dtile >= 0) redn[b3_diag4(NCB) ? rg : 0][el] = strided_sum_f64<4, 16>(partials + (size_t)pair * bpp * ZDIM + (NT3 + dtile) * 256 + el, rg, bpp, ZDIM);
+  }
   if (NPOSE == 12 && threadIdx.x < 72) {
     const int n = threadIdx.x / 6, i = threadIdx.x - n * 6;
     const float* M = BYVAL ? one.M : pairs[pair].M;
@@ -899,7 +966,15 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize_b3(const float* __restric
   }
   __syncthreads();
   if (rg == 0) red[0][el] = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
+  if (b3_diag4(NCB) && dtile >= 0 && rg == 1) redn[0][el] = ((redn[0][el] + redn[b3_diag4(NCB) ? 1 : 0][el]) + redn[b3_diag4(NCB) ? 2 : 0][el]) + redn[b3_diag4(NCB) ? 3 : 0][el];
   __syncthreads();
+  if (b3_diag4(NCB) && dtile >= 0) {   // Z = S + N + N^T
+    double v = 0.0;
+    if (rg == 0) v = red[0][el] + redn[0][el] + redn[0][(el & 15) * 16 + (el >> 4)];
+    __syncthreads();
+    if (rg == 0) red[0][el] = v;
+    __syncthreads();
+  }
   const double* S = red[0];   // S[row * 16 + col]
 
   float* item = reinterpret_cast<float*>(items + (size_t)pair * item_stride);

@@ -308,3 +308,59 @@ def test_bf16x3_tiles_cover_the_item_exactly_once_at_fp32_accuracy(cs):
     assert np.abs(H[iu] - ref[iu]).max() < 3e-8 * np.abs(ref).max()
     assert np.abs(g - J.T @ wr).max() < 3e-8 * max(1.0, np.abs(J.T @ wr).max())
     assert abs(residual - float(wr @ wr)) < 3e-8 * float(wr @ wr) and abs(inliers - inl.sum()) < 1e-6
+
+
+def test_bf16x3_psplit_lds_layout_hands_every_lane_its_eight_pixels():
+    """DFX_B3_PSPLIT (build flag, dfx_sfm_step.hip): phase A lane p (= pixel p of the chunk) writes the 16-bit pieces of its P rows at element
+    ((piece * 8 + row) * 64 + psl(p)); phase B lane (row, k) reads 16 bytes at byte ((row & 7) * 128 + k * 16 + piece * 1024 + h * 64) and must find
+    slots j = 0..7 = pixels 4 (8 h + j) + k of that row and piece, in order."""
+    lds = np.full(3 * 8 * 64, -1, np.int64)                      # 16-bit elements of the wave's region; value = encoded (piece, row, pixel)
+    for p in range(64):
+        psl = 32 * (p >> 5) + 8 * (p & 3) + ((p >> 2) & 7)
+        for X in range(3):
+            for q in range(8):
+                e = (X * 8 + q) * 64 + psl
+                assert lds[e] == -1
+                lds[e] = (X * 8 + q) * 64 + p
+    assert (lds >= 0).all()
+    for lane in range(64):
+        li, lk = lane & 15, lane >> 4
+        for X in range(3):
+            for h in range(2):
+                byte = (li & 7) * 128 + lk * 16 + X * 1024 + h * 64
+                assert byte % 16 == 0
+                got = lds[byte // 2: byte // 2 + 8]
+                want = [(X * 8 + (li & 7)) * 64 + 4 * (8 * h + j) + lk for j in range(8)]
+                assert list(got) == want
+
+
+@pytest.mark.parametrize("cs", [16, 32])
+def test_bf16x3_diag4_equals_the_six_product_tiles(cs):
+    """DFX_B3_DIAG4 (build flag): diagonal tiles keep S = hh + mm and N = hm + hl; Z = S + N + N^T equals the six-product tile."""
+    rng = np.random.default_rng(cs)
+    z = rng.normal(size=(64, 16)).astype(np.float32)
+    h, m, l = (a.astype(np.float64) for a in _split3(z))
+    ein = lambda A, B: np.einsum("pi,pj->ij", A, B)
+    six = ein(m, m) + ein(h, l) + ein(l, h) + ein(h, m) + ein(m, h) + ein(h, h)
+    S, N = ein(m, m) + ein(h, h), ein(h, l) + ein(h, m)
+    assert np.abs(S + N + N.T - six).max() < 1e-12 * np.abs(six).max()
+    # decode of a diagonal tile index as k_sfm_finalize_b3 does it
+    ncb = cs // 16
+    diag = {}
+    for blk in range(1 + ncb + ncb * (ncb + 1) // 2):
+        d = -1
+        if blk == 0:
+            d = 0
+        elif blk > ncb:
+            q = blk - 1 - ncb
+            for b in range(ncb):
+                if q == 0:
+                    d = 1 + b
+                    break
+                q -= ncb - b
+                if q < 0:
+                    break
+        diag[blk] = d
+    tiles = [(0, 0)] + [(0, 1 + b) for b in range(ncb)] + [(1 + b, 1 + b2) for b in range(ncb) for b2 in range(b, ncb)]
+    for blk, (ka, kb) in enumerate(tiles):
+        assert diag[blk] == (ka if ka == kb else -1), (blk, ka, kb, diag[blk])
