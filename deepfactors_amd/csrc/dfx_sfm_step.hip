@@ -73,6 +73,9 @@ namespace dfx {
                              // 16 = no P x P fmas, 32 = no ray-table / valid0 reads, 64 = no operand shuffles, 128 = no tap gathers
 #endif
 
+#ifndef DFX_B3_MIN_WAVES
+#define DFX_B3_MIN_WAVES DFX_MIN_WAVES   // DFX_MFMA_BF16X3, CS <= 32: 4 asks the register allocator for 128 VGPRs (the split mode compiles to 132 = three waves per SIMD); NOT YET MEASURED
+#endif
 #ifndef DFX_B3_PSPLIT
 #define DFX_B3_PSPLIT 0      // DFX_MFMA_BF16X3 only, NOT YET MEASURED (written without GPU time left in round 2): 1 = the P block is split once per
 #endif                       // pixel in phase A and handed to phase B as packed bf16 pieces through LDS (ds_write_b16 / ds_read_b128): -44 VALU per chunk
@@ -173,7 +176,7 @@ __device__ __forceinline__ float dpp_merge(float old, float src) {
 // price: which items a wave sums is decided at run time, so results are reproducible to fp32 re-association (1e-7 relative), not
 // bit for bit.  Teams mix the dispatch ages (members g, g + #pairs, ...) and are rotated across the XCDs.
 template <int NCB, int MODE, bool JDENSE, bool TABLDS, bool BYVAL, bool DYN, bool B3>
-__global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_WAVES) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmPairDev one, const SfmParamsDev prm,
+__global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX_B3_MIN_WAVES : DFX_MIN_WAVES)) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmPairDev one, const SfmParamsDev prm,
                                                        const int W, const int H, float* __restrict__ partials, const DynDev dyn) {
   static_assert(!DYN || (MODE == 0 && JDENSE && TABLDS && !BYVAL), "the dynamic schedule exists for the batched dense SfM step");
   static_assert(!B3 || DFX_ABLATE == 0, "the ablation switches exist for the fp32 chain only");
