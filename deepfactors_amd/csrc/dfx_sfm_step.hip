@@ -1046,7 +1046,9 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize_b3(const float* __restric
 }
 
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair) {
-  return (size_t)npairs * blocks_per_pair * sfm_zdim(cs / 16) * sizeof(float);
+  // one size for both evaluation modes: the fp32 chain's packed z-space or the bf16 split's tiles (more blocks only with DFX_B3_DIAG4)
+  const int zc = sfm_zdim(cs / 16), zb = b3_blocks(cs / 16) * 256;
+  return (size_t)npairs * blocks_per_pair * (zc > zb ? zc : zb) * sizeof(float);
 }
 
 template <int NCB, int MODE>
@@ -1061,7 +1063,8 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   const bool b3 = prec == 1;   // DFX_MFMA_BF16X3 (include/dfx.h): exact three-way bf16 split on v_mfma_f32_16x16x32_bf16; 0: the fp32 chain
   if (((long long)W * H) % 64 != 0) jac_dense = false;   // ragged last chunk: the per-vector addressing clamps pixels past the image
   // the ray table rides in dynamic LDS when it fits beside the static arrays (64 KB per workgroup); MODE 1 has no table
-  constexpr size_t kStaticLds = sizeof(float) * (size_t)kWaves * ((kUFloats > (1 + NACC) * 256) ? kUFloats : (1 + NACC) * 256);
+  constexpr int kZMax = (1 + NACC) * 256 > b3_blocks(NCB) * 256 ? (1 + NACC) * 256 : b3_blocks(NCB) * 256;   // either evaluation mode
+  constexpr size_t kStaticLds = sizeof(float) * (size_t)kWaves * ((kUFloats > kZMax) ? kUFloats : kZMax);
   const size_t tab_bytes = sizeof(float) * ((size_t)W + H + kRayTabSlack);
   const bool tab_lds = MODE == 0 && kStaticLds + tab_bytes + DFX_EXTRA_LDS <= 64 * 1024;
   const size_t dyn_lds = DFX_EXTRA_LDS + (tab_lds ? tab_bytes : 0);
