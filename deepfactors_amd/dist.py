@@ -153,6 +153,11 @@ class NormalEquations:
         half the xGMI traffic of an all-reduce.  The buffers of the other ranks are left as they were (partial)."""
         dist.reduce(self.buf, dst=root)
 
+    def reduce_async(self, dist, root=0):
+        """reduce() as a non-blocking collective: returns the work handle; `wait()` on it orders the caller's stream (RCCL) or the host
+        (gloo) behind the sum.  The buffer must not be written again before that wait."""
+        return dist.reduce(self.buf, dst=root, async_op=True)
+
     @staticmethod
     def gather_items(dist, items_u8, n_total, item_size, world):
         """Gather mode: every rank contributes the items of its contiguous shard (shard_range) and receives all n_total items in
@@ -184,3 +189,47 @@ class NormalEquations:
             M[ra, cb] += Ho[p]
             M[cb, ra] += Ho[p].T
         return M
+
+
+
+class PipelinedReduce:
+    """Reduce-mode exchange of a STREAM of independent batches (bench.py, N > 1): the collective of batch k runs on RCCL's stream beside
+    the kernels of batch k + 1.  `systems` are NormalEquations of the same graph used round robin; a system is handed out again only
+    after the reduce that last read it has been waited for (stream-side on RCCL: the host never blocks).
+
+        sys = pipe.next()        # assemble this batch's items into sys (enqueue the kernels) ...
+        pipe.submit()            # ... then start its reduce onto `root`
+        pipe.drain()             # before reading results / at the end of a timed region
+
+    A single Gauss-Newton loop cannot use this (its solve needs the reduced system before the next linearisation); a mapper with
+    several windows in flight, or a throughput measurement over independent batches, can."""
+
+    def __init__(self, dist, systems, root=0):
+        self.dist, self.systems, self.root = dist, list(systems), int(root)
+        assert len(self.systems) >= 1
+        self.pending = [None] * len(self.systems)
+        self.count = 0
+        self.cur = None
+
+    def next(self):
+        b = self.count % len(self.systems)
+        self.count += 1
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+        self.cur = b
+        return self.systems[b]
+
+    def submit(self):
+        assert self.cur is not None and self.pending[self.cur] is None
+        self.pending[self.cur] = self.systems[self.cur].reduce_async(self.dist, self.root)
+
+    def drain(self):
+        for b, w in enumerate(self.pending):
+            if w is not None:
+                w.wait()
+                self.pending[b] = None
+
+    def last(self):
+        """The system of the most recent batch (complete on `root` after drain())."""
+        return self.systems[self.cur]
