@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--window", action="store_true", help="also measure BASELINE configs[3]: 64 keyframes, 1024 pairs over the ranks")
     ap.add_argument("--schedule", choices=["auto", "static", "dynamic"], default="auto",
                     help="auto: measure the library's static default and its opt-in dynamic item queues during the untimed ramp and run the faster; static / dynamic: force one")
+    ap.add_argument("--mfma", choices=["f32", "bf16x3"], default="f32",
+                    help="evaluation mode of the step kernel: f32 = the library default (fp32 fmaf chain); bf16x3 = the opt-in exact three-way bf16 split")
     ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -123,7 +125,7 @@ def pmc_traffic(a):
     out = tempfile.mkdtemp(prefix="dfx_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     worker = [sys.executable, os.path.abspath(__file__), "--pmc-worker", "--pairs", str(a.pairs), "--width", str(a.width), "--height", str(a.height),
-              "--cs", str(a.cs), "--step-blocks", str(a.step_blocks), "--schedule", a.schedule]
+              "--cs", str(a.cs), "--step-blocks", str(a.step_blocks), "--schedule", a.schedule, "--mfma", a.mfma]
     passes = {"rd": ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"],
               "wr": ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"]}
     vals = {}
@@ -357,6 +359,8 @@ def main():
 
     W, H, CS, P = a.width, a.height, a.cs, a.pairs
     ctx = dfx.Context(local)
+    from deepfactors_amd import _lib as _dlm
+    ctx.set_mfma_mode(_dlm.DFX_MFMA_BF16X3 if a.mfma == "bf16x3" else _dlm.DFX_MFMA_F32_CHAIN)   # explicit: not whatever DFX_MFMA says
     if a.schedule != "auto":
         from deepfactors_amd import _lib as _dl0
         ctx.set_schedule(_dl0.DFX_SCHEDULE_STATIC if a.schedule == "static" else _dl0.DFX_SCHEDULE_DYNAMIC)
@@ -513,13 +517,17 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "fp32_tflops": flops_per_launch / kern_s / 1e12,
                          "schedule": "dynamic item queues (results reproducible to fp32 re-association)" if ctx.last_schedule_dynamic()
-                                     else "static partition (bit-reproducible)"},
+                                     else "static partition (bit-reproducible)",
+                         "mfma": "fp32 fmaf chain on v_mfma_f32_16x16x4_f32 (library default)" if a.mfma == "f32"
+                                 else "exact three-way bf16 split on v_mfma_f32_16x16x32_bf16, fp32 accumulate (opt-in DFX_MFMA_BF16X3)"},
         }
     ctx.set_schedule(_dl.DFX_SCHEDULE_AUTO)   # the secondary measurements below run the library's defaults
+    ctx.set_mfma_mode(_dl.DFX_MFMA_F32_CHAIN)
     configs = {}
     if world == 1 and not a.no_configs:
         # the timed workload once more on the opt-in exact bf16 split (static schedule; the line's `value` and `roofline` above are the fp32 chain's)
-        configs["headline_workload_bf16x3"] = mode_kernel_us(ctx, lambda: al.RunStepBatchAsync(arr, items), (20 + 4 * CS) * W * H * P, warm=150, steps=30)
+        if a.mfma == "f32":
+            configs["headline_workload_bf16x3"] = mode_kernel_us(ctx, lambda: al.RunStepBatchAsync(arr, items), (20 + 4 * CS) * W * H * P, warm=150, steps=30)
         configs.update(secondary_configs(dfx, synth, ctx, dev))
     if a.window:
         del keep, pairs, arr
