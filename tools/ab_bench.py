@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--cs", type=int, default=32)
-    ap.add_argument("--mode", type=int, default=0, help="0 = f32 chain MFMA (the only mode since the packed z-space layout)")
+    ap.add_argument("--mode", type=int, default=0, help="0 = fp32 chain (DFX_MFMA_F32_CHAIN), 1 = exact bf16 split (DFX_MFMA_BF16X3)")
     ap.add_argument("--preroll", type=int, default=150, help="untimed launches before the first measurement of a process (clock ramp)")
     ap.add_argument("--distinct", action="store_true", help="distinct synthetic pairs with a valid0 image, as bench.py builds them")
     ap.add_argument("--worker", action="store_true")
