@@ -1,0 +1,16 @@
+"""Pure host logic of the C++17 layer (include/dfx_host.hpp, dfx_shim.hpp) WITHOUT a GPU: the relinearisation test of
+PhotometricFactor::GetJacobiansIfNeeded (photometric_factor.cpp:296-306), the residual rescaling (:275-282), the HessianFactor block
+slicing (:105-161) and the item accessors -- tests/cpp/host_logic_test.cpp, plain g++, no device entry point is called."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_host_logic_without_a_gpu():
+    exe = os.path.join(ROOT, "tests", "cpp", "host_logic_test")
+    if not os.path.exists(exe):   # built by __graft_entry__.build(); build it here when the tests run first
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "host_logic_test"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60, stdin=subprocess.DEVNULL)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "host_logic_test OK" in out.stdout
