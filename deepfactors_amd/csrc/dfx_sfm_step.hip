@@ -69,7 +69,7 @@ namespace dfx {
 #define DFX_TRACE 0          // 1: per-wave s_memtime sums of phase A / phase B in the junk row 15 of the (P,P) partial
 #endif
 #ifndef DFX_ABLATE
-#define DFX_ABLATE 0         // diagnosis only (wrong results): 1 = no MFMAs, 2 = no phase-A math/gathers, 4 = no ring loads,
+#define DFX_ABLATE 0         // diagnosis only (wrong results; fp32 chain only, the bf16 split honours bit 4 alone): 1 = no MFMAs, 2 = no phase-A math/gathers, 4 = no ring loads,
                              // 16 = no P x P fmas, 32 = no ray-table / valid0 reads, 64 = no operand shuffles, 128 = no tap gathers
 #endif
 
@@ -179,7 +179,6 @@ template <int NCB, int MODE, bool JDENSE, bool TABLDS, bool BYVAL, bool DYN, boo
 __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX_B3_MIN_WAVES : DFX_MIN_WAVES)) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmPairDev one, const SfmParamsDev prm,
                                                        const int W, const int H, float* __restrict__ partials, const DynDev dyn) {
   static_assert(!DYN || (MODE == 0 && JDENSE && TABLDS && !BYVAL), "the dynamic schedule exists for the batched dense SfM step");
-  static_assert(!B3 || DFX_ABLATE == 0, "the ablation switches exist for the fp32 chain only");
   constexpr int NX = NCB * (NCB - 1) / 2, ND = (NCB + 1) / 2;   // X(b,b'), Dd(q); Pm(b): NCB
   constexpr int NACC = NX + NCB;                                 // 16x16x4 accumulators
   constexpr int NT3 = b3_tiles(NCB);                             // B3: plain 16x16 tiles (P,P), (P,C_b), (C_b,C_b') b <= b'
