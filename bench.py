@@ -101,9 +101,26 @@ def cpu_baseline(w, h, cs):
 
     allc, n_all, t_all = median_rate(cores, 10, 1.5)
     one, n_one, t_one = median_rate(1, 10, 0.0)
-    return dict(value=allc, unit="pair-evals/s", cores=cores, kind="port", single_thread=one,
-                sample=f"one {w}x{h} cs={cs} SfmAligner::RunStep pair, fp32 accumulate, g++ -O3 -march=native -ffp-contract=off: median of {n_all} "
-                       f"repetitions with OpenMP over rows on {cores} threads ({t_all:.1f} s), median of {n_one} repetitions on 1 thread ({t_one:.1f} s)")
+    out = dict(value=allc, unit="pair-evals/s", cores=cores, kind="port", single_thread=one,
+               sample=f"one {w}x{h} cs={cs} SfmAligner::RunStep pair, fp32 accumulate, g++ -O3 -march=native -ffp-contract=off: median of {n_all} "
+                      f"repetitions with OpenMP over rows on {cores} threads ({t_all:.1f} s), median of {n_one} repetitions on 1 thread ({t_one:.1f} s)")
+    # beside the port: the REFERENCE'S OWN per-pixel code (oracle/_ref: its unmodified dense_sfm.h / warping.h ... compiled against stand-in
+    # Eigen / Sophus / VisionCore headers, g++ -O2, the host loop of ut_sfmaligner.cpp:307-315, single-threaded like the reference) where the
+    # prebuilt library travelled with the snapshot; the same pair
+    try:
+        from oracle import dfx_ref
+        if dfx_ref.available():
+            dfx_ref.sfm_step(*args)
+            ts = []
+            while len(ts) < 7:
+                t0 = time.perf_counter()
+                dfx_ref.sfm_step(*args)
+                ts.append(time.perf_counter() - t0)
+            out["reference_code_single_thread"] = 1.0 / float(np.median(ts))
+            out["sample"] += f"; reference_code_single_thread: oracle/_ref (the reference's own DenseSfm host loop, g++ -O2, stand-in Eigen), median of {len(ts)}"
+    except Exception as e:   # noqa: BLE001 -- an extra figure, never the line
+        out["reference_code_error"] = f"{type(e).__name__}: {e}"
+    return out
 
 
 def build_pairs(dfx, synth, dev, rank, P, W, H, CS, same=False):
