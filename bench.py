@@ -349,6 +349,82 @@ def window_config(dfx, synth, ctx, dev, dist, rank, world):
                      "(not an HBM-roofline figure)")
 
 
+def run_protocol(a, dist, dev, ctx, step, barrier, P):
+    """The measurement protocol around `step` (one pass of the hot path): clock ramp in windows until the kernel time has settled,
+    schedule probe (--schedule auto), W warm-up steps, K timed steps between barriers, MAX over ranks.  Every decision that steers the
+    control flow (leaving the ramp, the schedule) is agreed between the ranks by a collective, so all ranks issue the same sequence of
+    steps and collectives (tests/test_bench_protocol.py runs it on two gloo ranks with fakes).  Returns a dict."""
+    import torch
+    # setup, untimed and not part of the W warm-up steps: after idle the GPU needs ~0.15 s of sustained work to reach its steady clocks
+    # (tools/clock_series.py, 128-pair steps: launches 0-49 average 1287 us, 50-99 1144 us, from 100 on 1065 +- 5 us for thousands
+    # of launches) and some boxes take longer, so the same steps run in windows until the step kernel's time has settled: three
+    # consecutive windows within 1 %, at least 6 windows (~0.35 s), at most 40 (~2.3 s).  All ranks leave the loop together.
+    win = max(25, 6400 // max(P, 1))
+    ramp_steps, hist = 0, []
+    ctx.set_profiling(True)
+    for w_i in range(40):
+        for _ in range(win):
+            step()
+        barrier()
+        n_w, ms_w = ctx.profile_read()
+        hist.append(ms_w / max(n_w, 1))
+        ramp_steps += win
+        settled = w_i >= 5 and max(hist[-3:]) <= 1.01 * min(hist[-3:])
+        go_on = torch.tensor([0 if settled else 1], dtype=torch.int32, device=dev)
+        if dist is not None:
+            dist.all_reduce(go_on, op=dist.ReduceOp.MAX)
+        if int(go_on.item()) == 0:
+            break
+    # Schedule choice (--schedule auto only, still untimed): the library's default is the static, bit-reproducible launch; its opt-in
+    # dynamic item queues are 1.5-2.3 % faster on most boxes and 4.5 % slower on some (DESIGN.md 3.1), so two windows of each are
+    # measured here, on this box, and the faster one runs the warm-up and the timed steps.  The choice and both figures are reported.
+    from deepfactors_amd import _lib as _dl
+    sched_probe = None
+    if a.schedule == "auto":
+        def window_us(mode):
+            ctx.set_schedule(mode)
+            for _ in range(win):
+                step()
+            barrier()
+            ctx.profile_read()
+            for _ in range(2 * win):
+                step()
+            barrier()
+            n_w, ms_w = ctx.profile_read()
+            return ms_w / max(n_w, 1) * 1e3
+        us_dyn = window_us(_dl.DFX_SCHEDULE_DYNAMIC)
+        ran_dyn = ctx.last_schedule_dynamic()          # the launch may be structurally unable to (then both windows were static)
+        us_sta = window_us(_dl.DFX_SCHEDULE_STATIC)
+        ramp_steps += 6 * win
+        keep_static = torch.tensor([0 if (ran_dyn and us_dyn < 0.995 * us_sta) else 1], dtype=torch.int32, device=dev)
+        if dist is not None:
+            dist.all_reduce(keep_static, op=dist.ReduceOp.MAX)   # every rank runs the same schedule
+        use_dyn = int(keep_static.item()) == 0
+        ctx.set_schedule(_dl.DFX_SCHEDULE_DYNAMIC if use_dyn else _dl.DFX_SCHEDULE_STATIC)
+        a.schedule = "dynamic" if use_dyn else "static"          # the PMC child run below measures the same kernel
+        sched_probe = {"static_kernel_us": round(us_sta, 1), "dynamic_kernel_us": round(us_dyn, 1) if ran_dyn else None,
+                       "chosen": "dynamic" if use_dyn else "static"}
+    ctx.set_profiling(False)
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    ctx.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    t1 = time.perf_counter()
+    n_launch, kern_ms = ctx.profile_read()
+    ctx.set_profiling(False)
+
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    return dict(hist=hist, ramp_steps=ramp_steps, sched_probe=sched_probe, elapsed=elapsed, n_launch=n_launch, kern_ms=kern_ms)
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ and not a.pmc_worker:
@@ -420,73 +496,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # setup, untimed and not part of the W warm-up steps: after idle the GPU needs ~0.15 s of sustained work to reach its steady clocks
-    # (tools/clock_series.py, 128-pair steps: launches 0-49 average 1287 us, 50-99 1144 us, from 100 on 1065 +- 5 us for thousands
-    # of launches) and some boxes take longer, so the same steps run in windows until the step kernel's time has settled: three
-    # consecutive windows within 1 %, at least 6 windows (~0.35 s), at most 40 (~2.3 s).  All ranks leave the loop together.
-    win = max(25, 6400 // max(P, 1))
-    ramp_steps, hist = 0, []
-    ctx.set_profiling(True)
-    for w_i in range(40):
-        for _ in range(win):
-            step()
-        barrier()
-        n_w, ms_w = ctx.profile_read()
-        hist.append(ms_w / max(n_w, 1))
-        ramp_steps += win
-        settled = w_i >= 5 and max(hist[-3:]) <= 1.01 * min(hist[-3:])
-        go_on = torch.tensor([0 if settled else 1], dtype=torch.int32, device=dev)
-        if dist is not None:
-            dist.all_reduce(go_on, op=dist.ReduceOp.MAX)
-        if int(go_on.item()) == 0:
-            break
-    # Schedule choice (--schedule auto only, still untimed): the library's default is the static, bit-reproducible launch; its opt-in
-    # dynamic item queues are 1.5-2.3 % faster on most boxes and 4.5 % slower on some, so two windows of each are
-    # measured here, on this box, and the faster one runs the warm-up and the timed steps.  The choice and both figures are reported.
+    pr = run_protocol(a, dist, dev, ctx, step, barrier, P)
+    hist, ramp_steps, sched_probe, elapsed, n_launch, kern_ms = pr["hist"], pr["ramp_steps"], pr["sched_probe"], pr["elapsed"], pr["n_launch"], pr["kern_ms"]
     from deepfactors_amd import _lib as _dl
-    sched_probe = None
-    if a.schedule == "auto":
-        def window_us(mode):
-            ctx.set_schedule(mode)
-            for _ in range(win):
-                step()
-            barrier()
-            ctx.profile_read()
-            for _ in range(2 * win):
-                step()
-            barrier()
-            n_w, ms_w = ctx.profile_read()
-            return ms_w / max(n_w, 1) * 1e3
-        us_dyn = window_us(_dl.DFX_SCHEDULE_DYNAMIC)
-        ran_dyn = ctx.last_schedule_dynamic()          # the launch may be structurally unable to (then both windows were static)
-        us_sta = window_us(_dl.DFX_SCHEDULE_STATIC)
-        ramp_steps += 6 * win
-        keep_static = torch.tensor([0 if (ran_dyn and us_dyn < 0.995 * us_sta) else 1], dtype=torch.int32, device=dev)
-        if dist is not None:
-            dist.all_reduce(keep_static, op=dist.ReduceOp.MAX)   # every rank runs the same schedule
-        use_dyn = int(keep_static.item()) == 0
-        ctx.set_schedule(_dl.DFX_SCHEDULE_DYNAMIC if use_dyn else _dl.DFX_SCHEDULE_STATIC)
-        a.schedule = "dynamic" if use_dyn else "static"          # the PMC child run below measures the same kernel
-        sched_probe = {"static_kernel_us": round(us_sta, 1), "dynamic_kernel_us": round(us_dyn, 1) if ran_dyn else None,
-                       "chosen": "dynamic" if use_dyn else "static"}
-    ctx.set_profiling(False)
-    for _ in range(a.warmup):
-        step()
-    barrier()
-    ctx.set_profiling(True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    barrier()
-    t1 = time.perf_counter()
-    n_launch, kern_ms = ctx.profile_read()
-    ctx.set_profiling(False)
-
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
 
     # sanity (untimed): results are real (inliers > half of the pixels on every pair) ...
     its = al.items_from_bytes(items.cpu().numpy(), CS)
