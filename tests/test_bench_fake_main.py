@@ -1,0 +1,158 @@
+"""bench.py's main() end to end WITHOUT a GPU: the device layer is replaced by fakes (a context with a synthetic kernel clock, an aligner
+whose items come from the CPU oracle and whose assembly is the torch formulation of deepfactors_amd.dist), `cuda` devices map to the
+CPU and RCCL to gloo.  What this pins is everything around the kernels that no 1-GPU box can show: the N = 2 path (shards, the
+overlapped reduce through two system buffers, the checksum of the exchanged system on rank 0, ONE JSON line from rank 0 only) and the
+contract fields of the line.  The oracle is used here as the stand-in device, in a test -- never by bench.py itself."""
+import contextlib
+import importlib.util
+import io
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--pairs", "48", "--width", "64", "--height", "48", "--cs", "16", "--steps", "3", "--warmup", "1", "--no-configs", "--no-traffic", "--no-cpu-baseline"]
+
+
+class FakeCtx:
+    def __init__(self, device=None, stream="torch"):
+        self.profiling, self.pending, self.dynamic, self.mfma = False, [], False, 0
+
+    def launch(self):
+        if self.profiling:
+            self.pending.append(1.0 if not self.dynamic else 0.97)
+
+    def set_profiling(self, on):
+        self.profiling, self.pending = bool(on), []
+
+    def profile_read(self):
+        n, ms = len(self.pending), sum(self.pending)
+        self.pending = []
+        return n, ms
+
+    def set_schedule(self, mode):
+        from deepfactors_amd import _lib
+        self.dynamic = mode == _lib.DFX_SCHEDULE_DYNAMIC
+
+    def last_schedule_dynamic(self):
+        return self.dynamic
+
+    def set_mfma_mode(self, mode):
+        self.mfma = mode
+
+    def sync(self):
+        pass
+
+
+class FakeAligner:
+    """Items from the CPU oracle (computed once per batch), assembly through NormalEquations.assemble (torch, CPU)."""
+
+    def __init__(self, params=None, code_size=32, ctx=None):
+        self.CS, self.ctx, self._bytes = int(code_size), ctx, None
+
+    def make_pairs(self, pairs):
+        return list(pairs)
+
+    def _items(self, arr):
+        if self._bytes is None:
+            from deepfactors_amd._lib import item_inliers_offset, item_jtj_len, item_size
+            from oracle import dfx_oracle as orc
+            orc.build()
+            NP = 12 + self.CS
+            raw = np.zeros((len(arr), item_size(NP)), np.uint8)
+            for k, p in enumerate(arr):
+                r = orc.sfm_step(p["pose0"], p["pose1"], p["cam"], p["img0"].numpy(), p["img1"].numpy(), p["dpt0"].numpy(), p["prx0_jac"].numpy(), p["grad1"].numpy())
+                f = raw[k, : (item_jtj_len(NP) + NP + 1) * 4].view(np.float32)
+                f[: item_jtj_len(NP)] = r.JtJ
+                f[item_jtj_len(NP): item_jtj_len(NP) + NP] = r.Jtr
+                f[item_jtj_len(NP) + NP] = r.residual
+                raw[k, item_inliers_offset(NP):].view(np.uint64)[0] = r.inliers
+            self._bytes = torch.from_numpy(raw.reshape(-1))
+        return self._bytes
+
+    def RunStepBatchAsync(self, arr, items):
+        items.copy_(self._items(arr))
+        self.ctx.launch()
+
+    def RunStepBatchAssembleAsync(self, arr, items, neq, first_pair):
+        from deepfactors_amd import item_size
+        self.RunStepBatchAsync(arr, items)
+        neq.assemble(items, first_pair, len(arr), item_size(12 + self.CS))
+
+    @staticmethod
+    def items_from_bytes(raw, cs):
+        from deepfactors_amd.aligners import SfmAligner
+        return SfmAligner.items_from_bytes(raw, cs)
+
+
+def _run_main(argv, out_path):
+    """bench.main() with the device layer faked; stdout of the call goes to out_path."""
+    import deepfactors_amd
+    import torch.distributed as tdist
+    spec = importlib.util.spec_from_file_location("dfx_bench", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    n_threads = torch.get_num_threads()
+    torch.set_num_threads(1)   # the stand-in device runs hundreds of tiny torch ops per second: intra-op threads only add wake-up latency (58 ms vs 0.3 ms per assembly)
+    real_device, real_init = torch.device, tdist.init_process_group
+    patches = [(torch.cuda, "is_available", lambda: True), (torch.cuda, "set_device", lambda d: None), (torch.cuda, "synchronize", lambda *a: None),
+               (torch, "device", lambda *a, **k: real_device("cpu")), (deepfactors_amd, "Context", FakeCtx), (deepfactors_amd, "SfmAligner", FakeAligner),
+               (tdist, "init_process_group", lambda backend, rank, world_size, device_id=None: real_init("gloo", rank=rank, world_size=world_size))]
+    saved = [(o, n, getattr(o, n)) for o, n, _ in patches]
+    old_argv = sys.argv
+    buf = io.StringIO()
+    try:
+        for o, n, v in patches:
+            setattr(o, n, v)
+        sys.argv = ["bench.py"] + argv
+        with contextlib.redirect_stdout(buf):
+            b.main()
+    finally:
+        sys.argv = old_argv
+        torch.set_num_threads(n_threads)
+        for o, n, v in saved:
+            setattr(o, n, v)
+    with open(out_path, "w") as fh:
+        fh.write(buf.getvalue())
+
+
+def _check_line(txt, world):
+    lines = [l for l in txt.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("keyframe-pair residual+Jacobian evals/sec") and d["unit"] == "pair-evals/s"
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] - world * 48 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert d["config"]["pairs_per_gpu"] == 48 and "workload" in d["config"] and ("RCCL reduce" in d["config"]["workload"]) == (world > 1)
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["launches"] == 3 and r["traffic"] is None and "traffic_source" in r and "mfma" in r and "schedule" in r
+    assert d["schedule_probe"]["chosen"] == "dynamic" and len(d["ramp_kernel_us"]) >= 6
+    return d
+
+
+def test_main_single_process(tmp_path, monkeypatch):
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    out = tmp_path / "n1.txt"
+    _run_main(ARGS, str(out))
+    _check_line(out.read_text(), 1)
+
+
+def _rank(rank, world, port, outdir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    _run_main(["--gpus", str(world)] + ARGS, os.path.join(outdir, f"rank{rank}.txt"))
+
+
+def test_main_two_ranks_over_gloo(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "rank1.txt").read_text().strip() == ""          # rank 0 alone prints the line
+    d = _check_line((tmp_path / "rank0.txt").read_text(), 2)
+    assert "not collected for N > 1" in d["roofline"]["traffic_source"] and "cpu_baseline" not in d
