@@ -50,15 +50,29 @@ class FakeCtx:
 
 
 class FakeAligner:
-    """Items from the CPU oracle (computed once per batch), assembly through NormalEquations.assemble (torch, CPU)."""
+    """Items from the CPU oracle (computed once per batch), assembly through NormalEquations.assemble (torch, CPU).  Only the FIRST
+    aligner of a process (main's timed workload, whose results main() checks) evaluates anything; the aligners of the secondary
+    measurements just tick the fake kernel clock."""
+    created = 0
 
     def __init__(self, params=None, code_size=32, ctx=None):
         self.CS, self.ctx, self._bytes = int(code_size), ctx, None
+        self.real = FakeAligner.created == 0
+        FakeAligner.created += 1
 
     def make_pairs(self, pairs):
         return list(pairs)
 
+    def RunStep(self, *args):
+        self.ctx.launch()
+
+    def LinearizeBatch(self, arr, prx, codes, items):
+        assert len(prx) == len(arr) == len(codes)
+        self.ctx.launch()
+
     def _items(self, arr):
+        if not self.real:
+            return None
         if self._bytes is None:
             from deepfactors_amd._lib import item_inliers_offset, item_jtj_len, item_size
             from oracle import dfx_oracle as orc
@@ -76,7 +90,9 @@ class FakeAligner:
         return self._bytes
 
     def RunStepBatchAsync(self, arr, items):
-        items.copy_(self._items(arr))
+        it = self._items(arr)
+        if it is not None:
+            items.copy_(it)
         self.ctx.launch()
 
     def RunStepBatchAssembleAsync(self, arr, items, neq, first_pair):
@@ -100,9 +116,16 @@ def _run_main(argv, out_path):
     n_threads = torch.get_num_threads()
     torch.set_num_threads(1)   # the stand-in device runs hundreds of tiny torch ops per second: intra-op threads only add wake-up latency (58 ms vs 0.3 ms per assembly)
     real_device, real_init = torch.device, tdist.init_process_group
+    from deepfactors_amd import synth
+    real_make_pair = synth.make_pair
+    FakeAligner.created = 0
+
+    def small_make_pair(w=640, h=480, cs=32, **kw):   # the secondary configurations ask for 640x480 ... 1280x960 pairs: content is irrelevant to the fakes
+        return real_make_pair(min(w, 64), min(h, 48), cs, **kw)
     patches = [(torch.cuda, "is_available", lambda: True), (torch.cuda, "set_device", lambda d: None), (torch.cuda, "synchronize", lambda *a: None),
                (torch, "device", lambda *a, **k: real_device("cpu")), (deepfactors_amd, "Context", FakeCtx), (deepfactors_amd, "SfmAligner", FakeAligner),
-               (tdist, "init_process_group", lambda backend, rank, world_size, device_id=None: real_init("gloo", rank=rank, world_size=world_size))]
+               (tdist, "init_process_group", lambda backend, rank, world_size, device_id=None: real_init("gloo", rank=rank, world_size=world_size)),
+               (synth, "make_pair", small_make_pair)]
     saved = [(o, n, getattr(o, n)) for o, n, _ in patches]
     old_argv = sys.argv
     buf = io.StringIO()
@@ -121,7 +144,7 @@ def _run_main(argv, out_path):
         fh.write(buf.getvalue())
 
 
-def _check_line(txt, world):
+def _check_line(txt, world, probe="dynamic"):
     lines = [l for l in txt.splitlines() if l.strip()]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
@@ -133,7 +156,7 @@ def _check_line(txt, world):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["launches"] == 3 and r["traffic"] is None and "traffic_source" in r and "mfma" in r and "schedule" in r
-    assert d["schedule_probe"]["chosen"] == "dynamic" and len(d["ramp_kernel_us"]) >= 6
+    assert (d["schedule_probe"]["chosen"] == probe if probe else d["schedule_probe"] is None) and len(d["ramp_kernel_us"]) >= 6
     return d
 
 
@@ -147,7 +170,7 @@ def test_main_single_process(tmp_path, monkeypatch):
 
 def _rank(rank, world, port, outdir):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    _run_main(["--gpus", str(world)] + ARGS, os.path.join(outdir, f"rank{rank}.txt"))
+    _run_main(["--gpus", str(world), "--window"] + ARGS, os.path.join(outdir, f"rank{rank}.txt"))
 
 
 def test_main_two_ranks_over_gloo(tmp_path):
@@ -156,3 +179,32 @@ def test_main_two_ranks_over_gloo(tmp_path):
     assert (tmp_path / "rank1.txt").read_text().strip() == ""          # rank 0 alone prints the line
     d = _check_line((tmp_path / "rank0.txt").read_text(), 2)
     assert "not collected for N > 1" in d["roofline"]["traffic_source"] and "cpu_baseline" not in d
+    w = d["configs"]["configs3_window64"]                               # --window: BASELINE configs[3] sharded over the two ranks
+    assert w["keyframes"] == 64 and w["pairs"] == 1024 and w["pairs_per_rank"] == 512 and w["evals_per_s"] > 0
+
+
+def test_main_with_the_secondary_configurations(tmp_path, monkeypatch):
+    """The default command's extra measurements (configs[1] single pair and pyramid, configs[4] on both evaluation modes, the configs[2]
+    relinearisation round, the headline batch on the bf16 split): every code path of secondary_configs / mode_kernel_us runs and lands in
+    the line."""
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    out = tmp_path / "cfg.txt"
+    _run_main([a for a in ARGS if a != "--no-configs"], str(out))
+    d = _check_line(out.read_text(), 1)
+    c = d["configs"]
+    assert set(c) >= {"headline_workload_bf16x3", "configs1_single_pair_blocking", "configs1_pyramid3_128pairs", "configs4_1280x960_cs64", "configs2_linearize_16kf_120pairs"}
+    assert c["headline_workload_bf16x3"]["kernel_us"] > 0 and "error" not in c["headline_workload_bf16x3"]
+    assert c["configs4_1280x960_cs64"]["bf16x3"]["kernel_us"] > 0 and "error" not in c["configs4_1280x960_cs64"]["bf16x3"]
+    assert c["configs4_1280x960_cs64"]["frac"] > 0 and len(c["configs1_pyramid3_128pairs"]["level_kernel_us"]) == 3
+
+
+def test_main_forced_modes(tmp_path, monkeypatch):
+    """--schedule static --mfma bf16x3 --window on one process: no probe, the line says which evaluation mode ran."""
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    out = tmp_path / "forced.txt"
+    _run_main(ARGS + ["--schedule", "static", "--mfma", "bf16x3", "--window"], str(out))
+    d = _check_line(out.read_text(), 1, probe=None)
+    assert "bf16" in d["roofline"]["mfma"] and "static" in d["roofline"]["schedule"]
+    assert d["configs"]["configs3_window64"]["pairs_per_rank"] == 1024
