@@ -386,10 +386,10 @@ DFX_API int dfx_ctx_create(int device, void* stream, dfx_ctx** out) {
   for (int i = 0; i < kStageSlots; ++i) {
     e = hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->slot_done[i], hipEventDisableTiming);
-    if (e != hipSuccess) { delete c; return fail(DFX_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { dfx_ctx_destroy(c); return fail(DFX_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(e)); }   // destroys what exists so far
   }
   e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
-  if (e != hipSuccess) { delete c; return fail(DFX_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+  if (e != hipSuccess) { dfx_ctx_destroy(c); return fail(DFX_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
   *out = c;
   return DFX_OK;
 }
