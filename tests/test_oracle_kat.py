@@ -147,3 +147,48 @@ def test_depth_aligner_matches_definition(oracle):
     assert np.abs(r.dense() - JtJ).max() <= 1e-9 * np.abs(JtJ).max()
     assert np.abs(r.Jtr - np.einsum("hwa,hw->a", J, diff)).max() <= 1e-9 * np.abs(r.Jtr).max()
     assert r.inliers == h * w and abs(r.residual - (diff ** 2).sum()) < 1e-9
+
+
+def test_bilinear_convention_matches_two_independent_implementations(oracle):
+    """SURVEY appendix B fixes getBilinear by specification (the VisionCore source is not in the reference tree): floor + lerp in x,
+    then in y, pixel centres at integer coordinates.  The same convention is what scipy.ndimage.map_coordinates(order=1) and
+    torch.nn.functional.grid_sample(align_corners=True, mode='bilinear') implement -- two independent code bases agree with the
+    oracle's sampler (and, through tests/test_oracle_vs_ref.py, with the stand-in the reference's own headers are compiled against)."""
+    import torch
+    from scipy import ndimage
+    rng = np.random.default_rng(42)
+    h, w = 37, 53
+    img = rng.normal(size=(h, w)).astype(np.float32)
+    u = rng.uniform(0.0, w - 1.001, 400)      # x
+    v = rng.uniform(0.0, h - 1.001, 400)      # y
+    u[:3] = [0.0, 5.0, w - 2.0]; v[:3] = [0.0, 7.5, h - 2.0]      # grid points and a half-way point included
+    got = np.array([oracle.bilinear(img, float(a), float(b))[0] for a, b in zip(u, v)], np.float64)
+    sp = ndimage.map_coordinates(img.astype(np.float64), np.stack([v, u]), order=1)
+    grid = torch.tensor(np.stack([2 * u / (w - 1) - 1, 2 * v / (h - 1) - 1], -1), dtype=torch.float64)[None, None]
+    th = torch.nn.functional.grid_sample(torch.from_numpy(img.astype(np.float64))[None, None], grid, mode="bilinear", align_corners=True)[0, 0, 0].numpy()
+    assert np.abs(got - sp).max() < 1e-5 and np.abs(got - th).max() < 1e-5
+    # the (gx, gy) gradient image is sampled component-wise
+    g2 = rng.normal(size=(h, w, 2)).astype(np.float32)
+    for a, b in zip(u[:20], v[:20]):
+        s = oracle.bilinear(g2, float(a), float(b))
+        for c in range(2):
+            assert abs(s[c] - ndimage.map_coordinates(g2[:, :, c].astype(np.float64), [[b], [a]], order=1)[0]) < 1e-5
+
+
+def test_quaternion_and_exponential_conventions_match_scipy(oracle):
+    """Sophus::SE3f stores a unit quaternion (x, y, z, w), Hamilton product, T * p = R p + t (SURVEY appendix B: Sophus is not in the
+    reference tree either).  scipy.spatial.transform.Rotation uses the same storage order and convention: quat -> R and the SO(3)
+    exponential of the oracle agree with it, and so does RelativePose = a^-1 * b composed from scipy rotations."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(7)
+    for _ in range(50):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        assert np.abs(oracle.quat_to_R(q) - Rotation.from_quat(q).as_matrix()).max() < 1e-12
+        wv = rng.normal(size=3) * rng.uniform(1e-6, 2.0)
+        assert np.abs(oracle.so3_exp(wv) - Rotation.from_rotvec(wv).as_matrix()).max() < 1e-12
+    qa, qb = rng.normal(size=4), rng.normal(size=4)
+    qa /= np.linalg.norm(qa); qb /= np.linalg.norm(qb)
+    ta, tb = rng.normal(size=3), rng.normal(size=3)
+    R, t, _, _ = oracle.relative_pose(np.concatenate([qa, ta]), np.concatenate([qb, tb]))
+    Ra, Rb = Rotation.from_quat(qa).as_matrix(), Rotation.from_quat(qb).as_matrix()
+    assert np.abs(R - Ra.T @ Rb).max() < 1e-12 and np.abs(t - Ra.T @ (tb - ta)).max() < 1e-12
