@@ -61,6 +61,8 @@ def parse():
                     help="auto: measure the library's static default and its opt-in dynamic item queues during the untimed ramp and run the faster; static / dynamic: force one")
     ap.add_argument("--mfma", choices=["f32", "bf16x3"], default="f32",
                     help="evaluation mode of the step kernel: f32 = the library default (fp32 fmaf chain); bf16x3 = the opt-in exact three-way bf16 split")
+    ap.add_argument("--foreign-valid0", action="store_true", help="keep the valid0 maps in torch tensors (memory the library does not own: the step kernel "
+                    "then re-reads the map every step, 4 B/px) instead of library-owned images with a 1-bit shadow")
     ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -123,10 +125,15 @@ def cpu_baseline(w, h, cs):
     return out
 
 
-def build_pairs(dfx, synth, dev, rank, P, W, H, CS, same=False):
+def build_pairs(dfx, synth, dev, rank, P, W, H, CS, same=False, ctx=None):
+    """P synthetic pairs.  With `ctx` every keyframe's valid map (kf->pyr_vld) is an image owned through the library, as the host layer's
+    keyframes keep it (include/dfx_host.hpp, Keyframe::pyr_vld): zero-filled, so the first step writes 1.0 at every inlier and the
+    steady state writes nothing -- and the library-owned map lets the step kernel consult its 1-bit shadow instead of re-reading it."""
     pairs, keep = [], []
     for k in range(P):
         p = synth.make_pair(W, H, CS, seed=0xDF02 + (0 if same else 1000 * rank + k), device=dev, motion_scale=(1.0 if same else 0.6 + 0.05 * (k % 8)))
+        if ctx is not None:
+            p["valid0"] = ctx.alloc_image(W, H)
         keep.append(p)
         pairs.append(dict(pose0=p["pose0"], pose1=p["pose1"], cam=p["cam"], img0=p["img0"], img1=p["img1"], dpt0=p["dpt0"],
                           prx0_jac=p["prx_jac"], grad1=p["grad1"], valid0=p["valid0"]))
@@ -227,7 +234,7 @@ def secondary_configs(dfx, synth, ctx, dev):
     # ---- SURVEY 8d "all pyramid levels" variant: the 128-pair batch at levels 0, 1, 2 (640x480, 320x240, 160x120), one launch per level
     lv_us = []
     for (w, h) in ((640, 480), (320, 240), (160, 120)):
-        pairs, keep = build_pairs(dfx, synth, dev, 3, 128, w, h, 32)
+        pairs, keep = build_pairs(dfx, synth, dev, 3, 128, w, h, 32, ctx=ctx)
         arr = al.make_pairs(pairs)
         items = torch.zeros(128 * dfx.item_size(12 + 32), dtype=torch.uint8, device=dev)
         for _ in range(300 if w == 640 else 1500):
@@ -246,7 +253,7 @@ def secondary_configs(dfx, synth, ctx, dev):
     # ---- configs[4]: 1280x960, cs = 64
     W, H, CS, P = 1280, 960, 64, 16
     al4 = dfx.SfmAligner(code_size=CS, ctx=ctx)
-    pairs, keep = build_pairs(dfx, synth, dev, 7, P, W, H, CS)
+    pairs, keep = build_pairs(dfx, synth, dev, 7, P, W, H, CS, ctx=ctx)
     arr = al4.make_pairs(pairs)
     items = torch.zeros(P * dfx.item_size(12 + CS), dtype=torch.uint8, device=dev)
     for _ in range(250):
@@ -460,7 +467,7 @@ def main():
     al = dfx.SfmAligner(dfx.SfmAlignerParams(step_blocks=a.step_blocks), code_size=CS, ctx=ctx)
 
     # ---- synthetic, device-resident input: P distinct keyframe->frame pairs per rank
-    pairs, keep = build_pairs(dfx, synth, dev, rank, P, W, H, CS, same=bool(os.environ.get("DFX_BENCH_SAME")))
+    pairs, keep = build_pairs(dfx, synth, dev, rank, P, W, H, CS, same=bool(os.environ.get("DFX_BENCH_SAME")), ctx=None if a.foreign_valid0 else ctx)
     arr = al.make_pairs(pairs)
     isz = dfx.item_size(12 + CS)
     items = torch.zeros(P * isz, dtype=torch.uint8, device=dev)

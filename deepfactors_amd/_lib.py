@@ -17,6 +17,7 @@ DFX_E_HIP = -2
 DFX_E_NOGPU = -3
 DFX_MFMA_F32_CHAIN = 0
 DFX_MFMA_BF16X3 = 1
+DFX_MFMA_AUTO = 2
 
 
 class DfxError(RuntimeError):
@@ -87,6 +88,8 @@ _PROTOS = {
     "dfx_sfm_set_step_blocks": (C.c_int, [C.c_void_p, C.c_int]),
     "dfx_device_cu_count": (C.c_int, [C.c_void_p]),
     "dfx_set_mfma_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "dfx_last_mfma_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "dfx_debug_read_valid0_shadow": (C.c_int, [C.c_void_p, C.POINTER(Img), C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]),
     "dfx_set_schedule": (C.c_int, [C.c_void_p, C.c_int]),
     "dfx_last_schedule": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "dfx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),

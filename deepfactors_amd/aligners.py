@@ -75,7 +75,64 @@ class SfmAlignerParams:
 # ------------------------------------------------------------------------------------------------------------
 # argument marshalling
 # ------------------------------------------------------------------------------------------------------------
+class DeviceImage:
+    """A device image OWNED THROUGH THE LIBRARY (dfx_img_alloc; include/dfx_host.hpp's ``dfx::DeviceImage``, the device side of the
+    reference's ``vc::Image2DManaged`` / SyncedBufferPyramid levels).  Accepted wherever a float32 CUDA tensor is.  What it buys over a
+    tensor: the library sees every writer, so a ``valid0`` map kept in one carries a 1-bit-per-pixel shadow and the SfM step stops
+    re-reading the map (include/dfx.h, dfx_img_alloc).  `elems_per_px` = 1 (float images; w counts floats) or 2 (gradients)."""
+
+    def __init__(self, ctx, w, h, elems_per_px=1):
+        self.ctx, self.elems = ctx, int(elems_per_px)
+        self.img = Img()
+        check(_lib.lib().dfx_img_alloc(ctx.handle, int(w), int(h), 4 * self.elems, C.byref(self.img)))
+
+    @property
+    def shape(self):
+        return (int(self.img.h), int(self.img.w)) if self.elems == 1 else (int(self.img.h), int(self.img.w), self.elems)
+
+    def fill(self, value):
+        if self.elems != 1:
+            raise ValueError("fill is defined for float images")
+        check(_lib.lib().dfx_img_fill_f32(self.ctx.handle, C.byref(self.img), float(value)))
+        return self
+
+    def upload(self, host):
+        a = np.ascontiguousarray(np.asarray(host, np.float32).reshape(self.shape))
+        check(_lib.lib().dfx_img_upload(self.ctx.handle, C.byref(self.img), a.ctypes.data_as(C.c_void_p), a.shape[1] * 4 * self.elems, 4 * self.elems))
+        return self
+
+    def download(self):
+        out = np.empty(self.shape, np.float32)
+        check(_lib.lib().dfx_img_download(self.ctx.handle, C.byref(self.img), out.ctypes.data_as(C.c_void_p), out.shape[1] * 4 * self.elems, 4 * self.elems))
+        return out
+
+    def valid0_shadow(self):
+        """Debug / tests: the map's shadow as a bool array [H, W] ("known to hold 1.0"), or None when it has none."""
+        n = (int(self.img.w) * int(self.img.h) + 63) // 64
+        words = np.zeros(n, np.uint64)
+        got = C.c_size_t(0)
+        check(_lib.lib().dfx_debug_read_valid0_shadow(self.ctx.handle, C.byref(self.img), words.ctypes.data_as(C.POINTER(C.c_uint64)), n, C.byref(got)))
+        if got.value == 0:
+            return None
+        bits = np.unpackbits(words.view(np.uint8), bitorder="little")[: int(self.img.w) * int(self.img.h)]
+        return bits.reshape(int(self.img.h), int(self.img.w)).astype(bool)
+
+    def free(self):
+        if self.img.ptr:
+            check(_lib.lib().dfx_img_free(self.ctx.handle, C.byref(self.img)))
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def _img(t, name, elems_per_px=1):
+    if isinstance(t, DeviceImage):
+        if t.elems != elems_per_px:
+            raise ValueError(f"{name}: image of {t.elems} floats per pixel, expected {elems_per_px}")
+        return Img(t.img.ptr, t.img.pitch_bytes, t.img.w, t.img.h)
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
     if not t.is_cuda:
@@ -150,9 +207,19 @@ class Context:
     def cu_count(self):
         return int(_lib.lib().dfx_device_cu_count(self._h))
 
+    def alloc_image(self, w, h, elems_per_px=1):
+        """A library-owned device image (zero-filled): see DeviceImage."""
+        return DeviceImage(self, w, h, elems_per_px)
+
+    def last_mfma_mode(self):
+        """_lib.DFX_MFMA_F32_CHAIN / DFX_MFMA_BF16X3: what DFX_MFMA_AUTO (or the pinned mode) resolved to in the last SfM / DepthAligner step."""
+        m = C.c_int(0)
+        check(_lib.lib().dfx_last_mfma_mode(self._h, C.byref(m)))
+        return int(m.value)
+
     def set_mfma_mode(self, mode):
-        """_lib.DFX_MFMA_F32_CHAIN (default: bitwise an fp32 fmaf chain) or _lib.DFX_MFMA_BF16X3 (opt-in: exact three-way bf16 split on the
-        bf16 matrix cores, fp32-accurate, faster for code size 64; see include/dfx.h)."""
+        """_lib.DFX_MFMA_AUTO (default: the library picks per code size), DFX_MFMA_F32_CHAIN (bitwise an fp32 fmaf chain) or DFX_MFMA_BF16X3
+        (exact three-way bf16 split on the bf16 matrix cores, fp32-accurate; see include/dfx.h)."""
         check(_lib.lib().dfx_set_mfma_mode(self._h, int(mode)))
 
     def set_schedule(self, mode):

@@ -8,12 +8,15 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -39,6 +42,33 @@ int fail(int code, const char* fmt, ...) {
 
 constexpr int kStageSlots = 8;
 
+// ---- images owned through the library (dfx_img_alloc) --------------------------------------------------------------------------
+// The library knows every writer of such an image (fill / upload / the kernels it launches into it), which is what lets a valid0 map
+// carry a SHADOW: one bit per pixel, set = "the pixel is known to hold 1.0" (dfx_sfm_step.hip).  The SfM step then reads 8 bytes per
+// 64-pixel chunk instead of the map's 256 to learn that nothing has to be written -- the map is a write-only output of the path
+// (dense_sfm.h:161), all ones from the keyframe build on (mapper.cpp:937).  Foreign memory (a caller's own hipMalloc, a torch tensor)
+// has writers the library cannot see and always takes the reading variant.  Shadow allocation: [stamp (8 bytes)][bits: one u64 per
+// 64 pixels]; the descriptor points at the bits, the stamp word sits right in front of them.
+struct ImgRec {
+  int device;
+  size_t pitch;
+  uint32_t w, h;
+  size_t elem;
+  unsigned long long* shadow;   // null until the image is first used as a valid0 map
+  bool uniform;                 // every element holds `value` (fresh allocation, dfx_img_fill_f32): initial state of a shadow created later
+  float value;
+};
+std::mutex g_img_mu;
+std::unordered_map<const void*, ImgRec> g_imgs;
+std::atomic<int> g_shadow_count{ 0 };
+std::atomic<unsigned> g_launch_id{ 0 };
+
+unsigned next_launch_id() {
+  unsigned id;
+  do { id = g_launch_id.fetch_add(1u, std::memory_order_relaxed) + 1u; } while (id == 0u);
+  return id;
+}
+
 }  // namespace
 
 struct dfx_ctx {
@@ -50,9 +80,10 @@ struct dfx_ctx {
   bool slot_busy[kStageSlots] = {};
   int cu_count = 0;
   int step_blocks = 0;   // 0 = auto
-  int mfma_mode = DFX_MFMA_F32_CHAIN;
+  int mfma_mode = DFX_MFMA_AUTO;
   int schedule = DFX_SCHEDULE_AUTO;
   int last_dynamic = 0;        // 1 when the last batched SfM step ran the dynamic schedule
+  int last_mfma = DFX_MFMA_F32_CHAIN;   // evaluation mode the last SfM / DepthAligner step resolved to
   unsigned* qhead = nullptr;   // dynamic schedule: one item-queue head per pair of a batch (rewound by the finalize kernel)
   size_t qhead_cap = 0;
   bool qhead_dirty = false;    // a dynamic launch failed between its step and its finalize kernel: the heads were not rewound
@@ -246,6 +277,8 @@ int check_img(const dfx_img* im, const char* name, uint32_t w, uint32_t h, size_
   return DFX_OK;
 }
 
+int valid0_shadow(dfx_ctx* c, const dfx_img* v, uint32_t W, uint32_t H, unsigned long long** out);   // below
+
 int fill_sfm_pair(dfx_ctx* c, int cs, const dfx_se3* pose0, const dfx_se3* pose1, const dfx_cam* cam, const dfx_img* img0,
                   const dfx_img* img1, const dfx_img* dpt0, const dfx_img* valid0, const dfx_img* jac, const dfx_img* grad1,
                   uint32_t W, uint32_t H, dfx::SfmPairDev* d) {
@@ -263,9 +296,11 @@ int fill_sfm_pair(dfx_ctx* c, int cs, const dfx_se3* pose0, const dfx_se3* pose1
     if ((rc = check_img(valid0, "valid0", W, H, 4))) return rc;
     d->valid0 = (float*)valid0->ptr;
     d->pitch_valid0 = (uint32_t)valid0->pitch_bytes;
+    if ((rc = valid0_shadow(c, valid0, W, H, &d->valid0_shadow))) return rc;
   } else {
     d->valid0 = nullptr;
     d->pitch_valid0 = 0;
+    d->valid0_shadow = nullptr;
   }
   relative_pose(*pose0, *pose1, d->R, d->t, d->M, d->HM);
   if ((rc = ray_table(c, cam, W, H, &d->ray_tab))) return rc;
@@ -354,6 +389,49 @@ int fetch_result(dfx_ctx* c, const void* dev, void* host_out, size_t bytes) {
 
 bool cs_supported(int cs) { return cs == 16 || cs == 32 || cs == 64; }
 
+// DFX_MFMA_AUTO: the evaluation mode the library picks per code size (include/dfx.h; measurements in DESIGN.md section 5)
+int resolve_mfma(dfx_ctx* c, int cs) {
+  int m = c->mfma_mode;
+  if (m == DFX_MFMA_AUTO) m = cs >= DFX_AUTO_BF16X3_MIN_CS ? DFX_MFMA_BF16X3 : DFX_MFMA_F32_CHAIN;
+  c->last_mfma = m;
+  return m;
+}
+
+size_t shadow_words(uint32_t w, uint32_t h) { return ((size_t)w * h + 63) / 64; }
+
+// A writer the library launches (or a fill / upload) is about to change a library-owned image: its shadow, if it has one, forgets
+// everything (value != 1) or learns that every pixel is 1.0 (a fill with 1.0).  Ordered on the context's stream like the write itself.
+int img_note_write(dfx_ctx* c, const dfx_img* im, bool uniform, float value) {
+  if (!im || !im->ptr) return DFX_OK;
+  std::lock_guard<std::mutex> lk(g_img_mu);
+  auto it = g_imgs.find(im->ptr);
+  if (it == g_imgs.end()) return DFX_OK;
+  ImgRec& r = it->second;
+  r.uniform = uniform; r.value = value;
+  if (r.shadow) DFX_HIP(hipMemsetAsync(r.shadow, (uniform && value == 1.0f) ? 0xFF : 0x00, 8 + 8 * shadow_words(r.w, r.h), c->stream));
+  return DFX_OK;
+}
+int img_note_write(dfx_ctx* c, const dfx_img* im) { return g_shadow_count.load(std::memory_order_relaxed) > 0 ? img_note_write(c, im, false, 0.f) : DFX_OK; }
+
+// The shadow of a valid0 map, created on first use; null for memory the library does not own (or a view that is not the whole image).
+int valid0_shadow(dfx_ctx* c, const dfx_img* v, uint32_t W, uint32_t H, unsigned long long** out) {
+  *out = nullptr;
+  std::lock_guard<std::mutex> lk(g_img_mu);
+  auto it = g_imgs.find(v->ptr);
+  if (it == g_imgs.end()) return DFX_OK;
+  ImgRec& r = it->second;
+  if (r.device != c->device || r.elem != 4 || r.w != W || r.h != H || r.pitch != v->pitch_bytes) return DFX_OK;
+  if (!r.shadow) {
+    const size_t bytes = 8 + 8 * shadow_words(W, H);
+    DFX_HIP(hipMalloc((void**)&r.shadow, bytes));
+    // the stamp word must never equal a launch id by accident: 0 and 0xFFFFFFFF are not ids (next_launch_id skips 0; 2^32 - 1 launches away)
+    DFX_HIP(hipMemsetAsync(r.shadow, (r.uniform && r.value == 1.0f) ? 0xFF : 0x00, bytes, c->stream));
+    g_shadow_count.fetch_add(1, std::memory_order_relaxed);
+  }
+  *out = r.shadow + 1;
+  return DFX_OK;
+}
+
 }  // namespace
 
 // -------------------------------------------------------------------------------------------------------------
@@ -378,8 +456,21 @@ DFX_API int dfx_ctx_create(int device, void* stream, dfx_ctx** out) {
   dfx_ctx* c = new dfx_ctx();
   c->device = device;
   c->cu_count = prop.multiProcessorCount;
-  if (const char* ev = std::getenv("DFX_MFMA")) c->mfma_mode = std::strcmp(ev, "bf16x3") == 0 ? DFX_MFMA_BF16X3 : DFX_MFMA_F32_CHAIN;   // tuning aid (tools/ab_bench.py)
-  if (const char* ev = std::getenv("DFX_SCHEDULE")) c->schedule = std::strcmp(ev, "static") == 0 ? DFX_SCHEDULE_STATIC : std::strcmp(ev, "dynamic") == 0 ? DFX_SCHEDULE_DYNAMIC : DFX_SCHEDULE_AUTO;   // tuning aid (tools/ab_bench.py)
+  // Testing aids (documented in include/dfx.h): the INITIAL evaluation mode / schedule of every context of the process.  They change
+  // result bits (the two MFMA modes agree to fp32 accuracy, not bit for bit), so a value that is not understood is an error, never
+  // silently the default; dfx_set_mfma_mode / dfx_set_schedule override them.
+  if (const char* ev = std::getenv("DFX_MFMA")) {
+    if (std::strcmp(ev, "bf16x3") == 0) c->mfma_mode = DFX_MFMA_BF16X3;
+    else if (std::strcmp(ev, "f32") == 0 || std::strcmp(ev, "f32_chain") == 0) c->mfma_mode = DFX_MFMA_F32_CHAIN;
+    else if (std::strcmp(ev, "auto") == 0) c->mfma_mode = DFX_MFMA_AUTO;
+    else { delete c; return fail(DFX_E_INVALID, "environment DFX_MFMA=%s: expected auto, f32 or bf16x3", ev); }
+  }
+  if (const char* ev = std::getenv("DFX_SCHEDULE")) {
+    if (std::strcmp(ev, "static") == 0) c->schedule = DFX_SCHEDULE_STATIC;
+    else if (std::strcmp(ev, "dynamic") == 0) c->schedule = DFX_SCHEDULE_DYNAMIC;
+    else if (std::strcmp(ev, "auto") == 0) c->schedule = DFX_SCHEDULE_AUTO;
+    else { delete c; return fail(DFX_E_INVALID, "environment DFX_SCHEDULE=%s: expected auto, static or dynamic", ev); }
+  }
   // NULL = the device's default stream, on which the reference runs everything (cuda/launch_utils.h:26-32): work is
   // then ordered with any other default-stream producer of the images (e.g. PyTorch ops on its default stream).
   c->stream = (hipStream_t)stream;
@@ -449,8 +540,14 @@ DFX_API int dfx_device_cu_count(dfx_ctx* c) { return c ? c->cu_count : 0; }
 
 DFX_API int dfx_set_mfma_mode(dfx_ctx* c, int mode) {
   if (!c) return fail(DFX_E_INVALID, "null context");
-  if (mode != DFX_MFMA_F32_CHAIN && mode != DFX_MFMA_BF16X3) return fail(DFX_E_INVALID, "unknown MFMA mode %d", mode);
+  if (mode != DFX_MFMA_F32_CHAIN && mode != DFX_MFMA_BF16X3 && mode != DFX_MFMA_AUTO) return fail(DFX_E_INVALID, "unknown MFMA mode %d", mode);
   c->mfma_mode = mode;
+  return DFX_OK;
+}
+
+DFX_API int dfx_last_mfma_mode(dfx_ctx* c, int* mode) {
+  if (!c || !mode) return fail(DFX_E_INVALID, "null argument");
+  *mode = c->last_mfma;
   return DFX_OK;
 }
 
@@ -508,7 +605,12 @@ DFX_API int dfx_img_alloc(dfx_ctx* c, uint32_t w, uint32_t h, size_t elem_bytes,
   if (pitch * (size_t)h >= 0x70000000ull) return fail(DFX_E_INVALID, "image of %zu bytes exceeds the 0x70000000-byte buffer-resource limit", pitch * (size_t)h);
   void* p = nullptr;
   DFX_HIP(hipMalloc(&p, pitch * (size_t)h));
-  DFX_HIP(hipMemsetAsync(p, 0, pitch * (size_t)h, c->stream));
+  hipError_t e = hipMemsetAsync(p, 0, pitch * (size_t)h, c->stream);
+  if (e != hipSuccess) { (void)hipFree(p); return fail(DFX_E_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e)); }
+  {
+    std::lock_guard<std::mutex> lk(g_img_mu);
+    g_imgs[p] = ImgRec{ c->device, pitch, w, h, elem_bytes, nullptr, true, 0.0f };
+  }
   *out = dfx_img{ p, pitch, w, h };
   return DFX_OK;
 }
@@ -519,6 +621,13 @@ DFX_API int dfx_img_free(dfx_ctx* c, dfx_img* img) {
   if ((rc = ensure_device(c))) return rc;
   if (img->ptr) {
     DFX_HIP(hipStreamSynchronize(c->stream));
+    unsigned long long* shadow = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(g_img_mu);
+      auto it = g_imgs.find(img->ptr);
+      if (it != g_imgs.end()) { shadow = it->second.shadow; g_imgs.erase(it); }
+    }
+    if (shadow) { (void)hipFree(shadow); g_shadow_count.fetch_sub(1, std::memory_order_relaxed); }
     DFX_HIP(hipFree(img->ptr));
   }
   *img = dfx_img{ nullptr, 0, 0, 0 };
@@ -531,6 +640,7 @@ DFX_API int dfx_img_upload(dfx_ctx* c, const dfx_img* dst, const void* host, siz
   if (host_pitch < row || dst->pitch_bytes < row) return fail(DFX_E_INVALID, "dfx_img_upload: pitch smaller than a row of %zu bytes", row);
   int rc;
   if ((rc = ensure_device(c))) return rc;
+  if ((rc = img_note_write(c, dst))) return rc;
   DFX_HIP(hipMemcpy2DAsync(dst->ptr, dst->pitch_bytes, host, host_pitch, row, dst->h, hipMemcpyHostToDevice, c->stream));
   DFX_HIP(hipStreamSynchronize(c->stream));
   return DFX_OK;
@@ -554,7 +664,28 @@ DFX_API int dfx_img_fill_f32(dfx_ctx* c, const dfx_img* dst, float value) {
   if ((rc = ensure_device(c))) return rc;
   int bits;
   std::memcpy(&bits, &value, 4);
+  if ((rc = img_note_write(c, dst, true, value))) return rc;
   DFX_HIP(hipMemsetD32Async((hipDeviceptr_t)dst->ptr, bits, dst->pitch_bytes / 4 * (size_t)dst->h, c->stream));   // row padding included
+  return DFX_OK;
+}
+
+DFX_API int dfx_debug_read_valid0_shadow(dfx_ctx* c, const dfx_img* img, uint64_t* host_words, size_t cap_words, size_t* n_words) {
+  if (!c || !img || !n_words) return fail(DFX_E_INVALID, "dfx_debug_read_valid0_shadow: null argument");
+  *n_words = 0;
+  unsigned long long* sh = nullptr;
+  size_t nw = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_img_mu);
+    auto it = g_imgs.find(img->ptr);
+    if (it != g_imgs.end() && it->second.shadow) { sh = it->second.shadow; nw = shadow_words(it->second.w, it->second.h); }
+  }
+  if (!sh) return DFX_OK;
+  if (!host_words || cap_words < nw) return fail(DFX_E_INVALID, "shadow has %zu words, buffer holds %zu", nw, cap_words);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  DFX_HIP(hipStreamSynchronize(c->stream));
+  DFX_HIP(hipMemcpy(host_words, sh + 1, nw * 8, hipMemcpyDeviceToHost));
+  *n_words = nw;
   return DFX_OK;
 }
 
@@ -615,7 +746,11 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
   if (params->step_blocks < 0 || params->step_blocks > 65535) return fail(DFX_E_INVALID, "step_blocks %d out of range [0,65535]", params->step_blocks);
   // the dense-stream variant needs every pair's Jacobian rows back to back; one pitched pair selects the general kernel
   bool jac_dense = true;
-  for (int p = 0; p < n; ++p) jac_dense = jac_dense && (hd[p].pitch_jac == W * (uint32_t)cs * 4u);
+  bool vsh = true;   // the shadow-reading kernel variant needs a shadow behind EVERY valid0 map of the batch (library-owned images)
+  for (int p = 0; p < n; ++p) {
+    jac_dense = jac_dense && (hd[p].pitch_jac == W * (uint32_t)cs * 4u);
+    vsh = vsh && (hd[p].valid0 == nullptr || hd[p].valid0_shadow != nullptr);
+  }
   // Dynamic schedule (k_sfm_step<..., DYN>, opt-in: DFX_SCHEDULE_DYNAMIC): resident wave-workers popping items from per-pair queues.
   // It needs 64-pixel columns (W % 64 == 0), dense Jacobian rows and the per-wave ray tables beside the P rows in LDS.  Measured
   // against the static launch on the same box, 128 pairs: -1.2 ... -1.5 % on four boxes, +-0 on one, +4.5 % on two -- its gain
@@ -629,7 +764,7 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
     const int team = n > 0 ? (4 * resident_wgs) / n : 0;
     const size_t dyn_lds = sizeof(float) * 4 * ((size_t)W + H + dfx::kRayTabSlack + 16 * 68);
     const bool team_ok = team >= 1 && team <= 1024;
-    if (c->schedule == DFX_SCHEDULE_DYNAMIC && params->step_blocks == 0 && c->step_blocks == 0 && team_ok && jac_dense && W % 64 == 0 &&
+    if (n > 1 && c->schedule == DFX_SCHEDULE_DYNAMIC && params->step_blocks == 0 && c->step_blocks == 0 && team_ok && jac_dense && W % 64 == 0 &&
         W / 64 <= 64 && dyn_lds <= 40 * 1024 && (size_t)W * H < (1u << 26)) {
       const int vs = (int)(W / 64);
       int R = (int)(((long long)H * vs) / ((long long)team * 24));
@@ -659,7 +794,7 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
   if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
   if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
 
-  dfx::SfmParamsDev prm{ params->huber_delta, params->avg_dpt, params->min_dpt, (float)params->valid_border };
+  dfx::SfmParamsDev prm{ params->huber_delta, params->avg_dpt, params->min_dpt, (float)params->valid_border, next_launch_id() };
   hipEvent_t eb = nullptr, ee = nullptr;
   if (c->profiling) {
     if (c->prof_used == c->prof_pool.size()) {
@@ -677,7 +812,7 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
     c->qhead_dirty = true;
   }
   DFX_HIP(dfx::launch_sfm_step(cs, dd, n, (int)W, (int)H, prm, bpp, c->partials, out_items_dev, dfx_item_size(12 + cs), c->stream,
-                               jac_dense, c->mfma_mode, eb, ee, n == 1 ? &one : nullptr, dyn.qhead ? &dyn : nullptr, dyn_grid));
+                               jac_dense, resolve_mfma(c, cs), eb, ee, n == 1 ? &one : nullptr, dyn.qhead ? &dyn : nullptr, dyn_grid, vsh));
   c->qhead_dirty = false;   // both kernels are enqueued: the finalize kernel rewinds the heads
   if (n > 1) {
     DFX_HIP(hipEventRecord(c->slot_done[slot], c->stream));
@@ -834,6 +969,7 @@ DFX_API int dfx_se3_warp(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam,
   if ((rc = ensure_device(c))) return rc;
   dfx::SimplePairDev d;
   if ((rc = fill_simple(pose_10, cam, img0, img1, dpt0, nullptr, img2_out, &d))) return rc;
+  if ((rc = img_note_write(c, img2_out))) return rc;
   const int blocks = simple_blocks(img0->w, img0->h);
   const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
   if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
@@ -1023,6 +1159,7 @@ DFX_API int dfx_update_depth(dfx_ctx* c, int cs, const float* code, const dfx_im
   if (((uintptr_t)prx_jac->ptr | prx_jac->pitch_bytes) & 15) return fail(DFX_E_INVALID, "prx_jac: pointer/pitch must be 16-byte aligned");
   float* code_dev;
   if ((rc = upload_code(c, cs, code, &code_dev))) return rc;
+  if ((rc = img_note_write(c, dpt_out))) return rc;
   DFX_HIP(dfx::launch_update_depth(cs, code_dev, (const float*)prx_orig->ptr, (uint32_t)prx_orig->pitch_bytes,
                                    (const float*)prx_jac->ptr, (uint32_t)prx_jac->pitch_bytes, avg_dpt, (float*)dpt_out->ptr,
                                    (uint32_t)dpt_out->pitch_bytes, (int)W, (int)H, c->stream));
@@ -1085,7 +1222,7 @@ DFX_API int dfx_update_depth_batch_async(dfx_ctx* c, int cs, int n, const float*
   const uint32_t W = prx_orig[0].w, H = prx_orig[0].h;
   std::vector<dfx::DepthJobDev> jobs((size_t)n);
   for (int k = 0; k < n; ++k)
-    if ((rc = fill_depth_job(cs, codes + (size_t)k * cs, &prx_orig[k], &prx_jac[k], &dpt_out[k], W, H, &jobs[k]))) {
+    if ((rc = fill_depth_job(cs, codes + (size_t)k * cs, &prx_orig[k], &prx_jac[k], &dpt_out[k], W, H, &jobs[k])) || (rc = img_note_write(c, &dpt_out[k]))) {
       g_last_error = "job " + std::to_string(k) + ": " + g_last_error;
       return rc;
     }
@@ -1104,23 +1241,22 @@ DFX_API int dfx_sfm_linearize_batch_async(dfx_ctx* c, int cs, const dfx_sfm_para
   // UpdateDepthMaps once per DISTINCT keyframe depth map of the batch (the reference decodes it again for every factor that
   // shares the keyframe, photometric_factor.cpp:229,332-341): pairs that share dpt0 must agree on code, prx_orig and prx_jac.
   std::vector<dfx::DepthJobDev> jobs;
-  std::vector<const void*> seen;
-  std::vector<int> first;
+  std::unordered_map<const void*, int> first;   // depth-map pointer -> first pair that writes it
+  auto same_img = [](const dfx_img& a, const dfx_img& b) { return a.ptr == b.ptr && a.pitch_bytes == b.pitch_bytes && a.w == b.w && a.h == b.h; };
   for (int p = 0; p < n; ++p) {
     const void* key = pairs[p].dpt0.ptr;
-    size_t k = 0;
-    while (k < seen.size() && seen[k] != key) ++k;
-    if (k == seen.size()) {
+    auto hit = first.find(key);
+    if (hit == first.end()) {
       dfx::DepthJobDev j;
-      if ((rc = fill_depth_job(cs, codes0 + (size_t)p * cs, &prx0_orig[p], &pairs[p].prx0_jac, &pairs[p].dpt0, W, H, &j))) {
+      if ((rc = fill_depth_job(cs, codes0 + (size_t)p * cs, &prx0_orig[p], &pairs[p].prx0_jac, &pairs[p].dpt0, W, H, &j)) || (rc = img_note_write(c, &pairs[p].dpt0))) {
         g_last_error = "pair " + std::to_string(p) + ": " + g_last_error;
         return rc;
       }
-      seen.push_back(key); first.push_back(p); jobs.push_back(j);
+      first.emplace(key, p); jobs.push_back(j);
     } else {
-      const int q = first[k];
-      if (std::memcmp(codes0 + (size_t)p * cs, codes0 + (size_t)q * cs, sizeof(float) * (size_t)cs) != 0 || prx0_orig[p].ptr != prx0_orig[q].ptr ||
-          pairs[p].prx0_jac.ptr != pairs[q].prx0_jac.ptr)
+      const int q = hit->second;
+      if (std::memcmp(codes0 + (size_t)p * cs, codes0 + (size_t)q * cs, sizeof(float) * (size_t)cs) != 0 || !same_img(pairs[p].dpt0, pairs[q].dpt0) ||
+          !same_img(prx0_orig[p], prx0_orig[q]) || !same_img(pairs[p].prx0_jac, pairs[q].prx0_jac))
         return fail(DFX_E_INVALID, "pairs %d and %d write the same depth map from different codes / decoder images", q, p);
     }
   }
@@ -1169,6 +1305,7 @@ DFX_API int dfx_gaussian_blur_down(dfx_ctx* c, const dfx_img* in, const dfx_img*
   if (!img_ok(in) || !img_ok(out)) return fail(DFX_E_INVALID, "null or empty image view");
   if ((rc = check_img(in, "in", in->w, in->h, 4))) return rc;
   if ((rc = check_img(out, "out", out->w, out->h, 4))) return rc;
+  if ((rc = img_note_write(c, out))) return rc;
   DFX_HIP(dfx::launch_blur_down((const float*)in->ptr, (uint32_t)in->pitch_bytes, (int)in->w, (int)in->h, (float*)out->ptr,
                                 (uint32_t)out->pitch_bytes, (int)out->w, (int)out->h, c->stream));
   DFX_HIP(hipStreamSynchronize(c->stream));
@@ -1230,7 +1367,7 @@ DFX_API int dfx_depth_aligner_step(dfx_ctx* c, int cs, const float* code, const 
   void* tgt;
   if ((rc = result_target(c, ibytes, &tgt))) return rc;
   DFX_HIP(dfx::launch_depth_aligner_step(cs, hd, (int)W, (int)H, avg_dpt, bpp, c->partials, tgt, c->stream,
-                                         prx_jac->pitch_bytes == (size_t)W * cs * 4, c->mfma_mode));
+                                         prx_jac->pitch_bytes == (size_t)W * cs * 4, resolve_mfma(c, cs)));
   return finish_result(c, out_item, ibytes);
 }
 

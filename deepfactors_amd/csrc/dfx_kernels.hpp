@@ -19,12 +19,14 @@ struct SfmPairDev {
   const float* jac;   // [H][W*CS]
   const float* grad1; // [H][W][2]
   const float* ray_tab;   // [W] (x - u0) / fx, then [H + kRayTabSlack] (y - v0) / fy   (SfmAligner::RunStep only)
+  unsigned long long* valid0_shadow;   // library-owned valid0 images: one bit per pixel (linear index), set = "holds 1.0"; else null
   uint32_t pitch_img0, pitch_img1, pitch_dpt0, pitch_valid0, pitch_jac, pitch_grad1;   // bytes
 };
 constexpr int kRayTabSlack = 80;   // rows a lane past the last pixel may index (<= 64 / W + 1), zero-filled
 
 struct SfmParamsDev {
   float huber_delta, avg_dpt, min_dpt, border;
+  unsigned launch_id;   // non-zero, unique per step launch of the process: stamps valid0 shadows that need a rebuild (dfx_sfm_step.hip)
 };
 
 // Device-side view of a keyframe graph (dfx_graph): CSR lists of the pairs incident to each node, ascending pair index.
@@ -46,13 +48,14 @@ struct DynDev {
   unsigned vs_magic;    // 2^32 / (W / 64) + 1: chunk id -> image row by one multiply-high
 };
 
-struct DepthJobDev {   // one UpdateDepth of a batch (k_update_depth_batch): dpt = a / (prx + jac . code) - a
-  float code[64];
+struct alignas(16) DepthJobDev {   // one UpdateDepth of a batch (k_update_depth_batch): dpt = a / (prx + jac . code) - a
+  float code[64];        // read as float4 vectors: the struct (and every slot of a descriptor array) is 16-byte aligned
   const float* prx;
   const float* jac;
   float* out;
   uint32_t pitch_prx, pitch_jac, pitch_out, _pad;
 };
+static_assert(sizeof(DepthJobDev) % 16 == 0 && alignof(DepthJobDev) == 16, "float4 loads of DepthJobDev::code need 16-byte slots");
 
 struct SimplePairDev {   // SE3Aligner / EvaluateError / Warp
   float R[9], t[3];
@@ -76,7 +79,8 @@ hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int 
                            int blocks_per_pair, float* partials_dev, void* items_dev, size_t item_stride,
                            hipStream_t stream, bool jac_dense, int prec, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr,
                            const SfmPairDev* one_host = nullptr,   // one_host (npairs == 1): the descriptor travels in the kernel arguments
-                           const DynDev* dyn = nullptr, int dyn_grid = 0);   // dyn: the dynamic schedule (workgroups = dyn_grid, partials = [pair][team])
+                           const DynDev* dyn = nullptr, int dyn_grid = 0,    // dyn: the dynamic schedule (workgroups = dyn_grid, partials = [pair][team])
+                           bool valid0_shadows = false);                     // every non-null valid0 of the batch carries a shadow (SfmPairDev::valid0_shadow)
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair);
 // system layout (floats): Hd [n_nodes][D][D], Ho [n_pairs][D][6], g [n_nodes][D]; contributions of the pairs [first_pair, first_pair + n_local)
 hipError_t launch_graph_assemble(int cs, const GraphDev& G, const void* items_dev, size_t item_stride, int first_pair, int n_local, float* sys_dev,

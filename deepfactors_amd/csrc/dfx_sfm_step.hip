@@ -95,6 +95,9 @@ namespace dfx {
 #define DFX_STREAM_AUX 1     // cache policy of the coalesced img0 / dpt0 loads (read once per launch): 1 = sc0, they bypass the CU's L1 and leave
                              // it to the bilinear taps; -1 % (1055-1059 vs 1067 us, 4 interleaved runs each); nt (2) and sc0+nt (3) are no better
 #endif
+#ifndef DFX_DYN_ROT
+#define DFX_DYN_ROT 4        // dynamic schedule: member row m of the teams serves the pairs rotated by DFX_DYN_ROT * m (0: a pair's team sits on one XCD)
+#endif
 #ifndef DFX_WAVES
 #define DFX_WAVES 4
 #endif
@@ -181,10 +184,13 @@ __device__ __forceinline__ float dpp_merge(float old, float src) {
 // -1.5 % kernel time on most boxes, +4.5 % on some, which is why the static launch is the default.  The
 // price: which items a wave sums is decided at run time, so results are reproducible to fp32 re-association (1e-7 relative), not
 // bit for bit.  Teams mix the dispatch ages (members g, g + #pairs, ...) and are rotated across the XCDs.
-template <int NCB, int MODE, bool JDENSE, bool TABLDS, bool BYVAL, bool DYN, bool B3>
+// VSH: every valid0 map of the launch is library-owned and carries a shadow (1 bit per pixel "known to hold 1.0"): 8 bytes are read per
+// chunk instead of the map's 256.
+template <int NCB, int MODE, bool JDENSE, bool TABLDS, bool BYVAL, bool DYN, bool B3, bool VSH>
 __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX_B3_MIN_WAVES : DFX_MIN_WAVES)) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmPairDev one, const SfmParamsDev prm,
                                                        const int W, const int H, float* __restrict__ partials, const DynDev dyn) {
   static_assert(!DYN || (MODE == 0 && JDENSE && TABLDS && !BYVAL), "the dynamic schedule exists for the batched dense SfM step");
+  static_assert(!VSH || MODE == 0, "valid0 maps exist for the SfM step only");
   constexpr int NX = NCB * (NCB - 1) / 2, ND = (NCB + 1) / 2;   // X(b,b'), Dd(q); Pm(b): NCB
   constexpr int NACC = NX + NCB;                                 // 16x16x4 accumulators
   constexpr int NT3 = b3_tiles(NCB);                             // B3: plain 16x16 tiles (P,P), (P,C_b), (C_b,C_b') b <= b'
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
   // member row m = gid / #pairs serves the pairs rotated by 4 m: workgroup b runs on XCD b mod 8, and without the rotation all
   // members of a pair (b = const mod 32 at 128 pairs) would sit on ONE XCD -- nothing would balance the XCDs against each other
   const int dyn_member = DYN ? dyn_gid / dyn.npairs : 0;
-  const int dyn_pair = DYN ? (dyn_gid - dyn_member * dyn.npairs + 4 * dyn_member) % dyn.npairs : 0;
+  const int dyn_pair = DYN ? (dyn_gid - dyn_member * dyn.npairs + DFX_DYN_ROT * dyn_member) % dyn.npairs : 0;
   if (DYN && dyn_member >= dyn.team) return;
   const SfmPairDev& P = BYVAL ? one : pairs[DYN ? dyn_pair : (int)blockIdx.y];
 
@@ -239,6 +245,17 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
   const char* const ray_tab = reinterpret_cast<const char*>(P.ray_tab);
   const char* const vld_base = valid0 ? reinterpret_cast<const char*>(valid0) : reinterpret_cast<const char*>(P.dpt0);
   const uint32_t vld_pitch = valid0 ? pitch_v0 : pitch_d0;
+  // valid0 images owned by the library (dfx_img_alloc) carry a 1-bit-per-pixel SHADOW: bit p of the word array = "pixel p (linear index
+  // y * W + x) is known to hold 1.0".  The wave then reads 8 bytes per 64-pixel chunk instead of 256 (the map is a write-only output of
+  // the path, dense_sfm.h:161, all ones from the keyframe build on, mapper.cpp:937: the 4 B/px read was 2.7 % of the kernel's traffic
+  // spent on learning that nothing has to be written).  A clear bit is always safe (the pixel is written again).  The bits are
+  // maintained by the finalize kernel: see the stamp at the end of this kernel and rebuild_valid0_shadow.
+  unsigned long long* const vshadow = (VSH && valid0) ? P.valid0_shadow : nullptr;
+  // read through a buffer resource: lane-constant offset (which half of the chunk's word) + the chunk's offset on the scalar unit.  A pair
+  // without a valid0 map reads the first bytes of its depth image instead (the load count stays static, the result is never used).
+  const __amdgpu_buffer_rsrc_t vsh_rs = make_rsrc(vshadow ? reinterpret_cast<const void*>(vshadow) : reinterpret_cast<const void*>(P.dpt0), 0x7fffffffu);
+  const unsigned vsh_lane_off = (unsigned)(lane >> 5) * 4u;
+  const unsigned vsh_lane_bit = 1u << (lane & 31);
 
   const int ntab = W + H + kRayTabSlack;
   float* const ray_w = DYN ? ray_lds + wave * ntab : ray_lds;   // DYN: the four waves of a workgroup serve four pairs (possibly four cameras)
@@ -350,7 +367,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
     int x, y;
     float d, i0;
     float rx, ry;         // K^-1 (x, y, 1) from the per-camera table
-    float vl;             // current valid0(x, y): pixels that already hold 1.0 are not written again
+    unsigned vl;          // bits of the current valid0(x, y), or the lane's half of the chunk's shadow word: pixels that already hold 1.0 are not written again
     f32x2 ia, ib;         // img1 taps (row iy, row iy+1)
     f32x4 ga, gb;         // grad1 taps
     Corr c;               // correspondence of A1 (kept: cheaper than re-deriving it, 5 IEEE divisions)
@@ -372,7 +389,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
     od = inb ? od : 0u; oi = inb ? oi : 0u;   // in range on purpose (weight 0), see the note on all-lanes-out-of-range loads
     q.d = bload<DFX_STREAM_AUX>(d0_rs, od, (float*)nullptr);
     q.i0 = bload<DFX_STREAM_AUX>(i0_rs, oi, (float*)nullptr);
-    if (DFX_ABLATE & 32) { q.rx = 0.01f * (float)q.x; q.ry = 0.01f * (float)q.y; q.vl = 1.0f; }
+    if (DFX_ABLATE & 32) { q.rx = 0.01f * (float)q.x; q.ry = 0.01f * (float)q.y; q.vl = 0x3f800000u; }
     else if (MODE == 0) {   // table rows are padded (kRayTabSlack), so lanes past the last pixel stay inside the allocation
 #if DFX_ABLATE & 512
       q.rx = ((float)q.x - g.u0) * (1.0f / g.fx); q.ry = ((float)q.y - g.v0) * (1.0f / g.fy);
@@ -384,9 +401,11 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
       // skipping pixels that already hold 1.0 makes the steady state write-free; HBM writes cost about twice their bytes.
       // Always issued (keeps the load count static): without a valid0 image the read goes to the depth image instead.
 #if DFX_ABLATE & 256
-      q.vl = 1.0f;
+      q.vl = 0x3f800000u;
 #else
-      q.vl = gload<float>(vld_base + (inb ? (unsigned)q.y * vld_pitch + (unsigned)q.x * 4u : 0u));
+      // one 4-byte load either way (the load count stays static): the lane's half of the chunk's shadow word, or its valid0 pixel
+      if (VSH) q.vl = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(vsh_rs, (int)vsh_lane_off, (int)(vshadow ? (pbase >> 6) * 8u : 0u), 0);
+      else q.vl = gload<unsigned>(vld_base + (inb ? (unsigned)q.y * vld_pitch + (unsigned)q.x * 4u : 0u));
 #endif
     }
   };
@@ -453,12 +472,14 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
   // in-order vmcnt queue in front of every counted wait and needs an exec-masked branch), so every lane collects its
   // chunks' validity bits in a register and the wave writes them in one burst per 32 chunks / at the end.
   unsigned vmask = 0;
+  bool wrote_valid = false;         // wave-uniform: this wave stored 1.0 somewhere -- the map's shadow is then rebuilt by the finalize kernel
   int vk = 0;                       // wave-uniform: chunks recorded in vmask
   int vx0 = cur.x, vy0 = cur.y;     // pixel of bit 0
   auto flush_valid = [&]() {
     // wave-uniform early-out: in the steady state (the map already holds 1.0 wherever a pixel is an inlier) no bit is set and the
     // burst loop -- ~10 VALU instructions per recorded chunk even when nothing is stored -- is skipped altogether
     if (MODE == 0 && valid0 && __builtin_amdgcn_ballot_w64(vmask != 0u) != 0ull) {
+      wrote_valid = true;
       int fx = vx0, fy = vy0;
       for (int k = 0; k < vk; ++k) {
         if ((vmask >> k) & 1u) gstore<float>((char*)valid0 + (size_t)fy * pitch_v0 + (size_t)fx * 4, 1.0f);
@@ -530,7 +551,8 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
         u16[6] = mul_zero_wins(wgt, r);
         u16[13] = mul_zero_wins(wgt, e);
         u16[14] = ok ? 1.0f : 0.0f;
-        vmask |= ((ok && cur.vl != 1.0f) ? 1u : 0u) << vk;   // valid0(x, y) = 1 (dense_sfm.h:161), written in bursts: flush_valid
+        const bool is_one = VSH ? (cur.vl & vsh_lane_bit) != 0u : cur.vl == 0x3f800000u;   // 0x3f800000 is the only pattern equal to 1.0f
+        vmask |= ((ok && !is_one) ? 1u : 0u) << vk;   // valid0(x, y) = 1 (dense_sfm.h:161), written in bursts: flush_valid
       }
       if constexpr (B3 && DFX_B3_PSPLIT != 0) {
         // the P block leaves phase A already split: 16-bit element ((piece * 8 + row) * 64 + [h][k][j]) of the wave's LDS region, so that lane
@@ -709,6 +731,10 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
   }
 
   flush_valid();
+  // shadow protocol: a wave that changed the map stamps the launch id into the word in front of the shadow's bit array; the finalize kernel of
+  // THIS launch then rebuilds the bits from the map itself (rebuild_valid0_shadow).  Steady state: no wave writes, nothing is rebuilt.
+  if (VSH && vshadow && wrote_valid && lane == 0)
+    gstore<unsigned>(reinterpret_cast<unsigned*>(vshadow - 1), prm.launch_id);
 
   // ---- epilogue: one z-space partial per workgroup = ((wave 0 + wave 1) + wave 2) + wave 3, element by element.
   // Every wave parks its accumulators in its own LDS region, ONE barrier, then all threads sum and store (the earlier
@@ -794,13 +820,33 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
 #endif
 }
 
+// ---- valid0 shadow maintenance (finalize kernels): when a wave of THIS launch stored 1.0 into the pair's valid0 map (stamp == launch id),
+// the shadow bits are recomputed from the map itself: bit p = (valid0[p] == 1.0f).  The pair's finalize workgroups split the words; a map
+// shared by several pairs of the launch is rebuilt by each of them with the same values.  Runs once per change of the inlier set
+// (first step on a fresh map, newly exposed pixels after a pose update) -- never in the steady state.
+__device__ __forceinline__ void rebuild_valid0_shadow(const SfmPairDev& P, int W, int H, unsigned launch_id, int part, int nparts) {
+  unsigned long long* const sh = P.valid0_shadow;
+  if (!sh || !P.valid0) return;
+  const unsigned npx = (unsigned)W * (unsigned)H, nwords = (npx + 63u) >> 6;
+  if (gload<unsigned>(reinterpret_cast<const unsigned*>(sh - 1)) != launch_id) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  for (unsigned wd = (unsigned)(part * nwv + wv); wd < nwords; wd += (unsigned)(nparts * nwv)) {
+    const unsigned p = wd * 64u + (unsigned)lane;
+    const unsigned y = p / (unsigned)W, x = p - y * (unsigned)W;
+    const bool one = p < npx && gload<unsigned>(reinterpret_cast<const char*>(P.valid0) + (size_t)y * P.pitch_valid0 + (size_t)x * 4u) == 0x3f800000u;
+    const unsigned long long bits = __builtin_amdgcn_ballot_w64(one);
+    if (lane == 0) sh[wd] = bits;
+  }
+}
+
 // ---- finalize: sum the workgroup partials of each pair (double, fixed order), map the relative-pose basis onto
 // (pose0, pose1) and scatter the packed z-space blocks into the item layout.
 // grid = (1 + NACC + 2 ND, npairs), 1024 threads: thread = (element of one 256-float block, 1 of 4 partial groups); groups
 // stride over the pair's `bpp` partials (1 KB coalesced reads, 8 loads in flight) and are folded in fixed order.
 template <int NCB, int NPOSE, bool BYVAL>
 __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs, const SfmPairDev one,
-                                                       char* __restrict__ items, const size_t item_stride, unsigned* __restrict__ qhead) {
+                                                       char* __restrict__ items, const size_t item_stride, unsigned* __restrict__ qhead,
+                                                       const int W, const int H, const unsigned launch_id) {
   constexpr int CS = 16 * NCB;
   constexpr int NP = NPOSE + CS;
   constexpr int NX = NCB * (NCB - 1) / 2, ND = (NCB + 1) / 2;
@@ -812,6 +858,7 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
 
   const int blk = blockIdx.x, pair = blockIdx.y;
   const int el = threadIdx.x & 255, rg = threadIdx.x >> 8;
+  if (NPOSE == 12) rebuild_valid0_shadow(BYVAL ? one : pairs[pair], W, H, launch_id, blk, (int)gridDim.x);
   if (qhead && blk == 0 && threadIdx.x == 0) qhead[pair] = 0u;   // dynamic schedule: the pair's item queue is rewound for the next launch
   const float* src = partials + (size_t)pair * bpp * ZDIM + blk * 256 + el;
   red[rg][el] = strided_sum_f64<4, 16>(src, rg, bpp, ZDIM);   // a single pair has 240 partials: 60 rows per group = 4 round trips
@@ -938,7 +985,8 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
 // C_b x C_b', b <= b', row-major), entry i of C_b = code NCB * i + b.  Same reduction (double, fixed order), same T map, same item.
 template <int NCB, int NPOSE, bool BYVAL>
 __global__ __launch_bounds__(1024) void k_sfm_finalize_b3(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs, const SfmPairDev one,
-                                                          char* __restrict__ items, const size_t item_stride, unsigned* __restrict__ qhead) {
+                                                          char* __restrict__ items, const size_t item_stride, unsigned* __restrict__ qhead,
+                                                          const int W, const int H, const unsigned launch_id) {
   constexpr int CS = 16 * NCB;
   constexpr int NP = NPOSE + CS;
   constexpr int NT3 = b3_tiles(NCB);
@@ -950,6 +998,7 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize_b3(const float* __restric
 
   const int blk = blockIdx.x, pair = blockIdx.y;
   const int el = threadIdx.x & 255, rg = threadIdx.x >> 8;
+  if (NPOSE == 12) rebuild_valid0_shadow(BYVAL ? one : pairs[pair], W, H, launch_id, blk, (int)gridDim.x);
   if (qhead && blk == 0 && threadIdx.x == 0) qhead[pair] = 0u;
   const float* src = partials + (size_t)pair * bpp * ZDIM + blk * 256 + el;
   red[rg][el] = strided_sum_f64<4, 16>(src, rg, bpp, ZDIM);
@@ -1060,7 +1109,7 @@ template <int NCB, int MODE>
 static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm, int bpp,
                            float* partials_dev, void* items_dev, size_t item_stride, hipStream_t stream, bool jac_dense, int prec,
                            hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, const SfmPairDev* one_host = nullptr,
-                           const DynDev* dyn = nullptr, int dyn_grid = 0) {
+                           const DynDev* dyn = nullptr, int dyn_grid = 0, bool vsh = false) {
   constexpr int NACC = NCB * (NCB - 1) / 2 + NCB + 2 * ((NCB + 1) / 2);   // 256-float blocks after block 0 (16x16x4 and 4x4x1 accumulators)
   hipError_t e;
   if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
@@ -1080,23 +1129,26 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
     // dynamic schedule: a resident grid of wave-workers (see k_sfm_step); partials = [pair][team member]
     if constexpr (MODE == 0) {
       const size_t dlds = sizeof(float) * (size_t)kWaves * ((size_t)W + H + kRayTabSlack);
-      if (b3) hipLaunchKernelGGL((k_sfm_step<NCB, 0, true, true, false, true, true>), dim3(dyn_grid), block, dlds, stream, pairs_dev, one, prm, W, H, partials_dev, *dyn);
-      else hipLaunchKernelGGL((k_sfm_step<NCB, 0, true, true, false, true, false>), dim3(dyn_grid), block, dlds, stream, pairs_dev, one, prm, W, H, partials_dev, *dyn);
+#define DFX_LAUNCH_DYN(B3_, VSH_) hipLaunchKernelGGL((k_sfm_step<NCB, 0, true, true, false, true, B3_, VSH_>), dim3(dyn_grid), block, dlds, stream, pairs_dev, one, prm, W, H, partials_dev, *dyn)
+      if (b3) { if (vsh) DFX_LAUNCH_DYN(true, true); else DFX_LAUNCH_DYN(true, false); }
+      else { if (vsh) DFX_LAUNCH_DYN(false, true); else DFX_LAUNCH_DYN(false, false); }
+#undef DFX_LAUNCH_DYN
       e = hipGetLastError();
       if (e != hipSuccess) return e;
       if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
       if (b3) hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, 12, false>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, stream,
-                                 (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead);
+                                 (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id);
       else hipLaunchKernelGGL((k_sfm_finalize<NCB, 12, false>), dim3(1 + NACC, npairs), dim3(1024), 0, stream,
-                              (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead);
+                              (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id);
       return hipGetLastError();
     }
   }
-#define DFX_LAUNCH_STEP_(M_, JD_, TL_, B3_)                                                                                                        \
+#define DFX_LAUNCH_STEP__(M_, JD_, TL_, B3_, VSH_)                                                                                                  \
   do {                                                                                                                                             \
-    if (byval) hipLaunchKernelGGL((k_sfm_step<NCB, M_, JD_, TL_, true, false, B3_>), grid, block, dyn_lds, stream, (const SfmPairDev*)nullptr, one, prm, W, H, partials_dev, nodyn); \
-    else hipLaunchKernelGGL((k_sfm_step<NCB, M_, JD_, TL_, false, false, B3_>), grid, block, dyn_lds, stream, pairs_dev, one, prm, W, H, partials_dev, nodyn);              \
+    if (byval) hipLaunchKernelGGL((k_sfm_step<NCB, M_, JD_, TL_, true, false, B3_, VSH_>), grid, block, dyn_lds, stream, (const SfmPairDev*)nullptr, one, prm, W, H, partials_dev, nodyn); \
+    else hipLaunchKernelGGL((k_sfm_step<NCB, M_, JD_, TL_, false, false, B3_, VSH_>), grid, block, dyn_lds, stream, pairs_dev, one, prm, W, H, partials_dev, nodyn);              \
   } while (0)
+#define DFX_LAUNCH_STEP_(M_, JD_, TL_, B3_) do { if (M_ == 0 && vsh) DFX_LAUNCH_STEP__(M_, JD_, TL_, B3_, (M_ == 0)); else DFX_LAUNCH_STEP__(M_, JD_, TL_, B3_, false); } while (0)
 #define DFX_LAUNCH_STEP(M_, JD_, TL_) do { if (b3) DFX_LAUNCH_STEP_(M_, JD_, TL_, true); else DFX_LAUNCH_STEP_(M_, JD_, TL_, false); } while (0)
   if (MODE == 0 && tab_lds) {
     if (jac_dense) DFX_LAUNCH_STEP(0, true, true); else DFX_LAUNCH_STEP(0, false, true);
@@ -1105,6 +1157,7 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   }
 #undef DFX_LAUNCH_STEP
 #undef DFX_LAUNCH_STEP_
+#undef DFX_LAUNCH_STEP__
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
@@ -1112,14 +1165,14 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   const SfmPairDev* fpairs = byval ? (const SfmPairDev*)nullptr : pairs_dev;
   if (b3) {
     if (byval) hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, true>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, stream,
-                                  (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr);
+                                  (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id);
     else hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, false>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, stream,
-                            (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr);
+                            (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id);
   } else {
     if (byval) hipLaunchKernelGGL((k_sfm_finalize<NCB, NPOSE, true>), dim3(1 + NACC, npairs), dim3(1024), 0, stream,
-                                  (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr);
+                                  (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id);
     else hipLaunchKernelGGL((k_sfm_finalize<NCB, NPOSE, false>), dim3(1 + NACC, npairs), dim3(1024), 0, stream,
-                            (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr);
+                            (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id);
   }
   return hipGetLastError();
 }
@@ -1127,11 +1180,11 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
 hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm,
                            int blocks_per_pair, float* partials_dev, void* items_dev, size_t item_stride,
                            hipStream_t stream, bool jac_dense, int prec, hipEvent_t eb, hipEvent_t ee, const SfmPairDev* one_host,
-                           const DynDev* dyn, int dyn_grid) {
+                           const DynDev* dyn, int dyn_grid, bool vsh) {
   switch (cs) {
-    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid);
-    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid);
-    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid);
+    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh);
+    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh);
+    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh);
     default: return hipErrorInvalidValue;
   }
 }

@@ -134,7 +134,16 @@ DFX_API int dfx_device_cu_count(dfx_ctx* ctx);
  *                      and had been removed; this one costs 11 vector-ALU instructions per pair of values. */
 #define DFX_MFMA_F32_CHAIN 0
 #define DFX_MFMA_BF16X3 1
+/*  DFX_MFMA_AUTO       (default) the library's choice per code size: the exact bf16 split from DFX_AUTO_BF16X3_MIN_CS on (the fp32 chain is
+ *                      matrix-bound there), the fp32 chain below.  Both are fp32-accurate against the fp64 oracle and bit-reproducible for
+ *                      a launch shape; a caller that needs the SAME bits for every code size pins one mode. */
+#define DFX_MFMA_AUTO 2
+#define DFX_AUTO_BF16X3_MIN_CS 64
 DFX_API int dfx_set_mfma_mode(dfx_ctx* ctx, int mode);
+/* *mode = the evaluation mode (DFX_MFMA_F32_CHAIN / DFX_MFMA_BF16X3) the context's last SfM / DepthAligner step resolved to. */
+DFX_API int dfx_last_mfma_mode(dfx_ctx* ctx, int* mode);
+/* Testing aids: the environment variables DFX_MFMA = auto | f32 | bf16x3 and DFX_SCHEDULE = auto | static | dynamic set the INITIAL mode of
+ * every context this process creates (e.g. to run a whole test suite in one mode); any other value makes dfx_ctx_create fail. */
 /* Launch schedule of the batched SfM step (no reference counterpart: the reference has one fixed 11 x 32 grid, cu_sfmaligner.cpp:60).
  *  DFX_SCHEDULE_AUTO     (default) the library's choice -- today always the static partition.
  *  DFX_SCHEDULE_STATIC   the static partition: bit-reproducible for a given launch shape, like the reference's fixed grid.
@@ -164,11 +173,21 @@ DFX_API int dfx_debug_read_partials(dfx_ctx* ctx, void* host, size_t bytes);
  * cuda/synced_pyramid.h:30-217 / vc::Image2DManaged).  elem_bytes = 4 (float images; prx_jac has w = W*CS) or 8 (gradients).  Rows
  * are 16-byte aligned and otherwise unpadded, so a Jacobian allocated here takes the dense-stream kernel variant.  upload /
  * download block like the reference's copyFrom; fill only enqueues. */
+/* valid0 maps allocated HERE get a shadow (1 bit per pixel, "known to hold 1.0", created when the image is first handed to an SfM step as
+ * valid0, kept consistent by dfx_img_fill_f32 / dfx_img_upload / every kernel the library launches into the image): the step kernel then
+ * reads 8 bytes per 64-pixel chunk of it instead of the map's 256 to learn that nothing is left to write -- the map is a write-only output
+ * of the path (dense_sfm.h:161; all ones from the keyframe build on, mapper.cpp:937), and that read was 2.7 % of the kernel's HBM traffic.
+ * Contract: the memory of a library-owned image is written only through this API (the whole image view, as returned).  valid0 maps in
+ * foreign memory (hipMalloc of the caller, a VisionCore buffer, a torch tensor) have writers the library cannot see; they are read every
+ * step as before (same results, 4 B/px more traffic). */
 DFX_API int dfx_img_alloc(dfx_ctx* ctx, uint32_t w, uint32_t h, size_t elem_bytes, dfx_img* out);
 DFX_API int dfx_img_free(dfx_ctx* ctx, dfx_img* img);
 DFX_API int dfx_img_upload(dfx_ctx* ctx, const dfx_img* dst, const void* host, size_t host_pitch_bytes, size_t elem_bytes);
 DFX_API int dfx_img_download(dfx_ctx* ctx, const dfx_img* src, void* host, size_t host_pitch_bytes, size_t elem_bytes);
 DFX_API int dfx_img_fill_f32(dfx_ctx* ctx, const dfx_img* dst, float value);
+/* Debug / tests: copies the valid0 shadow of a library-owned image to the host (one uint64 per 64 pixels of the linear index y*w + x,
+ * bit = pixel known to hold 1.0).  *n_words = 0 when the image has no shadow (foreign memory, or never used as valid0). */
+DFX_API int dfx_debug_read_valid0_shadow(dfx_ctx* ctx, const dfx_img* img, uint64_t* host_words, size_t cap_words, size_t* n_words);
 
 /* ---- SE3Aligner<float> (cuda/cu_se3aligner.h:52-72) ----------------------------------------- */
 /* RunStep (cu_se3aligner.cpp:153-176): out_item = JTJJrReductionItem<float,6> on the HOST (120 bytes). */

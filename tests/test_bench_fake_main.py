@@ -48,6 +48,13 @@ class FakeCtx:
     def sync(self):
         pass
 
+    def alloc_image(self, w, h, elems_per_px=1):   # library-owned valid0 maps of bench.build_pairs: plain host memory here
+        import torch
+        return torch.zeros((h, w), dtype=torch.float32)
+
+    def last_mfma_mode(self):
+        return self.mfma
+
 
 class FakeAligner:
     """Items from the CPU oracle (computed once per batch), assembly through NormalEquations.assemble (torch, CPU).  Only the FIRST

@@ -24,6 +24,7 @@ def worker(a):
         for k in range(a.pairs):
             if a.distinct:   # bench.py's workload: every pair its own scene, motion and validity pattern
                 t = synth.make_pair(a.width, a.height, a.cs, seed=0xDF02 + k, device=dev, motion_scale=0.6 + 0.05 * (k % 8))
+                t["valid0"] = ctx.alloc_image(a.width, a.height)   # library-owned map (shadowed), as bench.py keeps it
             else:
                 t = {n: (v.clone() if isinstance(v, torch.Tensor) else v) for n, v in base.items()}
             keep.append(t)

@@ -17,14 +17,18 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--preroll", type=int, default=300)
     ap.add_argument("--schedule", default="static")
+    ap.add_argument("--foreign-valid0", action="store_true", help="valid0 maps in torch tensors (re-read every step) instead of library-owned images")
     a = ap.parse_args()
     import torch
     import deepfactors_amd as dfx
     from deepfactors_amd import _lib, synth
     dev = torch.device("cuda", 0)
     keep, pairs = [], []
+    own = dfx.Context(0)   # owner of the library-owned valid0 maps (shadowed; shared by both contexts below)
     for k in range(a.pairs):
         t = synth.make_pair(a.width, a.height, a.cs, seed=0xDF02 + k, device=dev, motion_scale=0.6 + 0.05 * (k % 8))
+        if not a.foreign_valid0:
+            t["valid0"] = own.alloc_image(a.width, a.height)
         keep.append(t)
         pairs.append(dict(pose0=t["pose0"], pose1=t["pose1"], cam=t["cam"], img0=t["img0"], img1=t["img1"], dpt0=t["dpt0"], prx0_jac=t["prx_jac"], grad1=t["grad1"],
                           valid0=t["valid0"]))
