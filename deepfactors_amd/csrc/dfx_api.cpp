@@ -88,7 +88,8 @@ struct dfx_ctx {
   size_t qhead_cap = 0;
   bool qhead_dirty = false;    // a dynamic launch failed between its step and its finalize kernel: the heads were not rewound
 
-  float* partials = nullptr;   // device scratch for workgroup partials
+  char* partials_base = nullptr;   // allocation: [kZeroPageBytes of zeros][partials]
+  float* partials = nullptr;   // device scratch for workgroup partials (preceded by the zero page the step kernel streams for dead chunks)
   size_t partials_bytes = 0;
   char* items_dev = nullptr;   // device result items (sync API)
   size_t items_bytes = 0;
@@ -141,6 +142,21 @@ int grow_dev(void** p, size_t* cap, size_t need, hipStream_t stream) {
   DFX_HIP(hipMalloc(p, n));
   DFX_HIP(hipMemsetAsync(*p, 0, n, stream));
   *cap = n;
+  return DFX_OK;
+}
+
+// Workgroup-partials scratch, preceded by the zero page (dfx_kernels.hpp, kZeroPageBytes).  Growing drains the stream first (the old
+// buffer may be in use); the clear is ordered on the context's stream in front of the kernels that use the buffer.
+int grow_partials(dfx_ctx* c, size_t need) {
+  if (c->partials_bytes >= need) return DFX_OK;
+  DFX_HIP(hipStreamSynchronize(c->stream));
+  if (c->partials_base) DFX_HIP(hipFree(c->partials_base));
+  c->partials_base = nullptr; c->partials = nullptr; c->partials_bytes = 0;
+  const size_t n = need + need / 2;
+  DFX_HIP(hipMalloc((void**)&c->partials_base, n + dfx::kZeroPageBytes));
+  DFX_HIP(hipMemsetAsync(c->partials_base, 0, n + dfx::kZeroPageBytes, c->stream));
+  c->partials = reinterpret_cast<float*>(c->partials_base + dfx::kZeroPageBytes);
+  c->partials_bytes = n;
   return DFX_OK;
 }
 
@@ -489,7 +505,7 @@ DFX_API void dfx_ctx_destroy(dfx_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  if (c->partials) (void)hipFree(c->partials);
+  if (c->partials_base) (void)hipFree(c->partials_base);
   if (c->items_dev) (void)hipFree(c->items_dev);
   if (c->pairs_dev) (void)hipFree(c->pairs_dev);
   if (c->code_dev) (void)hipFree(c->code_dev);
@@ -791,8 +807,7 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
   c->last_dynamic = dyn.qhead ? 1 : 0;
   const int bpp = dyn.qhead ? dyn.team : auto_step_blocks(c, W, H, n, cs, params->step_blocks);
   const size_t pbytes = dfx::sfm_step_partials_bytes(cs, n, bpp);
-  if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
-  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
+  if ((rc = grow_partials(c, pbytes))) return rc;
 
   dfx::SfmParamsDev prm{ params->huber_delta, params->avg_dpt, params->min_dpt, (float)params->valid_border, next_launch_id() };
   hipEvent_t eb = nullptr, ee = nullptr;
@@ -936,8 +951,7 @@ DFX_API int dfx_sfm_error(dfx_ctx* c, const dfx_se3* pose0, const dfx_se3* pose1
   for (int i = 0; i < 9; ++i) d.R[i] = R10[i];
   const int blocks = simple_blocks(img0->w, img0->h);
   const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
-  if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
-  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
+  if ((rc = grow_partials(c, pbytes))) return rc;
   void* tgt;
   if ((rc = result_target(c, sizeof(dfx_corr_item), &tgt))) return rc;
   DFX_HIP(dfx::launch_sfm_error(d, (int)img0->w, (int)img0->h, params->huber_delta, blocks, c->partials, tgt, c->stream));
@@ -954,8 +968,7 @@ DFX_API int dfx_se3_step(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam,
   if ((rc = fill_simple(pose_10, cam, img0, img1, dpt0, grad1, nullptr, &d))) return rc;
   const int blocks = simple_blocks(img0->w, img0->h);
   const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
-  if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
-  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
+  if ((rc = grow_partials(c, pbytes))) return rc;
   void* tgt;
   if ((rc = result_target(c, dfx_item_size(6), &tgt))) return rc;
   DFX_HIP(dfx::launch_se3_step(d, (int)img0->w, (int)img0->h, huber_delta, blocks, c->partials, tgt, c->stream));
@@ -972,8 +985,7 @@ DFX_API int dfx_se3_warp(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam,
   if ((rc = img_note_write(c, img2_out))) return rc;
   const int blocks = simple_blocks(img0->w, img0->h);
   const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
-  if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
-  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
+  if ((rc = grow_partials(c, pbytes))) return rc;
   void* tgt;
   if ((rc = result_target(c, sizeof(dfx_corr_item), &tgt))) return rc;
   DFX_HIP(dfx::launch_se3_warp(d, (int)img0->w, (int)img0->h, blocks, c->partials, tgt, c->stream));
@@ -1026,8 +1038,7 @@ int track_frames_impl(dfx_ctx* c, int n, const dfx_se3* pose_init, const dfx_tra
       if (b > max_blocks) max_blocks = b;
     }
   const size_t pbytes = (size_t)n * max_blocks * dfx::kSimpleRow * sizeof(float);
-  if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
-  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
+  if ((rc = grow_partials(c, pbytes))) return rc;
   if (c->track_bytes < total) {
     DFX_HIP(hipStreamSynchronize(c->stream));
     if (c->track_state_dev) DFX_HIP(hipFree(c->track_state_dev));
@@ -1321,8 +1332,7 @@ DFX_API int dfx_squared_error(dfx_ctx* c, const dfx_img* a, const dfx_img* b, fl
   if ((rc = check_img(b, "b", a->w, a->h, 4))) return rc;
   const int blocks = simple_blocks(a->w, a->h);
   const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
-  if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
-  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
+  if ((rc = grow_partials(c, pbytes))) return rc;
   void* tgt;
   if ((rc = result_target(c, sizeof(float), &tgt))) return rc;
   DFX_HIP(dfx::launch_squared_error((const float*)a->ptr, (uint32_t)a->pitch_bytes, (const float*)b->ptr, (uint32_t)b->pitch_bytes,
@@ -1361,8 +1371,7 @@ DFX_API int dfx_depth_aligner_step(dfx_ctx* c, int cs, const float* code, const 
   hd->jac = (const float*)prx_jac->ptr; hd->pitch_jac = (uint32_t)prx_jac->pitch_bytes;
   const int bpp = auto_step_blocks(c, W, H, 1, cs);
   const size_t pbytes = dfx::sfm_step_partials_bytes(cs, 1, bpp);
-  if (c->partials_bytes < pbytes) DFX_HIP(hipStreamSynchronize(c->stream));
-  if ((rc = grow_dev((void**)&c->partials, &c->partials_bytes, pbytes, c->stream))) return rc;
+  if ((rc = grow_partials(c, pbytes))) return rc;
   const size_t ibytes = dfx_item_size(cs);
   void* tgt;
   if ((rc = result_target(c, ibytes, &tgt))) return rc;

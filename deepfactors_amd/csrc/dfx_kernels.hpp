@@ -22,6 +22,9 @@ struct SfmPairDev {
   unsigned long long* valid0_shadow;   // library-owned valid0 images: one bit per pixel (linear index), set = "holds 1.0"; else null
   uint32_t pitch_img0, pitch_img1, pitch_dpt0, pitch_valid0, pitch_jac, pitch_grad1;   // bytes
 };
+// The partials scratch handed to launch_sfm_step / launch_depth_aligner_step must be preceded by kZeroPageBytes of ZEROS in the same
+// allocation: what the step kernel streams instead of the Jacobian of a chunk without a single correspondence (256 * CS bytes per chunk).
+constexpr int kZeroPageBytes = 16384;
 constexpr int kRayTabSlack = 80;   // rows a lane past the last pixel may index (<= 64 / W + 1), zero-filled
 
 struct SfmParamsDev {

@@ -95,6 +95,10 @@ namespace dfx {
 #define DFX_STREAM_AUX 1     // cache policy of the coalesced img0 / dpt0 loads (read once per launch): 1 = sc0, they bypass the CU's L1 and leave
                              // it to the bilinear taps; -1 % (1055-1059 vs 1067 us, 4 interleaved runs each); nt (2) and sc0+nt (3) are no better
 #endif
+#ifndef DFX_SKIP_DEAD
+#define DFX_SKIP_DEAD 0      // 1: the Jacobian of a chunk none of whose 64 pixels has a correspondence is not streamed (see `live1`); costs 8 VGPRs
+                             // (133 instead of 125 at CS = 32: three waves per SIMD instead of four) for ~2 % of the stream -- A/B pending
+#endif
 #ifndef DFX_DYN_ROT
 #define DFX_DYN_ROT 4        // dynamic schedule: member row m of the teams serves the pairs rotated by DFX_DYN_ROT * m (0: a pair's team sits on one XCD)
 #endif
@@ -251,11 +255,13 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
   // spent on learning that nothing has to be written).  A clear bit is always safe (the pixel is written again).  The bits are
   // maintained by the finalize kernel: see the stamp at the end of this kernel and rebuild_valid0_shadow.
   unsigned long long* const vshadow = (VSH && valid0) ? P.valid0_shadow : nullptr;
-  // read through a buffer resource: lane-constant offset (which half of the chunk's word) + the chunk's offset on the scalar unit.  A pair
-  // without a valid0 map reads the first bytes of its depth image instead (the load count stays static, the result is never used).
-  const __amdgpu_buffer_rsrc_t vsh_rs = make_rsrc(vshadow ? reinterpret_cast<const void*>(vshadow) : reinterpret_cast<const void*>(P.dpt0), 0x7fffffffu);
-  const unsigned vsh_lane_off = (unsigned)(lane >> 5) * 4u;
-  const unsigned vsh_lane_bit = 1u << (lane & 31);
+  // read as (uniform base) + (32-bit lane offset): the chunk's word, the lane's half of it.  A pair without a valid0 map reads the first
+  // bytes of its depth image instead (the load count stays static, the result is never used).  No buffer resource: the kernel is short
+  // of scalar registers (a spilled SGPR costs a VGPR lane, and the chain kernel sits at the 128-VGPR step of four waves per SIMD).
+  const char* const vsh_base = vshadow ? reinterpret_cast<const char*>(vshadow) : reinterpret_cast<const char*>(P.dpt0);
+  // (lane-derived constants of the shadow path are recomputed per chunk from an opaque copy of `lane` -- 4 VALU instructions -- instead of
+  // living in two more loop-invariant registers: the chain kernel sits at the 128-register step of four waves per SIMD)
+  auto opaque_lane = [&]() { unsigned l = (unsigned)lane; asm volatile("" : "+v"(l)); return l; };
 
   const int ntab = W + H + kRayTabSlack;
   float* const ray_w = DYN ? ray_lds + wave * ntab : ray_lds;   // DYN: the four waves of a workgroup serve four pairs (possibly four cameras)
@@ -404,7 +410,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
       q.vl = 0x3f800000u;
 #else
       // one 4-byte load either way (the load count stays static): the lane's half of the chunk's shadow word, or its valid0 pixel
-      if (VSH) q.vl = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(vsh_rs, (int)vsh_lane_off, (int)(vshadow ? (pbase >> 6) * 8u : 0u), 0);
+      if (VSH) q.vl = gload<unsigned>(vsh_base + (((opaque_lane() >> 3) & 4u) + (vshadow ? (pbase >> 6) * 8u : 0u)));
       else q.vl = gload<unsigned>(vld_base + (inb ? (unsigned)q.y * vld_pitch + (unsigned)q.x * 4u : 0u));
 #endif
     }
@@ -551,7 +557,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
         u16[6] = mul_zero_wins(wgt, r);
         u16[13] = mul_zero_wins(wgt, e);
         u16[14] = ok ? 1.0f : 0.0f;
-        const bool is_one = VSH ? (cur.vl & vsh_lane_bit) != 0u : cur.vl == 0x3f800000u;   // 0x3f800000 is the only pattern equal to 1.0f
+        const bool is_one = VSH ? ((cur.vl >> (opaque_lane() & 31u)) & 1u) != 0u : cur.vl == 0x3f800000u;   // 0x3f800000 is the only pattern equal to 1.0f
         vmask |= ((ok && !is_one) ? 1u : 0u) << vk;   // valid0(x, y) = 1 (dense_sfm.h:161), written in bursts: flush_valid
       }
       if constexpr (B3 && DFX_B3_PSPLIT != 0) {
@@ -596,8 +602,16 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
     __builtin_amdgcn_sched_barrier(0);
 #endif
     // ---- phase B: rank-4 updates on the matrix cores; operand ring refilled behind the consumer
-    const __amdgpu_buffer_rsrc_t nrs = ring_rsrc(nbase);
-    const unsigned rlo = ring_opaque_off(has1);
+    // A next chunk without a single correspondence (image rows that left the view, the border rows: 2 - 3 % of the chunks of a typical
+    // pair) needs no Jacobian: every weight of it is 0 (v_mul_legacy).  Its refills then read the library's zero page instead (one
+    // 256 * NCB * 16-byte region per device, L2-resident: loads that touch memory and keep the counted waits exact, but no HBM traffic) --
+    // a choice of buffer resource, i.e. scalar registers only.  The reference returns before it touches prx_jac (dense_sfm.h:154-159).
+    const bool live1 = has1 && (!DFX_SKIP_DEAD || MODE != 0 || __builtin_amdgcn_ballot_w64(cur.ok) != 0ull);   // `cur` holds chunk c+1 since A1 above
+    const bool to_zero = JDENSE && DFX_SKIP_DEAD && MODE == 0 && has1 && !live1;
+    // the zero page sits right in front of the partials (kZeroPageBytes; launch_sfm_step's contract): no pointer of its own to keep
+    const __amdgpu_buffer_rsrc_t nrs = to_zero ? make_rsrc(reinterpret_cast<const char*>(partials) - kZeroPageBytes, 256u * NCB * 16u) : ring_rsrc(nbase);
+    const bool rreal = JDENSE ? has1 : live1;   // pitched rows: per-vector offsets, the refills of a dead chunk collapse to one line each
+    const unsigned rlo = ring_opaque_off(rreal);
     if constexpr (B3) {
       // ---- phase B, exact bf16 split (DFX_MFMA_BF16X3): every fp32 entry of z is split into three bf16 pieces, x = h + m + l EXACTLY
       // (h = RNE_bf16(x), m = RNE_bf16(x - h), l = x - h - m: 8 + 8 + 8 significant bits and a sign each), and z z^T is summed as
@@ -629,7 +643,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
 #pragma unroll
             for (int b = 0; b < NCB; ++b) x[1 + b][e] = mul_zero_wins(s, jv_get<NCB>(jv[gq], b));
 #if !(DFX_ABLATE & 4)
-            jv[gq] = ring_load(nrs, rlo, nbase, gq, has1);
+            jv[gq] = ring_load(nrs, rlo, nbase, gq, rreal);
 #endif
           }
 #pragma unroll
@@ -693,7 +707,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
 #pragma unroll
       for (int b = 0; b < NCB; ++b) sc[b] = mul_zero_wins(s, jv_get<NCB>(jv[gq], b));
 #if !(DFX_ABLATE & 4)
-      jv[gq] = ring_load(nrs, rlo, nbase, gq, has1);
+      jv[gq] = ring_load(nrs, rlo, nbase, gq, rreal);
 #endif
 #if DFX_ABLATE & 1
       acc[0][0] += uP;
@@ -1192,7 +1206,7 @@ hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int 
 // DepthAligner::RunStep: `pair_host` describes ONE pseudo-pair with img0 = target depth, dpt0 = current depth, jac (passed by value).
 hipError_t launch_depth_aligner_step(int cs, const SfmPairDev* pair_host, int W, int H, float avg_dpt, int blocks,
                                      float* partials_dev, void* item_dev, hipStream_t stream, bool jac_dense, int prec) {
-  SfmParamsDev prm{ 0.f, avg_dpt, 0.f, 0.f };
+  SfmParamsDev prm{ 0.f, avg_dpt, 0.f, 0.f, 0u };
   switch (cs) {
     case 16: return launch_t<1, 1>(nullptr, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec, nullptr, nullptr, pair_host);
     case 32: return launch_t<2, 1>(nullptr, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec, nullptr, nullptr, pair_host);

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--preroll", type=int, default=300)
     ap.add_argument("--schedule", default="static")
+    ap.add_argument("--clone", action="store_true", help="generate 8 scenes and clone them into --pairs distinct allocations (fast set-up for A/B runs)")
     ap.add_argument("--foreign-valid0", action="store_true", help="valid0 maps in torch tensors (re-read every step) instead of library-owned images")
     a = ap.parse_args()
     import torch
@@ -25,8 +26,14 @@ def main():
     dev = torch.device("cuda", 0)
     keep, pairs = [], []
     own = dfx.Context(0)   # owner of the library-owned valid0 maps (shadowed; shared by both contexts below)
+    protos = {}
     for k in range(a.pairs):
-        t = synth.make_pair(a.width, a.height, a.cs, seed=0xDF02 + k, device=dev, motion_scale=0.6 + 0.05 * (k % 8))
+        if a.clone:   # 8 generated scenes, cloned into distinct allocations (same HBM footprint and access pattern, 1/16 of the set-up time)
+            if k % 8 not in protos:
+                protos[k % 8] = synth.make_pair(a.width, a.height, a.cs, seed=0xDF02 + k, device=dev, motion_scale=0.6 + 0.05 * (k % 8))
+            t = {n: (v.clone() if isinstance(v, torch.Tensor) else v) for n, v in protos[k % 8].items()}
+        else:
+            t = synth.make_pair(a.width, a.height, a.cs, seed=0xDF02 + k, device=dev, motion_scale=0.6 + 0.05 * (k % 8))
         if not a.foreign_valid0:
             t["valid0"] = own.alloc_image(a.width, a.height)
         keep.append(t)
