@@ -58,9 +58,11 @@ def parse():
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary configs[1] / configs[4] measurements")
     ap.add_argument("--window", action="store_true", help="also measure BASELINE configs[3]: 64 keyframes, 1024 pairs over the ranks")
     ap.add_argument("--schedule", choices=["auto", "static", "dynamic"], default="auto",
-                    help="auto: measure the library's static default and its opt-in dynamic item queues during the untimed ramp and run the faster; static / dynamic: force one")
-    ap.add_argument("--mfma", choices=["f32", "bf16x3"], default="f32",
-                    help="evaluation mode of the step kernel: f32 = the library default (fp32 fmaf chain); bf16x3 = the opt-in exact three-way bf16 split")
+                    help="auto: the library's default (DFX_SCHEDULE_AUTO); static / dynamic: force one")
+    ap.add_argument("--mfma", choices=["auto", "f32", "bf16x3"], default="auto",
+                    help="evaluation mode of the step kernel: auto = the library's default (DFX_MFMA_AUTO); f32 = fp32 fmaf chain; bf16x3 = exact three-way bf16 split")
+    ap.add_argument("--no-deferred-tail", action="store_true",
+                    help="run the reduction tail of every step (finalize kernel, graph assembly) on the launch stream instead of on a second stream beside the next step's kernel")
     ap.add_argument("--foreign-valid0", action="store_true", help="keep the valid0 maps in torch tensors (memory the library does not own: the step kernel "
                     "then re-reads the map every step, 4 B/px) instead of library-owned images with a 1-bit shadow")
     ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)
@@ -149,7 +151,7 @@ def pmc_traffic(a):
     out = tempfile.mkdtemp(prefix="dfx_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     worker = [sys.executable, os.path.abspath(__file__), "--pmc-worker", "--pairs", str(a.pairs), "--width", str(a.width), "--height", str(a.height),
-              "--cs", str(a.cs), "--step-blocks", str(a.step_blocks), "--schedule", a.schedule, "--mfma", a.mfma]
+              "--cs", str(a.cs), "--step-blocks", str(a.step_blocks), "--schedule", a.schedule, "--mfma", a.mfma] + (["--foreign-valid0"] if a.foreign_valid0 else [])
     passes = {"rd": ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"],
               "wr": ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"]}
     vals = {}
@@ -182,12 +184,16 @@ def pmc_traffic(a):
         shutil.rmtree(out, ignore_errors=True)
 
 
-def mode_kernel_us(ctx, launch, bytes_per_launch, warm, steps):
-    """Step-kernel time of `launch` with the context switched to DFX_MFMA_BF16X3 (the opt-in exact three-way bf16 split); the context
-    is switched back whatever happens, and a failure is reported instead of raised (this is a secondary figure of the bench line)."""
+MFMA_NAMES = {0: "fp32 fmaf chain on v_mfma_f32_16x16x4_f32 (DFX_MFMA_F32_CHAIN)",
+              1: "exact three-way bf16 split on v_mfma_f32_16x16x32_bf16, fp32 accumulate (DFX_MFMA_BF16X3; fp32-accurate, tests/test_gpu_bf16x3.py)"}
+
+
+def mode_kernel_us(ctx, launch, bytes_per_launch, warm, steps, mode):
+    """Step-kernel time of `launch` with the context pinned to evaluation mode `mode`; the context goes back to DFX_MFMA_AUTO whatever
+    happens, and a failure is reported instead of raised (this is a secondary figure of the bench line)."""
     from deepfactors_amd import _lib
     try:
-        ctx.set_mfma_mode(_lib.DFX_MFMA_BF16X3)
+        ctx.set_mfma_mode(mode)
         for _ in range(warm):
             launch()
         ctx.sync()
@@ -197,19 +203,71 @@ def mode_kernel_us(ctx, launch, bytes_per_launch, warm, steps):
         n, ms = ctx.profile_read()
         ctx.set_profiling(False)
         ks = ms / 1e3 / max(n, 1)
-        return dict(kernel_us=ks * 1e6, algorithmic_gbs=bytes_per_launch / ks / 1e9, frac=bytes_per_launch / ks / 1e9 / HBM_PEAK_GBS,
-                    mfma="exact three-way bf16 split on v_mfma_f32_16x16x32_bf16, fp32 accumulate (opt-in DFX_MFMA_BF16X3; fp32-accurate, tests/test_gpu_bf16x3.py)")
+        return dict(kernel_us=ks * 1e6, algorithmic_gbs=bytes_per_launch / ks / 1e9, frac=bytes_per_launch / ks / 1e9 / HBM_PEAK_GBS, mfma=MFMA_NAMES[ctx.last_mfma_mode()])
     except Exception as e:   # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}
     finally:
         try:
             ctx.set_profiling(False)
-            ctx.set_mfma_mode(_lib.DFX_MFMA_F32_CHAIN)
+            ctx.set_mfma_mode(_lib.DFX_MFMA_AUTO)
         except Exception:   # noqa: BLE001
             pass
 
 
-def secondary_configs(dfx, synth, ctx, dev):
+def event_time_us(torch, enqueue, reps, warm):
+    """Average device time of `enqueue()` (kernels on the current torch stream = the context's stream) from a pair of events around
+    `reps` back-to-back enqueues, after `warm` untimed ones."""
+    for _ in range(warm):
+        enqueue()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        enqueue()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def small_operator_rooflines(dfx, synth, ctx, dev):
+    """HBM-resident sweeps of the operators beside the SfM step (SURVEY 8d byte counts): the code-Jacobian decoder UpdateDepth (136 B/px at
+    CS = 32) over 64 distinct keyframes (2.7 GB), SE3Aligner::RunStep (20 B/px) and SfmAligner::EvaluateError (12 B/px) over 128 distinct
+    pairs in one launch each.  Times are event pairs around back-to-back enqueues on the context's stream: they include the operator's
+    finalize kernel and its 10-20 KB descriptor upload, i.e. they are a few microseconds pessimistic for the kernel itself."""
+    import torch
+    W, H, CS = 640, 480, 32
+    out = {}
+    K = 64
+    kfs = [synth.make_pair(W, H, CS, seed=0x2200 + k, device=dev) for k in range(K)]
+    codes = np.stack([np.asarray(k["code"], np.float32) for k in kfs])
+    outs = [torch.empty_like(k["img0"]) for k in kfs]
+    us = event_time_us(torch, lambda: dfx.UpdateDepthBatch(codes, [k["prx_orig"] for k in kfs], [k["prx_jac"] for k in kfs], 2.0, outs, ctx=ctx), reps=40, warm=150)
+    byts = (8 + 4 * CS) * W * H * K
+    out["update_depth_batch_64kf"] = dict(us=us, algorithmic_bytes=byts, algorithmic_gbs=byts / us / 1e3, frac=byts / us / 1e3 / HBM_PEAK_GBS,
+                                          note="k_update_depth_batch<32>: dpt = a / (prx + jac . code) - a for 64 distinct 640x480 keyframes in one launch (2.7 GB)")
+    P = 128
+    al, se3 = dfx.SfmAligner(code_size=CS, ctx=ctx), dfx.SE3Aligner(ctx=ctx)
+    prs = [kfs[k % K] for k in range(P)]
+    # 128 distinct (img0, img1, dpt0, grad1) sets: the 64 keyframes plus clones (distinct HBM)
+    extra = [{n: (v.clone() if isinstance(v, torch.Tensor) else v) for n, v in kfs[k].items()} for k in range(P - K)]
+    prs = kfs + extra
+    sarr = se3.make_pairs([dict(se3=synth.IDENTITY, cam=p["cam"], img0=p["img0"], img1=p["img1"], dpt0=p["dpt0"], grad1=p["grad1"]) for p in prs])
+    sitems = torch.zeros(P * dfx.item_size(6), dtype=torch.uint8, device=dev)
+    us = event_time_us(torch, lambda: se3.RunStepBatch(sarr, sitems), reps=60, warm=300)
+    byts = 20 * W * H * P
+    out["se3_step_batch_128pairs"] = dict(us=us, algorithmic_bytes=byts, algorithmic_gbs=byts / us / 1e3, frac=byts / us / 1e3 / HBM_PEAK_GBS,
+                                          note="k_se3_step_batch + finalize: 128 distinct 640x480 pairs in one launch (786 MB: beyond the 256 MB Infinity Cache)")
+    earr = al.make_pairs([dict(pose0=p["pose0"], pose1=p["pose1"], cam=p["cam"], img0=p["img0"], img1=p["img1"], dpt0=p["dpt0"], prx0_jac=p["prx_jac"],
+                               grad1=p["grad1"]) for p in prs])
+    eitems = torch.zeros(P * 16, dtype=torch.uint8, device=dev)
+    us = event_time_us(torch, lambda: al.EvaluateErrorBatch(earr, eitems), reps=60, warm=300)
+    byts = 12 * W * H * P
+    out["sfm_error_batch_128pairs"] = dict(us=us, algorithmic_bytes=byts, algorithmic_gbs=byts / us / 1e3, frac=byts / us / 1e3 / HBM_PEAK_GBS,
+                                           note="k_sfm_error_batch + finalize: 128 distinct 640x480 pairs in one launch (472 MB)")
+    return out
+
+
+def secondary_configs(dfx, synth, ctx, dev, headline=None):
     """configs[1] as the reference calls it (ONE pair per blocking call, photometric_factor.cpp:267-274), its 3-level pyramid variant, configs[4]
     (1280x960, 64-code; 16 pairs per launch, 5.5 GB working set)."""
     import torch
@@ -234,6 +292,9 @@ def secondary_configs(dfx, synth, ctx, dev):
     # ---- SURVEY 8d "all pyramid levels" variant: the 128-pair batch at levels 0, 1, 2 (640x480, 320x240, 160x120), one launch per level
     lv_us = []
     for (w, h) in ((640, 480), (320, 240), (160, 120)):
+        if w == 640 and headline is not None:   # level 0 = the headline batch itself: not generated a second time
+            lv_us.append(headline)
+            continue
         pairs, keep = build_pairs(dfx, synth, dev, 3, 128, w, h, 32, ctx=ctx)
         arr = al.make_pairs(pairs)
         items = torch.zeros(128 * dfx.item_size(12 + 32), dtype=torch.uint8, device=dev)
@@ -267,9 +328,10 @@ def secondary_configs(dfx, synth, ctx, dev):
     kern_s = ms / 1e3 / n
     bpl = (20 + 4 * CS) * W * H * P
     out["configs4_1280x960_cs64"] = dict(pairs_per_launch=P, kernel_us=kern_s * 1e6, algorithmic_gbs=bpl / kern_s / 1e9, frac=bpl / kern_s / 1e9 / HBM_PEAK_GBS,
-                                         evals_per_s=P / kern_s, mfma="fp32 chain (library default)")
-    # the same batch on the opt-in exact three-way bf16 split (DFX_MFMA_BF16X3): CS = 64 is matrix-bound on the fp32 chain
-    out["configs4_1280x960_cs64"]["bf16x3"] = mode_kernel_us(ctx, lambda: al4.RunStepBatchAsync(arr, items), bpl, warm=150, steps=20)
+                                         evals_per_s=P / kern_s, mfma=MFMA_NAMES[ctx.last_mfma_mode()] + " -- the library default (DFX_MFMA_AUTO)")
+    # the same batch pinned to the fp32 chain (matrix-bound at CS = 64: the reason DFX_MFMA_AUTO picks the split)
+    from deepfactors_amd import _lib as _dl4
+    out["configs4_1280x960_cs64"]["f32_chain"] = mode_kernel_us(ctx, lambda: al4.RunStepBatchAsync(arr, items), bpl, warm=150, steps=20, mode=_dl4.DFX_MFMA_F32_CHAIN)
     del pairs, keep, arr, items
     # ---- configs[2] as the reference's relinearisation round (PhotometricFactor::RunAlignmentStep, photometric_factor.cpp:225-293, for every
     # factor of a 16-keyframe window): UpdateDepth once per keyframe whose code moved + one batched RunStep over the 120 pairs
@@ -357,10 +419,11 @@ def window_config(dfx, synth, ctx, dev, dist, rank, world):
 
 
 def run_protocol(a, dist, dev, ctx, step, barrier, P):
-    """The measurement protocol around `step` (one pass of the hot path): clock ramp in windows until the kernel time has settled,
-    schedule probe (--schedule auto), W warm-up steps, K timed steps between barriers, MAX over ranks.  Every decision that steers the
-    control flow (leaving the ramp, the schedule) is agreed between the ranks by a collective, so all ranks issue the same sequence of
-    steps and collectives (tests/test_bench_protocol.py runs it on two gloo ranks with fakes).  Returns a dict."""
+    """The measurement protocol around `step` (one pass of the hot path): clock ramp in windows until the kernel time has settled, W
+    warm-up steps, K timed steps between barriers, MAX over ranks.  The decision that steers the control flow (leaving the ramp) is agreed
+    between the ranks by a collective, so all ranks issue the same sequence of steps and collectives (tests/test_bench_protocol.py runs it
+    on two gloo ranks with fakes).  Schedule and evaluation mode are the library's defaults unless forced on the command line: nothing is
+    probed here.  Returns a dict."""
     import torch
     # setup, untimed and not part of the W warm-up steps: after idle the GPU needs ~0.15 s of sustained work to reach its steady clocks
     # (tools/clock_series.py, 128-pair steps: launches 0-49 average 1287 us, 50-99 1144 us, from 100 on 1065 +- 5 us for thousands
@@ -382,35 +445,6 @@ def run_protocol(a, dist, dev, ctx, step, barrier, P):
             dist.all_reduce(go_on, op=dist.ReduceOp.MAX)
         if int(go_on.item()) == 0:
             break
-    # Schedule choice (--schedule auto only, still untimed): the library's default is the static, bit-reproducible launch; its opt-in
-    # dynamic item queues are 1.5-2.3 % faster on most boxes and 4.5 % slower on some, so two windows of each are
-    # measured here, on this box, and the faster one runs the warm-up and the timed steps.  The choice and both figures are reported.
-    from deepfactors_amd import _lib as _dl
-    sched_probe = None
-    if a.schedule == "auto":
-        def window_us(mode):
-            ctx.set_schedule(mode)
-            for _ in range(win):
-                step()
-            barrier()
-            ctx.profile_read()
-            for _ in range(2 * win):
-                step()
-            barrier()
-            n_w, ms_w = ctx.profile_read()
-            return ms_w / max(n_w, 1) * 1e3
-        us_dyn = window_us(_dl.DFX_SCHEDULE_DYNAMIC)
-        ran_dyn = ctx.last_schedule_dynamic()          # the launch may be structurally unable to (then both windows were static)
-        us_sta = window_us(_dl.DFX_SCHEDULE_STATIC)
-        ramp_steps += 6 * win
-        keep_static = torch.tensor([0 if (ran_dyn and us_dyn < 0.995 * us_sta) else 1], dtype=torch.int32, device=dev)
-        if dist is not None:
-            dist.all_reduce(keep_static, op=dist.ReduceOp.MAX)   # every rank runs the same schedule
-        use_dyn = int(keep_static.item()) == 0
-        ctx.set_schedule(_dl.DFX_SCHEDULE_DYNAMIC if use_dyn else _dl.DFX_SCHEDULE_STATIC)
-        a.schedule = "dynamic" if use_dyn else "static"          # the PMC child run below measures the same kernel
-        sched_probe = {"static_kernel_us": round(us_sta, 1), "dynamic_kernel_us": round(us_dyn, 1) if ran_dyn else None,
-                       "chosen": "dynamic" if use_dyn else "static"}
     ctx.set_profiling(False)
     for _ in range(a.warmup):
         step()
@@ -422,14 +456,14 @@ def run_protocol(a, dist, dev, ctx, step, barrier, P):
         step()
     barrier()
     t1 = time.perf_counter()
-    n_launch, kern_ms = ctx.profile_read()
+    n_launch, kern_ms, kern_min, kern_max = ctx.profile_read_ex()
     ctx.set_profiling(False)
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
-    return dict(hist=hist, ramp_steps=ramp_steps, sched_probe=sched_probe, elapsed=elapsed, n_launch=n_launch, kern_ms=kern_ms)
+    return dict(hist=hist, ramp_steps=ramp_steps, elapsed=elapsed, n_launch=n_launch, kern_ms=kern_ms, kern_min_ms=kern_min, kern_max_ms=kern_max)
 
 
 def main():
@@ -454,16 +488,15 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import deepfactors_amd as dfx
+    from deepfactors_amd import _lib as _dl
     from deepfactors_amd import synth
     from deepfactors_amd.dist import NormalEquations, PairGraph, PipelinedReduce
 
     W, H, CS, P = a.width, a.height, a.cs, a.pairs
     ctx = dfx.Context(local)
-    from deepfactors_amd import _lib as _dlm
-    ctx.set_mfma_mode(_dlm.DFX_MFMA_BF16X3 if a.mfma == "bf16x3" else _dlm.DFX_MFMA_F32_CHAIN)   # explicit: not whatever DFX_MFMA says
-    if a.schedule != "auto":
-        from deepfactors_amd import _lib as _dl0
-        ctx.set_schedule(_dl0.DFX_SCHEDULE_STATIC if a.schedule == "static" else _dl0.DFX_SCHEDULE_DYNAMIC)
+    # library defaults unless forced: explicit calls, so that stray DFX_MFMA / DFX_SCHEDULE environment variables cannot steer the line
+    ctx.set_mfma_mode({"auto": _dl.DFX_MFMA_AUTO, "f32": _dl.DFX_MFMA_F32_CHAIN, "bf16x3": _dl.DFX_MFMA_BF16X3}[a.mfma])
+    ctx.set_schedule({"auto": _dl.DFX_SCHEDULE_AUTO, "static": _dl.DFX_SCHEDULE_STATIC, "dynamic": _dl.DFX_SCHEDULE_DYNAMIC}[a.schedule])
     al = dfx.SfmAligner(dfx.SfmAlignerParams(step_blocks=a.step_blocks), code_size=CS, ctx=ctx)
 
     # ---- synthetic, device-resident input: P distinct keyframe->frame pairs per rank
@@ -478,11 +511,16 @@ def main():
         ctx.sync()
         return
 
+    # Consecutive steps are independent batches, so the reduction tail of step k (finalize kernel + graph assembly, ~30 us of short
+    # dependent kernels) runs on a second stream beside the 1 ms step kernel of step k + 1 (dfx_set_tail_stream); for N > 1 the RCCL
+    # reduce of step k is issued on that stream too.  Every tail and every reduce has completed when the timed region ends (barrier()).
+    tail = None if a.no_deferred_tail else torch.cuda.Stream(device=dev)
+    if tail is not None:
+        ctx.set_tail_stream(tail)
+
     # the pairs of all ranks form one trajectory: pair p links keyframe node p -> frame node p + 1
     graph = PairGraph.chain(world * P)
-    # N > 1: consecutive steps are independent batches, so the RCCL reduce of step k runs on RCCL's stream beside the kernels of
-    # step k + 1 (two system buffers, deepfactors_amd.dist.PipelinedReduce); every reduce has completed when the timed region ends
-    pipe = PipelinedReduce(dist, [NormalEquations(graph, CS, dev) for _ in range(2)], root=0) if world > 1 else None
+    pipe = PipelinedReduce(dist, [NormalEquations(graph, CS, dev) for _ in range(2)], root=0, stream=tail) if world > 1 else None
     neq = NormalEquations(graph, CS, dev) if pipe is None else None
 
     def step():
@@ -494,18 +532,22 @@ def main():
             return
         al.RunStepBatchAssembleAsync(arr, items, neq, rank * P)
         if dist is not None:
-            neq.reduce(dist, root=0)
+            if tail is not None:
+                with torch.cuda.stream(tail):
+                    neq.reduce(dist, root=0)
+            else:
+                neq.reduce(dist, root=0)
 
     def barrier():
         if pipe is not None:
             pipe.drain()
+        ctx.tail_join()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
     pr = run_protocol(a, dist, dev, ctx, step, barrier, P)
-    hist, ramp_steps, sched_probe, elapsed, n_launch, kern_ms = pr["hist"], pr["ramp_steps"], pr["sched_probe"], pr["elapsed"], pr["n_launch"], pr["kern_ms"]
-    from deepfactors_amd import _lib as _dl
+    hist, ramp_steps, elapsed, n_launch, kern_ms = pr["hist"], pr["ramp_steps"], pr["elapsed"], pr["n_launch"], pr["kern_ms"]
 
     # sanity (untimed): results are real (inliers > half of the pixels on every pair) ...
     its = al.items_from_bytes(items.cpu().numpy(), CS)
@@ -521,10 +563,11 @@ def main():
         assert abs(got - float(chk[0])) <= 1e-4 * float(chk[1]) + 1e-6, (got, chk.tolist())
 
     out = None
+    mode_ran, dyn_ran = ctx.last_mfma_mode(), ctx.last_schedule_dynamic()
+    kern_s = kern_ms / 1e3 / max(n_launch, 1)
     if rank == 0:
         evals = world * P * a.steps
         bytes_per_launch = (20 + 4 * CS) * W * H * P          # 148 B/px compulsory at CS=32
-        kern_s = kern_ms / 1e3 / max(n_launch, 1)
         achieved = bytes_per_launch / kern_s / 1e9
         flops_per_launch = 2.0 * ((12 + CS) * (13 + CS) / 2 + (12 + CS) + 1) * W * H * P   # JtJ + Jtr + r^2 (FMA = 2)
         out = {
@@ -536,7 +579,6 @@ def main():
             "warmup": a.warmup,
             "ramp_steps": ramp_steps,
             "ramp_kernel_us": [round(h * 1e3, 1) for h in hist],
-            "schedule_probe": sched_probe,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
@@ -545,28 +587,37 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1] geometry in the batch size of configs[3] (1k pairs / 8 GPUs): {P} independent {W}x{H} pairs per GPU per step, "
                                    f"CS={CS}, SfmAligner::RunStep (SE3+code Jacobians, JtJ/Jtr) in one launch, level 0; "
-                                   "+ block-sparse normal-equation assembly" + (" + RCCL reduce to rank 0 (the reduce of step k overlaps the kernels of step k + 1)" if world > 1 else ""),
+                                   "+ block-sparse normal-equation assembly" + (" + RCCL reduce to rank 0" if world > 1 else "")
+                                   + ("; the reduction tail of step k (finalize, assembly" + (", reduce" if world > 1 else "") + ") runs on a second stream beside the kernel of step k + 1"
+                                      if tail is not None else ""),
                        "pairs_per_gpu": P, "width": W, "height": H, "code_size": CS,
                        "parallelism": f"pairs sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_sfm_step<2,0>", "kernel_us": kern_s * 1e6, "launches": n_launch,
+                         "traffic": None, "kernel": f"k_sfm_step<NCB={CS // 16}, {'bf16x3' if mode_ran == _dl.DFX_MFMA_BF16X3 else 'f32 chain'}, {'dynamic' if dyn_ran else 'static'}>",
+                         "kernel_us": kern_s * 1e6, "kernel_us_min": pr["kern_min_ms"] * 1e3, "kernel_us_max": pr["kern_max_ms"] * 1e3, "launches": n_launch,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "fp32_tflops": flops_per_launch / kern_s / 1e12,
-                         "schedule": "dynamic item queues (results reproducible to fp32 re-association)" if ctx.last_schedule_dynamic()
-                                     else "static partition (bit-reproducible)",
-                         "mfma": "fp32 fmaf chain on v_mfma_f32_16x16x4_f32 (library default)" if a.mfma == "f32"
-                                 else "exact three-way bf16 split on v_mfma_f32_16x16x32_bf16, fp32 accumulate (opt-in DFX_MFMA_BF16X3)"},
+                         "schedule": ("dynamic item queues (results reproducible to fp32 re-association)" if dyn_ran else "static partition (bit-reproducible)")
+                                     + (" -- the library default" if a.schedule == "auto" else " -- forced by --schedule"),
+                         "mfma": MFMA_NAMES[mode_ran] + (" -- the library default (DFX_MFMA_AUTO)" if a.mfma == "auto" else " -- forced by --mfma")},
         }
-    ctx.set_schedule(_dl.DFX_SCHEDULE_AUTO)   # the secondary measurements below run the library's defaults
-    ctx.set_mfma_mode(_dl.DFX_MFMA_F32_CHAIN)
+    # the secondary measurements below run the library's defaults, in order on one stream
+    ctx.set_tail_stream(None)
+    ctx.set_schedule(_dl.DFX_SCHEDULE_AUTO)
+    ctx.set_mfma_mode(_dl.DFX_MFMA_AUTO)
     configs = {}
     if world == 1 and not a.no_configs:
-        # the timed workload once more on the opt-in exact bf16 split (static schedule; the line's `value` and `roofline` above are the fp32 chain's)
-        if a.mfma == "f32":
-            configs["headline_workload_bf16x3"] = mode_kernel_us(ctx, lambda: al.RunStepBatchAsync(arr, items), (20 + 4 * CS) * W * H * P, warm=150, steps=30)
-        configs.update(secondary_configs(dfx, synth, ctx, dev))
-    if a.window:
-        del keep, pairs, arr
+        # the timed workload once more, pinned to the evaluation mode the line did NOT run
+        other = _dl.DFX_MFMA_F32_CHAIN if mode_ran == _dl.DFX_MFMA_BF16X3 else _dl.DFX_MFMA_BF16X3
+        configs["headline_workload_other_mode"] = mode_kernel_us(ctx, lambda: al.RunStepBatchAsync(arr, items), (20 + 4 * CS) * W * H * P, warm=150, steps=30, mode=other)
+    del keep, pairs, arr
+    torch.cuda.empty_cache()
+    if world == 1 and not a.no_configs:
+        configs.update(secondary_configs(dfx, synth, ctx, dev, headline=kern_s * 1e6 if (W, H, CS, P) == (640, 480, 32, 128) else None))
+        torch.cuda.empty_cache()
+        configs.update(small_operator_rooflines(dfx, synth, ctx, dev))
+        torch.cuda.empty_cache()
+    if a.window or (world == 1 and not a.no_configs):
         configs["configs3_window64"] = window_config(dfx, synth, ctx, dev, dist, rank, world)
     if dist is not None:
         dist.barrier()

@@ -63,6 +63,10 @@ class SfmPair(C.Structure):
                 ("valid0", Img), ("prx0_jac", Img), ("grad1", Img)]
 
 
+class SE3Pair(C.Structure):
+    _fields_ = [("pose_10", SE3), ("cam", Cam), ("img0", Img), ("img1", Img), ("dpt0", Img), ("grad1", Img)]
+
+
 def item_jtj_len(np_):
     return np_ * (np_ + 1) // 2
 
@@ -82,6 +86,8 @@ _PROTOS = {
     "dfx_ctx_destroy": (None, [C.c_void_p]),
     "dfx_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dfx_ctx_device": (C.c_int, [C.c_void_p]),
+    "dfx_set_tail_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dfx_tail_join": (C.c_int, [C.c_void_p]),
     "dfx_last_error": (C.c_char_p, []),
     "dfx_version": (C.c_char_p, []),
     "dfx_sync": (C.c_int, [C.c_void_p]),
@@ -94,6 +100,7 @@ _PROTOS = {
     "dfx_last_schedule": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "dfx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "dfx_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "dfx_profile_read_ex": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dfx_debug_read_partials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "dfx_img_alloc": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t, C.POINTER(Img)]),
     "dfx_img_free": (C.c_int, [C.c_void_p, C.POINTER(Img)]),
@@ -104,6 +111,10 @@ _PROTOS = {
                                C.POINTER(Img), C.c_float, C.c_void_p]),
     "dfx_se3_warp": (C.c_int, [C.c_void_p, C.POINTER(SE3), C.POINTER(Cam), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img),
                                C.POINTER(Img), C.POINTER(CorrItem)]),
+    "dfx_se3_step_batch_async": (C.c_int, [C.c_void_p, C.POINTER(SE3Pair), C.c_int, C.c_float, C.c_void_p]),
+    "dfx_se3_step_batch": (C.c_int, [C.c_void_p, C.POINTER(SE3Pair), C.c_int, C.c_float, C.c_void_p]),
+    "dfx_sfm_error_batch_async": (C.c_int, [C.c_void_p, C.POINTER(SfmParams), C.POINTER(SfmPair), C.c_int, C.c_void_p]),
+    "dfx_sfm_error_batch": (C.c_int, [C.c_void_p, C.POINTER(SfmParams), C.POINTER(SfmPair), C.c_int, C.POINTER(CorrItem)]),
     "dfx_track_frame": (C.c_int, [C.c_void_p, C.POINTER(SE3), C.POINTER(TrackLevel), C.c_int, C.c_float, C.POINTER(TrackResult)]),
     "dfx_track_frame_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SE3), C.POINTER(TrackLevel), C.c_int, C.c_float, C.POINTER(TrackResult)]),
     "dfx_sparse_geometric_linearize": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SE3), C.POINTER(SE3), C.POINTER(C.c_float), C.POINTER(C.c_float),

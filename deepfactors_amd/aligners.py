@@ -199,6 +199,17 @@ class Context:
     def use_current_stream(self):
         self.set_stream(torch.cuda.current_stream(self.device))
 
+    def set_tail_stream(self, stream):
+        """Deferred-tail mode (dfx_set_tail_stream, include/dfx.h): the reduction tail (finalize kernel, graph assembly) of every *_async
+        batched step runs on `stream` (a torch.cuda.Stream of this device, or None to switch the mode off), beside the step kernel of the
+        next launch.  Results are then complete on THAT stream; `tail_join()` orders the context's stream behind them."""
+        self._tail = stream   # keep the torch stream alive
+        sh = stream.cuda_stream if isinstance(stream, torch.cuda.Stream) else stream
+        check(_lib.lib().dfx_set_tail_stream(self._h, C.c_void_p(int(sh)) if sh else None))
+
+    def tail_join(self):
+        check(_lib.lib().dfx_tail_join(self._h))
+
     def check_device(self, *tensors):
         for t in tensors:
             if isinstance(t, torch.Tensor) and t.is_cuda and t.device.index != self.device:
@@ -241,6 +252,12 @@ class Context:
         n, ms = C.c_int(0), C.c_double(0.0)
         check(_lib.lib().dfx_profile_read(self._h, C.byref(n), C.byref(ms)))
         return int(n.value), float(ms.value)
+
+    def profile_read_ex(self):
+        """(n_launches, total_ms, min_ms, max_ms) of the step kernel since the last read."""
+        n, ms, lo, hi = C.c_int(0), C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
+        check(_lib.lib().dfx_profile_read_ex(self._h, C.byref(n), C.byref(ms), C.byref(lo), C.byref(hi)))
+        return int(n.value), float(ms.value), float(lo.value), float(hi.value)
 
     def close(self):
         if self._h:
@@ -331,6 +348,21 @@ class SfmAligner:
         check(_lib.lib().dfx_sfm_error(self.ctx.handle, C.byref(s0), C.byref(s1), C.byref(cm), C.byref(p), C.byref(i0), C.byref(i1),
                                        C.byref(d0), C.byref(sd) if sd else None, C.byref(g1) if g1 else None, C.byref(out)))
         return CorrespondenceReductionItem(out.residual, out.inliers)
+
+    def EvaluateErrorBatch(self, pair_array, out_items_dev=None):
+        """EvaluateError of n pairs in ONE launch (dfx_sfm_error_batch[_async]): PhotometricFactor::error over a factor set
+        (photometric_factor.cpp:61-81,197-216).  `pair_array` from make_pairs (only poses, cam, img0, img1, dpt0 are read).  With
+        `out_items_dev` (uint8 CUDA tensor, 16 bytes per pair) it only enqueues; otherwise it returns the items."""
+        n = len(pair_array)
+        p = self._p()
+        if out_items_dev is not None:
+            if out_items_dev.numel() * out_items_dev.element_size() < 16 * n:
+                raise ValueError("output buffer too small")
+            check(_lib.lib().dfx_sfm_error_batch_async(self.ctx.handle, C.byref(p), pair_array, n, C.c_void_p(out_items_dev.data_ptr())))
+            return None
+        out = (CorrItem * n)()
+        check(_lib.lib().dfx_sfm_error_batch(self.ctx.handle, C.byref(p), pair_array, n, out))
+        return [CorrespondenceReductionItem(o.residual, o.inliers) for o in out]
 
     # ---- batched extension (one launch over n independent pairs) ----
     def make_pairs(self, pairs):
@@ -425,6 +457,31 @@ class SE3Aligner:
         check(_lib.lib().dfx_se3_step(self.ctx.handle, C.byref(s), C.byref(cm), C.byref(i0), C.byref(i1), C.byref(d0), C.byref(g1),
                                       self.huber_delta_, raw.ctypes.data_as(C.c_void_p)))
         return JTJJrReductionItem(6, raw)
+
+    def make_pairs(self, pairs):
+        """pairs: iterable of dicts with keys se3 (pose_10), cam, img0, img1, dpt0, grad1 -> SE3Pair array for RunStepBatch."""
+        pairs = list(pairs)
+        arr = (_lib.SE3Pair * len(pairs))()
+        for k, q in enumerate(pairs):
+            self.ctx.check_device(q["img0"], q["img1"], q["dpt0"], q["grad1"])
+            arr[k].pose_10, arr[k].cam = _se3(q["se3"]), _cam(q["cam"])
+            arr[k].img0, arr[k].img1, arr[k].dpt0 = _img(q["img0"], "img0"), _img(q["img1"], "img1"), _img(q["dpt0"], "dpt0")
+            arr[k].grad1 = _img(q["grad1"], "grad1", 2)
+        return arr
+
+    def RunStepBatch(self, pair_array, out_items_dev=None):
+        """n independent RunStep of one image size in ONE launch (dfx_se3_step_batch[_async]).  With `out_items_dev` (uint8 CUDA tensor,
+        120 bytes per pair) it only enqueues; otherwise it returns the items."""
+        n = len(pair_array)
+        isz = item_size(6)
+        if out_items_dev is not None:
+            if out_items_dev.numel() * out_items_dev.element_size() < isz * n:
+                raise ValueError("output buffer too small")
+            check(_lib.lib().dfx_se3_step_batch_async(self.ctx.handle, pair_array, n, self.huber_delta_, C.c_void_p(out_items_dev.data_ptr())))
+            return None
+        raw = np.zeros(n * isz, np.uint8)
+        check(_lib.lib().dfx_se3_step_batch(self.ctx.handle, pair_array, n, self.huber_delta_, raw.ctypes.data_as(C.c_void_p)))
+        return [JTJJrReductionItem(6, raw[k * isz:(k + 1) * isz]) for k in range(n)]
 
     def Warp(self, se3, cam, img0, img1, dpt0, img2):
         """cu_se3aligner.cpp:125-151: renders img1 into frame 0 (`img2`), returns the signed residual sum + inliers."""

@@ -88,9 +88,19 @@ struct dfx_ctx {
   size_t qhead_cap = 0;
   bool qhead_dirty = false;    // a dynamic launch failed between its step and its finalize kernel: the heads were not rewound
 
-  char* partials_base = nullptr;   // allocation: [kZeroPageBytes of zeros][partials]
-  float* partials = nullptr;   // device scratch for workgroup partials (preceded by the zero page the step kernel streams for dead chunks)
-  size_t partials_bytes = 0;
+  char* partials_base = nullptr;   // allocation (two halves in deferred-tail mode)
+  float* partials = nullptr;   // device scratch for workgroup partials
+  float* partials_alt = nullptr;   // deferred-tail mode: second half, used by every other batched step
+  size_t partials_bytes = 0;   // per half
+
+  // Deferred tail (dfx_set_tail_stream): the reduction tail of a batched SfM step (finalize kernel, then graph assembly) runs on
+  // `tail_stream`, beside the step kernel of the NEXT batched launch on `stream`; the two halves of partials / queue heads alternate.
+  hipStream_t tail_stream = nullptr;
+  int tail_parity = 0;
+  hipEvent_t ev_mid[2] = {};    // step kernel done (recorded on `stream`): the tail may start
+  hipEvent_t ev_tail[2] = {};   // finalize done (recorded on `tail_stream`): the half may be written again
+  bool tail_busy[2] = {};
+  hipEvent_t ev_join = nullptr;
   char* items_dev = nullptr;   // device result items (sync API)
   size_t items_bytes = 0;
   dfx::SfmPairDev* pairs_dev = nullptr;
@@ -98,6 +108,8 @@ struct dfx_ctx {
   float* code_dev = nullptr;   // 64 floats per stage slot
   float* depth_scratch = nullptr;
   size_t depth_scratch_bytes = 0;
+  char* sdesc_dev = nullptr;   // descriptor arrays of the batched SE3 / error launches, one region per stage slot
+  size_t sdesc_cap = 0;        // bytes per slot
   dfx::DepthJobDev* jobs_dev = nullptr;   // batched UpdateDepth descriptors, one region per stage slot
   size_t jobs_cap = 0;
 
@@ -145,18 +157,26 @@ int grow_dev(void** p, size_t* cap, size_t need, hipStream_t stream) {
   return DFX_OK;
 }
 
-// Workgroup-partials scratch, preceded by the zero page (dfx_kernels.hpp, kZeroPageBytes).  Growing drains the stream first (the old
+// Workgroup-partials scratch.  Growing drains the stream first (the old
 // buffer may be in use); the clear is ordered on the context's stream in front of the kernels that use the buffer.
-int grow_partials(dfx_ctx* c, size_t need) {
-  if (c->partials_bytes >= need) return DFX_OK;
-  DFX_HIP(hipStreamSynchronize(c->stream));
-  if (c->partials_base) DFX_HIP(hipFree(c->partials_base));
-  c->partials_base = nullptr; c->partials = nullptr; c->partials_bytes = 0;
-  const size_t n = need + need / 2;
-  DFX_HIP(hipMalloc((void**)&c->partials_base, n + dfx::kZeroPageBytes));
-  DFX_HIP(hipMemsetAsync(c->partials_base, 0, n + dfx::kZeroPageBytes, c->stream));
-  c->partials = reinterpret_cast<float*>(c->partials_base + dfx::kZeroPageBytes);
-  c->partials_bytes = n;
+// `for_step` = false (every user but the batched SfM step): the caller is about to write half 0 from the context's stream, so that stream
+// first waits for deferred tails still reading it.
+int grow_partials(dfx_ctx* c, size_t need, bool for_step = false) {
+  if (c->partials_bytes < need) {
+    DFX_HIP(hipStreamSynchronize(c->stream));
+    if (c->tail_stream) DFX_HIP(hipStreamSynchronize(c->tail_stream));
+    c->tail_busy[0] = c->tail_busy[1] = false;
+    if (c->partials_base) DFX_HIP(hipFree(c->partials_base));
+    c->partials_base = nullptr; c->partials = c->partials_alt = nullptr; c->partials_bytes = 0;
+    const size_t n = (need + need / 2 + 255) & ~(size_t)255, half = n;
+    const int halves = c->tail_stream ? 2 : 1;
+    DFX_HIP(hipMalloc((void**)&c->partials_base, half * halves));
+    DFX_HIP(hipMemsetAsync(c->partials_base, 0, half * halves, c->stream));
+    c->partials = reinterpret_cast<float*>(c->partials_base);
+    if (halves == 2) c->partials_alt = reinterpret_cast<float*>(c->partials_base + half);
+    c->partials_bytes = n;
+  }
+  if (!for_step && c->tail_busy[0]) { DFX_HIP(hipStreamWaitEvent(c->stream, c->ev_tail[0], 0)); c->tail_busy[0] = false; }
   return DFX_OK;
 }
 
@@ -505,12 +525,16 @@ DFX_API void dfx_ctx_destroy(dfx_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->tail_stream) (void)hipStreamSynchronize(c->tail_stream);
+  for (int i = 0; i < 2; ++i) { if (c->ev_mid[i]) (void)hipEventDestroy(c->ev_mid[i]); if (c->ev_tail[i]) (void)hipEventDestroy(c->ev_tail[i]); }
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->partials_base) (void)hipFree(c->partials_base);
   if (c->items_dev) (void)hipFree(c->items_dev);
   if (c->pairs_dev) (void)hipFree(c->pairs_dev);
   if (c->code_dev) (void)hipFree(c->code_dev);
   if (c->depth_scratch) (void)hipFree(c->depth_scratch);
   if (c->jobs_dev) (void)hipFree(c->jobs_dev);
+  if (c->sdesc_dev) (void)hipFree(c->sdesc_dev);
   if (c->qhead) (void)hipFree(c->qhead);
   if (c->track_state_dev) (void)hipFree(c->track_state_dev);
   if (c->sg_dev) (void)hipFree(c->sg_dev);
@@ -532,6 +556,8 @@ DFX_API int dfx_ctx_set_stream(dfx_ctx* c, void* stream) {
   if ((hipStream_t)stream == c->stream) return DFX_OK;
   DFX_HIP(hipStreamSynchronize(c->stream));   // staging slots, scratch and result area are ordered on the old stream
   DFX_HIP(hipStreamSynchronize(c->copy_stream));
+  if (c->tail_stream) DFX_HIP(hipStreamSynchronize(c->tail_stream));
+  c->tail_busy[0] = c->tail_busy[1] = false;
   c->stream = (hipStream_t)stream;
   for (int i = 0; i < kStageSlots; ++i) { c->stage_used[i] = false; c->slot_busy[i] = false; }
   return DFX_OK;
@@ -542,6 +568,42 @@ DFX_API int dfx_ctx_device(dfx_ctx* c) { return c ? c->device : -1; }
 DFX_API int dfx_sync(dfx_ctx* c) {
   if (!c) return fail(DFX_E_INVALID, "null context");
   DFX_HIP(hipStreamSynchronize(c->stream));
+  if (c->tail_stream) DFX_HIP(hipStreamSynchronize(c->tail_stream));
+  return DFX_OK;
+}
+
+DFX_API int dfx_set_tail_stream(dfx_ctx* c, void* tail_stream) {
+  if (!c) return fail(DFX_E_INVALID, "null context");
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  if ((hipStream_t)tail_stream == c->tail_stream) return DFX_OK;
+  if (tail_stream && (hipStream_t)tail_stream == c->stream) return fail(DFX_E_INVALID, "the tail stream must differ from the context's stream");
+  DFX_HIP(hipStreamSynchronize(c->stream));
+  if (c->tail_stream) DFX_HIP(hipStreamSynchronize(c->tail_stream));
+  DFX_HIP(hipStreamSynchronize(c->copy_stream));
+  for (int i = 0; i < 2 && tail_stream; ++i) {
+    if (!c->ev_mid[i]) DFX_HIP(hipEventCreateWithFlags(&c->ev_mid[i], hipEventDisableTiming));
+    if (!c->ev_tail[i]) DFX_HIP(hipEventCreateWithFlags(&c->ev_tail[i], hipEventDisableTiming));
+  }
+  if (tail_stream && !c->ev_join) DFX_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  c->tail_stream = (hipStream_t)tail_stream;
+  c->tail_busy[0] = c->tail_busy[1] = false;
+  c->tail_parity = 0;
+  for (int i = 0; i < kStageSlots; ++i) { c->stage_used[i] = false; c->slot_busy[i] = false; }
+  // the scratch is re-created with (or without) its second half on next use
+  if (c->partials_base) DFX_HIP(hipFree(c->partials_base));
+  c->partials_base = nullptr; c->partials = c->partials_alt = nullptr; c->partials_bytes = 0;
+  if (c->qhead) DFX_HIP(hipFree(c->qhead));
+  c->qhead = nullptr; c->qhead_cap = 0; c->qhead_dirty = false;
+  return DFX_OK;
+}
+
+DFX_API int dfx_tail_join(dfx_ctx* c) {
+  if (!c) return fail(DFX_E_INVALID, "null context");
+  if (!c->tail_stream) return DFX_OK;
+  DFX_HIP(hipEventRecord(c->ev_join, c->tail_stream));
+  DFX_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+  c->tail_busy[0] = c->tail_busy[1] = false;   // everything enqueued on the context's stream from here on is behind every tail
   return DFX_OK;
 }
 
@@ -596,20 +658,26 @@ DFX_API int dfx_debug_read_partials(dfx_ctx* c, void* host, size_t bytes) {
   return DFX_OK;
 }
 
-DFX_API int dfx_profile_read(dfx_ctx* c, int* n_launches, double* total_ms) {
+DFX_API int dfx_profile_read_ex(dfx_ctx* c, int* n_launches, double* total_ms, double* min_ms, double* max_ms) {
   if (!c || !n_launches || !total_ms) return fail(DFX_E_INVALID, "null argument");
   DFX_HIP(hipStreamSynchronize(c->stream));
-  double tot = 0;
+  double tot = 0, lo = 0, hi = 0;
   for (size_t i = 0; i < c->prof_used; ++i) {
     float ms = 0;
     DFX_HIP(hipEventElapsedTime(&ms, c->prof_pool[i].first, c->prof_pool[i].second));
     tot += ms;
+    if (i == 0 || ms < lo) lo = ms;
+    if (i == 0 || ms > hi) hi = ms;
   }
   *n_launches = (int)c->prof_used;
   *total_ms = tot;
+  if (min_ms) *min_ms = lo;
+  if (max_ms) *max_ms = hi;
   c->prof_used = 0;
   return DFX_OK;
 }
+
+DFX_API int dfx_profile_read(dfx_ctx* c, int* n_launches, double* total_ms) { return dfx_profile_read_ex(c, n_launches, total_ms, nullptr, nullptr); }
 
 // ---- library-owned device images -------------------------------------------------------------------------------
 DFX_API int dfx_img_alloc(dfx_ctx* c, uint32_t w, uint32_t h, size_t elem_bytes, dfx_img* out) {
@@ -706,8 +774,15 @@ DFX_API int dfx_debug_read_valid0_shadow(dfx_ctx* c, const dfx_img* img, uint64_
 }
 
 // ---- SfmAligner ------------------------------------------------------------------------------------------------
+static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n, void* out_items_dev, bool allow_defer);
+
 DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
                                      void* out_items_dev) {
+  return sfm_step_batch_impl(c, cs, params, pairs, n, out_items_dev, true);
+}
+
+// allow_defer = false (the blocking entry points): the finalize kernel runs on the context's stream even in deferred-tail mode
+static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n, void* out_items_dev, bool allow_defer) {
   if (!c || !params || !pairs || !out_items_dev) return fail(DFX_E_INVALID, "dfx_sfm_step_batch: null argument");
   if (!cs_supported(cs)) return fail(DFX_E_INVALID, "unsupported code size %d (16, 32, 64)", cs);
   if (n <= 0 || n > 65535) return fail(DFX_E_INVALID, "batch size %d out of range [1,65535]", n);
@@ -795,19 +870,27 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
       dyn_grid = resident_wgs;
       if (c->qhead_cap < (size_t)n) {
         DFX_HIP(hipStreamSynchronize(c->stream));
+        if (c->tail_stream) DFX_HIP(hipStreamSynchronize(c->tail_stream));
         if (c->qhead) DFX_HIP(hipFree(c->qhead));
         c->qhead = nullptr;
-        DFX_HIP(hipMalloc((void**)&c->qhead, sizeof(unsigned) * (size_t)n * 2));
-        DFX_HIP(hipMemsetAsync(c->qhead, 0, sizeof(unsigned) * (size_t)n * 2, c->stream));
+        DFX_HIP(hipMalloc((void**)&c->qhead, sizeof(unsigned) * (size_t)n * 4));   // two halves (deferred-tail mode alternates them)
+        DFX_HIP(hipMemsetAsync(c->qhead, 0, sizeof(unsigned) * (size_t)n * 4, c->stream));
         c->qhead_cap = (size_t)n * 2;
       }
-      dyn.qhead = c->qhead;
+      dyn.qhead = c->qhead;   // + the half's offset below
     }
   }
   c->last_dynamic = dyn.qhead ? 1 : 0;
   const int bpp = dyn.qhead ? dyn.team : auto_step_blocks(c, W, H, n, cs, params->step_blocks);
   const size_t pbytes = dfx::sfm_step_partials_bytes(cs, n, bpp);
-  if ((rc = grow_partials(c, pbytes))) return rc;
+  if ((rc = grow_partials(c, pbytes, true))) return rc;
+  // Deferred tail: this launch's finalize kernel goes to the tail stream and runs beside the NEXT launch's step kernel; the two halves of
+  // the partials (and of the queue heads) alternate, and a half is written again only after the finalize that read it (ev_tail).
+  const bool defer = allow_defer && c->tail_stream != nullptr;
+  const int par = c->tail_stream ? c->tail_parity : 0;
+  float* const partials = par ? c->partials_alt : c->partials;
+  if (c->tail_busy[par]) { DFX_HIP(hipStreamWaitEvent(c->stream, c->ev_tail[par], 0)); c->tail_busy[par] = false; }
+  if (dyn.qhead) dyn.qhead = c->qhead + (size_t)par * c->qhead_cap;
 
   dfx::SfmParamsDev prm{ params->huber_delta, params->avg_dpt, params->min_dpt, (float)params->valid_border, next_launch_id() };
   hipEvent_t eb = nullptr, ee = nullptr;
@@ -823,14 +906,24 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
     c->prof_used++;
   }
   if (dyn.qhead) {
-    if (c->qhead_dirty) DFX_HIP(hipMemsetAsync(c->qhead, 0, sizeof(unsigned) * c->qhead_cap, c->stream));
+    if (c->qhead_dirty) {   // a failed launch left heads behind: nothing may be in flight on them when they are cleared
+      if (c->tail_stream) DFX_HIP(hipStreamSynchronize(c->tail_stream));
+      DFX_HIP(hipMemsetAsync(c->qhead, 0, sizeof(unsigned) * c->qhead_cap * 2, c->stream));
+    }
     c->qhead_dirty = true;
   }
-  DFX_HIP(dfx::launch_sfm_step(cs, dd, n, (int)W, (int)H, prm, bpp, c->partials, out_items_dev, dfx_item_size(12 + cs), c->stream,
-                               jac_dense, resolve_mfma(c, cs), eb, ee, n == 1 ? &one : nullptr, dyn.qhead ? &dyn : nullptr, dyn_grid, vsh));
+  hipStream_t const fin_stream = defer ? c->tail_stream : c->stream;
+  DFX_HIP(dfx::launch_sfm_step(cs, dd, n, (int)W, (int)H, prm, bpp, partials, out_items_dev, dfx_item_size(12 + cs), c->stream,
+                               jac_dense, resolve_mfma(c, cs), eb, ee, n == 1 ? &one : nullptr, dyn.qhead ? &dyn : nullptr, dyn_grid, vsh,
+                               fin_stream, defer ? c->ev_mid[par] : nullptr));
   c->qhead_dirty = false;   // both kernels are enqueued: the finalize kernel rewinds the heads
-  if (n > 1) {
-    DFX_HIP(hipEventRecord(c->slot_done[slot], c->stream));
+  if (defer) {
+    DFX_HIP(hipEventRecord(c->ev_tail[par], fin_stream));
+    c->tail_busy[par] = true;
+  }
+  if (c->tail_stream) c->tail_parity ^= 1;
+  if (n > 1) {   // the finalize kernel reads the descriptors too
+    DFX_HIP(hipEventRecord(c->slot_done[slot], fin_stream));
     c->slot_busy[slot] = true;
   }
   return DFX_OK;
@@ -897,7 +990,9 @@ DFX_API int dfx_graph_assemble_async(dfx_ctx* c, const dfx_graph* g, const void*
     return fail(DFX_E_INVALID, "pairs [%d, %d) are not inside the graph's %d pairs", first_pair, first_pair + n_local, g->n_pairs);
   int rc;
   if ((rc = ensure_device(c))) return rc;
-  DFX_HIP(dfx::launch_graph_assemble(g->cs, g->view, items_dev, dfx_item_size(12 + g->cs), first_pair, n_local, sys_dev, c->stream));
+  // deferred-tail mode: the items are produced on the tail stream, so the assembly runs there as well
+  DFX_HIP(dfx::launch_graph_assemble(g->cs, g->view, items_dev, dfx_item_size(12 + g->cs), first_pair, n_local, sys_dev,
+                                     c->tail_stream ? c->tail_stream : c->stream));
   return DFX_OK;
 }
 
@@ -912,12 +1007,12 @@ DFX_API int dfx_sfm_step_batch(dfx_ctx* c, int cs, const dfx_sfm_params* params,
   if (bytes <= kDirectResultMax) {
     void* tgt;
     if ((rc = result_target(c, bytes, &tgt))) return rc;
-    if ((rc = dfx_sfm_step_batch_async(c, cs, params, pairs, n, tgt))) return rc;
+    if ((rc = sfm_step_batch_impl(c, cs, params, pairs, n, tgt, false))) return rc;
     return finish_result(c, out_items_host, bytes);
   }
   if (c->items_bytes < bytes) DFX_HIP(hipStreamSynchronize(c->stream));
   if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, bytes, c->stream))) return rc;
-  if ((rc = dfx_sfm_step_batch_async(c, cs, params, pairs, n, c->items_dev))) return rc;
+  if ((rc = sfm_step_batch_impl(c, cs, params, pairs, n, c->items_dev, false))) return rc;
   return fetch_result(c, c->items_dev, out_items_host, bytes);
 }
 
@@ -956,6 +1051,129 @@ DFX_API int dfx_sfm_error(dfx_ctx* c, const dfx_se3* pose0, const dfx_se3* pose1
   if ((rc = result_target(c, sizeof(dfx_corr_item), &tgt))) return rc;
   DFX_HIP(dfx::launch_sfm_error(d, (int)img0->w, (int)img0->h, params->huber_delta, blocks, c->partials, tgt, c->stream));
   return finish_result(c, out, sizeof(dfx_corr_item));
+}
+
+// ---- batched EvaluateError / SE3 step -------------------------------------------------------------------------------
+namespace {
+// uploads n SimplePairDev through the staging ring and returns their device copy; `slot` must be released after the launches
+int upload_simple(dfx_ctx* c, const std::vector<dfx::SimplePairDev>& descs, const dfx::SimplePairDev** dev_out, int* slot_out) {
+  int rc, slot;
+  char* host;
+  const size_t bytes = sizeof(dfx::SimplePairDev) * descs.size();
+  if ((rc = stage_acquire(c, bytes, &slot, &host))) return rc;
+  std::memcpy(host, descs.data(), bytes);
+  if (c->sdesc_cap < bytes) {
+    DFX_HIP(hipStreamSynchronize(c->stream));
+    if (c->sdesc_dev) DFX_HIP(hipFree(c->sdesc_dev));
+    c->sdesc_dev = nullptr;
+    const size_t cap = (bytes * 2 + 255) & ~(size_t)255;
+    DFX_HIP(hipMalloc((void**)&c->sdesc_dev, cap * kStageSlots));
+    c->sdesc_cap = cap;
+  }
+  char* dd = c->sdesc_dev + (size_t)slot * c->sdesc_cap;
+  DFX_HIP(hipMemcpyAsync(dd, host, bytes, hipMemcpyHostToDevice, c->stream));
+  *dev_out = reinterpret_cast<const dfx::SimplePairDev*>(dd);
+  *slot_out = slot;
+  return DFX_OK;
+}
+
+// workgroups per pair of a batched simple kernel: ~24 per CU over the whole batch, at least one wave-row of pixels each
+int batch_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int n) {
+  int b = simple_blocks(W, H);
+  const int cap = (24 * c->cu_count + n - 1) / n;
+  if (b > cap) b = cap;
+  return b < 1 ? 1 : b;
+}
+}  // namespace
+
+DFX_API int dfx_sfm_error_batch_async(dfx_ctx* c, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n, dfx_corr_item* out_items_dev) {
+  if (!c || !params || !pairs || !out_items_dev) return fail(DFX_E_INVALID, "dfx_sfm_error_batch: null argument");
+  if (n <= 0 || n > 65535) return fail(DFX_E_INVALID, "batch size %d out of range [1,65535]", n);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  if (!img_ok(&pairs[0].img0)) return fail(DFX_E_INVALID, "pair 0: img0 null or empty");
+  const uint32_t W = pairs[0].img0.w, H = pairs[0].img0.h;
+  std::vector<dfx::SimplePairDev> descs((size_t)n);
+  for (int p = 0; p < n; ++p) {
+    dfx_se3 p10;
+    float R10[9], HM[9];
+    relative_pose(pairs[p].pose0, pairs[p].pose1, R10, p10.t, nullptr, HM);
+    p10.q[0] = p10.q[1] = p10.q[2] = 0; p10.q[3] = 1;
+    if (pairs[p].img0.w != W || pairs[p].img0.h != H) return fail(DFX_E_INVALID, "pair %d: image size differs from pair 0 (one pyramid level per batch)", p);
+    if ((rc = fill_simple(&p10, &pairs[p].cam, &pairs[p].img0, &pairs[p].img1, &pairs[p].dpt0, nullptr, nullptr, &descs[p]))) {
+      g_last_error = "pair " + std::to_string(p) + ": " + g_last_error;
+      return rc;
+    }
+    for (int i = 0; i < 9; ++i) descs[p].R[i] = R10[i];
+  }
+  const int blocks = batch_blocks(c, W, H, n);
+  if ((rc = grow_partials(c, (size_t)n * blocks * dfx::kSimpleRow * sizeof(float)))) return rc;
+  const dfx::SimplePairDev* dd;
+  int slot;
+  if ((rc = upload_simple(c, descs, &dd, &slot))) return rc;
+  DFX_HIP(dfx::launch_sfm_error_batch(dd, n, (int)W, (int)H, params->huber_delta, blocks, c->partials, out_items_dev, c->stream));
+  return stage_release(c, slot);
+}
+
+DFX_API int dfx_sfm_error_batch(dfx_ctx* c, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n, dfx_corr_item* out_items_host) {
+  if (!c || !out_items_host) return fail(DFX_E_INVALID, "dfx_sfm_error_batch: null argument");
+  if (n <= 0) return fail(DFX_E_INVALID, "batch size %d", n);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  const size_t bytes = sizeof(dfx_corr_item) * (size_t)n;
+  if (bytes <= kDirectResultMax) {
+    void* tgt;
+    if ((rc = result_target(c, bytes, &tgt))) return rc;
+    if ((rc = dfx_sfm_error_batch_async(c, params, pairs, n, (dfx_corr_item*)tgt))) return rc;
+    return finish_result(c, out_items_host, bytes);
+  }
+  if (c->items_bytes < bytes) DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, bytes, c->stream))) return rc;
+  if ((rc = dfx_sfm_error_batch_async(c, params, pairs, n, (dfx_corr_item*)c->items_dev))) return rc;
+  return fetch_result(c, c->items_dev, out_items_host, bytes);
+}
+
+DFX_API int dfx_se3_step_batch_async(dfx_ctx* c, const dfx_se3_pair* pairs, int n, float huber_delta, void* out_items_dev) {
+  if (!c || !pairs || !out_items_dev) return fail(DFX_E_INVALID, "dfx_se3_step_batch: null argument");
+  if (n <= 0 || n > 65535) return fail(DFX_E_INVALID, "batch size %d out of range [1,65535]", n);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  if (!img_ok(&pairs[0].img0)) return fail(DFX_E_INVALID, "pair 0: img0 null or empty");
+  const uint32_t W = pairs[0].img0.w, H = pairs[0].img0.h;
+  std::vector<dfx::SimplePairDev> descs((size_t)n);
+  for (int p = 0; p < n; ++p) {
+    if (pairs[p].img0.w != W || pairs[p].img0.h != H) return fail(DFX_E_INVALID, "pair %d: image size differs from pair 0 (one pyramid level per batch)", p);
+    if ((rc = fill_simple(&pairs[p].pose_10, &pairs[p].cam, &pairs[p].img0, &pairs[p].img1, &pairs[p].dpt0, &pairs[p].grad1, nullptr, &descs[p]))) {
+      g_last_error = "pair " + std::to_string(p) + ": " + g_last_error;
+      return rc;
+    }
+    if (!descs[p].grad1) return fail(DFX_E_INVALID, "pair %d: grad1 is null", p);
+  }
+  const int blocks = batch_blocks(c, W, H, n);
+  if ((rc = grow_partials(c, (size_t)n * blocks * dfx::kSimpleRow * sizeof(float)))) return rc;
+  const dfx::SimplePairDev* dd;
+  int slot;
+  if ((rc = upload_simple(c, descs, &dd, &slot))) return rc;
+  DFX_HIP(dfx::launch_se3_step_batch(dd, n, (int)W, (int)H, huber_delta, blocks, c->partials, out_items_dev, c->stream));
+  return stage_release(c, slot);
+}
+
+DFX_API int dfx_se3_step_batch(dfx_ctx* c, const dfx_se3_pair* pairs, int n, float huber_delta, void* out_items_host) {
+  if (!c || !out_items_host) return fail(DFX_E_INVALID, "dfx_se3_step_batch: null argument");
+  if (n <= 0) return fail(DFX_E_INVALID, "batch size %d", n);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  const size_t bytes = dfx_item_size(6) * (size_t)n;
+  if (bytes <= kDirectResultMax) {
+    void* tgt;
+    if ((rc = result_target(c, bytes, &tgt))) return rc;
+    if ((rc = dfx_se3_step_batch_async(c, pairs, n, huber_delta, tgt))) return rc;
+    return finish_result(c, out_items_host, bytes);
+  }
+  if (c->items_bytes < bytes) DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, bytes, c->stream))) return rc;
+  if ((rc = dfx_se3_step_batch_async(c, pairs, n, huber_delta, c->items_dev))) return rc;
+  return fetch_result(c, c->items_dev, out_items_host, bytes);
 }
 
 // ---- SE3Aligner ------------------------------------------------------------------------------------------------
@@ -1240,8 +1458,16 @@ DFX_API int dfx_update_depth_batch_async(dfx_ctx* c, int cs, int n, const float*
   return update_depth_jobs(c, cs, jobs, avg_dpt, W, H);
 }
 
+static int sfm_linearize_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, const dfx_img* prx0_orig,
+                                    const float* codes0, int n, void* out_items_dev, bool allow_defer);
+
 DFX_API int dfx_sfm_linearize_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, const dfx_img* prx0_orig,
                                           const float* codes0, int n, void* out_items_dev) {
+  return sfm_linearize_batch_impl(c, cs, params, pairs, prx0_orig, codes0, n, out_items_dev, true);
+}
+
+static int sfm_linearize_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, const dfx_img* prx0_orig,
+                                    const float* codes0, int n, void* out_items_dev, bool allow_defer) {
   if (!c || !params || !pairs || !prx0_orig || !codes0 || !out_items_dev) return fail(DFX_E_INVALID, "dfx_sfm_linearize_batch: null argument");
   if (!cs_supported(cs)) return fail(DFX_E_INVALID, "unsupported code size %d (16, 32, 64)", cs);
   if (n <= 0 || n > 65535) return fail(DFX_E_INVALID, "batch size %d out of range [1,65535]", n);
@@ -1272,7 +1498,7 @@ DFX_API int dfx_sfm_linearize_batch_async(dfx_ctx* c, int cs, const dfx_sfm_para
     }
   }
   if ((rc = update_depth_jobs(c, cs, jobs, params->avg_dpt, W, H))) return rc;
-  return dfx_sfm_step_batch_async(c, cs, params, pairs, n, out_items_dev);
+  return sfm_step_batch_impl(c, cs, params, pairs, n, out_items_dev, allow_defer);
 }
 
 DFX_API int dfx_sfm_linearize_batch(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, const dfx_img* prx0_orig,
@@ -1285,12 +1511,12 @@ DFX_API int dfx_sfm_linearize_batch(dfx_ctx* c, int cs, const dfx_sfm_params* pa
   if (bytes <= kDirectResultMax) {
     void* tgt;
     if ((rc = result_target(c, bytes, &tgt))) return rc;
-    if ((rc = dfx_sfm_linearize_batch_async(c, cs, params, pairs, prx0_orig, codes0, n, tgt))) return rc;
+    if ((rc = sfm_linearize_batch_impl(c, cs, params, pairs, prx0_orig, codes0, n, tgt, false))) return rc;
     return finish_result(c, out_items_host, bytes);
   }
   if (c->items_bytes < bytes) DFX_HIP(hipStreamSynchronize(c->stream));
   if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, bytes, c->stream))) return rc;
-  if ((rc = dfx_sfm_linearize_batch_async(c, cs, params, pairs, prx0_orig, codes0, n, c->items_dev))) return rc;
+  if ((rc = sfm_linearize_batch_impl(c, cs, params, pairs, prx0_orig, codes0, n, c->items_dev, false))) return rc;
   return fetch_result(c, c->items_dev, out_items_host, bytes);
 }
 

@@ -22,9 +22,6 @@ struct SfmPairDev {
   unsigned long long* valid0_shadow;   // library-owned valid0 images: one bit per pixel (linear index), set = "holds 1.0"; else null
   uint32_t pitch_img0, pitch_img1, pitch_dpt0, pitch_valid0, pitch_jac, pitch_grad1;   // bytes
 };
-// The partials scratch handed to launch_sfm_step / launch_depth_aligner_step must be preceded by kZeroPageBytes of ZEROS in the same
-// allocation: what the step kernel streams instead of the Jacobian of a chunk without a single correspondence (256 * CS bytes per chunk).
-constexpr int kZeroPageBytes = 16384;
 constexpr int kRayTabSlack = 80;   // rows a lane past the last pixel may index (<= 64 / W + 1), zero-filled
 
 struct SfmParamsDev {
@@ -83,7 +80,8 @@ hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int 
                            hipStream_t stream, bool jac_dense, int prec, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr,
                            const SfmPairDev* one_host = nullptr,   // one_host (npairs == 1): the descriptor travels in the kernel arguments
                            const DynDev* dyn = nullptr, int dyn_grid = 0,    // dyn: the dynamic schedule (workgroups = dyn_grid, partials = [pair][team])
-                           bool valid0_shadows = false);                     // every non-null valid0 of the batch carries a shadow (SfmPairDev::valid0_shadow)
+                           bool valid0_shadows = false,                      // every non-null valid0 of the batch carries a shadow (SfmPairDev::valid0_shadow)
+                           hipStream_t fin_stream = nullptr, hipEvent_t ev_mid = nullptr);   // deferred tail: the finalize kernel runs on fin_stream behind ev_mid
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair);
 // system layout (floats): Hd [n_nodes][D][D], Ho [n_pairs][D][6], g [n_nodes][D]; contributions of the pairs [first_pair, first_pair + n_local)
 hipError_t launch_graph_assemble(int cs, const GraphDev& G, const void* items_dev, size_t item_stride, int first_pair, int n_local, float* sys_dev,
@@ -93,6 +91,11 @@ hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_del
                            void* item_dev, hipStream_t stream);
 hipError_t launch_sfm_error(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
                             void* corr_item_dev, hipStream_t stream);
+// batched forms: descs_dev[n], partials [n][blocks][kSimpleRow], results packed (16 bytes per dfx_corr_item, 120 per JTJJrReductionItem<float,6>)
+hipError_t launch_sfm_error_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
+                                  void* corr_items_dev, hipStream_t stream);
+hipError_t launch_se3_step_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
+                                 void* items_dev, hipStream_t stream);
 hipError_t launch_se3_warp(const SimplePairDev& p, int W, int H, int blocks, float* partials_dev, void* corr_item_dev,
                            hipStream_t stream);
 hipError_t launch_update_depth(int cs, const float* code_dev, const float* prx_orig, uint32_t pitch_prx, const float* jac,

@@ -341,12 +341,11 @@ hipError_t launch_sparse_geometric(int cs, const void* desc_host, const float* c
 }
 
 // ---- SfM error: sum (w r)^2, inliers -----------------------------------------------------------------------
-__global__ __launch_bounds__(kT) void k_sfm_error(const SimplePairDev p, const int W, const int H, const float huber_delta,
-                                                  float* __restrict__ partials) {
-  const Geo g = geo_from(p);
+__device__ __forceinline__ void sfm_error_accumulate(const Geo& g, const SimplePairDev& p, const int W, const int H, const float huber_delta,
+                                                     float (&acc)[2]) {
   const ImgRef I0{ (const char*)p.img0, p.pitch_img0 }, I1{ (const char*)p.img1, p.pitch_img1 };
   const ImgRef D0{ (const char*)p.dpt0, p.pitch_dpt0 };
-  float acc[2] = { 0.f, 0.f };
+  acc[0] = acc[1] = 0.f;
   const int npx = W * H;
   for (int i = blockIdx.x * kT + threadIdx.x; i < npx; i += gridDim.x * kT) {
     const int y = i / W, x = i - y * W;
@@ -361,7 +360,35 @@ __global__ __launch_bounds__(kT) void k_sfm_error(const SimplePairDev p, const i
       acc[1] += 1.0f;
     }
   }
+}
+
+__global__ __launch_bounds__(kT) void k_sfm_error(const SimplePairDev p, const int W, const int H, const float huber_delta,
+                                                  float* __restrict__ partials) {
+  const Geo g = geo_from(p);
+  float acc[2];
+  sfm_error_accumulate(g, p, W, H, huber_delta, acc);
   block_reduce_store<2>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
+}
+
+// ---- batched forms (blockIdx.y = pair): PhotometricFactor::error over a factor set evaluates one pair per blocking call in the reference
+// (core/gtsam/photometric_factor.cpp:61-81,197-216); a relocalisation / loop-closure check steps one live frame against many keyframes.
+// Same per-pair arithmetic and reduction order as the single-pair kernels launched with the same number of workgroups.
+__global__ __launch_bounds__(kT) void k_sfm_error_batch(const SimplePairDev* __restrict__ descs, const int W, const int H, const float huber_delta,
+                                                        float* __restrict__ partials_all) {
+  const SimplePairDev& p = descs[blockIdx.y];
+  const Geo g = geo_from(p);
+  float acc[2];
+  sfm_error_accumulate(g, p, W, H, huber_delta, acc);
+  block_reduce_store<2>(acc, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
+}
+
+__global__ __launch_bounds__(kT) void k_se3_step_batch(const SimplePairDev* __restrict__ descs, const int W, const int H, const float huber_delta,
+                                                       float* __restrict__ partials_all) {
+  const SimplePairDev& p = descs[blockIdx.y];
+  const Geo g = geo_from(p);
+  float acc[29];
+  se3_accumulate(g, p, W, H, huber_delta, acc);
+  block_reduce_store<29>(acc, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
 }
 
 // ---- Warp: render img1 into frame 0, SIGNED residual sum (cu_se3aligner.cpp:106) ----------------------------
@@ -405,8 +432,11 @@ __global__ __launch_bounds__(kT) void k_squared_error(const float* __restrict__ 
 // ---- finalize: out[e] = sum_b partials[b][e] in double, fixed order; layout-specific scatter -------------------
 enum FinalKind { kFinalItem6 = 0, kFinalCorr = 1, kFinalScalar = 2 };
 
-__global__ __launch_bounds__(1024) void k_finalize_rows(const float* __restrict__ partials, const int nblocks, const int kind,
-                                                        char* __restrict__ out) {
+__global__ __launch_bounds__(1024) void k_finalize_rows(const float* __restrict__ partials_all, const int nblocks, const int kind,
+                                                        char* __restrict__ out_all, const size_t out_stride) {
+  // blockIdx.x = pair of a batched launch (0 for the single-pair operators)
+  const float* partials = partials_all + (size_t)blockIdx.x * nblocks * kSimpleRow;
+  char* out = out_all + (size_t)blockIdx.x * out_stride;
   __shared__ double red[32][kSimpleRow];
   const int e = threadIdx.x & 31, rg = threadIdx.x >> 5;   // 32 row groups
   static_assert(kMaxSimpleBlocks <= 32 * 32, "one load per row group and thread");
@@ -549,7 +579,7 @@ hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_del
   hipLaunchKernelGGL(k_se3_step, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalItem6, (char*)item_dev);
+  hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalItem6, (char*)item_dev, (size_t)0);
   return hipGetLastError();
 }
 
@@ -558,7 +588,25 @@ hipError_t launch_sfm_error(const SimplePairDev& p, int W, int H, float huber_de
   hipLaunchKernelGGL(k_sfm_error, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalCorr, (char*)corr_item_dev);
+  hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalCorr, (char*)corr_item_dev, (size_t)0);
+  return hipGetLastError();
+}
+
+hipError_t launch_sfm_error_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
+                                  void* corr_items_dev, hipStream_t stream) {
+  hipLaunchKernelGGL(k_sfm_error_batch, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_finalize_rows, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalCorr, (char*)corr_items_dev, (size_t)16);
+  return hipGetLastError();
+}
+
+hipError_t launch_se3_step_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
+                                 void* items_dev, hipStream_t stream) {
+  hipLaunchKernelGGL(k_se3_step_batch, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_finalize_rows, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalItem6, (char*)items_dev, (size_t)120);
   return hipGetLastError();
 }
 
@@ -567,7 +615,7 @@ hipError_t launch_se3_warp(const SimplePairDev& p, int W, int H, int blocks, flo
   hipLaunchKernelGGL(k_se3_warp, dim3(blocks), dim3(kT), 0, stream, p, W, H, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalCorr, (char*)corr_item_dev);
+  hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalCorr, (char*)corr_item_dev, (size_t)0);
   return hipGetLastError();
 }
 
@@ -576,7 +624,7 @@ hipError_t launch_squared_error(const float* a, uint32_t pitch_a, const float* b
   hipLaunchKernelGGL(k_squared_error, dim3(blocks), dim3(kT), 0, stream, a, pitch_a, b, pitch_b, W, H, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalScalar, (char*)out_dev);
+  hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalScalar, (char*)out_dev, (size_t)0);
   return hipGetLastError();
 }
 

@@ -79,25 +79,17 @@ namespace dfx {
                              // 16 = no P x P fmas, 32 = no ray-table / valid0 reads, 64 = no operand shuffles, 128 = no tap gathers
 #endif
 
-#ifndef DFX_B3_MIN_WAVES
-#define DFX_B3_MIN_WAVES DFX_MIN_WAVES   // DFX_MFMA_BF16X3, CS <= 32: 4 asks the register allocator for 128 VGPRs (the split mode compiles to 132 = three waves per SIMD); NOT YET MEASURED
-#endif
-#ifndef DFX_B3_PSPLIT
-#define DFX_B3_PSPLIT 0      // DFX_MFMA_BF16X3 only, NOT YET MEASURED (written without GPU time left in round 2): 1 = the P block is split once per
-#endif                       // pixel in phase A and handed to phase B as packed bf16 pieces through LDS (ds_write_b16 / ds_read_b128): -44 VALU per chunk
-#ifndef DFX_B3_DIAG4
-#define DFX_B3_DIAG4 0       // DFX_MFMA_BF16X3 only, NOT YET MEASURED: 1 = (CS <= 32) the diagonal tiles take four products instead of six:
-#endif                       // S = hh + mm and N = hm + hl in two accumulators, Z = S + N + N^T in the finalize kernel (-12 of 72 MFMAs at CS = 32)
+#ifndef DFX_B3_DIAG4_MAX_NCB
+#define DFX_B3_DIAG4_MAX_NCB 2   // DFX_MFMA_BF16X3: up to this many code blocks the diagonal tiles (C_b,C_b) take four products instead of six: S = hh + mm
+#endif                           // and N = hm + hl in two accumulators, Z = S + N + N^T in the finalize kernel.  MI355X, 128 pairs, CS = 32: 1039.5 -> 1004.0 us
+                                 // (profiles/r03_ab_variants.txt).  0 disables it.  Two round-2 ideas measured in the same call and removed: the P block
+                                 // split in phase A and handed over as packed bf16 through LDS (+2.4 %), 128 registers for a fourth wave (spills: +37 %).
 #ifndef DFX_RING_AUX
 #define DFX_RING_AUX 2       // cache policy of the code-Jacobian stream loads: 2 = nt (read once: do not displace the img1 / grad1 rows
 #endif                       // the bilinear taps of the next chunk row re-use from the L2); -1.6 % kernel time, -3 % read requests with the collapse below
 #ifndef DFX_STREAM_AUX
 #define DFX_STREAM_AUX 1     // cache policy of the coalesced img0 / dpt0 loads (read once per launch): 1 = sc0, they bypass the CU's L1 and leave
                              // it to the bilinear taps; -1 % (1055-1059 vs 1067 us, 4 interleaved runs each); nt (2) and sc0+nt (3) are no better
-#endif
-#ifndef DFX_SKIP_DEAD
-#define DFX_SKIP_DEAD 0      // 1: the Jacobian of a chunk none of whose 64 pixels has a correspondence is not streamed (see `live1`); costs 8 VGPRs
-                             // (133 instead of 125 at CS = 32: three waves per SIMD instead of four) for ~2 % of the stream -- A/B pending
 #endif
 #ifndef DFX_DYN_ROT
 #define DFX_DYN_ROT 4        // dynamic schedule: member row m of the teams serves the pairs rotated by DFX_DYN_ROT * m (0: a pair's team sits on one XCD)
@@ -143,8 +135,8 @@ __device__ __forceinline__ unsigned jv_offset(unsigned pbase, int gq, int li, in
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));   // operand type of __builtin_amdgcn_mfma_f32_16x16x32_bf16 (8 bf16 = 4 VGPRs)
 constexpr int b3_tiles(int ncb) { return 1 + ncb + ncb * (ncb + 1) / 2; }
-constexpr bool b3_diag4(int ncb) { return DFX_B3_DIAG4 != 0 && ncb <= 2; }                          // two accumulators per diagonal tile: registers allow it up to CS = 32
-constexpr int b3_blocks(int ncb) { return b3_tiles(ncb) + (b3_diag4(ncb) ? 1 + ncb : 0); }      // 256-float blocks of a partial: the tiles, then N of (P,P), (C_b,C_b)
+constexpr bool b3_diag4(int ncb) { return ncb <= DFX_B3_DIAG4_MAX_NCB; }                     // two accumulators per diagonal (C_b,C_b) tile
+constexpr int b3_blocks(int ncb) { return b3_tiles(ncb) + 1 + (b3_diag4(ncb) ? ncb : 0); }   // 256-float blocks of a partial: the tiles, then the N parts of (P,P) [, (C_b,C_b)]
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {   // {RNE_bf16(lo) in bits 0..15, RNE_bf16(hi) in bits 16..31}
   unsigned r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
@@ -191,7 +183,7 @@ __device__ __forceinline__ float dpp_merge(float old, float src) {
 // VSH: every valid0 map of the launch is library-owned and carries a shadow (1 bit per pixel "known to hold 1.0"): 8 bytes are read per
 // chunk instead of the map's 256.
 template <int NCB, int MODE, bool JDENSE, bool TABLDS, bool BYVAL, bool DYN, bool B3, bool VSH>
-__global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX_B3_MIN_WAVES : DFX_MIN_WAVES)) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmPairDev one, const SfmParamsDev prm,
+__global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_WAVES) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmPairDev one, const SfmParamsDev prm,
                                                        const int W, const int H, float* __restrict__ partials, const DynDev dyn) {
   static_assert(!DYN || (MODE == 0 && JDENSE && TABLDS && !BYVAL), "the dynamic schedule exists for the batched dense SfM step");
   static_assert(!VSH || MODE == 0, "valid0 maps exist for the SfM step only");
@@ -274,11 +266,9 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
   if (MODE == 0 && TABLDS && !DYN) __syncthreads();
   float* U = lds + wave * (DYN ? kUFloats : SLOT);
   if (lane < 16) U[(lane >> 1) * kUStride + 64 + (lane & 1)] = 0.f;   // padding columns 64, 65 of P rows 0..7 (read as zeros by the 4x4 tiles)
-  if (B3) U[15 * kUStride + lane] = 0.f;   // B3: the P block's rows 8..15 are zeros -- lanes 8..15 of every 16-lane row read this LDS row instead
   f32x4 acc3[B3 ? NB3 : 1];                // B3: one accumulator per tile (+ the N parts of the diagonal tiles with DFX_B3_DIAG4)
 #pragma unroll
   for (int a = 0; a < (B3 ? NB3 : 1); ++a) acc3[a] = f32x4{ 0.f, 0.f, 0.f, 0.f };
-  const int psl = 32 * (lane >> 5) + 8 * (lane & 3) + ((lane >> 2) & 7);   // DFX_B3_PSPLIT: 16-bit slot of pixel `lane` = 32 h + 4 j + k inside a (piece, row) line: [h][k][j]
 
   f32x4 acc[NACC];
 #pragma unroll
@@ -560,20 +550,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
         const bool is_one = VSH ? ((cur.vl >> (opaque_lane() & 31u)) & 1u) != 0u : cur.vl == 0x3f800000u;   // 0x3f800000 is the only pattern equal to 1.0f
         vmask |= ((ok && !is_one) ? 1u : 0u) << vk;   // valid0(x, y) = 1 (dense_sfm.h:161), written in bursts: flush_valid
       }
-      if constexpr (B3 && DFX_B3_PSPLIT != 0) {
-        // the P block leaves phase A already split: 16-bit element ((piece * 8 + row) * 64 + [h][k][j]) of the wave's LDS region, so that lane
-        // (row, k) of phase B finds the eight slots of a half-chunk as ONE 16-byte vector per piece (rows 0..11 of U; s stays fp32 in row 13)
-        unsigned short* const UH = reinterpret_cast<unsigned short*>(U);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          unsigned ph, pm, pl;
-          split3_bf16(u16[2 * r], r == 3 ? u16[14] : u16[2 * r + 1], ph, pm, pl);   // row 7 = inlier flag
-          UH[(0 * 8 + 2 * r) * 64 + psl] = (unsigned short)ph; UH[(0 * 8 + 2 * r + 1) * 64 + psl] = (unsigned short)(ph >> 16);
-          UH[(1 * 8 + 2 * r) * 64 + psl] = (unsigned short)pm; UH[(1 * 8 + 2 * r + 1) * 64 + psl] = (unsigned short)(pm >> 16);
-          UH[(2 * 8 + 2 * r) * 64 + psl] = (unsigned short)pl; UH[(2 * 8 + 2 * r + 1) * 64 + psl] = (unsigned short)(pl >> 16);
-        }
-        U[13 * kUStride + lane] = u16[13];
-      } else {
+      {
 #pragma unroll
       for (int q = 0; q < 7; ++q) U[q * kUStride + lane] = u16[q];
       U[7 * kUStride + lane] = u16[14];    // inlier flag: its square sums to the inlier count
@@ -602,16 +579,11 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
     __builtin_amdgcn_sched_barrier(0);
 #endif
     // ---- phase B: rank-4 updates on the matrix cores; operand ring refilled behind the consumer
-    // A next chunk without a single correspondence (image rows that left the view, the border rows: 2 - 3 % of the chunks of a typical
-    // pair) needs no Jacobian: every weight of it is 0 (v_mul_legacy).  Its refills then read the library's zero page instead (one
-    // 256 * NCB * 16-byte region per device, L2-resident: loads that touch memory and keep the counted waits exact, but no HBM traffic) --
-    // a choice of buffer resource, i.e. scalar registers only.  The reference returns before it touches prx_jac (dense_sfm.h:154-159).
-    const bool live1 = has1 && (!DFX_SKIP_DEAD || MODE != 0 || __builtin_amdgcn_ballot_w64(cur.ok) != 0ull);   // `cur` holds chunk c+1 since A1 above
-    const bool to_zero = JDENSE && DFX_SKIP_DEAD && MODE == 0 && has1 && !live1;
-    // the zero page sits right in front of the partials (kZeroPageBytes; launch_sfm_step's contract): no pointer of its own to keep
-    const __amdgpu_buffer_rsrc_t nrs = to_zero ? make_rsrc(reinterpret_cast<const char*>(partials) - kZeroPageBytes, 256u * NCB * 16u) : ring_rsrc(nbase);
-    const bool rreal = JDENSE ? has1 : live1;   // pitched rows: per-vector offsets, the refills of a dead chunk collapse to one line each
-    const unsigned rlo = ring_opaque_off(rreal);
+    const __amdgpu_buffer_rsrc_t nrs = ring_rsrc(nbase);
+    const unsigned rlo = ring_opaque_off(has1);
+    // (Tried in round 3: not streaming the Jacobian of a next chunk none of whose 64 pixels has a correspondence -- 2 - 3 % of the chunks of
+    // a typical pair -- by pointing its refills at an L2-resident zero page.  The extra scalar state cost 8 VGPRs, i.e. the fourth wave per
+    // SIMD of the fp32 chain: 1064 -> 1077 us; +-0 for the bf16 split.  Removed.)
     if constexpr (B3) {
       // ---- phase B, exact bf16 split (DFX_MFMA_BF16X3): every fp32 entry of z is split into three bf16 pieces, x = h + m + l EXACTLY
       // (h = RNE_bf16(x), m = RNE_bf16(x - h), l = x - h - m: 8 + 8 + 8 significant bits and a sign each), and z z^T is summed as
@@ -619,18 +591,16 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
       // the product, i.e. below the rounding of an fp32 multiply).  A bf16 MFMA covers 32 pixels: half a chunk; lane (li, lk), slot j
       // of a half h holds pixel 4 (8 h + j) + lk -- the ring registers jv[8 h + j] as they are.  A and B use the same
       // pixel -> (lane group, slot) assignment, which is all the sum over k needs.  z blocks: 0 = P (rows 0..7; 8..15 zero), 1 + b = C_b.
-      const int prow = lo8 ? li * kUStride : 15 * kUStride;
-      // DFX_B3_PSPLIT: lanes 8..15 of a row read the pieces of P rows 0..7 again -- rows / columns 8..15 of the P tiles are never read
-      // by the finalize kernel, so any finite content will do and no zero row is needed
-      const char* const pbytes = reinterpret_cast<const char*>(U) + (li & 7) * 128 + lk * 16;
+      // P stacking: the P block has 8 rows, a tile 16.  Both halves of a 16-lane row read P row (li & 7) and split it; lanes 0..7 keep the
+      // h piece and lanes 8..15 the m piece (operand Pa = [P_h ; P_m]), and Pl0 = [P_l ; 0].  One MFMA then yields two products:
+      //   (P,C_b):  Pa x C_h = [hh ; mh],  Pa x C_m = [hm ; mm],  Pa x C_l = [hl ; (ml)],  Pl0 x C_h = [lh ; 0]      4 instead of 6 MFMAs
+      //   (P,P)  :  Pa x Pa  = [hh hm ; mh mm]   and   Pl0 x Pa = [lh (lm) ; 0 0] in a second accumulator             2 instead of 6
+      // (terms in parentheses are of the dropped 2^-24 class: harmless).  The finalize kernel adds the row halves / quadrants and
+      // symmetrises lh (P P^T = sum of p p^T: hl = lh^T).  CS = 32 with the four-product diagonal tiles: 48 MFMAs per chunk (72 plain).
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        u32x4 oh[1 + NCB], om[1 + NCB], ol[1 + NCB];   // packed bf16 pairs (slots 2 jp, 2 jp + 1) of the three pieces of every block
-        if constexpr (DFX_B3_PSPLIT != 0) {
-          oh[0] = *reinterpret_cast<const u32x4*>(pbytes + 0 * 1024 + h * 64);
-          om[0] = *reinterpret_cast<const u32x4*>(pbytes + 1 * 1024 + h * 64);
-          ol[0] = *reinterpret_cast<const u32x4*>(pbytes + 2 * 1024 + h * 64);
-        }
+        u32x4 oh[1 + NCB], om[1 + NCB], ol[1 + NCB];   // packed bf16 pairs (slots 2 jp, 2 jp + 1) of the three pieces of the code blocks (index 0 unused)
+        u32x4 pa, pl0;
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
           float x[1 + NCB][2];
@@ -639,57 +609,62 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
             const int gq = 8 * h + 2 * jp + e;
             const int pp = 4 * gq + lk;
             const float s = U[13 * kUStride + pp];
-            x[0][e] = DFX_B3_PSPLIT != 0 ? 0.f : U[prow + pp];
+            x[0][e] = U[uP_row + pp];
 #pragma unroll
             for (int b = 0; b < NCB; ++b) x[1 + b][e] = mul_zero_wins(s, jv_get<NCB>(jv[gq], b));
 #if !(DFX_ABLATE & 4)
-            jv[gq] = ring_load(nrs, rlo, nbase, gq, rreal);
+            jv[gq] = ring_load(nrs, rlo, nbase, gq, has1);
 #endif
           }
+          {
+            unsigned ph, pm, pl;
+            split3_bf16(x[0][0], x[0][1], ph, pm, pl);
+            pa[jp] = lo8 ? ph : pm;
+            pl0[jp] = lo8 ? pl : 0u;
+          }
 #pragma unroll
-          for (int k = (DFX_B3_PSPLIT != 0 ? 1 : 0); k < 1 + NCB; ++k) {
+          for (int k = 1; k < 1 + NCB; ++k) {
             unsigned ph, pm, pl;
             split3_bf16(x[k][0], x[k][1], ph, pm, pl);
             oh[k][jp] = ph; om[k][jp] = pm; ol[k][jp] = pl;
           }
         }
-        // tiles: t = 0 (P,P); 1 + b (P,C_b); then (C_b,C_b') for b <= b' in row-major order.  Product-major issue order: consecutive
-        // MFMAs write different accumulators; small terms first.
-        auto tiles = [&](const u32x4 (&A)[1 + NCB], const u32x4 (&Bv)[1 + NCB]) {
-          int t = 0;
-          acc3[t] = mfma_bf16(A[0], Bv[0], acc3[t]); ++t;
+        // blocks of the partial: 0 = (P,P); 1 + b = (P,C_b); then (C_b,C_b') for b <= b' in row-major order; NT3 = N part of (P,P); with the
+        // four-product diagonals NT3 + 1 + b = N part of (C_b,C_b).  Issue order: consecutive MFMAs write different accumulators; small terms first.
+        auto pc = [&](const u32x4& PA, const u32x4 (&Bv)[1 + NCB]) {
 #pragma unroll
-          for (int b = 0; b < NCB; ++b, ++t) acc3[t] = mfma_bf16(A[0], Bv[1 + b], acc3[t]);
+          for (int b = 0; b < NCB; ++b) acc3[1 + b] = mfma_bf16(PA, Bv[1 + b], acc3[1 + b]);
+        };
+        auto cc_off = [&](const u32x4 (&A)[1 + NCB], const u32x4 (&Bv)[1 + NCB]) {
+          int t = 1 + NCB;
 #pragma unroll
           for (int b = 0; b < NCB; ++b)
 #pragma unroll
-            for (int b2 = b; b2 < NCB; ++b2, ++t) acc3[t] = mfma_bf16(A[1 + b], Bv[1 + b2], acc3[t]);
+            for (int b2 = b; b2 < NCB; ++b2, ++t) if (b2 != b) acc3[t] = mfma_bf16(A[1 + b], Bv[1 + b2], acc3[t]);
         };
-        if constexpr (b3_diag4(NCB)) {
-          // off-diagonal tiles: all six products; diagonal tiles d = 0 (P,P), 1 + b (C_b,C_b): S = mm + hh in their tile, N = hl + hm in acc3[NT3 + d]
-          auto offd = [&](const u32x4 (&A)[1 + NCB], const u32x4 (&Bv)[1 + NCB]) {
+        auto cc_diag = [&](const u32x4 (&A)[1 + NCB], const u32x4 (&Bv)[1 + NCB], bool npart) {
+          int t = 1 + NCB;
 #pragma unroll
-            for (int b = 0; b < NCB; ++b) acc3[1 + b] = mfma_bf16(A[0], Bv[1 + b], acc3[1 + b]);
-            int t = 1 + NCB;
-#pragma unroll
-            for (int b = 0; b < NCB; ++b)
-#pragma unroll
-              for (int b2 = b; b2 < NCB; ++b2, ++t) if (b2 != b) acc3[t] = mfma_bf16(A[1 + b], Bv[1 + b2], acc3[t]);
-          };
-          auto diag = [&](const u32x4 (&A)[1 + NCB], const u32x4 (&Bv)[1 + NCB], bool npart) {
-            acc3[npart ? NT3 : 0] = mfma_bf16(A[0], Bv[0], acc3[npart ? NT3 : 0]);
-            int t = 1 + NCB;
-#pragma unroll
-            for (int b = 0; b < NCB; ++b) {
-              const int td = npart ? NT3 + 1 + b : t;
-              acc3[td] = mfma_bf16(A[1 + b], Bv[1 + b], acc3[td]);
-              t += NCB - b;
-            }
-          };
-          offd(om, om); diag(om, om, false); offd(oh, ol); diag(oh, ol, true); offd(ol, oh); offd(oh, om); diag(oh, om, true); offd(om, oh);
-          offd(oh, oh); diag(oh, oh, false);
+          for (int b = 0; b < NCB; ++b) {
+            const int td = npart ? NT3 + 1 + b : t;
+            acc3[td] = mfma_bf16(A[1 + b], Bv[1 + b], acc3[td]);
+            t += NCB - b;
+          }
+        };
+        if constexpr (b3_diag4(NCB)) {   // diagonal tiles: S = mm + hh in the tile, N = hl + hm in its N block
+          pc(pl0, oh); cc_off(om, om); cc_diag(om, om, false);
+          pc(pa, ol); cc_off(oh, ol); cc_diag(oh, ol, true); cc_off(ol, oh);
+          pc(pa, om); cc_off(oh, om); cc_diag(oh, om, true); cc_off(om, oh);
+          acc3[NT3] = mfma_bf16(pl0, pa, acc3[NT3]);
+          pc(pa, oh); cc_off(oh, oh); cc_diag(oh, oh, false);
+          acc3[0] = mfma_bf16(pa, pa, acc3[0]);
         } else {
-        tiles(om, om); tiles(oh, ol); tiles(ol, oh); tiles(oh, om); tiles(om, oh); tiles(oh, oh);
+          pc(pl0, oh); cc_off(om, om); cc_diag(om, om, false);
+          pc(pa, ol); cc_off(oh, ol); cc_diag(oh, ol, false); cc_off(ol, oh); cc_diag(ol, oh, false);
+          pc(pa, om); cc_off(oh, om); cc_diag(oh, om, false); cc_off(om, oh); cc_diag(om, oh, false);
+          acc3[NT3] = mfma_bf16(pl0, pa, acc3[NT3]);
+          pc(pa, oh); cc_off(oh, oh); cc_diag(oh, oh, false);
+          acc3[0] = mfma_bf16(pa, pa, acc3[0]);
         }
       }
     } else {
@@ -707,7 +682,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
 #pragma unroll
       for (int b = 0; b < NCB; ++b) sc[b] = mul_zero_wins(s, jv_get<NCB>(jv[gq], b));
 #if !(DFX_ABLATE & 4)
-      jv[gq] = ring_load(nrs, rlo, nbase, gq, rreal);
+      jv[gq] = ring_load(nrs, rlo, nbase, gq, has1);
 #endif
 #if DFX_ABLATE & 1
       acc[0][0] += uP;
@@ -1007,7 +982,7 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize_b3(const float* __restric
   constexpr int ZDIM = b3_blocks(NCB) * 256;
   constexpr int NT = NP * (NP + 1) / 2;
   __shared__ double red[4][256];
-  __shared__ double redn[b3_diag4(NCB) ? 4 : 1][256];   // DFX_B3_DIAG4: the N part of a diagonal tile
+  __shared__ double redn[4][256];   // the N part of (P,P) [and of the diagonal tiles (C_b,C_b) with the four-product diagonals]
   __shared__ double T[12][6];   // d(pose0, pose1) <- d(relative pose): J = gC * T^T
 
   const int blk = blockIdx.x, pair = blockIdx.y;
@@ -1016,13 +991,11 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize_b3(const float* __restric
   if (qhead && blk == 0 && threadIdx.x == 0) qhead[pair] = 0u;
   const float* src = partials + (size_t)pair * bpp * ZDIM + blk * 256 + el;
   red[rg][el] = strided_sum_f64<4, 16>(src, rg, bpp, ZDIM);
-  // DFX_B3_DIAG4: diagonal tile d = 0 (P,P) / 1 + b (C_b,C_b) keeps S = hh + mm in its own block and N = hm + hl in block NT3 + d
+  // blocks with an N part in block NT3 + d: d = 0 (P,P): N = P_l x [P_h P_m]; d = 1 + b (C_b,C_b), four-product diagonals: N = hm + hl
   int dtile = -1;
-  if (b3_diag4(NCB)) {
-    if (blk == 0) dtile = 0;
-    else if (blk > NCB) { int q = blk - 1 - NCB; for (int b = 0; b < NCB; ++b) { if (q == 0) { dtile = 1 + b; break; } q -= NCB - b; if (q < 0) break; } }
-    if (dtile >= 0) redn[b3_diag4(NCB) ? rg : 0][el] = strided_sum_f64<4, 16>(partials + (size_t)pair * bpp * ZDIM + (NT3 + dtile) * 256 + el, rg, bpp, ZDIM);
-  }
+  if (blk == 0) dtile = 0;
+  else if (b3_diag4(NCB) && blk > NCB) { int q = blk - 1 - NCB; for (int b = 0; b < NCB; ++b) { if (q == 0) { dtile = 1 + b; break; } q -= NCB - b; if (q < 0) break; } }
+  if (dtile >= 0) redn[rg][el] = strided_sum_f64<4, 16>(partials + (size_t)pair * bpp * ZDIM + (NT3 + dtile) * 256 + el, rg, bpp, ZDIM);
   if (NPOSE == 12 && threadIdx.x < 72) {
     const int n = threadIdx.x / 6, i = threadIdx.x - n * 6;
     const float* M = BYVAL ? one.M : pairs[pair].M;
@@ -1037,13 +1010,30 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize_b3(const float* __restric
   }
   __syncthreads();
   if (rg == 0) red[0][el] = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
-  if (b3_diag4(NCB) && dtile >= 0 && rg == 1) redn[0][el] = ((redn[0][el] + redn[b3_diag4(NCB) ? 1 : 0][el]) + redn[b3_diag4(NCB) ? 2 : 0][el]) + redn[b3_diag4(NCB) ? 3 : 0][el];
+  if (dtile >= 0 && rg == 1) redn[0][el] = ((redn[0][el] + redn[1][el]) + redn[2][el]) + redn[3][el];
   __syncthreads();
-  if (b3_diag4(NCB) && dtile >= 0) {   // Z = S + N + N^T
+  {
+    // undo the packing of the step kernel (same order for every launch: deterministic)
+    const int r = el >> 4, cc = el & 15;
     double v = 0.0;
-    if (rg == 0) v = red[0][el] + redn[0][el] + redn[0][(el & 15) * 16 + (el >> 4)];
+    bool put_back = false;
+    if (rg == 0) {
+      if (blk == 0) {            // (P,P): quadrants [hh hm ; mh mm] of P stacked as [P_h ; P_m], plus lh + lh^T from the N block's top-left quadrant
+        if (r < 8 && cc < 8) {
+          v = ((red[0][r * 16 + cc] + red[0][r * 16 + 8 + cc]) + red[0][(8 + r) * 16 + cc]) + red[0][(8 + r) * 16 + 8 + cc];
+          v += redn[0][r * 16 + cc] + redn[0][cc * 16 + r];
+        }
+        put_back = true;
+      } else if (blk <= NCB) {   // (P,C_b): rows 0..7 = (h + l) pieces, rows 8..15 = m pieces of the same P rows
+        if (r < 8) v = red[0][r * 16 + cc] + red[0][(8 + r) * 16 + cc];
+        put_back = true;
+      } else if (dtile >= 0) {   // (C_b,C_b) with four products: Z = S + N + N^T
+        v = red[0][el] + redn[0][el] + redn[0][cc * 16 + r];
+        put_back = true;
+      }
+    }
     __syncthreads();
-    if (rg == 0) red[0][el] = v;
+    if (put_back) red[0][el] = v;
     __syncthreads();
   }
   const double* S = red[0];   // S[row * 16 + col]
@@ -1123,7 +1113,7 @@ template <int NCB, int MODE>
 static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm, int bpp,
                            float* partials_dev, void* items_dev, size_t item_stride, hipStream_t stream, bool jac_dense, int prec,
                            hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, const SfmPairDev* one_host = nullptr,
-                           const DynDev* dyn = nullptr, int dyn_grid = 0, bool vsh = false) {
+                           const DynDev* dyn = nullptr, int dyn_grid = 0, bool vsh = false, hipStream_t fin_stream = nullptr, hipEvent_t ev_mid = nullptr) {
   constexpr int NACC = NCB * (NCB - 1) / 2 + NCB + 2 * ((NCB + 1) / 2);   // 256-float blocks after block 0 (16x16x4 and 4x4x1 accumulators)
   hipError_t e;
   if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
@@ -1139,6 +1129,15 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   const bool byval = one_host != nullptr && npairs == 1;
   const SfmPairDev one = byval ? *one_host : SfmPairDev{};
   const DynDev nodyn{ nullptr, 0, 0, 0, 0, 0u };
+  // deferred tail: the finalize kernel runs on `fin_stream`, behind an event recorded after the step kernel
+  hipStream_t fstream = stream;
+  auto to_fin_stream = [&]() -> hipError_t {
+    if (!fin_stream || fin_stream == stream || !ev_mid) return hipSuccess;
+    hipError_t e2 = hipEventRecord(ev_mid, stream);
+    if (e2 == hipSuccess) e2 = hipStreamWaitEvent(fin_stream, ev_mid, 0);
+    fstream = fin_stream;
+    return e2;
+  };
   if (dyn && dyn->qhead) {
     // dynamic schedule: a resident grid of wave-workers (see k_sfm_step); partials = [pair][team member]
     if constexpr (MODE == 0) {
@@ -1150,9 +1149,10 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
       e = hipGetLastError();
       if (e != hipSuccess) return e;
       if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
-      if (b3) hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, 12, false>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, stream,
+      if ((e = to_fin_stream()) != hipSuccess) return e;
+      if (b3) hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, 12, false>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
                                  (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id);
-      else hipLaunchKernelGGL((k_sfm_finalize<NCB, 12, false>), dim3(1 + NACC, npairs), dim3(1024), 0, stream,
+      else hipLaunchKernelGGL((k_sfm_finalize<NCB, 12, false>), dim3(1 + NACC, npairs), dim3(1024), 0, fstream,
                               (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id);
       return hipGetLastError();
     }
@@ -1175,17 +1175,18 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
+  if ((e = to_fin_stream()) != hipSuccess) return e;
   constexpr int NPOSE = MODE == 0 ? 12 : 0;
   const SfmPairDev* fpairs = byval ? (const SfmPairDev*)nullptr : pairs_dev;
   if (b3) {
-    if (byval) hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, true>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, stream,
+    if (byval) hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, true>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
                                   (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id);
-    else hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, false>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, stream,
+    else hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, false>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
                             (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id);
   } else {
-    if (byval) hipLaunchKernelGGL((k_sfm_finalize<NCB, NPOSE, true>), dim3(1 + NACC, npairs), dim3(1024), 0, stream,
+    if (byval) hipLaunchKernelGGL((k_sfm_finalize<NCB, NPOSE, true>), dim3(1 + NACC, npairs), dim3(1024), 0, fstream,
                                   (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id);
-    else hipLaunchKernelGGL((k_sfm_finalize<NCB, NPOSE, false>), dim3(1 + NACC, npairs), dim3(1024), 0, stream,
+    else hipLaunchKernelGGL((k_sfm_finalize<NCB, NPOSE, false>), dim3(1 + NACC, npairs), dim3(1024), 0, fstream,
                             (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id);
   }
   return hipGetLastError();
@@ -1194,11 +1195,11 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
 hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm,
                            int blocks_per_pair, float* partials_dev, void* items_dev, size_t item_stride,
                            hipStream_t stream, bool jac_dense, int prec, hipEvent_t eb, hipEvent_t ee, const SfmPairDev* one_host,
-                           const DynDev* dyn, int dyn_grid, bool vsh) {
+                           const DynDev* dyn, int dyn_grid, bool vsh, hipStream_t fin_stream, hipEvent_t ev_mid) {
   switch (cs) {
-    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh);
-    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh);
-    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh);
+    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid);
+    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid);
+    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid);
     default: return hipErrorInvalidValue;
   }
 }

@@ -204,30 +204,40 @@ class PipelinedReduce:
     A single Gauss-Newton loop cannot use this (its solve needs the reduced system before the next linearisation); a mapper with
     several windows in flight, or a throughput measurement over independent batches, can."""
 
-    def __init__(self, dist, systems, root=0):
-        self.dist, self.systems, self.root = dist, list(systems), int(root)
+    def __init__(self, dist, systems, root=0, stream=None):
+        """`stream`: the torch.cuda.Stream the systems are WRITTEN on (the context's tail stream in deferred-tail mode, see
+        Context.set_tail_stream); None = the current stream.  The collective is issued, and later waited for, with that stream current:
+        RCCL starts behind the assembly enqueued there, and the next writer of the buffer (on the same stream) is ordered behind the sum."""
+        self.dist, self.systems, self.root, self.stream = dist, list(systems), int(root), stream
         assert len(self.systems) >= 1
         self.pending = [None] * len(self.systems)
         self.count = 0
         self.cur = None
 
+    def _on_stream(self):
+        import contextlib
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
     def next(self):
         b = self.count % len(self.systems)
         self.count += 1
         if self.pending[b] is not None:
-            self.pending[b].wait()
+            with self._on_stream():
+                self.pending[b].wait()
             self.pending[b] = None
         self.cur = b
         return self.systems[b]
 
     def submit(self):
         assert self.cur is not None and self.pending[self.cur] is None
-        self.pending[self.cur] = self.systems[self.cur].reduce_async(self.dist, self.root)
+        with self._on_stream():
+            self.pending[self.cur] = self.systems[self.cur].reduce_async(self.dist, self.root)
 
     def drain(self):
         for b, w in enumerate(self.pending):
             if w is not None:
-                w.wait()
+                with self._on_stream():
+                    w.wait()
                 self.pending[b] = None
 
     def last(self):

@@ -111,11 +111,27 @@ static inline uint64_t dfx_item_inliers(const void* item, int np) {
 DFX_API int dfx_ctx_create(int device, void* stream, dfx_ctx** out);
 /* Re-binds the context to another stream of its device (waits for the work already enqueued on the old one). */
 DFX_API int dfx_ctx_set_stream(dfx_ctx* ctx, void* stream);
+/* Deferred tail (no reference counterpart; the reference finishes every RunStep with a second kernel + sync on one stream,
+ * cu_sfmaligner.cpp:60-69,175-183).  A batched SfM step is a ~1 ms streaming kernel followed by a reduction tail of two short dependent
+ * kernels (finalize, graph assembly: ~30 us of launch boundaries and latency-bound work at 128 pairs).  With a tail stream set, the
+ * *_async entries enqueue the step kernel on the context's stream and the tail on `tail_stream` (another stream of the same device,
+ * owned by the caller), so the tail of launch k runs beside the step kernel of launch k + 1; the library alternates two halves of its
+ * scratch and orders them with events.  Consequences for the caller:
+ *   - items / assembled systems of *_async calls (dfx_sfm_step_batch_async, dfx_sfm_linearize_batch_async, dfx_graph_assemble_async) are
+ *     complete on the TAIL stream: consume them there, or call dfx_tail_join first (the context's stream then waits for every tail
+ *     enqueued so far -- a stream-side wait, the host does not block);
+ *   - output buffers handed to consecutive launches are written from the tail stream in launch order, so ONE items buffer / system can be
+ *     reused by consecutive launches, but a consumer on another stream must have been ordered before the next launch overwrites them;
+ *   - blocking entry points are unaffected (their tail runs on the context's stream); dfx_sync waits for both streams.
+ * NULL switches the mode off.  Useful for a stream of independent batches (several windows in flight, throughput runs); a single
+ * Gauss-Newton loop needs each result before the next launch and gains nothing. */
+DFX_API int dfx_set_tail_stream(dfx_ctx* ctx, void* tail_stream);
+DFX_API int dfx_tail_join(dfx_ctx* ctx);
 DFX_API int dfx_ctx_device(dfx_ctx* ctx);
 DFX_API void dfx_ctx_destroy(dfx_ctx* ctx);
 DFX_API const char* dfx_last_error(void);
 DFX_API const char* dfx_version(void);
-/* Waits for everything enqueued on the context's stream. */
+/* Waits for everything enqueued on the context's stream (and on its tail stream, if one is set). */
 DFX_API int dfx_sync(dfx_ctx* ctx);
 /* Context-wide default of dfx_sfm_params.step_blocks (workgroups per pair of the step kernel); 0 = automatic (sized from the
  * CU count and the batch).  A non-zero dfx_sfm_params.step_blocks overrides it per call. */
@@ -134,11 +150,13 @@ DFX_API int dfx_device_cu_count(dfx_ctx* ctx);
  *                      and had been removed; this one costs 11 vector-ALU instructions per pair of values. */
 #define DFX_MFMA_F32_CHAIN 0
 #define DFX_MFMA_BF16X3 1
-/*  DFX_MFMA_AUTO       (default) the library's choice per code size: the exact bf16 split from DFX_AUTO_BF16X3_MIN_CS on (the fp32 chain is
- *                      matrix-bound there), the fp32 chain below.  Both are fp32-accurate against the fp64 oracle and bit-reproducible for
- *                      a launch shape; a caller that needs the SAME bits for every code size pins one mode. */
+/*  DFX_MFMA_AUTO       (default) the library's choice per code size, by measurement on MI355X: the exact bf16 split
+ *                      from DFX_AUTO_BF16X3_MIN_CS on -- since round 3 every code size: 640x480, CS = 32, 128 pairs 1064 -> 1004 us or better,
+ *                      1280x960, CS = 64, 16 pairs 1183 -> 1000 us.  Both modes are fp32-accurate against the fp64 oracle (stated tolerance
+ *                      1e-4, measured < 5e-6 of the block scale) and bit-reproducible for a launch shape; they differ from each other in
+ *                      the last bits.  A caller that wants the fmaf-chain bits pins DFX_MFMA_F32_CHAIN. */
 #define DFX_MFMA_AUTO 2
-#define DFX_AUTO_BF16X3_MIN_CS 64
+#define DFX_AUTO_BF16X3_MIN_CS 16
 DFX_API int dfx_set_mfma_mode(dfx_ctx* ctx, int mode);
 /* *mode = the evaluation mode (DFX_MFMA_F32_CHAIN / DFX_MFMA_BF16X3) the context's last SfM / DepthAligner step resolved to. */
 DFX_API int dfx_last_mfma_mode(dfx_ctx* ctx, int* mode);
@@ -166,6 +184,8 @@ DFX_API int dfx_last_schedule(dfx_ctx* ctx, int* dynamic);
  * duration in milliseconds since the last read, and resets the counters. */
 DFX_API int dfx_set_profiling(dfx_ctx* ctx, int enable);
 DFX_API int dfx_profile_read(dfx_ctx* ctx, int* n_launches, double* total_ms);
+/* Same, plus the shortest and the longest bracketed launch (either may be NULL). */
+DFX_API int dfx_profile_read_ex(dfx_ctx* ctx, int* n_launches, double* total_ms, double* min_ms, double* max_ms);
 /* Debug: copies the first `bytes` of the workgroup-partials scratch of the last launch to the host. */
 DFX_API int dfx_debug_read_partials(dfx_ctx* ctx, void* host, size_t bytes);
 
@@ -239,6 +259,17 @@ DFX_API int dfx_sfm_error(dfx_ctx* ctx, const dfx_se3* pose0, const dfx_se3* pos
                           const dfx_sfm_params* params, const dfx_img* img0, const dfx_img* img1, const dfx_img* dpt0,
                           const dfx_img* std0, const dfx_img* grad1, dfx_corr_item* out);
 
+/* n independent SE3Aligner::RunStep of one image size in ONE launch (new): item p (120 bytes, JTJJrReductionItem<float,6>) is written to
+ * (char*)out_items + p * dfx_item_size(6).  Same per-pair arithmetic and reduction order as dfx_se3_step launched with the same number of
+ * workgroups; the reference steps one frame against one keyframe per blocking call (cu_se3aligner.cpp:153-176). */
+typedef struct dfx_se3_pair {
+  dfx_se3 pose_10;
+  dfx_cam cam;
+  dfx_img img0, img1, dpt0, grad1;
+} dfx_se3_pair;
+DFX_API int dfx_se3_step_batch_async(dfx_ctx* ctx, const dfx_se3_pair* pairs, int n, float huber_delta, void* out_items_dev);
+DFX_API int dfx_se3_step_batch(dfx_ctx* ctx, const dfx_se3_pair* pairs, int n, float huber_delta, void* out_items_host);
+
 /* One keyframe->frame pair of a batch: the argument list of SfmAligner::RunStep as a POD. */
 typedef struct dfx_sfm_pair {
   dfx_se3 pose0, pose1;
@@ -255,6 +286,13 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* ctx, int cs, const dfx_sfm_params*
 /* Same, then copies the n items to `out_items_host` and waits. */
 DFX_API int dfx_sfm_step_batch(dfx_ctx* ctx, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
                                void* out_items_host);
+
+/* Batched EvaluateError (new): PhotometricFactor::error -> RunWarping is one blocking SfmAligner::EvaluateError per factor in the reference
+ * (core/gtsam/photometric_factor.cpp:61-81,197-216; cu_sfmaligner.cpp:120-147).  Here n pairs of one image size in ONE launch; only
+ * pose0, pose1, cam, img0, img1, dpt0 of a dfx_sfm_pair are read (valid0 / prx0_jac / grad1 may be zeroed).  border 1, min_dpt 0 as in
+ * dfx_sfm_error.  out_items[p] = CorrespondenceReductionItem of pair p (device memory for _async, host memory for the blocking form). */
+DFX_API int dfx_sfm_error_batch_async(dfx_ctx* ctx, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n, dfx_corr_item* out_items_dev);
+DFX_API int dfx_sfm_error_batch(dfx_ctx* ctx, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n, dfx_corr_item* out_items_host);
 
 /* PhotometricFactor::RunAlignmentStep (core/gtsam/photometric_factor.cpp:225-293) over a batch: UpdateDepthMaps (:332-341: dpt0 =
  * decode(code0) with the keyframe's prx_orig / prx_jac) followed by SfmAligner::RunStep, for n pairs in two launches and no host
@@ -281,7 +319,7 @@ DFX_API int dfx_sfm_linearize_batch(dfx_ctx* ctx, int cs, const dfx_sfm_params* 
  * dfx_graph_assemble_async overwrites the WHOLE buffer with the contribution of the pairs [first_pair, first_pair + n_local)
  * whose items (JTJJrReductionItem<float,12+cs>, device memory, item l at l * dfx_item_size(12+cs)) this rank holds: every
  * node's incident pairs are summed in ascending pair order in double and written once (no atomics: bit-reproducible; with
- * all items on one rank -- gather mode -- independent of the world size).  Enqueue only. */
+ * all items on one rank -- gather mode -- independent of the world size).  Enqueue only (on the tail stream when one is set). */
 typedef struct dfx_graph dfx_graph;
 DFX_API int dfx_graph_create(dfx_ctx* ctx, int cs, int n_nodes, int n_pairs, const int32_t* pair_nodes, dfx_graph** out);
 DFX_API void dfx_graph_destroy(dfx_graph* graph);

@@ -189,8 +189,8 @@ class PhotometricFactor {
  public:
   typedef df::SfmAligner<float, CS> AlignerT;
   typedef typename AlignerT::ReductionItem ReductionItem;
-  PhotometricFactor(const dfx_cam& cam, std::shared_ptr<Keyframe<CS>> kf, std::shared_ptr<Frame> fr, int pyrlevel, float avg_dpt = 2.0f)
-      : cam_(cam), kf_(std::move(kf)), fr_(std::move(fr)), pyrlevel_(pyrlevel), avg_dpt_(avg_dpt) {}
+  PhotometricFactor(const dfx_cam& cam, std::shared_ptr<Keyframe<CS>> kf, std::shared_ptr<Frame> fr, int pyrlevel)
+      : cam_(cam), kf_(std::move(kf)), fr_(std::move(fr)), pyrlevel_(pyrlevel) {}
 
   // GetJacobiansIfNeeded's test (:298-306): relinearise when a value moved by >= 1e-6 in its tangent space
   bool NeedsLinearization(const dfx_se3& pose0, const dfx_se3& pose1, const std::array<float, CS>& code0) const {
@@ -229,11 +229,13 @@ class PhotometricFactor {
     H.f = lin_system_.residual;
     return H;
   }
-  // error (:60-81): UpdateDepthMaps, EvaluateError, 0.5 * rescaled residual
+  // error (:60-81): UpdateDepthMaps, EvaluateError, 0.5 * rescaled residual.  The decoder scale is the aligner's avg_dpt -- the one
+  // dfx_sfm_linearize_batch decodes with, so error() and linearize() see the same depth map for the same code (the reference hard-codes
+  // 2.0 in both paths, :332-341)
   double error(AlignerT& aligner, const dfx_se3& pose0, const dfx_se3& pose1, const std::array<float, CS>& code0) {
-    check(dfx_update_depth_batch_async(aligner.ContextHandle(), CS, 1, code0.data(), &kf_->pyr_prx_orig[pyrlevel_].c_img(), &kf_->pyr_jac[pyrlevel_].c_img(),
-                                       avg_dpt_, &kf_->pyr_dpt[pyrlevel_].c_img()));
     const dfx_sfm_params prm = aligner.Params();
+    check(dfx_update_depth_batch_async(aligner.ContextHandle(), CS, 1, code0.data(), &kf_->pyr_prx_orig[pyrlevel_].c_img(), &kf_->pyr_jac[pyrlevel_].c_img(),
+                                       prm.avg_dpt, &kf_->pyr_dpt[pyrlevel_].c_img()));
     dfx_corr_item out;
     check(dfx_sfm_error(aligner.ContextHandle(), &pose0, &pose1, &cam_, &prm, &kf_->pyr_img[pyrlevel_].c_img(), &fr_->pyr_img[pyrlevel_].c_img(),
                         &kf_->pyr_dpt[pyrlevel_].c_img(), nullptr, nullptr, &out));
@@ -257,7 +259,6 @@ class PhotometricFactor {
   std::shared_ptr<Keyframe<CS>> kf_;
   std::shared_ptr<Frame> fr_;
   int pyrlevel_;
-  float avg_dpt_;
   bool first_ = true;
   dfx_se3 lin_pose0_{}, lin_pose1_{};
   std::array<float, CS> lin_code0_{};
@@ -298,6 +299,51 @@ int LinearizeAll(df::SfmAligner<float, CS>& aligner, const std::vector<Photometr
     }
   }
   return done;
+}
+
+// PhotometricFactor::error over a factor set (what a Gauss-Newton / iSAM2 step evaluates to accept or reject an update; the reference
+// calls error() factor by factor, each a blocking UpdateDepth + EvaluateError: photometric_factor.cpp:61-81,197-216).  Per pyramid level:
+// ONE batched decode of the distinct keyframes and ONE batched EvaluateError (dfx_sfm_error_batch).  Returns sum_k error_k and, if asked,
+// the per-factor values (0.5 * residual / inliers * w * h, +inf without overlap).
+template <int CS>
+double ErrorAll(df::SfmAligner<float, CS>& aligner, const std::vector<PhotometricFactor<CS>*>& factors, const std::vector<FactorValues<CS>>& values,
+                std::vector<double>* per_factor = nullptr) {
+  if (factors.size() != values.size()) throw Error(DFX_E_INVALID, "ErrorAll: one value triple per factor");
+  std::map<int, std::vector<std::size_t>> by_level;
+  for (std::size_t k = 0; k < factors.size(); ++k) by_level[factors[k]->pyrlevel()].push_back(k);
+  const dfx_sfm_params prm = aligner.Params();
+  std::vector<double> err(factors.size(), 0.0);
+  for (auto& lv : by_level) {
+    const std::vector<std::size_t>& idx = lv.second;
+    std::vector<dfx_sfm_pair> pairs;
+    std::vector<dfx_img> prx, jac, dpt;
+    std::vector<float> codes;
+    std::map<const void*, std::size_t> seen;   // depth map -> first factor that decodes it
+    for (std::size_t k : idx) {
+      pairs.push_back(factors[k]->MakePair(values[k].pose0, values[k].pose1));
+      const auto& kf = factors[k]->keyframe();
+      const void* key = kf->pyr_dpt[lv.first].c_img().ptr;
+      auto hit = seen.find(key);
+      if (hit == seen.end()) {
+        seen.emplace(key, k);
+        prx.push_back(kf->pyr_prx_orig[lv.first].c_img()); jac.push_back(kf->pyr_jac[lv.first].c_img()); dpt.push_back(kf->pyr_dpt[lv.first].c_img());
+        codes.insert(codes.end(), values[k].code0.begin(), values[k].code0.end());
+      } else if (values[hit->second].code0 != values[k].code0) {
+        throw Error(DFX_E_INVALID, "ErrorAll: two factors of one keyframe carry different codes");
+      }
+    }
+    check(dfx_update_depth_batch_async(aligner.ContextHandle(), CS, (int)prx.size(), codes.data(), prx.data(), jac.data(), prm.avg_dpt, dpt.data()));
+    std::vector<dfx_corr_item> items(idx.size());
+    check(dfx_sfm_error_batch(aligner.ContextHandle(), &prm, pairs.data(), (int)idx.size(), items.data()));
+    for (std::size_t q = 0; q < idx.size(); ++q) {
+      const dfx_sfm_pair& p = pairs[q];
+      err[idx[q]] = items[q].inliers > 0 ? 0.5 * (double)(items[q].residual / items[q].inliers * p.cam.w * p.cam.h) : std::numeric_limits<double>::infinity();
+    }
+  }
+  double total = 0.0;
+  for (double e : err) total += e;
+  if (per_factor) *per_factor = err;
+  return total;
 }
 
 }  // namespace dfx

@@ -130,6 +130,18 @@ int main() {
       REQUIRE(std::fabs(Hb.f - want) <= 2e-5 * want);
       const double e = factors[3]->error(aligner, moved[3].pose0, moved[3].pose1, moved[3].code0);
       REQUIRE(e > 0 && std::isfinite(e));
+      // error() over the whole factor set in one decode + one EvaluateError launch per level == factor by factor (same per-pair arithmetic;
+      // the number of workgroups per pair, hence the fp32 summation order, may differ between the batched and the single launch)
+      std::vector<double> per;
+      const double total = dfx::ErrorAll<CS>(aligner, factors, moved, &per);
+      REQUIRE((int)per.size() == n && std::fabs(per[3] - e) <= 1e-5 * e && std::isfinite(total));
+      double sum = 0;
+      for (int k = 0; k < n; ++k) {
+        const double ek = factors[k]->error(aligner, moved[k].pose0, moved[k].pose1, moved[k].code0);
+        REQUIRE(std::fabs(per[k] - ek) <= 1e-5 * ek);
+        sum += per[k];
+      }
+      REQUIRE(sum == total);
     }
     std::printf("host_test OK (%d factors, %d relinearised after moving one node)\n", n, expect);
   } catch (const std::exception& e) {

@@ -35,6 +35,17 @@ class FakeCtx:
         self.pending = []
         return n, ms
 
+    def profile_read_ex(self):
+        lo, hi = (min(self.pending), max(self.pending)) if self.pending else (0.0, 0.0)
+        n, ms = self.profile_read()
+        return n, ms, lo, hi
+
+    def set_tail_stream(self, stream):
+        self.tail = stream
+
+    def tail_join(self):
+        self.joins = getattr(self, "joins", 0) + 1
+
     def set_schedule(self, mode):
         from deepfactors_amd import _lib
         self.dynamic = mode == _lib.DFX_SCHEDULE_DYNAMIC
@@ -53,7 +64,8 @@ class FakeCtx:
         return torch.zeros((h, w), dtype=torch.float32)
 
     def last_mfma_mode(self):
-        return self.mfma
+        from deepfactors_amd import _lib
+        return _lib.DFX_MFMA_BF16X3 if self.mfma == _lib.DFX_MFMA_AUTO else self.mfma
 
 
 class FakeAligner:
@@ -96,6 +108,9 @@ class FakeAligner:
             self._bytes = torch.from_numpy(raw.reshape(-1))
         return self._bytes
 
+    def EvaluateErrorBatch(self, arr, items=None):
+        self.ctx.launch()
+
     def RunStepBatchAsync(self, arr, items):
         it = self._items(arr)
         if it is not None:
@@ -111,6 +126,33 @@ class FakeAligner:
     def items_from_bytes(raw, cs):
         from deepfactors_amd.aligners import SfmAligner
         return SfmAligner.items_from_bytes(raw, cs)
+
+
+class FakeSE3:
+    def __init__(self, ctx=None):
+        self.ctx = ctx
+
+    def make_pairs(self, pairs):
+        return list(pairs)
+
+    def RunStepBatch(self, arr, items=None):
+        self.ctx.launch()
+
+
+class FakeEvent:
+    def __init__(self, enable_timing=False):
+        pass
+
+    def record(self):
+        pass
+
+    def elapsed_time(self, other):
+        return 1.0
+
+
+class FakeStream:
+    def __init__(self, device=None):
+        pass
 
 
 def _run_main(argv, out_path):
@@ -132,6 +174,8 @@ def _run_main(argv, out_path):
     patches = [(torch.cuda, "is_available", lambda: True), (torch.cuda, "set_device", lambda d: None), (torch.cuda, "synchronize", lambda *a: None),
                (torch, "device", lambda *a, **k: real_device("cpu")), (deepfactors_amd, "Context", FakeCtx), (deepfactors_amd, "SfmAligner", FakeAligner),
                (tdist, "init_process_group", lambda backend, rank, world_size, device_id=None: real_init("gloo", rank=rank, world_size=world_size)),
+               (torch.cuda, "Stream", FakeStream), (torch.cuda, "stream", lambda s: contextlib.nullcontext()), (torch.cuda, "empty_cache", lambda: None),
+               (torch.cuda, "Event", FakeEvent), (deepfactors_amd, "SE3Aligner", FakeSE3), (deepfactors_amd, "UpdateDepthBatch", lambda *a, **k: None),
                (synth, "make_pair", small_make_pair)]
     saved = [(o, n, getattr(o, n)) for o, n, _ in patches]
     old_argv = sys.argv
@@ -151,7 +195,7 @@ def _run_main(argv, out_path):
         fh.write(buf.getvalue())
 
 
-def _check_line(txt, world, probe="dynamic"):
+def _check_line(txt, world):
     lines = [l for l in txt.splitlines() if l.strip()]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
@@ -163,7 +207,9 @@ def _check_line(txt, world, probe="dynamic"):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["launches"] == 3 and r["traffic"] is None and "traffic_source" in r and "mfma" in r and "schedule" in r
-    assert (d["schedule_probe"]["chosen"] == probe if probe else d["schedule_probe"] is None) and len(d["ramp_kernel_us"]) >= 6
+    assert "schedule_probe" not in d and len(d["ramp_kernel_us"]) >= 6
+    assert 0 < r["kernel_us_min"] <= r["kernel_us"] <= r["kernel_us_max"] and "library default" in r["mfma"] + r["schedule"]
+    assert "second stream" in d["config"]["workload"]
     return d
 
 
@@ -200,10 +246,13 @@ def test_main_with_the_secondary_configurations(tmp_path, monkeypatch):
     _run_main([a for a in ARGS if a != "--no-configs"], str(out))
     d = _check_line(out.read_text(), 1)
     c = d["configs"]
-    assert set(c) >= {"headline_workload_bf16x3", "configs1_single_pair_blocking", "configs1_pyramid3_128pairs", "configs4_1280x960_cs64", "configs2_linearize_16kf_120pairs"}
-    assert c["headline_workload_bf16x3"]["kernel_us"] > 0 and "error" not in c["headline_workload_bf16x3"]
-    assert c["configs4_1280x960_cs64"]["bf16x3"]["kernel_us"] > 0 and "error" not in c["configs4_1280x960_cs64"]["bf16x3"]
+    assert set(c) >= {"headline_workload_other_mode", "configs1_single_pair_blocking", "configs1_pyramid3_128pairs", "configs4_1280x960_cs64", "configs2_linearize_16kf_120pairs",
+                      "update_depth_batch_64kf", "se3_step_batch_128pairs", "sfm_error_batch_128pairs", "configs3_window64"}
+    assert c["headline_workload_other_mode"]["kernel_us"] > 0 and "error" not in c["headline_workload_other_mode"] and "fp32 fmaf chain" in c["headline_workload_other_mode"]["mfma"]
+    assert c["configs4_1280x960_cs64"]["f32_chain"]["kernel_us"] > 0 and "error" not in c["configs4_1280x960_cs64"]["f32_chain"]
     assert c["configs4_1280x960_cs64"]["frac"] > 0 and len(c["configs1_pyramid3_128pairs"]["level_kernel_us"]) == 3
+    for k in ("update_depth_batch_64kf", "se3_step_batch_128pairs", "sfm_error_batch_128pairs"):
+        assert c[k]["us"] > 0 and c[k]["frac"] > 0
 
 
 def test_main_forced_modes(tmp_path, monkeypatch):
@@ -212,6 +261,6 @@ def test_main_forced_modes(tmp_path, monkeypatch):
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     out = tmp_path / "forced.txt"
     _run_main(ARGS + ["--schedule", "static", "--mfma", "bf16x3", "--window"], str(out))
-    d = _check_line(out.read_text(), 1, probe=None)
-    assert "bf16" in d["roofline"]["mfma"] and "static" in d["roofline"]["schedule"]
+    d = json.loads(out.read_text().strip())
+    assert "bf16" in d["roofline"]["mfma"] and "forced by --mfma" in d["roofline"]["mfma"] and "static" in d["roofline"]["schedule"] and "forced" in d["roofline"]["schedule"]
     assert d["configs"]["configs3_window64"]["pairs_per_rank"] == 1024

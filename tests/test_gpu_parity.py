@@ -347,3 +347,41 @@ def test_tiny_and_narrow_images(dfx, oracle, w, h):
     dfx.UpdateDepth(n["code"], g2["prx_orig"], g2["prx_jac"], 2.0, out)
     d_ref = oracle.update_depth(n["code"], n2["prx_orig"], n2["prx_jac"], 2.0)
     assert np.abs(out.cpu().numpy() - d_ref).max() <= 2e-6 * float(((2.0 + d_ref) ** 2 / 2.0).max())
+
+
+def test_batched_error_and_se3_step_match_the_single_pair_operators_and_the_oracle(dfx, oracle):
+    """dfx_sfm_error_batch / dfx_se3_step_batch: n pairs in one launch -- against the oracle (border-1 quirk of EvaluateError kept,
+    dense_sfm.h:91) and against the blocking single-pair operators."""
+    from deepfactors_amd import synth
+    w, h, cs, n = 192, 144, 32, 7
+    ctx = dfx.Context(0)
+    al, se3 = dfx.SfmAligner(code_size=cs, ctx=ctx), dfx.SE3Aligner(ctx=ctx)
+    plist, slist, keep = [], [], []
+    for k in range(n):
+        p = synth.make_pair(w, h, cs, seed=900 + k, device="cpu", motion_scale=0.4 + 0.2 * k)
+        nn, g = synth.to_numpy(p), synth.to_device(p, "cuda")
+        keep.append((nn, g))
+        plist.append(dict(pose0=nn["pose0"], pose1=nn["pose1"], cam=nn["cam"], img0=g["img0"], img1=g["img1"], dpt0=g["dpt0"],
+                          prx0_jac=g["prx_jac"], grad1=g["grad1"]))
+        slist.append(dict(se3=nn["pose10_true"] if k % 2 else synth.IDENTITY, cam=nn["cam"], img0=g["img0"], img1=g["img1"], dpt0=g["dpt0"], grad1=g["grad1"]))
+    errs = al.EvaluateErrorBatch(al.make_pairs(plist))
+    steps = se3.RunStepBatch(se3.make_pairs(slist))
+    for k, (nn, g) in enumerate(keep):
+        ref = oracle.sfm_error(nn["pose0"], nn["pose1"], nn["cam"], nn["img0"], nn["img1"], nn["dpt0"], 0.1)
+        assert errs[k].inliers == ref.inliers
+        assert abs(errs[k].residual - ref.residual) <= 1e-4 * abs(ref.residual) + 1e-6
+        one = al.EvaluateError(nn["pose0"], nn["pose1"], nn["cam"], g["img0"], g["img1"], g["dpt0"], None, g["grad1"])
+        assert one.inliers == errs[k].inliers and abs(one.residual - errs[k].residual) <= 2e-6 * abs(one.residual)
+        sref = oracle.se3_step(slist[k]["se3"], nn["cam"], nn["img0"], nn["img1"], nn["dpt0"], nn["grad1"], 0.1)
+        assert_item_close(steps[k], sref, w, h, what=f"se3 batch pair {k}")
+    # device-side outputs of the async forms equal the blocking forms bit for bit
+    ed = torch.zeros(16 * n, dtype=torch.uint8, device="cuda")
+    sd = torch.zeros(dfx.item_size(6) * n, dtype=torch.uint8, device="cuda")
+    al.EvaluateErrorBatch(al.make_pairs(plist), ed)
+    se3.RunStepBatch(se3.make_pairs(slist), sd)
+    ctx.sync()
+    e = ed.cpu().numpy()
+    for k in range(n):
+        assert np.frombuffer(e[16 * k:16 * k + 4].tobytes(), np.float32)[0] == np.float32(errs[k].residual)
+        assert int(np.frombuffer(e[16 * k + 8:16 * k + 16].tobytes(), np.uint64)[0]) == errs[k].inliers
+    assert np.array_equal(sd.cpu().numpy(), np.concatenate([s.raw for s in steps]))

@@ -207,25 +207,45 @@ def test_three_way_bf16_split_is_exact():
         assert not (p.view(np.uint32) & 0xFFFF).any()
 
 
+DIAG4_MAX_NCB = 2   # DFX_B3_DIAG4_MAX_NCB of dfx_sfm_step.hip
+
+
 def _model_item_b3(gC, wr, inl, s, jac, M, HM, cs):
-    """The bf16x3 step + k_sfm_finalize_b3 in numpy: z blocks 0 = P (8 rows + 8 zero rows), 1 + b = C_b; tile t: 0 (P,P), 1 + b (P,C_b),
-    then (C_b,C_b') for b <= b' row-major; every tile = hh + hm + mh + hl + lh + mm of the split operands (fp32 accumulate on the
-    hardware, float64 here)."""
+    """The bf16x3 step + k_sfm_finalize_b3 in numpy.  z blocks: P (8 rows), C_b (16 rows each).  What the step kernel accumulates
+    (fp32 on the hardware, float64 here), with the P block STACKED as Pa = [P_h ; P_m], Pl0 = [P_l ; 0]:
+      block 0       Pa Pa^T                          = [hh hm ; mh mm] quadrants
+      block 1 + b   Pa (C_h + C_m + C_l)^T + Pl0 C_h^T : rows 0..7 = hh + hm + hl + lh, rows 8..15 = mh + mm + ml
+      (C_b,C_b')    b < b': the six products; b = b': S = hh + mm with N = hm + hl in its own block (four-product diagonals, ncb <= 2),
+                    else the six products
+      N block of (P,P): Pl0 Pa^T: top-left quadrant = lh
+    and what the finalize kernel makes of it: quadrant / row-half sums, lh + lh^T, Z = S + N + N^T."""
     ncb = cs // 16
     NP = 12 + cs
     N = len(wr)
-    P16 = np.concatenate([gC, wr[:, None], inl[:, None], np.zeros((N, 8))], axis=1).astype(np.float32)
-    blocks = [P16] + [(s[:, None].astype(np.float32) * jac[:, b::ncb].astype(np.float32)).astype(np.float32) for b in range(ncb)]
-    pieces = [_split3(b) for b in blocks]
-
-    def tile(ka, kb):
-        (ha, ma, la), (hb, mb, lb) = pieces[ka], pieces[kb]
-        acc = np.zeros((16, 16))
-        for A, B in ((ma, mb), (ha, lb), (la, hb), (ha, mb), (ma, hb), (ha, hb)):
-            acc += np.einsum("pi,pj->ij", A.astype(np.float64), B.astype(np.float64))
-        return acc
-
-    tiles = [tile(0, 0)] + [tile(0, 1 + b) for b in range(ncb)] + [tile(1 + b, 1 + b2) for b in range(ncb) for b2 in range(b, ncb)]
+    P8 = np.concatenate([gC, wr[:, None], inl[:, None]], axis=1).astype(np.float32)
+    cblocks = [(s[:, None].astype(np.float32) * jac[:, b::ncb].astype(np.float32)).astype(np.float32) for b in range(ncb)]
+    ein = lambda A, B: np.einsum("pi,pj->ij", A.astype(np.float64), B.astype(np.float64))
+    ph, pm, pl = _split3(P8)
+    Pa, Pl0 = np.concatenate([ph, pm], axis=1), np.concatenate([pl, np.zeros_like(pl)], axis=1)
+    cp = [_split3(b) for b in cblocks]
+    raw0, rawN = ein(Pa, Pa), ein(Pl0, Pa)
+    t0 = np.zeros((16, 16))
+    t0[:8, :8] = raw0[:8, :8] + raw0[:8, 8:] + raw0[8:, :8] + raw0[8:, 8:] + rawN[:8, :8] + rawN[:8, :8].T
+    tiles = [t0]
+    for b in range(ncb):
+        h, m, l = cp[b]
+        raw = ein(Pl0, h) + ein(Pa, l) + ein(Pa, m) + ein(Pa, h)
+        t = np.zeros((16, 16))
+        t[:8] = raw[:8] + raw[8:]
+        tiles.append(t)
+    for b in range(ncb):
+        for b2 in range(b, ncb):
+            (ha, ma, la), (hb, mb, lb) = cp[b], cp[b2]
+            if b == b2 and ncb <= DIAG4_MAX_NCB:
+                S, Nn = ein(ma, mb) + ein(ha, hb), ein(ha, lb) + ein(ha, mb)
+                tiles.append(S + Nn + Nn.T)
+            else:
+                tiles.append(ein(ma, mb) + ein(ha, lb) + ein(la, hb) + ein(ha, mb) + ein(ma, hb) + ein(ha, hb))
     assert len(tiles) == 1 + ncb + ncb * (ncb + 1) // 2
 
     T = np.zeros((12, 6))
@@ -310,33 +330,9 @@ def test_bf16x3_tiles_cover_the_item_exactly_once_at_fp32_accuracy(cs):
     assert abs(residual - float(wr @ wr)) < 3e-8 * float(wr @ wr) and abs(inliers - inl.sum()) < 1e-6
 
 
-def test_bf16x3_psplit_lds_layout_hands_every_lane_its_eight_pixels():
-    """DFX_B3_PSPLIT (build flag, dfx_sfm_step.hip): phase A lane p (= pixel p of the chunk) writes the 16-bit pieces of its P rows at element
-    ((piece * 8 + row) * 64 + psl(p)); phase B lane (row, k) reads 16 bytes at byte ((row & 7) * 128 + k * 16 + piece * 1024 + h * 64) and must find
-    slots j = 0..7 = pixels 4 (8 h + j) + k of that row and piece, in order."""
-    lds = np.full(3 * 8 * 64, -1, np.int64)                      # 16-bit elements of the wave's region; value = encoded (piece, row, pixel)
-    for p in range(64):
-        psl = 32 * (p >> 5) + 8 * (p & 3) + ((p >> 2) & 7)
-        for X in range(3):
-            for q in range(8):
-                e = (X * 8 + q) * 64 + psl
-                assert lds[e] == -1
-                lds[e] = (X * 8 + q) * 64 + p
-    assert (lds >= 0).all()
-    for lane in range(64):
-        li, lk = lane & 15, lane >> 4
-        for X in range(3):
-            for h in range(2):
-                byte = (li & 7) * 128 + lk * 16 + X * 1024 + h * 64
-                assert byte % 16 == 0
-                got = lds[byte // 2: byte // 2 + 8]
-                want = [(X * 8 + (li & 7)) * 64 + 4 * (8 * h + j) + lk for j in range(8)]
-                assert list(got) == want
-
-
 @pytest.mark.parametrize("cs", [16, 32])
 def test_bf16x3_diag4_equals_the_six_product_tiles(cs):
-    """DFX_B3_DIAG4 (build flag): diagonal tiles keep S = hh + mm and N = hm + hl; Z = S + N + N^T equals the six-product tile."""
+    """Four-product diagonal tiles (DFX_B3_DIAG4_MAX_NCB): they keep S = hh + mm and N = hm + hl; Z = S + N + N^T equals the six-product tile."""
     rng = np.random.default_rng(cs)
     z = rng.normal(size=(64, 16)).astype(np.float32)
     h, m, l = (a.astype(np.float64) for a in _split3(z))
