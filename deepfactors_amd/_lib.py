@@ -132,6 +132,15 @@ _PROTOS = {
     "dfx_graph_destroy": (None, [C.c_void_p]),
     "dfx_graph_system_floats": (C.c_size_t, [C.c_void_p]),
     "dfx_graph_assemble_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "dfx_comm_get_unique_id": (C.c_int, [C.c_void_p]),
+    "dfx_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "dfx_comm_destroy": (None, [C.c_void_p]),
+    "dfx_comm_rank": (C.c_int, [C.c_void_p]),
+    "dfx_comm_world": (C.c_int, [C.c_void_p]),
+    "dfx_shard_range": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dfx_graph_reduce_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "dfx_comm_reduce_f32_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "dfx_items_all_gather_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dfx_update_depth": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(Img), C.POINTER(Img), C.c_float,
                                    C.POINTER(Img)]),
     "dfx_update_depth_batch_async": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(Img), C.POINTER(Img), C.c_float, C.POINTER(Img)]),

@@ -470,6 +470,12 @@ int valid0_shadow(dfx_ctx* c, const dfx_img* v, uint32_t W, uint32_t H, unsigned
 
 }  // namespace
 
+// ---- hooks for the other translation units of the library (dfx_comm.cpp); not exported --------------------------
+extern "C" int dfx_internal_fail(int code, const char* msg) { g_last_error = msg ? msg : ""; return code; }
+// the stream the results of the batched step become complete on: where an exchange of them has to be enqueued
+extern "C" void* dfx_internal_exchange_stream(dfx_ctx* c) { return c->tail_stream ? (void*)c->tail_stream : (void*)c->stream; }
+extern "C" int dfx_internal_ctx_device(dfx_ctx* c) { (void)hipSetDevice(c->device); return c->device; }
+
 // -------------------------------------------------------------------------------------------------------------
 extern "C" {
 

@@ -327,6 +327,33 @@ DFX_API size_t dfx_graph_system_floats(const dfx_graph* graph);
 DFX_API int dfx_graph_assemble_async(dfx_ctx* ctx, const dfx_graph* graph, const void* items_dev, int first_pair, int n_local,
                                      float* sys_dev);
 
+/* ---- multi-GPU exchange (new: SURVEY section 8e; the reference is single-GPU) ---------------------------------------
+ * One process per GPU; every rank evaluates a contiguous shard of the pair list (dfx_shard_range) with keyframe pyramids replicated,
+ * then ONE collective over RCCL / xGMI brings the results together:
+ *   reduce mode  dfx_graph_assemble_async (this rank's pairs) -> dfx_graph_reduce_async: the ranks' flat systems are summed in place onto
+ *                `root` (ncclReduce), or onto every rank when root < 0 (ncclAllReduce).  1.3 MB for 64 keyframes / 1024 pairs at CS = 32.
+ *   gather mode  dfx_items_all_gather_async: every rank contributes bytes_per_rank bytes of items (its shard, padded to the largest shard)
+ *                and receives world * bytes_per_rank bytes in rank order -- the host can then emit one gtsam::HessianFactor per pair
+ *                exactly as the reference does (core/gtsam/photometric_factor.cpp:180).
+ * A communicator is created collectively: rank 0 calls dfx_comm_get_unique_id (DFX_COMM_ID_BYTES bytes), the host program hands the id to
+ * the other ranks by its own means (MPI, a socket, a file), every rank calls dfx_comm_create with the context of its GPU.  The collectives
+ * only enqueue, on the stream the step's results are complete on (the context's tail stream when one is set, else its stream).  librccl
+ * is loaded at run time on first use (a copy the process already holds is reused; DFX_RCCL_LIB names a specific library); single-GPU
+ * users never load it. */
+typedef struct dfx_comm dfx_comm;
+#define DFX_COMM_ID_BYTES 128
+DFX_API int dfx_comm_get_unique_id(void* id_out);
+DFX_API int dfx_comm_create(dfx_ctx* ctx, const void* id, int rank, int world, dfx_comm** out);
+DFX_API void dfx_comm_destroy(dfx_comm* comm);
+DFX_API int dfx_comm_rank(const dfx_comm* comm);
+DFX_API int dfx_comm_world(const dfx_comm* comm);
+/* The contiguous shard [first, first + count) of n pairs that `rank` of `world` evaluates (the first n % world ranks hold one more). */
+DFX_API int dfx_shard_range(int n, int rank, int world, int* first, int* count);
+DFX_API int dfx_graph_reduce_async(dfx_ctx* ctx, dfx_comm* comm, const dfx_graph* graph, float* sys_dev, int root);
+/* The collective underneath: n floats summed in place over the ranks (what dfx_graph_reduce_async does with dfx_graph_system_floats(graph)). */
+DFX_API int dfx_comm_reduce_f32_async(dfx_ctx* ctx, dfx_comm* comm, float* buf_dev, size_t n, int root);
+DFX_API int dfx_items_all_gather_async(dfx_ctx* ctx, dfx_comm* comm, const void* items_local_dev, size_t bytes_per_rank, void* items_all_dev);
+
 /* ---- image-proc free functions (cuda/cu_image_proc.h:27-46) ---------------------------------- */
 /* UpdateDepth (cu_image_proc.cpp:248-277): dpt = a/(prx_orig + prx_jac . code) - a; code is a HOST array of cs floats. */
 DFX_API int dfx_update_depth(dfx_ctx* ctx, int cs, const float* code, const dfx_img* prx_orig, const dfx_img* prx_jac,

@@ -14,3 +14,15 @@ def test_cpp_host_logic_without_a_gpu():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=60, stdin=subprocess.DEVNULL)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "host_logic_test OK" in out.stdout
+
+
+def test_cpp_exchange_step_two_ranks_over_a_stub_rccl():
+    """tests/cpp/comm_test.cpp: dfx_comm_* / dfx_shard_range / dfx_comm_reduce_f32_async / dfx_items_all_gather_async of the C ABI with world
+    size 2 (two threads) -- libdfx resolves RCCL at run time, here from the host-memory stand-in tests/cpp/librccl_stub.so (DFX_RCCL_LIB)."""
+    d = os.path.join(ROOT, "tests", "cpp")
+    if not (os.path.exists(os.path.join(d, "comm_test")) and os.path.exists(os.path.join(d, "librccl_stub.so"))):
+        subprocess.check_call(["make", "-C", d, "comm_test", "librccl_stub.so"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, DFX_RCCL_LIB=os.path.join(d, "librccl_stub.so"))
+    out = subprocess.run([os.path.join(d, "comm_test")], capture_output=True, text=True, timeout=60, stdin=subprocess.DEVNULL, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "comm_test OK" in out.stdout

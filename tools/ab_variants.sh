@@ -7,6 +7,6 @@ mkdir -p ../../gpurun_build
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 $flags -shared \
-     dfx_sfm_step.hip dfx_misc_kernels.hip dfx_graph.hip -x hip dfx_api.cpp -o ../../gpurun_build/libdfx_$name.so 2>&1 | grep -E "error" || true
+     dfx_sfm_step.hip dfx_misc_kernels.hip dfx_graph.hip -x hip dfx_api.cpp dfx_comm.cpp -ldl -o ../../gpurun_build/libdfx_$name.so 2>&1 | grep -E "error" || true
   echo "built $name ($flags)"
 done
