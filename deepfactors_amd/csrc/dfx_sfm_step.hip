@@ -137,10 +137,16 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));   // operand type of _
 constexpr int b3_tiles(int ncb) { return 1 + ncb + ncb * (ncb + 1) / 2; }
 constexpr bool b3_diag4(int ncb) { return ncb <= DFX_B3_DIAG4_MAX_NCB; }                     // two accumulators per diagonal (C_b,C_b) tile
 constexpr int b3_blocks(int ncb) { return b3_tiles(ncb) + 1 + (b3_diag4(ncb) ? ncb : 0); }   // 256-float blocks of a partial: the tiles, then the N parts of (P,P) [, (C_b,C_b)]
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {   // {RNE_bf16(lo) in bits 0..15, RNE_bf16(hi) in bits 16..31}
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+// {RNE_bf16(lo) in bits 0..15, RNE_bf16(hi) in bits 16..31}: one v_cvt_pk_bf16_f32.  Written as a vector conversion, NOT as inline assembly:
+// the compiler's hazard recognizer does not look inside an asm statement, so the wait states gfx950 needs between a vector-ALU write of
+// a register and a matrix instruction reading it were missing whenever the scheduler put the two next to each other -- the MFMA then
+// read the register's PREVIOUS content.  With the l pieces (2^-16 of a value) that is an error of ~1e-5 of single entries that varies
+// from run to run with the waves' interleaving: found in round 3 as run-to-run differences of the (C_0,C_1) tile once the four-product
+// diagonals had changed the instruction order (tools/diag_nan_batch.py, profiles/r03_inline_asm_hazard.txt).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  const f32x2 v = { lo, hi };
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 // Exact three-way split of two fp32 values into packed bf16 pieces (tools/ubench/bf16x3_probe.cpp: 2^20 inputs reconstructed exactly
 // on the hardware).  The subtractions are exact (Sterbenz-like: each remainder fits the fp32 mantissa).
