@@ -61,8 +61,11 @@ def parse():
                     help="auto: the library's default (DFX_SCHEDULE_AUTO); static / dynamic: force one")
     ap.add_argument("--mfma", choices=["auto", "f32", "bf16x3"], default="auto",
                     help="evaluation mode of the step kernel: auto = the library's default (DFX_MFMA_AUTO); f32 = fp32 fmaf chain; bf16x3 = exact three-way bf16 split")
-    ap.add_argument("--no-deferred-tail", action="store_true",
-                    help="run the reduction tail of every step (finalize kernel, graph assembly) on the launch stream instead of on a second stream beside the next step's kernel")
+    ap.add_argument("--deferred-tail", action="store_true",
+                    help="run the reduction tail of every step (finalize kernel, graph assembly) on a second stream beside the next step's kernel (dfx_set_tail_stream) instead "
+                         "of in order on the launch stream.  Measured on MI355X (profiles/r03_bench_tail_modes.txt): the gap between step time and kernel time falls "
+                         "from 38 to 27 us, but the 768 finalize workgroups take CU slots from the next step kernel (+15 us): 1.0233 vs 1.0200 ms per step -- so "
+                         "the default stays in order")
     ap.add_argument("--foreign-valid0", action="store_true", help="keep the valid0 maps in torch tensors (memory the library does not own: the step kernel "
                     "then re-reads the map every step, 4 B/px) instead of library-owned images with a 1-bit shadow")
     ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)
@@ -511,10 +514,10 @@ def main():
         ctx.sync()
         return
 
-    # Consecutive steps are independent batches, so the reduction tail of step k (finalize kernel + graph assembly, ~30 us of short
-    # dependent kernels) runs on a second stream beside the 1 ms step kernel of step k + 1 (dfx_set_tail_stream); for N > 1 the RCCL
-    # reduce of step k is issued on that stream too.  Every tail and every reduce has completed when the timed region ends (barrier()).
-    tail = None if a.no_deferred_tail else torch.cuda.Stream(device=dev)
+    # --deferred-tail: consecutive steps are independent batches, so the reduction tail of step k (finalize kernel + graph assembly, ~35 us
+    # of short dependent kernels) can run on a second stream beside the 1 ms step kernel of step k + 1 (dfx_set_tail_stream); for N > 1 the
+    # RCCL reduce of step k is then issued on that stream too.  Every tail and every reduce has completed when the timed region ends.
+    tail = torch.cuda.Stream(device=dev) if a.deferred_tail else None
     if tail is not None:
         ctx.set_tail_stream(tail)
 

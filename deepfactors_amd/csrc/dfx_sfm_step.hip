@@ -80,10 +80,11 @@ namespace dfx {
 #endif
 
 #ifndef DFX_B3_DIAG4_MAX_NCB
-#define DFX_B3_DIAG4_MAX_NCB 2   // DFX_MFMA_BF16X3: up to this many code blocks the diagonal tiles (C_b,C_b) take four products instead of six: S = hh + mm
-#endif                           // and N = hm + hl in two accumulators, Z = S + N + N^T in the finalize kernel.  MI355X, 128 pairs, CS = 32: 1039.5 -> 1004.0 us
-                                 // (profiles/r03_ab_variants.txt).  0 disables it.  Two round-2 ideas measured in the same call and removed: the P block
-                                 // split in phase A and handed over as packed bf16 through LDS (+2.4 %), 128 registers for a fourth wave (spills: +37 %).
+#define DFX_B3_DIAG4_MAX_NCB 4   // DFX_MFMA_BF16X3: up to this many code blocks the diagonal tiles (C_b,C_b) take four products instead of six: S = hh + mm
+#endif                           // and N = hm + hl in two accumulators, Z = S + N + N^T in the finalize kernel.  MI355X (profiles/r03_ab_variants.txt): CS = 32,
+                                 // 128 pairs 1039.5 -> 1004.0 us; CS = 64, 1280x960, 16 pairs 950.9 -> 929.9 us (232 -> 247 VGPRs, still two waves).  0 disables
+                                 // it.  Two round-2 ideas measured in round 3 and removed: the P block split in phase A and handed over as packed bf16
+                                 // through LDS (+2.4 %), 128 registers for a fourth wave (spills: +37 %).
 #ifndef DFX_RING_AUX
 #define DFX_RING_AUX 2       // cache policy of the code-Jacobian stream loads: 2 = nt (read once: do not displace the img1 / grad1 rows
 #endif                       // the bilinear taps of the next chunk row re-use from the L2); -1.6 % kernel time, -3 % read requests with the collapse below

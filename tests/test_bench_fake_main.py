@@ -209,7 +209,7 @@ def _check_line(txt, world):
     assert r["launches"] == 3 and r["traffic"] is None and "traffic_source" in r and "mfma" in r and "schedule" in r
     assert "schedule_probe" not in d and len(d["ramp_kernel_us"]) >= 6
     assert 0 < r["kernel_us_min"] <= r["kernel_us"] <= r["kernel_us_max"] and "library default" in r["mfma"] + r["schedule"]
-    assert "second stream" in d["config"]["workload"]
+    assert "second stream" not in d["config"]["workload"]   # the tail runs in order unless --deferred-tail
     return d
 
 
@@ -260,7 +260,8 @@ def test_main_forced_modes(tmp_path, monkeypatch):
     monkeypatch.delenv("RANK", raising=False)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     out = tmp_path / "forced.txt"
-    _run_main(ARGS + ["--schedule", "static", "--mfma", "bf16x3", "--window"], str(out))
+    _run_main(ARGS + ["--schedule", "static", "--mfma", "bf16x3", "--window", "--deferred-tail"], str(out))
     d = json.loads(out.read_text().strip())
+    assert "second stream" in d["config"]["workload"]
     assert "bf16" in d["roofline"]["mfma"] and "forced by --mfma" in d["roofline"]["mfma"] and "static" in d["roofline"]["schedule"] and "forced" in d["roofline"]["schedule"]
     assert d["configs"]["configs3_window64"]["pairs_per_rank"] == 1024

@@ -207,7 +207,7 @@ def test_three_way_bf16_split_is_exact():
         assert not (p.view(np.uint32) & 0xFFFF).any()
 
 
-DIAG4_MAX_NCB = 2   # DFX_B3_DIAG4_MAX_NCB of dfx_sfm_step.hip
+DIAG4_MAX_NCB = 4   # DFX_B3_DIAG4_MAX_NCB of dfx_sfm_step.hip
 
 
 def _model_item_b3(gC, wr, inl, s, jac, M, HM, cs):
@@ -330,7 +330,7 @@ def test_bf16x3_tiles_cover_the_item_exactly_once_at_fp32_accuracy(cs):
     assert abs(residual - float(wr @ wr)) < 3e-8 * float(wr @ wr) and abs(inliers - inl.sum()) < 1e-6
 
 
-@pytest.mark.parametrize("cs", [16, 32])
+@pytest.mark.parametrize("cs", [16, 32, 64])
 def test_bf16x3_diag4_equals_the_six_product_tiles(cs):
     """Four-product diagonal tiles (DFX_B3_DIAG4_MAX_NCB): they keep S = hh + mm and N = hm + hl; Z = S + N + N^T equals the six-product tile."""
     rng = np.random.default_rng(cs)
