@@ -270,7 +270,7 @@ def small_operator_rooflines(dfx, synth, ctx, dev):
     return out
 
 
-def secondary_configs(dfx, synth, ctx, dev, headline=None):
+def secondary_configs(dfx, synth, ctx, dev):
     """configs[1] as the reference calls it (ONE pair per blocking call, photometric_factor.cpp:267-274), its 3-level pyramid variant, configs[4]
     (1280x960, 64-code; 16 pairs per launch, 5.5 GB working set)."""
     import torch
@@ -292,28 +292,34 @@ def secondary_configs(dfx, synth, ctx, dev, headline=None):
     out["configs1_single_pair_blocking"] = dict(call_us=dt * 1e6, kernel_us=ms / n * 1e3, evals_per_s=1.0 / dt,
                                                 note="one 640x480 cs=32 pair per blocking SfmAligner::RunStep call (46 MB: Infinity-Cache resident, not an HBM figure)")
     del p
-    # ---- SURVEY 8d "all pyramid levels" variant: the 128-pair batch at levels 0, 1, 2 (640x480, 320x240, 160x120), one launch per level
-    lv_us = []
+    # ---- SURVEY 8d "all pyramid levels" variant: levels 0, 1, 2 (640x480, 320x240, 160x120) of 128 factor sets -- 384 pairs -- in ONE launch
+    # (pairs of several image sizes share a launch: workgroups in proportion to the pixel count, large pairs first), and level by level
+    P3 = 128
+    lv_pairs, lv_keep = [], []
     for (w, h) in ((640, 480), (320, 240), (160, 120)):
-        if w == 640 and headline is not None:   # level 0 = the headline batch itself: not generated a second time
-            lv_us.append(headline)
-            continue
-        pairs, keep = build_pairs(dfx, synth, dev, 3, 128, w, h, 32, ctx=ctx)
-        arr = al.make_pairs(pairs)
-        items = torch.zeros(128 * dfx.item_size(12 + 32), dtype=torch.uint8, device=dev)
-        for _ in range(300 if w == 640 else 1500):
+        pr, kp = build_pairs(dfx, synth, dev, 3, P3, w, h, 32, ctx=ctx)
+        lv_pairs.append(pr); lv_keep.append(kp)
+    items = torch.zeros(3 * P3 * dfx.item_size(12 + 32), dtype=torch.uint8, device=dev)
+
+    def kernel_us(arr, warm, reps):
+        for _ in range(warm):
             al.RunStepBatchAsync(arr, items)
         ctx.sync()
         ctx.set_profiling(True)
-        for _ in range(30):
+        for _ in range(reps):
             al.RunStepBatchAsync(arr, items)
-        n, ms = ctx.profile_read()
+        nl, ms = ctx.profile_read()
         ctx.set_profiling(False)
-        lv_us.append(ms / n * 1e3)
-        del pairs, keep, arr, items
-    tot = sum(lv_us) * 1e-6
-    out["configs1_pyramid3_128pairs"] = dict(level_kernel_us=lv_us, evals_per_s=128 / tot, algorithmic_gbs=148 * (640 * 480 + 320 * 240 + 160 * 120) * 128 / tot / 1e9,
-                                             note="SfmAligner::RunStep over levels 0-2 of 128 pairs (one launch per level, step kernels only): one 'evaluation' = all three levels")
+        return ms / nl * 1e3
+    lv_us = [kernel_us(al.make_pairs(pr), 300 if k == 0 else 1200, 30) for k, pr in enumerate(lv_pairs)]
+    one_us = kernel_us(al.make_pairs([p for pr in lv_pairs for p in pr]), 300, 30)
+    px3 = (640 * 480 + 320 * 240 + 160 * 120) * P3
+    out["configs1_pyramid3_128pairs"] = dict(one_launch_kernel_us=one_us, evals_per_s=P3 / (one_us * 1e-6), algorithmic_gbs=148 * px3 / (one_us * 1e-6) / 1e9,
+                                             frac=148 * px3 / (one_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                             level_by_level_kernel_us=lv_us, level_by_level_frac=148 * px3 / (sum(lv_us) * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                             note="SfmAligner::RunStep over pyramid levels 0-2 of 128 factor sets: one 'evaluation' = all three levels; ONE launch over the 384 "
+                                                  "pairs (dfx_sfm_step_batch_async accepts pairs of several image sizes) vs one launch per level; step kernels only")
+    del lv_pairs, lv_keep, items
     # ---- configs[4]: 1280x960, cs = 64
     W, H, CS, P = 1280, 960, 64, 16
     al4 = dfx.SfmAligner(code_size=CS, ctx=ctx)
@@ -616,7 +622,7 @@ def main():
     del keep, pairs, arr
     torch.cuda.empty_cache()
     if world == 1 and not a.no_configs:
-        configs.update(secondary_configs(dfx, synth, ctx, dev, headline=kern_s * 1e6 if (W, H, CS, P) == (640, 480, 32, 128) else None))
+        configs.update(secondary_configs(dfx, synth, ctx, dev))
         torch.cuda.empty_cache()
         configs.update(small_operator_rooflines(dfx, synth, ctx, dev))
         torch.cuda.empty_cache()

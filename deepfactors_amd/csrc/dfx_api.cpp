@@ -8,12 +8,14 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -103,8 +105,8 @@ struct dfx_ctx {
   hipEvent_t ev_join = nullptr;
   char* items_dev = nullptr;   // device result items (sync API)
   size_t items_bytes = 0;
-  dfx::SfmPairDev* pairs_dev = nullptr;
-  size_t pairs_cap = 0;        // per stage slot
+  dfx::SfmPairDev* pairs_dev = nullptr;   // per stage slot: the pair descriptors of a batch, then (mixed image sizes) its workgroup map
+  size_t pairs_cap = 0;        // BYTES per stage slot
   float* code_dev = nullptr;   // 64 floats per stage slot
   float* depth_scratch = nullptr;
   size_t depth_scratch_bytes = 0;
@@ -794,58 +796,110 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
   if (n <= 0 || n > 65535) return fail(DFX_E_INVALID, "batch size %d out of range [1,65535]", n);
   int rc;
   if ((rc = ensure_device(c))) return rc;
-  if (!img_ok(&pairs[0].img0)) return fail(DFX_E_INVALID, "pair 0: img0 null or empty");
-  const uint32_t W = pairs[0].img0.w, H = pairs[0].img0.h;
-  if ((size_t)W * H >= (1ull << 31)) return fail(DFX_E_INVALID, "image too large");
+  if (params->step_blocks < 0 || params->step_blocks > 65535) return fail(DFX_E_INVALID, "step_blocks %d out of range [0,65535]", params->step_blocks);
+  // Image sizes: a batch may mix pyramid levels (the reference walks all levels of a factor set per relinearisation,
+  // core/mapping/df_work.cpp:118-136, tools/kernel_benchmark.cpp:192-203).  W, H = the largest width / height (ray-table LDS).
+  uint32_t W = 0, H = 0;
+  bool uniform = true;
+  for (int p = 0; p < n; ++p) {
+    if (!img_ok(&pairs[p].img0)) return fail(DFX_E_INVALID, "pair %d: img0 null or empty", p);
+    const uint32_t w = pairs[p].img0.w, h = pairs[p].img0.h;
+    if ((size_t)w * h >= (1ull << 31)) return fail(DFX_E_INVALID, "pair %d: image too large", p);
+    uniform = uniform && w == pairs[0].img0.w && h == pairs[0].img0.h;
+    W = w > W ? w : W; H = h > H ? h : H;
+  }
+  // Launch shape of a mixed batch: one chunks-per-wave figure for all pairs (so that a 160x120 pair gets 1/16 of the workgroups of a
+  // 640x480 one instead of the same number of much shorter ones), a 1-D grid, the large pairs first: the small levels fill the tail.
+  std::vector<uint32_t> nblk, blk0;
+  std::vector<int> order;
+  int total_blocks = 0;
+  if (!uniform) {
+    long long total_chunks = 0;
+    for (int p = 0; p < n; ++p) total_chunks += ((long long)pairs[p].img0.w * pairs[p].img0.h + 63) / 64;
+    const long long resident_waves = (cs >= 64 ? 8LL : 12LL) * c->cu_count;
+    int cpw = (int)(4 * total_chunks / (5 * resident_waves));
+    if (cpw < 5) cpw = 5;
+    if (cpw > 30) cpw = 30;
+    if (params->step_blocks > 0 || c->step_blocks > 0) {   // an explicit request is read as "workgroups of a pair of the LARGEST size"
+      const int req = params->step_blocks > 0 ? params->step_blocks : c->step_blocks;
+      const long long big = ((long long)W * H + 63) / 64;
+      cpw = (int)((big + 4LL * req - 1) / (4LL * req));
+      if (cpw < 1) cpw = 1;
+    }
+    nblk.resize((size_t)n); blk0.resize((size_t)n); order.resize((size_t)n);
+    for (int p = 0; p < n; ++p) {
+      const long long nch = ((long long)pairs[p].img0.w * pairs[p].img0.h + 63) / 64;
+      long long b = (nch + 4LL * cpw - 1) / (4LL * cpw);
+      if (b < 1) b = 1;
+      if (b > 65535) b = 65535;
+      nblk[p] = (uint32_t)b;
+      order[p] = p;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return (size_t)pairs[a].img0.w * pairs[a].img0.h > (size_t)pairs[b].img0.w * pairs[b].img0.h; });
+    for (int p : order) { blk0[p] = (uint32_t)total_blocks; total_blocks += (int)nblk[p]; }
+  }
 
   if ((rc = ray_table_gc(c))) return rc;
   // n == 1 (the reference's call pattern: one pair per blocking call): the descriptor travels in the kernel arguments -- no
-  // staging slot, no host-to-device copy in front of the launch.  n > 1: descriptor array in device memory.
+  // staging slot, no host-to-device copy in front of the launch.  n > 1: descriptor array (+ the workgroup map of a mixed batch) in
+  // device memory.
   dfx::SfmPairDev one;
   dfx::SfmPairDev* hd = &one;
   dfx::SfmPairDev* dd = nullptr;
+  unsigned* map_dev = nullptr;
   int slot = -1;
-  const size_t desc_bytes = sizeof(dfx::SfmPairDev) * (size_t)n;
+  const size_t desc_bytes = (sizeof(dfx::SfmPairDev) * (size_t)n + 15) & ~(size_t)15;
+  const size_t map_bytes = sizeof(unsigned) * (size_t)total_blocks;
   if (n > 1) {
     char* host;
-    if ((rc = stage_acquire(c, desc_bytes, &slot, &host))) return rc;
+    if ((rc = stage_acquire(c, desc_bytes + map_bytes, &slot, &host))) return rc;
     hd = reinterpret_cast<dfx::SfmPairDev*>(host);
+    unsigned* hm = reinterpret_cast<unsigned*>(host + desc_bytes);
+    size_t g = 0;
+    for (int p : order)
+      for (uint32_t b = 0; b < nblk[p]; ++b) hm[g++] = ((unsigned)p << 16) | b;
   }
   for (int p = 0; p < n; ++p) {
     const dfx_sfm_pair& q = pairs[p];
-    if ((rc = fill_sfm_pair(c, cs, &q.pose0, &q.pose1, &q.cam, &q.img0, &q.img1, &q.dpt0, &q.valid0, &q.prx0_jac, &q.grad1, W, H, &hd[p]))) {
+    if ((rc = fill_sfm_pair(c, cs, &q.pose0, &q.pose1, &q.cam, &q.img0, &q.img1, &q.dpt0, &q.valid0, &q.prx0_jac, &q.grad1, q.img0.w, q.img0.h, &hd[p]))) {
       g_last_error = "pair " + std::to_string(p) + ": " + g_last_error;
       return rc;
     }
+    hd[p].w_px = q.img0.w; hd[p].h_px = q.img0.h;
+    hd[p].nblk = uniform ? 0u : nblk[p];
+    hd[p].blk0 = uniform ? 0u : blk0[p];
   }
   if (n > 1) {
-    // device descriptor array: one region per stage slot so that in-flight launches keep their own copy.  The upload runs on
-    // the context's copy stream, beside the kernels of the previous launches (it used to sit between them on the launch stream:
-    // ~10 us per step); the launch stream waits for it, and the copy stream waits for the last kernels that read this slot.
-    if (c->pairs_cap < (size_t)n) {
+    // device copy: one region per stage slot so that in-flight launches keep their own.  The upload runs on the context's copy stream,
+    // beside the kernels of the previous launches (it used to sit between them on the launch stream: ~10 us per step); the launch
+    // stream waits for it, and the copy stream waits for the last kernels that read this slot.
+    if (c->pairs_cap < desc_bytes + map_bytes) {
       DFX_HIP(hipStreamSynchronize(c->stream));
       DFX_HIP(hipStreamSynchronize(c->copy_stream));
+      if (c->tail_stream) DFX_HIP(hipStreamSynchronize(c->tail_stream));
       if (c->pairs_dev) DFX_HIP(hipFree(c->pairs_dev));
       c->pairs_dev = nullptr;
-      const size_t cap = (size_t)n * 2;
-      DFX_HIP(hipMalloc((void**)&c->pairs_dev, sizeof(dfx::SfmPairDev) * cap * kStageSlots));
+      const size_t cap = ((desc_bytes + map_bytes) * 2 + 255) & ~(size_t)255;
+      DFX_HIP(hipMalloc((void**)&c->pairs_dev, cap * kStageSlots));
       c->pairs_cap = cap;
       for (int i = 0; i < kStageSlots; ++i) c->slot_busy[i] = false;
     }
-    dd = c->pairs_dev + (size_t)slot * c->pairs_cap;
+    char* region = reinterpret_cast<char*>(c->pairs_dev) + (size_t)slot * c->pairs_cap;
+    dd = reinterpret_cast<dfx::SfmPairDev*>(region);
+    if (!uniform) map_dev = reinterpret_cast<unsigned*>(region + desc_bytes);
     if (c->slot_busy[slot]) DFX_HIP(hipStreamWaitEvent(c->copy_stream, c->slot_done[slot], 0));
-    DFX_HIP(hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, c->copy_stream));
+    DFX_HIP(hipMemcpyAsync(region, hd, desc_bytes + map_bytes, hipMemcpyHostToDevice, c->copy_stream));
     DFX_HIP(hipEventRecord(c->stage_ev[slot], c->copy_stream));
     c->stage_used[slot] = true;
     DFX_HIP(hipStreamWaitEvent(c->stream, c->stage_ev[slot], 0));
   }
 
-  if (params->step_blocks < 0 || params->step_blocks > 65535) return fail(DFX_E_INVALID, "step_blocks %d out of range [0,65535]", params->step_blocks);
-  // the dense-stream variant needs every pair's Jacobian rows back to back; one pitched pair selects the general kernel
+  // the dense-stream variant needs every pair's Jacobian rows back to back (and, in a mixed batch, whole 64-pixel chunks: the launcher
+  // checks that for a batch of one size); one pitched pair selects the general kernel
   bool jac_dense = true;
   bool vsh = true;   // the shadow-reading kernel variant needs a shadow behind EVERY valid0 map of the batch (library-owned images)
   for (int p = 0; p < n; ++p) {
-    jac_dense = jac_dense && (hd[p].pitch_jac == W * (uint32_t)cs * 4u);
+    jac_dense = jac_dense && (hd[p].pitch_jac == hd[p].w_px * (uint32_t)cs * 4u) && (uniform || ((size_t)hd[p].w_px * hd[p].h_px) % 64 == 0);
     vsh = vsh && (hd[p].valid0 == nullptr || hd[p].valid0_shadow != nullptr);
   }
   // Dynamic schedule (k_sfm_step<..., DYN>, opt-in: DFX_SCHEDULE_DYNAMIC): resident wave-workers popping items from per-pair queues.
@@ -861,7 +915,7 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
     const int team = n > 0 ? (4 * resident_wgs) / n : 0;
     const size_t dyn_lds = sizeof(float) * 4 * ((size_t)W + H + dfx::kRayTabSlack + 16 * 68);
     const bool team_ok = team >= 1 && team <= 1024;
-    if (n > 1 && c->schedule == DFX_SCHEDULE_DYNAMIC && params->step_blocks == 0 && c->step_blocks == 0 && team_ok && jac_dense && W % 64 == 0 &&
+    if (n > 1 && uniform && c->schedule == DFX_SCHEDULE_DYNAMIC && params->step_blocks == 0 && c->step_blocks == 0 && team_ok && jac_dense && W % 64 == 0 &&
         W / 64 <= 64 && dyn_lds <= 40 * 1024 && (size_t)W * H < (1u << 26)) {
       const int vs = (int)(W / 64);
       int R = (int)(((long long)H * vs) / ((long long)team * 24));
@@ -887,8 +941,8 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
     }
   }
   c->last_dynamic = dyn.qhead ? 1 : 0;
-  const int bpp = dyn.qhead ? dyn.team : auto_step_blocks(c, W, H, n, cs, params->step_blocks);
-  const size_t pbytes = dfx::sfm_step_partials_bytes(cs, n, bpp);
+  const int bpp = dyn.qhead ? dyn.team : (uniform ? auto_step_blocks(c, W, H, n, cs, params->step_blocks) : 0);
+  const size_t pbytes = uniform ? dfx::sfm_step_partials_bytes(cs, n, bpp) : dfx::sfm_step_partials_bytes(cs, 1, total_blocks);
   if ((rc = grow_partials(c, pbytes, true))) return rc;
   // Deferred tail: this launch's finalize kernel goes to the tail stream and runs beside the NEXT launch's step kernel; the two halves of
   // the partials (and of the queue heads) alternate, and a half is written again only after the finalize that read it (ev_tail).
@@ -921,7 +975,7 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
   hipStream_t const fin_stream = defer ? c->tail_stream : c->stream;
   DFX_HIP(dfx::launch_sfm_step(cs, dd, n, (int)W, (int)H, prm, bpp, partials, out_items_dev, dfx_item_size(12 + cs), c->stream,
                                jac_dense, resolve_mfma(c, cs), eb, ee, n == 1 ? &one : nullptr, dyn.qhead ? &dyn : nullptr, dyn_grid, vsh,
-                               fin_stream, defer ? c->ev_mid[par] : nullptr));
+                               fin_stream, defer ? c->ev_mid[par] : nullptr, map_dev, total_blocks));
   c->qhead_dirty = false;   // both kernels are enqueued: the finalize kernel rewinds the heads
   if (defer) {
     DFX_HIP(hipEventRecord(c->ev_tail[par], fin_stream));
@@ -1479,14 +1533,14 @@ static int sfm_linearize_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* pa
   if (n <= 0 || n > 65535) return fail(DFX_E_INVALID, "batch size %d out of range [1,65535]", n);
   int rc;
   if ((rc = ensure_device(c))) return rc;
-  if (!img_ok(&pairs[0].img0)) return fail(DFX_E_INVALID, "pair 0: img0 null or empty");
-  const uint32_t W = pairs[0].img0.w, H = pairs[0].img0.h;
   // UpdateDepthMaps once per DISTINCT keyframe depth map of the batch (the reference decodes it again for every factor that
   // shares the keyframe, photometric_factor.cpp:229,332-341): pairs that share dpt0 must agree on code, prx_orig and prx_jac.
-  std::vector<dfx::DepthJobDev> jobs;
+  std::map<std::pair<uint32_t, uint32_t>, std::vector<dfx::DepthJobDev>> jobs;   // one decoder launch per image size (pyramid level) of the batch
   std::unordered_map<const void*, int> first;   // depth-map pointer -> first pair that writes it
   auto same_img = [](const dfx_img& a, const dfx_img& b) { return a.ptr == b.ptr && a.pitch_bytes == b.pitch_bytes && a.w == b.w && a.h == b.h; };
   for (int p = 0; p < n; ++p) {
+    if (!img_ok(&pairs[p].img0)) return fail(DFX_E_INVALID, "pair %d: img0 null or empty", p);
+    const uint32_t W = pairs[p].img0.w, H = pairs[p].img0.h;
     const void* key = pairs[p].dpt0.ptr;
     auto hit = first.find(key);
     if (hit == first.end()) {
@@ -1495,7 +1549,7 @@ static int sfm_linearize_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* pa
         g_last_error = "pair " + std::to_string(p) + ": " + g_last_error;
         return rc;
       }
-      first.emplace(key, p); jobs.push_back(j);
+      first.emplace(key, p); jobs[std::make_pair(W, H)].push_back(j);
     } else {
       const int q = hit->second;
       if (std::memcmp(codes0 + (size_t)p * cs, codes0 + (size_t)q * cs, sizeof(float) * (size_t)cs) != 0 || !same_img(pairs[p].dpt0, pairs[q].dpt0) ||
@@ -1503,7 +1557,8 @@ static int sfm_linearize_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* pa
         return fail(DFX_E_INVALID, "pairs %d and %d write the same depth map from different codes / decoder images", q, p);
     }
   }
-  if ((rc = update_depth_jobs(c, cs, jobs, params->avg_dpt, W, H))) return rc;
+  for (auto& lv : jobs)
+    if ((rc = update_depth_jobs(c, cs, lv.second, params->avg_dpt, lv.first.first, lv.first.second))) return rc;
   return sfm_step_batch_impl(c, cs, params, pairs, n, out_items_dev, allow_defer);
 }
 

@@ -21,6 +21,9 @@ struct SfmPairDev {
   const float* ray_tab;   // [W] (x - u0) / fx, then [H + kRayTabSlack] (y - v0) / fy   (SfmAligner::RunStep only)
   unsigned long long* valid0_shadow;   // library-owned valid0 images: one bit per pixel (linear index), set = "holds 1.0"; else null
   uint32_t pitch_img0, pitch_img1, pitch_dpt0, pitch_valid0, pitch_jac, pitch_grad1;   // bytes
+  // batches whose pairs differ in image size (several pyramid levels in ONE launch): the pair's own size, its share of the 1-D grid and
+  // the index of its first workgroup partial (`blkmap` of launch_sfm_step); unused (0) by launches of one image size
+  uint32_t w_px, h_px, nblk, blk0;
 };
 constexpr int kRayTabSlack = 80;   // rows a lane past the last pixel may index (<= 64 / W + 1), zero-filled
 
@@ -81,7 +84,10 @@ hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int 
                            const SfmPairDev* one_host = nullptr,   // one_host (npairs == 1): the descriptor travels in the kernel arguments
                            const DynDev* dyn = nullptr, int dyn_grid = 0,    // dyn: the dynamic schedule (workgroups = dyn_grid, partials = [pair][team])
                            bool valid0_shadows = false,                      // every non-null valid0 of the batch carries a shadow (SfmPairDev::valid0_shadow)
-                           hipStream_t fin_stream = nullptr, hipEvent_t ev_mid = nullptr);   // deferred tail: the finalize kernel runs on fin_stream behind ev_mid
+                           hipStream_t fin_stream = nullptr, hipEvent_t ev_mid = nullptr,   // deferred tail: the finalize kernel runs on fin_stream behind ev_mid
+                           const unsigned* blkmap_dev = nullptr, int total_blocks = 0);   // pairs of several image sizes: 1-D grid, workgroup g serves pair
+                                                                                           // blkmap[g] >> 16 as its block blkmap[g] & 0xffff (of SfmPairDev::nblk);
+                                                                                           // W, H = the largest width / height (ray-table LDS); blocks_per_pair unused
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair);
 // system layout (floats): Hd [n_nodes][D][D], Ho [n_pairs][D][6], g [n_nodes][D]; contributions of the pairs [first_pair, first_pair + n_local)
 hipError_t launch_graph_assemble(int cs, const GraphDev& G, const void* items_dev, size_t item_stride, int first_pair, int n_local, float* sys_dev,

@@ -191,7 +191,8 @@ __device__ __forceinline__ float dpp_merge(float old, float src) {
 // chunk instead of the map's 256.
 template <int NCB, int MODE, bool JDENSE, bool TABLDS, bool BYVAL, bool DYN, bool B3, bool VSH>
 __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_WAVES) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmPairDev one, const SfmParamsDev prm,
-                                                       const int W, const int H, float* __restrict__ partials, const DynDev dyn) {
+                                                       const int Wk, const int Hk, float* __restrict__ partials, const DynDev dyn,
+                                                       const unsigned* __restrict__ blkmap) {
   static_assert(!DYN || (MODE == 0 && JDENSE && TABLDS && !BYVAL), "the dynamic schedule exists for the batched dense SfM step");
   static_assert(!VSH || MODE == 0, "valid0 maps exist for the SfM step only");
   constexpr int NX = NCB * (NCB - 1) / 2, ND = (NCB + 1) / 2;   // X(b,b'), Dd(q); Pm(b): NCB
@@ -218,7 +219,15 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   const int dyn_member = DYN ? dyn_gid / dyn.npairs : 0;
   const int dyn_pair = DYN ? (dyn_gid - dyn_member * dyn.npairs + DFX_DYN_ROT * dyn_member) % dyn.npairs : 0;
   if (DYN && dyn_member >= dyn.team) return;
-  const SfmPairDev& P = BYVAL ? one : pairs[DYN ? dyn_pair : (int)blockIdx.y];
+  // Pairs of ONE image size: grid = (workgroups per pair, pairs).  Pairs of several sizes (pyramid levels in one launch): a 1-D grid and
+  // `blkmap` (workgroup -> pair << 16 | block of that pair), the large pairs first so that the small levels fill the tail of the launch;
+  // the pair's size, its number of workgroups and the index of its first partial come from its descriptor.
+  const bool ragged = !BYVAL && !DYN && blkmap != nullptr;   // wave-uniform
+  const unsigned bm = ragged ? blkmap[blockIdx.x] : 0u;
+  const SfmPairDev& P = BYVAL ? one : pairs[DYN ? dyn_pair : (ragged ? (int)(bm >> 16) : (int)blockIdx.y)];
+  const int W = ragged ? (int)P.w_px : Wk, H = ragged ? (int)P.h_px : Hk;
+  const int blk_in_pair = ragged ? (int)(bm & 0xffffu) : (int)blockIdx.x;
+  const int blks_of_pair = ragged ? (int)P.nblk : (int)gridDim.x;
 
   Geo g;
 #pragma unroll
@@ -311,8 +320,8 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   // img1 / grad1 rows its bilinear taps share with the chunk below are re-read by the same CU (L2 hit) instead of by a
   // wave on another XCD (a second HBM fetch).  The Jacobian stream is still one contiguous 256*NCB*16-byte run per chunk.
   // Grids with fewer waves than chunks per row fall back to the interleaved map (wave w: w, w + #waves, ...).
-  const int total_waves = gridDim.x * kWaves;
-  const int wid = blockIdx.x * kWaves + wave;
+  const int total_waves = blks_of_pair * kWaves;
+  const int wid = blk_in_pair * kWaves + wave;
   const int vs = (W + 32) >> 6;   // chunk stride of one image row (exact when W % 64 == 0)
   int chunk, cstride, cend;
   // DYN: item t of a pair = column t % vs, image rows [t / vs * R, + R): chunks row * vs + column, one image row apart
@@ -792,7 +801,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
       for (int r = 0; r < 4; ++r) mine[(1 + NACC + a) * 256 + ppb * 16 + r * 4 + ppi] = accd[a][r];
     }
   }
-  float* out = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ZDIM;
+  float* out = partials + (ragged ? (size_t)P.blk0 + blk_in_pair : (size_t)blockIdx.y * gridDim.x + blockIdx.x) * ZDIM;
   __syncthreads();
   for (int e = threadIdx.x; e < ZDIM; e += kThreads) {
     float v = lds[e];
@@ -842,7 +851,7 @@ __device__ __forceinline__ void rebuild_valid0_shadow(const SfmPairDev& P, int W
 template <int NCB, int NPOSE, bool BYVAL>
 __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs, const SfmPairDev one,
                                                        char* __restrict__ items, const size_t item_stride, unsigned* __restrict__ qhead,
-                                                       const int W, const int H, const unsigned launch_id) {
+                                                       const int Wk, const int Hk, const unsigned launch_id, const int ragged) {
   constexpr int CS = 16 * NCB;
   constexpr int NP = NPOSE + CS;
   constexpr int NX = NCB * (NCB - 1) / 2, ND = (NCB + 1) / 2;
@@ -854,10 +863,15 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
 
   const int blk = blockIdx.x, pair = blockIdx.y;
   const int el = threadIdx.x & 255, rg = threadIdx.x >> 8;
-  if (NPOSE == 12) rebuild_valid0_shadow(BYVAL ? one : pairs[pair], W, H, launch_id, blk, (int)gridDim.x);
+  // pairs of several image sizes in one launch (`ragged`): size, number of partials and first partial come from the pair's descriptor
+  const SfmPairDev& PD = BYVAL ? one : pairs[pair];
+  const int W = ragged ? (int)PD.w_px : Wk, H = ragged ? (int)PD.h_px : Hk;
+  const int nparts = ragged ? (int)PD.nblk : bpp;
+  const size_t part0 = ragged ? (size_t)PD.blk0 : (size_t)pair * bpp;
+  if (NPOSE == 12) rebuild_valid0_shadow(PD, W, H, launch_id, blk, (int)gridDim.x);
   if (qhead && blk == 0 && threadIdx.x == 0) qhead[pair] = 0u;   // dynamic schedule: the pair's item queue is rewound for the next launch
-  const float* src = partials + (size_t)pair * bpp * ZDIM + blk * 256 + el;
-  red[rg][el] = strided_sum_f64<4, 16>(src, rg, bpp, ZDIM);   // a single pair has 240 partials: 60 rows per group = 4 round trips
+  const float* src = partials + part0 * ZDIM + blk * 256 + el;
+  red[rg][el] = strided_sum_f64<4, 16>(src, rg, nparts, ZDIM);   // a single pair has 240 partials: 60 rows per group = 4 round trips
   if (NPOSE == 12 && threadIdx.x < 72) {
     const int n = threadIdx.x / 6, i = threadIdx.x - n * 6;
     const float* M = BYVAL ? one.M : pairs[pair].M;
@@ -982,7 +996,7 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
 template <int NCB, int NPOSE, bool BYVAL>
 __global__ __launch_bounds__(1024) void k_sfm_finalize_b3(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs, const SfmPairDev one,
                                                           char* __restrict__ items, const size_t item_stride, unsigned* __restrict__ qhead,
-                                                          const int W, const int H, const unsigned launch_id) {
+                                                          const int Wk, const int Hk, const unsigned launch_id, const int ragged) {
   constexpr int CS = 16 * NCB;
   constexpr int NP = NPOSE + CS;
   constexpr int NT3 = b3_tiles(NCB);
@@ -994,15 +1008,19 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize_b3(const float* __restric
 
   const int blk = blockIdx.x, pair = blockIdx.y;
   const int el = threadIdx.x & 255, rg = threadIdx.x >> 8;
-  if (NPOSE == 12) rebuild_valid0_shadow(BYVAL ? one : pairs[pair], W, H, launch_id, blk, (int)gridDim.x);
+  const SfmPairDev& PD = BYVAL ? one : pairs[pair];
+  const int W = ragged ? (int)PD.w_px : Wk, H = ragged ? (int)PD.h_px : Hk;
+  const int nparts = ragged ? (int)PD.nblk : bpp;
+  const size_t part0 = ragged ? (size_t)PD.blk0 : (size_t)pair * bpp;
+  if (NPOSE == 12) rebuild_valid0_shadow(PD, W, H, launch_id, blk, (int)gridDim.x);
   if (qhead && blk == 0 && threadIdx.x == 0) qhead[pair] = 0u;
-  const float* src = partials + (size_t)pair * bpp * ZDIM + blk * 256 + el;
-  red[rg][el] = strided_sum_f64<4, 16>(src, rg, bpp, ZDIM);
+  const float* src = partials + part0 * ZDIM + blk * 256 + el;
+  red[rg][el] = strided_sum_f64<4, 16>(src, rg, nparts, ZDIM);
   // blocks with an N part in block NT3 + d: d = 0 (P,P): N = P_l x [P_h P_m]; d = 1 + b (C_b,C_b), four-product diagonals: N = hm + hl
   int dtile = -1;
   if (blk == 0) dtile = 0;
   else if (b3_diag4(NCB) && blk > NCB) { int q = blk - 1 - NCB; for (int b = 0; b < NCB; ++b) { if (q == 0) { dtile = 1 + b; break; } q -= NCB - b; if (q < 0) break; } }
-  if (dtile >= 0) redn[rg][el] = strided_sum_f64<4, 16>(partials + (size_t)pair * bpp * ZDIM + (NT3 + dtile) * 256 + el, rg, bpp, ZDIM);
+  if (dtile >= 0) redn[rg][el] = strided_sum_f64<4, 16>(partials + part0 * ZDIM + (NT3 + dtile) * 256 + el, rg, nparts, ZDIM);
   if (NPOSE == 12 && threadIdx.x < 72) {
     const int n = threadIdx.x / 6, i = threadIdx.x - n * 6;
     const float* M = BYVAL ? one.M : pairs[pair].M;
@@ -1120,13 +1138,17 @@ template <int NCB, int MODE>
 static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm, int bpp,
                            float* partials_dev, void* items_dev, size_t item_stride, hipStream_t stream, bool jac_dense, int prec,
                            hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, const SfmPairDev* one_host = nullptr,
-                           const DynDev* dyn = nullptr, int dyn_grid = 0, bool vsh = false, hipStream_t fin_stream = nullptr, hipEvent_t ev_mid = nullptr) {
+                           const DynDev* dyn = nullptr, int dyn_grid = 0, bool vsh = false, hipStream_t fin_stream = nullptr, hipEvent_t ev_mid = nullptr,
+                           const unsigned* blkmap = nullptr, int total_blocks = 0) {
   constexpr int NACC = NCB * (NCB - 1) / 2 + NCB + 2 * ((NCB + 1) / 2);   // 256-float blocks after block 0 (16x16x4 and 4x4x1 accumulators)
   hipError_t e;
   if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
-  const dim3 grid(bpp, npairs), block(kThreads);
+  const bool ragged_l = blkmap != nullptr;
+  const dim3 grid = ragged_l ? dim3(total_blocks) : dim3(bpp, npairs);
+  const dim3 block(kThreads);
+  const int ragged = ragged_l ? 1 : 0;
   const bool b3 = prec == 1;   // DFX_MFMA_BF16X3 (include/dfx.h): exact three-way bf16 split on v_mfma_f32_16x16x32_bf16; 0: the fp32 chain
-  if (((long long)W * H) % 64 != 0) jac_dense = false;   // ragged last chunk: the per-vector addressing clamps pixels past the image
+  if (!ragged_l && ((long long)W * H) % 64 != 0) jac_dense = false;   // ragged last chunk: the per-vector addressing clamps pixels past the image (pairs of several sizes: checked by the caller)
   // the ray table rides in dynamic LDS when it fits beside the static arrays (64 KB per workgroup); MODE 1 has no table
   constexpr int kZMax = (1 + NACC) * 256 > b3_blocks(NCB) * 256 ? (1 + NACC) * 256 : b3_blocks(NCB) * 256;   // either evaluation mode
   constexpr size_t kStaticLds = sizeof(float) * (size_t)kWaves * ((kUFloats > kZMax) ? kUFloats : kZMax);
@@ -1149,7 +1171,7 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
     // dynamic schedule: a resident grid of wave-workers (see k_sfm_step); partials = [pair][team member]
     if constexpr (MODE == 0) {
       const size_t dlds = sizeof(float) * (size_t)kWaves * ((size_t)W + H + kRayTabSlack);
-#define DFX_LAUNCH_DYN(B3_, VSH_) hipLaunchKernelGGL((k_sfm_step<NCB, 0, true, true, false, true, B3_, VSH_>), dim3(dyn_grid), block, dlds, stream, pairs_dev, one, prm, W, H, partials_dev, *dyn)
+#define DFX_LAUNCH_DYN(B3_, VSH_) hipLaunchKernelGGL((k_sfm_step<NCB, 0, true, true, false, true, B3_, VSH_>), dim3(dyn_grid), block, dlds, stream, pairs_dev, one, prm, W, H, partials_dev, *dyn, (const unsigned*)nullptr)
       if (b3) { if (vsh) DFX_LAUNCH_DYN(true, true); else DFX_LAUNCH_DYN(true, false); }
       else { if (vsh) DFX_LAUNCH_DYN(false, true); else DFX_LAUNCH_DYN(false, false); }
 #undef DFX_LAUNCH_DYN
@@ -1158,16 +1180,16 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
       if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
       if ((e = to_fin_stream()) != hipSuccess) return e;
       if (b3) hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, 12, false>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
-                                 (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id);
+                                 (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0);
       else hipLaunchKernelGGL((k_sfm_finalize<NCB, 12, false>), dim3(1 + NACC, npairs), dim3(1024), 0, fstream,
-                              (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id);
+                              (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0);
       return hipGetLastError();
     }
   }
 #define DFX_LAUNCH_STEP__(M_, JD_, TL_, B3_, VSH_)                                                                                                  \
   do {                                                                                                                                             \
-    if (byval) hipLaunchKernelGGL((k_sfm_step<NCB, M_, JD_, TL_, true, false, B3_, VSH_>), grid, block, dyn_lds, stream, (const SfmPairDev*)nullptr, one, prm, W, H, partials_dev, nodyn); \
-    else hipLaunchKernelGGL((k_sfm_step<NCB, M_, JD_, TL_, false, false, B3_, VSH_>), grid, block, dyn_lds, stream, pairs_dev, one, prm, W, H, partials_dev, nodyn);              \
+    if (byval) hipLaunchKernelGGL((k_sfm_step<NCB, M_, JD_, TL_, true, false, B3_, VSH_>), grid, block, dyn_lds, stream, (const SfmPairDev*)nullptr, one, prm, W, H, partials_dev, nodyn, (const unsigned*)nullptr); \
+    else hipLaunchKernelGGL((k_sfm_step<NCB, M_, JD_, TL_, false, false, B3_, VSH_>), grid, block, dyn_lds, stream, pairs_dev, one, prm, W, H, partials_dev, nodyn, blkmap);              \
   } while (0)
 #define DFX_LAUNCH_STEP_(M_, JD_, TL_, B3_) do { if (M_ == 0 && vsh) DFX_LAUNCH_STEP__(M_, JD_, TL_, B3_, (M_ == 0)); else DFX_LAUNCH_STEP__(M_, JD_, TL_, B3_, false); } while (0)
 #define DFX_LAUNCH_STEP(M_, JD_, TL_) do { if (b3) DFX_LAUNCH_STEP_(M_, JD_, TL_, true); else DFX_LAUNCH_STEP_(M_, JD_, TL_, false); } while (0)
@@ -1187,14 +1209,14 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   const SfmPairDev* fpairs = byval ? (const SfmPairDev*)nullptr : pairs_dev;
   if (b3) {
     if (byval) hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, true>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
-                                  (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id);
+                                  (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged);
     else hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, false>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
-                            (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id);
+                            (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged);
   } else {
     if (byval) hipLaunchKernelGGL((k_sfm_finalize<NCB, NPOSE, true>), dim3(1 + NACC, npairs), dim3(1024), 0, fstream,
-                                  (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id);
+                                  (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged);
     else hipLaunchKernelGGL((k_sfm_finalize<NCB, NPOSE, false>), dim3(1 + NACC, npairs), dim3(1024), 0, fstream,
-                            (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id);
+                            (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged);
   }
   return hipGetLastError();
 }
@@ -1202,11 +1224,11 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
 hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm,
                            int blocks_per_pair, float* partials_dev, void* items_dev, size_t item_stride,
                            hipStream_t stream, bool jac_dense, int prec, hipEvent_t eb, hipEvent_t ee, const SfmPairDev* one_host,
-                           const DynDev* dyn, int dyn_grid, bool vsh, hipStream_t fin_stream, hipEvent_t ev_mid) {
+                           const DynDev* dyn, int dyn_grid, bool vsh, hipStream_t fin_stream, hipEvent_t ev_mid, const unsigned* blkmap_dev, int total_blocks) {
   switch (cs) {
-    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid);
-    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid);
-    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid);
+    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks);
+    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks);
+    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks);
     default: return hipErrorInvalidValue;
   }
 }

@@ -280,7 +280,10 @@ typedef struct dfx_sfm_pair {
 /* Batched RunStep over n independent pairs in ONE launch (new; the reference evaluates pairs one by one
  * from PhotometricFactor::linearize, photometric_factor.cpp:267-274).  Enqueues on the context's stream and
  * returns immediately; item p is written to DEVICE memory at (char*)out_items_dev + p*dfx_item_size(12+cs).
- * All pairs must share (w, h) -- one pyramid level per batch. */
+ * The pairs of a batch may differ in image size -- e.g. all pyramid levels of a factor set in ONE launch, as the reference's
+ * relinearisation walks them (core/mapping/df_work.cpp:118-136, tools/kernel_benchmark.cpp:192-203): every pair then gets workgroups in
+ * proportion to its pixel count (a 160x120 level 1/16 of a 640x480 one), the large pairs are dispatched first and the small levels
+ * fill the tail of the launch.  Each pair's images must agree with its own img0 size.  (The dynamic schedule needs one size.) */
 DFX_API int dfx_sfm_step_batch_async(dfx_ctx* ctx, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs,
                                      int n, void* out_items_dev);
 /* Same, then copies the n items to `out_items_host` and waits. */

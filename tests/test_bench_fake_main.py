@@ -250,7 +250,7 @@ def test_main_with_the_secondary_configurations(tmp_path, monkeypatch):
                       "update_depth_batch_64kf", "se3_step_batch_128pairs", "sfm_error_batch_128pairs", "configs3_window64"}
     assert c["headline_workload_other_mode"]["kernel_us"] > 0 and "error" not in c["headline_workload_other_mode"] and "fp32 fmaf chain" in c["headline_workload_other_mode"]["mfma"]
     assert c["configs4_1280x960_cs64"]["f32_chain"]["kernel_us"] > 0 and "error" not in c["configs4_1280x960_cs64"]["f32_chain"]
-    assert c["configs4_1280x960_cs64"]["frac"] > 0 and len(c["configs1_pyramid3_128pairs"]["level_kernel_us"]) == 3
+    assert c["configs4_1280x960_cs64"]["frac"] > 0 and len(c["configs1_pyramid3_128pairs"]["level_by_level_kernel_us"]) == 3 and c["configs1_pyramid3_128pairs"]["one_launch_kernel_us"] > 0
     for k in ("update_depth_batch_64kf", "se3_step_batch_128pairs", "sfm_error_batch_128pairs"):
         assert c[k]["us"] > 0 and c[k]["frac"] > 0
 

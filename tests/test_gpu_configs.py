@@ -262,3 +262,51 @@ def test_dynamic_schedule_matches_the_oracle_and_the_static_schedule(dfx, oracle
     for a, b in zip(valid_dyn, valid_sta):
         assert torch.equal(a, b)
     assert any(float(v.max()) == 1.0 for v in valid_dyn)
+
+
+@pytest.mark.parametrize("mode", ["auto", "f32"])
+def test_pyramid_levels_in_one_launch(dfx, oracle, mode):
+    """A batch whose pairs differ in image size: the three pyramid levels (640x480, 320x240, 160x120) of four factor sets in ONE launch
+    (1-D grid, workgroups per pair in proportion to the pixel count, large pairs first).  Every item against the fp64 oracle, against the
+    same pairs launched level by level, bit-reproducible, valid0 maps (library-owned, shadowed) written per level; then the same through
+    dfx_sfm_linearize_batch (one decoder launch per image size)."""
+    from deepfactors_amd import _lib, synth
+    cs = 32
+    ctx = dfx.Context(0)
+    ctx.set_mfma_mode(_lib.DFX_MFMA_AUTO if mode == "auto" else _lib.DFX_MFMA_F32_CHAIN)
+    al = dfx.SfmAligner(code_size=cs, ctx=ctx)
+    sizes = [(640, 480), (320, 240), (160, 120)]
+    plist, meta = [], []
+    for k in range(4):
+        for lv, (w, h) in enumerate(sizes):
+            p = synth.make_pair(w, h, cs, seed=0x9A0 + k, device="cpu", motion_scale=0.5 + 0.15 * k)
+            n, g = synth.to_numpy(p), synth.to_device(p, "cuda")
+            vld = ctx.alloc_image(w, h)
+            plist.append(dict(pose0=n["pose0"], pose1=n["pose1"], cam=n["cam"], img0=g["img0"], img1=g["img1"], dpt0=g["dpt0"], prx0_jac=g["prx_jac"],
+                              grad1=g["grad1"], valid0=vld))
+            meta.append((w, h, n, g, vld))
+    # interleaved order on purpose: the library sorts the workgroups by size itself
+    items = al.RunStepBatch(al.make_pairs(plist))
+    again = al.RunStepBatch(al.make_pairs(plist))
+    for q, (it, (w, h, n, g, vld)) in enumerate(zip(items, meta)):
+        vref = np.zeros_like(n["img0"])
+        ref = oracle.sfm_step(n["pose0"], n["pose1"], n["cam"], n["img0"], n["img1"], n["dpt0"], n["prx_jac"], n["grad1"], valid0=vref, accum_f64=True)
+        assert_item_close(it, ref, w, h, what=f"mixed batch pair {q} ({w}x{h})")
+        assert np.array_equal(it.raw, again[q].raw), "a mixed batch is bit-reproducible like any static launch"
+        v = vld.download()
+        assert int((v != vref).sum()) <= max(1, int(1e-5 * w * h))
+        assert np.array_equal(vld.valid0_shadow(), v == 1.0)
+    # level by level (one image size per launch): same sums up to fp32 re-association (the number of workgroups per pair differs)
+    for lv in range(3):
+        sel = [q for q in range(len(plist)) if q % 3 == lv]
+        sub = al.RunStepBatch(al.make_pairs([plist[q] for q in sel]))
+        for q, it in zip(sel, sub):
+            assert it.inliers == items[q].inliers
+            assert np.abs(it.JtJ.astype(np.float64) - items[q].JtJ).max() <= 3e-6 * np.abs(items[q].JtJ).max()
+    # the decoder in front: dpt0 of every pair is re-decoded from (prx_orig, prx_jac, code), one launch per size, then the mixed step
+    prx = [m[3]["prx_orig"] for m in meta]
+    codes = np.stack([m[2]["code"] for m in meta])
+    lin = al.LinearizeBatch(al.make_pairs(plist), prx, codes)
+    for q, it in enumerate(lin):
+        assert it.inliers == items[q].inliers
+        assert np.abs(it.JtJ.astype(np.float64) - items[q].JtJ).max() <= 2e-5 * np.abs(items[q].JtJ).max()   # dpt0 is decoded in fp32 here, in fp64 by the generator
