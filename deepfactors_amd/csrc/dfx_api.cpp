@@ -385,7 +385,7 @@ int simple_blocks(uint32_t W, uint32_t H) {
   return b < 1 ? 1 : b;
 }
 
-int fill_simple(const dfx_se3* pose_10, const dfx_cam* cam, const dfx_img* img0, const dfx_img* img1, const dfx_img* dpt0,
+int fill_simple(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam, const dfx_img* img0, const dfx_img* img1, const dfx_img* dpt0,
                 const dfx_img* grad1, const dfx_img* img2, dfx::SimplePairDev* d) {
   if (!pose_10 || !cam) return fail(DFX_E_INVALID, "null pose/camera");
   if (!img_ok(img0)) return fail(DFX_E_INVALID, "img0: null or empty image view");
@@ -403,6 +403,7 @@ int fill_simple(const dfx_se3* pose_10, const dfx_cam* cam, const dfx_img* img0,
   d->pitch_img0 = (uint32_t)img0->pitch_bytes; d->pitch_img1 = (uint32_t)img1->pitch_bytes;
   d->pitch_dpt0 = (uint32_t)dpt0->pitch_bytes;
   d->grad1 = nullptr; d->pitch_grad1 = 0; d->img2 = nullptr; d->pitch_img2 = 0;
+  if ((rc = ray_table(c, cam, W, H, &d->ray_tab))) return rc;   // K^-1 (x, y, 1) per column / row, staged in LDS by the reduction kernels
   if (grad1) {
     if ((rc = check_img(grad1, "grad1", W, H, 8))) return rc;
     if (((uintptr_t)grad1->ptr | grad1->pitch_bytes) & 7) return fail(DFX_E_INVALID, "grad1: pointer/pitch must be 8-byte aligned");
@@ -1097,12 +1098,13 @@ DFX_API int dfx_sfm_error(dfx_ctx* c, const dfx_se3* pose0, const dfx_se3* pose1
   if (!c || !pose0 || !pose1 || !params || !out) return fail(DFX_E_INVALID, "dfx_sfm_error: null argument");
   int rc;
   if ((rc = ensure_device(c))) return rc;
+  if ((rc = ray_table_gc(c))) return rc;
   dfx_se3 p10;
   float R10[9], HM[9];
   relative_pose(*pose0, *pose1, R10, p10.t, nullptr, HM);
   dfx::SimplePairDev d;
   p10.q[0] = p10.q[1] = p10.q[2] = 0; p10.q[3] = 1;
-  if ((rc = fill_simple(&p10, cam, img0, img1, dpt0, nullptr, nullptr, &d))) return rc;
+  if ((rc = fill_simple(c, &p10, cam, img0, img1, dpt0, nullptr, nullptr, &d))) return rc;
   for (int i = 0; i < 9; ++i) d.R[i] = R10[i];
   const int blocks = simple_blocks(img0->w, img0->h);
   const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
@@ -1151,6 +1153,7 @@ DFX_API int dfx_sfm_error_batch_async(dfx_ctx* c, const dfx_sfm_params* params, 
   if (n <= 0 || n > 65535) return fail(DFX_E_INVALID, "batch size %d out of range [1,65535]", n);
   int rc;
   if ((rc = ensure_device(c))) return rc;
+  if ((rc = ray_table_gc(c))) return rc;
   if (!img_ok(&pairs[0].img0)) return fail(DFX_E_INVALID, "pair 0: img0 null or empty");
   const uint32_t W = pairs[0].img0.w, H = pairs[0].img0.h;
   std::vector<dfx::SimplePairDev> descs((size_t)n);
@@ -1160,7 +1163,7 @@ DFX_API int dfx_sfm_error_batch_async(dfx_ctx* c, const dfx_sfm_params* params, 
     relative_pose(pairs[p].pose0, pairs[p].pose1, R10, p10.t, nullptr, HM);
     p10.q[0] = p10.q[1] = p10.q[2] = 0; p10.q[3] = 1;
     if (pairs[p].img0.w != W || pairs[p].img0.h != H) return fail(DFX_E_INVALID, "pair %d: image size differs from pair 0 (one pyramid level per batch)", p);
-    if ((rc = fill_simple(&p10, &pairs[p].cam, &pairs[p].img0, &pairs[p].img1, &pairs[p].dpt0, nullptr, nullptr, &descs[p]))) {
+    if ((rc = fill_simple(c, &p10, &pairs[p].cam, &pairs[p].img0, &pairs[p].img1, &pairs[p].dpt0, nullptr, nullptr, &descs[p]))) {
       g_last_error = "pair " + std::to_string(p) + ": " + g_last_error;
       return rc;
     }
@@ -1198,12 +1201,13 @@ DFX_API int dfx_se3_step_batch_async(dfx_ctx* c, const dfx_se3_pair* pairs, int 
   if (n <= 0 || n > 65535) return fail(DFX_E_INVALID, "batch size %d out of range [1,65535]", n);
   int rc;
   if ((rc = ensure_device(c))) return rc;
+  if ((rc = ray_table_gc(c))) return rc;
   if (!img_ok(&pairs[0].img0)) return fail(DFX_E_INVALID, "pair 0: img0 null or empty");
   const uint32_t W = pairs[0].img0.w, H = pairs[0].img0.h;
   std::vector<dfx::SimplePairDev> descs((size_t)n);
   for (int p = 0; p < n; ++p) {
     if (pairs[p].img0.w != W || pairs[p].img0.h != H) return fail(DFX_E_INVALID, "pair %d: image size differs from pair 0 (one pyramid level per batch)", p);
-    if ((rc = fill_simple(&pairs[p].pose_10, &pairs[p].cam, &pairs[p].img0, &pairs[p].img1, &pairs[p].dpt0, &pairs[p].grad1, nullptr, &descs[p]))) {
+    if ((rc = fill_simple(c, &pairs[p].pose_10, &pairs[p].cam, &pairs[p].img0, &pairs[p].img1, &pairs[p].dpt0, &pairs[p].grad1, nullptr, &descs[p]))) {
       g_last_error = "pair " + std::to_string(p) + ": " + g_last_error;
       return rc;
     }
@@ -1242,8 +1246,9 @@ DFX_API int dfx_se3_step(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam,
   if (!c || !out_item || !grad1) return fail(DFX_E_INVALID, "dfx_se3_step: null argument");
   int rc;
   if ((rc = ensure_device(c))) return rc;
+  if ((rc = ray_table_gc(c))) return rc;
   dfx::SimplePairDev d;
-  if ((rc = fill_simple(pose_10, cam, img0, img1, dpt0, grad1, nullptr, &d))) return rc;
+  if ((rc = fill_simple(c, pose_10, cam, img0, img1, dpt0, grad1, nullptr, &d))) return rc;
   const int blocks = simple_blocks(img0->w, img0->h);
   const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
   if ((rc = grow_partials(c, pbytes))) return rc;
@@ -1258,8 +1263,9 @@ DFX_API int dfx_se3_warp(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam,
   if (!c || !out || !img2_out) return fail(DFX_E_INVALID, "dfx_se3_warp: null argument");
   int rc;
   if ((rc = ensure_device(c))) return rc;
+  if ((rc = ray_table_gc(c))) return rc;
   dfx::SimplePairDev d;
-  if ((rc = fill_simple(pose_10, cam, img0, img1, dpt0, nullptr, img2_out, &d))) return rc;
+  if ((rc = fill_simple(c, pose_10, cam, img0, img1, dpt0, nullptr, img2_out, &d))) return rc;
   if ((rc = img_note_write(c, img2_out))) return rc;
   const int blocks = simple_blocks(img0->w, img0->h);
   const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
@@ -1290,6 +1296,7 @@ int track_frames_impl(dfx_ctx* c, int n, const dfx_se3* pose_init, const dfx_tra
   if (n_levels <= 0 || n_levels > 16) return fail(DFX_E_INVALID, "n_levels %d out of range [1,16]", n_levels);
   int rc;
   if ((rc = ensure_device(c))) return rc;
+  if ((rc = ray_table_gc(c))) return rc;
   // one staged upload: [TrackState x n][SimplePairDev x n_levels x n (level-major)]
   const size_t sbytes = dfx::track_state_bytes();
   const size_t off_desc = ((sbytes * (size_t)n + 15) / 16) * 16;
@@ -1308,7 +1315,7 @@ int track_frames_impl(dfx_ctx* c, int n, const dfx_se3* pose_init, const dfx_tra
       if (L.iterations < 0) return fail(DFX_E_INVALID, "candidate %d level %d: negative iteration count", k, l);
       if (L.iterations != L0.iterations || L.img0.w != L0.img0.w || L.img0.h != L0.img0.h)
         return fail(DFX_E_INVALID, "candidate %d level %d: schedule / image size differs from candidate 0", k, l);
-      if ((rc = fill_simple(&ident, &L.cam, &L.img0, &L.img1, &L.dpt0, &L.grad1, nullptr, &hdesc[(size_t)l * n + k]))) {
+      if ((rc = fill_simple(c, &ident, &L.cam, &L.img0, &L.img1, &L.dpt0, &L.grad1, nullptr, &hdesc[(size_t)l * n + k]))) {
         g_last_error = "candidate " + std::to_string(k) + " level " + std::to_string(l) + ": " + g_last_error;
         return rc;
       }

@@ -68,6 +68,7 @@ struct SimplePairDev {   // SE3Aligner / EvaluateError / Warp
   const float* dpt0;
   const float* grad1;   // null for error / warp
   float* img2;          // warp output or null
+  const float* ray_tab; // per-camera ray table ([W] (x - u0) / fx, then [H ...] (y - v0) / fy) or null: the rays are then computed per pixel
   uint32_t pitch_img0, pitch_img1, pitch_dpt0, pitch_grad1, pitch_img2;
 };
 

@@ -40,21 +40,60 @@ __device__ __forceinline__ Geo geo_from(const SimplePairDev& p) {
   return g;
 }
 
+// ---- the per-thread pixel walk shared by the reductions below -------------------------------------------------------
+// Thread t of workgroup b visits pixels b * kT + t, + gridDim.x * kT, ...: (x, y) advance by a fixed step (no division per pixel), the
+// depth / intensity of the NEXT pixel are loaded before the current one is processed (their latency hides under the warp + taps + sums
+// of the current pixel), and K^-1 (x, y, 1) comes from the per-camera ray table staged in LDS (the same IEEE expressions the reference
+// evaluates per pixel, pinhole_camera_impl.h:77-86, evaluated once per column / row on the host: dfx_api.cpp ray_table) instead of two
+// IEEE divisions per pixel.  These operators are vector-ALU bound (exact-IEEE geometry: ~150-200 instructions per pixel), not HBM bound.
+struct RayLds {
+  const float* tab;   // LDS: [W] x rays, [H] y rays; null -> compute
+  int W;
+};
+template <bool TAB>
+__device__ __forceinline__ RayLds stage_ray_table(const float* __restrict__ ray_tab, float* lds_tab, int W, int H) {
+  if (!TAB) return RayLds{ nullptr, W };
+  for (int e = threadIdx.x; e < W + H; e += kT) lds_tab[e] = ray_tab[e];
+  __syncthreads();
+  return RayLds{ lds_tab, W };
+}
+constexpr int kRayLdsMax = 4096;   // floats of LDS a simple kernel spends on the table (W + H <= 4096; larger images compute the rays)
+
+template <bool TAB, typename F>
+__device__ __forceinline__ void walk_pixels(const Geo& g, const SimplePairDev& p, const RayLds& rt, const int W, const int H, const float border,
+                                            const float min_dpt, F&& body) {
+  const ImgRef I0{ (const char*)p.img0, p.pitch_img0 }, D0{ (const char*)p.dpt0, p.pitch_dpt0 };
+  const unsigned npx = (unsigned)W * (unsigned)H;
+  const unsigned step = gridDim.x * kT;
+  unsigned i = blockIdx.x * kT + threadIdx.x;
+  if (i >= npx) return;
+  int y = (int)(i / (unsigned)W), x = (int)(i - (unsigned)y * (unsigned)W);
+  const int sdy = (int)(step / (unsigned)W), sdx = (int)(step - (unsigned)sdy * (unsigned)W);
+  float d = D0.at(x, y), i0 = I0.at(x, y);
+  while (true) {
+    const unsigned inext = i + step;
+    int xn = x + sdx, yn = y + sdy;
+    if (xn >= W) { xn -= W; ++yn; }
+    const bool more = inext < npx;
+    const int xl = more ? xn : x, yl = more ? yn : y;   // last pixel: a harmless re-load of itself
+    const float dn = D0.at(xl, yl), i0n = I0.at(xl, yl);
+    const Corr c = TAB ? find_correspondence_ray(g, rt.tab[x], rt.tab[rt.W + y], d, border, min_dpt) : find_correspondence(g, x, y, d, border, min_dpt);
+    body(x, y, d, i0, c);
+    if (!more) break;
+    i = inext; x = xn; y = yn; d = dn; i0 = i0n;
+  }
+}
+
 // ---- SE3 step: 21 JtJ + 6 Jtr + r^2 + inliers = 29 floats per lane -----------------------------------------
 // Per-lane sums of one SE3 Gauss-Newton step over this thread's pixels (lucas_kanade_se3.h:41-77): shared by the blocking
 // operator and by the device-resident tracker.
-__device__ __forceinline__ void se3_accumulate(const Geo& g, const SimplePairDev& p, const int W, const int H, const float huber_delta,
+template <bool TAB>
+__device__ __forceinline__ void se3_accumulate(const Geo& g, const SimplePairDev& p, const RayLds& rt, const int W, const int H, const float huber_delta,
                                                float (&acc)[29]) {
-  const ImgRef I0{ (const char*)p.img0, p.pitch_img0 }, I1{ (const char*)p.img1, p.pitch_img1 };
-  const ImgRef D0{ (const char*)p.dpt0, p.pitch_dpt0 }, G1{ (const char*)p.grad1, p.pitch_grad1 };
+  const ImgRef I1{ (const char*)p.img1, p.pitch_img1 }, G1{ (const char*)p.grad1, p.pitch_grad1 };
 #pragma unroll
   for (int q = 0; q < 29; ++q) acc[q] = 0.f;
-  const int npx = W * H;
-  for (int i = blockIdx.x * kT + threadIdx.x; i < npx; i += gridDim.x * kT) {
-    const int y = i / W, x = i - y * W;
-    const float d = D0.at(x, y);
-    const float i0 = I0.at(x, y);
-    const Corr c = find_correspondence(g, x, y, d, 1.0f, 0.0f);
+  walk_pixels<TAB>(g, p, rt, W, H, 1.0f, 0.0f, [&](int, int, float d, float i0, const Corr& c) {
     if (c.valid) {
       const Taps tp = make_taps(c.u, c.v);
       float gx, gy;
@@ -77,14 +116,17 @@ __device__ __forceinline__ void se3_accumulate(const Geo& g, const SimplePairDev
       acc[27] += r * r;
       acc[28] += 1.0f;
     }
-  }
+  });
 }
 
+template <bool TAB>
 __global__ __launch_bounds__(kT) void k_se3_step(const SimplePairDev p, const int W, const int H, const float huber_delta,
                                                  float* __restrict__ partials) {
+  __shared__ float ray_lds[TAB ? kRayLdsMax : 1];
   const Geo g = geo_from(p);
+  const RayLds rt = stage_ray_table<TAB>(p.ray_tab, ray_lds, W, H);
   float acc[29];
-  se3_accumulate(g, p, W, H, huber_delta, acc);
+  se3_accumulate<TAB>(g, p, rt, W, H, huber_delta, acc);
   block_reduce_store<29>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
@@ -100,6 +142,7 @@ struct TrackState {      // device-resident
 
 // blockIdx.y = candidate: Relocalize / the loop-closure geometry checks track ONE live frame against N keyframes
 // (deepfactors.cpp:713-743, loop_detector.cpp:146-167); descriptors, states and partials are arrays over candidates.
+template <bool TAB>
 __global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev* __restrict__ descs, const TrackState* __restrict__ states, const int W,
                                                      const int H, const float huber_delta, float* __restrict__ partials_all) {
   const SimplePairDev& p = descs[blockIdx.y];
@@ -109,8 +152,10 @@ __global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev* __rest
 #pragma unroll
   for (int q = 0; q < 9; ++q) g.R[q] = st->Rf[q];
   g.t[0] = st->tf[0]; g.t[1] = st->tf[1]; g.t[2] = st->tf[2];
+  __shared__ float ray_lds[TAB ? kRayLdsMax : 1];
+  const RayLds rt = stage_ray_table<TAB>(p.ray_tab, ray_lds, W, H);
   float acc[29];
-  se3_accumulate(g, p, W, H, huber_delta, acc);
+  se3_accumulate<TAB>(g, p, rt, W, H, huber_delta, acc);
   block_reduce_store<29>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
@@ -218,7 +263,8 @@ size_t track_state_bytes() { return sizeof(TrackState); }
 
 hipError_t launch_track_iteration(const SimplePairDev* descs_dev, int n, void* states_dev, int W, int H, float huber_delta, int blocks,
                                   float* partials_dev, hipStream_t stream) {
-  hipLaunchKernelGGL(k_se3_step_dev, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (const TrackState*)states_dev, W, H, huber_delta, partials_dev);
+  const bool tab_ok = W + H <= kRayLdsMax;   // the per-camera ray table fits the kernels' LDS budget (every descriptor carries one)
+  if (tab_ok) hipLaunchKernelGGL((k_se3_step_dev<true>), dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (const TrackState*)states_dev, W, H, huber_delta, partials_dev); else hipLaunchKernelGGL((k_se3_step_dev<false>), dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (const TrackState*)states_dev, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_track_update, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (TrackState*)states_dev);
@@ -341,17 +387,12 @@ hipError_t launch_sparse_geometric(int cs, const void* desc_host, const float* c
 }
 
 // ---- SfM error: sum (w r)^2, inliers -----------------------------------------------------------------------
-__device__ __forceinline__ void sfm_error_accumulate(const Geo& g, const SimplePairDev& p, const int W, const int H, const float huber_delta,
+template <bool TAB>
+__device__ __forceinline__ void sfm_error_accumulate(const Geo& g, const SimplePairDev& p, const RayLds& rt, const int W, const int H, const float huber_delta,
                                                      float (&acc)[2]) {
-  const ImgRef I0{ (const char*)p.img0, p.pitch_img0 }, I1{ (const char*)p.img1, p.pitch_img1 };
-  const ImgRef D0{ (const char*)p.dpt0, p.pitch_dpt0 };
+  const ImgRef I1{ (const char*)p.img1, p.pitch_img1 };
   acc[0] = acc[1] = 0.f;
-  const int npx = W * H;
-  for (int i = blockIdx.x * kT + threadIdx.x; i < npx; i += gridDim.x * kT) {
-    const int y = i / W, x = i - y * W;
-    const float d = D0.at(x, y);
-    const float i0 = I0.at(x, y);
-    const Corr c = find_correspondence(g, x, y, d, 1.0f, 0.0f);   // dense_sfm.h:91: default border 1, min_dpt 0
+  walk_pixels<TAB>(g, p, rt, W, H, 1.0f, 0.0f, [&](int, int, float, float i0, const Corr& c) {   // dense_sfm.h:91: default border 1, min_dpt 0
     if (c.valid) {
       const Taps tp = make_taps(c.u, c.v);
       float r = i0 - sample_img(I1, tp);
@@ -359,35 +400,44 @@ __device__ __forceinline__ void sfm_error_accumulate(const Geo& g, const SimpleP
       acc[0] += r * r;
       acc[1] += 1.0f;
     }
-  }
+  });
 }
 
+template <bool TAB>
 __global__ __launch_bounds__(kT) void k_sfm_error(const SimplePairDev p, const int W, const int H, const float huber_delta,
                                                   float* __restrict__ partials) {
+  __shared__ float ray_lds[TAB ? kRayLdsMax : 1];
   const Geo g = geo_from(p);
+  const RayLds rt = stage_ray_table<TAB>(p.ray_tab, ray_lds, W, H);
   float acc[2];
-  sfm_error_accumulate(g, p, W, H, huber_delta, acc);
+  sfm_error_accumulate<TAB>(g, p, rt, W, H, huber_delta, acc);
   block_reduce_store<2>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
 // ---- batched forms (blockIdx.y = pair): PhotometricFactor::error over a factor set evaluates one pair per blocking call in the reference
 // (core/gtsam/photometric_factor.cpp:61-81,197-216); a relocalisation / loop-closure check steps one live frame against many keyframes.
 // Same per-pair arithmetic and reduction order as the single-pair kernels launched with the same number of workgroups.
+template <bool TAB>
 __global__ __launch_bounds__(kT) void k_sfm_error_batch(const SimplePairDev* __restrict__ descs, const int W, const int H, const float huber_delta,
                                                         float* __restrict__ partials_all) {
+  __shared__ float ray_lds[TAB ? kRayLdsMax : 1];
   const SimplePairDev& p = descs[blockIdx.y];
   const Geo g = geo_from(p);
+  const RayLds rt = stage_ray_table<TAB>(p.ray_tab, ray_lds, W, H);
   float acc[2];
-  sfm_error_accumulate(g, p, W, H, huber_delta, acc);
+  sfm_error_accumulate<TAB>(g, p, rt, W, H, huber_delta, acc);
   block_reduce_store<2>(acc, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
 }
 
+template <bool TAB>
 __global__ __launch_bounds__(kT) void k_se3_step_batch(const SimplePairDev* __restrict__ descs, const int W, const int H, const float huber_delta,
                                                        float* __restrict__ partials_all) {
+  __shared__ float ray_lds[TAB ? kRayLdsMax : 1];
   const SimplePairDev& p = descs[blockIdx.y];
   const Geo g = geo_from(p);
+  const RayLds rt = stage_ray_table<TAB>(p.ray_tab, ray_lds, W, H);
   float acc[29];
-  se3_accumulate(g, p, W, H, huber_delta, acc);
+  se3_accumulate<TAB>(g, p, rt, W, H, huber_delta, acc);
   block_reduce_store<29>(acc, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
 }
 
@@ -475,19 +525,29 @@ __device__ __forceinline__ void update_depth_body(const float* __restrict__ code
   const f32x4 c4 = *reinterpret_cast<const f32x4*>(code + 4 * q);
   const int npx = W * H;
   const int nchunks = (npx + 63) >> 6;
+  // Fast path (every image of the reference's pyramids): rows are whole chunks (W % 64 == 0), so a chunk lies in ONE image row and its
+  // 64 * CS Jacobian floats are one contiguous run -- no per-load row arithmetic, no bounds branches, and the stream is read with the
+  // non-temporal policy (read once; keeps the L2 for the 8 B/px of prx / depth traffic next to it).
+  const bool rows_are_chunks = (W & 63) == 0;
   for (int chunk = blockIdx.x * (kT / 64) + wave; chunk < nchunks; chunk += gridDim.x * (kT / 64)) {
     const int base = chunk << 6;
     const int y0 = base / W, x0 = base - y0 * W;
     // sub-step s: lane group `grp` handles pixel base + grp*NSUB + s  -> after NSUB steps lane l owns pixel base + l
     f32x4 v[NSUB];
+    if (rows_are_chunks) {
+      const f32x4* row = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>((const char*)jac + (size_t)y0 * pitch_jac) + (size_t)x0 * CS) + q;
 #pragma unroll
-    for (int s = 0; s < NSUB; ++s) {
-      const int off = grp * NSUB + s;
-      int x = x0 + off, y = y0;
-      while (x >= W) { x -= W; ++y; }
-      f32x4 t = f32x4{ 0.f, 0.f, 0.f, 0.f };
-      if (base + off < npx) t = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>((const char*)jac + (size_t)y * pitch_jac) + (size_t)x * CS + 4 * q);
-      v[s] = t;
+      for (int s = 0; s < NSUB; ++s) v[s] = __builtin_nontemporal_load(row + (grp * NSUB + s) * LPP);
+    } else {
+#pragma unroll
+      for (int s = 0; s < NSUB; ++s) {
+        const int off = grp * NSUB + s;
+        int x = x0 + off, y = y0;
+        while (x >= W) { x -= W; ++y; }
+        f32x4 t = f32x4{ 0.f, 0.f, 0.f, 0.f };
+        if (base + off < npx) t = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>((const char*)jac + (size_t)y * pitch_jac) + (size_t)x * CS + 4 * q);
+        v[s] = t;
+      }
     }
     float mine = 0.f;
 #pragma unroll
@@ -498,8 +558,8 @@ __device__ __forceinline__ void update_depth_body(const float* __restrict__ code
       if (q == s) mine = d;   // lane l = grp*LPP + q keeps pixel grp*NSUB + q = l (NSUB == LPP)
     }
     int x = x0 + lane, y = y0;
-    while (x >= W) { x -= W; ++y; }
-    if (base + lane < npx) {
+    if (!rows_are_chunks) while (x >= W) { x -= W; ++y; }
+    if (rows_are_chunks || base + lane < npx) {
       const float p0 = reinterpret_cast<const float*>((const char*)prx + (size_t)y * pitch_prx)[x];
       const float pr = p0 + mine;
       reinterpret_cast<float*>((char*)out + (size_t)y * pitch_out)[x] = avg_dpt / pr - avg_dpt;
@@ -576,7 +636,8 @@ __global__ __launch_bounds__(kT) void k_blur_down(const float* __restrict__ in, 
 // ---------------------------------------------------------------------------------------------------------------
 hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
                            void* item_dev, hipStream_t stream) {
-  hipLaunchKernelGGL(k_se3_step, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
+  const bool tab_ok = W + H <= kRayLdsMax;   // the per-camera ray table fits the kernels' LDS budget (every descriptor carries one)
+  if (tab_ok) hipLaunchKernelGGL((k_se3_step<true>), dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev); else hipLaunchKernelGGL((k_se3_step<false>), dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalItem6, (char*)item_dev, (size_t)0);
@@ -585,7 +646,8 @@ hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_del
 
 hipError_t launch_sfm_error(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
                             void* corr_item_dev, hipStream_t stream) {
-  hipLaunchKernelGGL(k_sfm_error, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
+  const bool tab_ok = W + H <= kRayLdsMax;   // the per-camera ray table fits the kernels' LDS budget (every descriptor carries one)
+  if (tab_ok) hipLaunchKernelGGL((k_sfm_error<true>), dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev); else hipLaunchKernelGGL((k_sfm_error<false>), dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalCorr, (char*)corr_item_dev, (size_t)0);
@@ -594,7 +656,8 @@ hipError_t launch_sfm_error(const SimplePairDev& p, int W, int H, float huber_de
 
 hipError_t launch_sfm_error_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
                                   void* corr_items_dev, hipStream_t stream) {
-  hipLaunchKernelGGL(k_sfm_error_batch, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
+  const bool tab_ok = W + H <= kRayLdsMax;   // the per-camera ray table fits the kernels' LDS budget (every descriptor carries one)
+  if (tab_ok) hipLaunchKernelGGL((k_sfm_error_batch<true>), dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev); else hipLaunchKernelGGL((k_sfm_error_batch<false>), dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_finalize_rows, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalCorr, (char*)corr_items_dev, (size_t)16);
@@ -603,7 +666,8 @@ hipError_t launch_sfm_error_batch(const SimplePairDev* descs_dev, int n, int W, 
 
 hipError_t launch_se3_step_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
                                  void* items_dev, hipStream_t stream) {
-  hipLaunchKernelGGL(k_se3_step_batch, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
+  const bool tab_ok = W + H <= kRayLdsMax;   // the per-camera ray table fits the kernels' LDS budget (every descriptor carries one)
+  if (tab_ok) hipLaunchKernelGGL((k_se3_step_batch<true>), dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev); else hipLaunchKernelGGL((k_se3_step_batch<false>), dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_finalize_rows, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalItem6, (char*)items_dev, (size_t)120);
