@@ -145,3 +145,35 @@ def huber_weight(x, delta):
 
 def depth_jacobian_prx(d, a):
     return float(lib().ref_depth_jacobian_prx_f32(d, a))
+
+
+def sparse_geometric(pose0_qt, pose1_qt, code0, code1, cam, points, prx0, jac0, prx1, jac1, dpt_grad1, huber_delta):
+    """The reference's SparseGeometricFactor<float,32>::linearize (core/gtsam/sparse_geometric_factor.cpp:147-275, compiled unmodified by
+    oracle/ref_harness_f3.cpp): rows [N][12 + 64 + 1] = [pose0 | pose1 | code0 | code1 | err] of the JacobianFactor (doubles, as GTSAM holds
+    them).  avg_dpt is 2.0 inside the reference."""
+    prx0, jac0, prx1, jac1, dpt_grad1 = (_f32(a).copy() for a in (prx0, jac0, prx1, jac1, dpt_grad1))
+    h, w = prx0.shape
+    assert jac0.reshape(h, -1).shape[1] == 32 * w, "the harness instantiates the reference's code size 32"
+    pts = np.ascontiguousarray(np.asarray(points, np.int32).reshape(-1, 2))
+    rows = np.zeros((len(pts), 12 + 64 + 1), np.float64)
+    L = lib()
+    L.ref_sparse_geometric_cs32.restype = C.c_int
+    rc = L.ref_sparse_geometric_cs32(_p(_f32(pose0_qt)), _p(_f32(pose1_qt)), _p(_f32(code0)), _p(_f32(code1)), _p(_f32(cam)), C.c_int(w), C.c_int(h), _p(pts),
+                                     C.c_int(len(pts)), _p(prx0), _p(jac0), _p(prx1), _p(jac1), _p(dpt_grad1), C.c_float(huber_delta), _p(rows))
+    if rc != 0:
+        raise RuntimeError(f"ref_sparse_geometric_cs32 failed: {rc}")
+    return rows
+
+
+def depth_aligner_step(code, tgt_dpt, prx_orig, prx_jac):
+    """The reference's kernel_depthaligner_run_step (cuda/cu_depthaligner.cpp:32-72, cut out at build time and run as a host loop over all
+    pixels in order, float accumulation like one CUDA thread): JTJJrReductionItem<float,32>.  avg_dpt is 2.0 inside the reference."""
+    tgt_dpt, prx_orig, prx_jac = (_f32(a).copy() for a in (tgt_dpt, prx_orig, prx_jac))
+    h, w = prx_orig.shape
+    assert prx_jac.reshape(h, -1).shape[1] == 32 * w
+    res = StepResult(32)
+    jtj, jtr = np.zeros(32 * 33 // 2, np.float32), np.zeros(32, np.float32)
+    r, n = C.c_float(0), C.c_uint64(0)
+    lib().ref_depth_aligner_step_cs32(_p(_f32(code)), _p(tgt_dpt), _p(prx_orig), _p(prx_jac), C.c_int(w), C.c_int(h), _p(jtj), _p(jtr), C.byref(r), C.byref(n))
+    res.JtJ, res.Jtr, res.residual, res.inliers = jtj.astype(np.float64), jtr.astype(np.float64), float(r.value), int(n.value)
+    return res

@@ -62,7 +62,44 @@ def main():
                     f"{name}_dpt": dpt})
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
+    make_f3(synth, ref)
+
+
+OUT_F3 = os.path.join(HERE, "ref_vectors_f3.npz")
+
+
+def make_f3(synth, ref):
+    """tests/golden/ref_vectors_f3.npz: SparseGeometricFactor<float,32>::linearize (core/gtsam/sparse_geometric_factor.cpp:147-275, compiled
+    unmodified) and kernel_depthaligner_run_step (cuda/cu_depthaligner.cpp:32-72) of the reference on stored inputs (oracle/ref_harness_f3.cpp)."""
+    from oracle import dfx_oracle as orc   # only for the Sobel gradient of kf1's depth, an INPUT of the factor (mapper.cpp:998-1000)
+    w, h, cs, npts = 64, 40, 32, 240
+    k0 = synth.to_numpy(synth.make_pair(w, h, cs, seed=0x6F30, device="cpu"))
+    k1 = synth.to_numpy(synth.make_pair(w, h, cs, seed=0x6F31, device="cpu", motion_scale=0.7))
+    rng = np.random.default_rng(0x6F3)
+    pts = np.stack([rng.integers(0, w, npts), rng.integers(0, h, npts)], axis=1).astype(np.int32)
+    dgrad1 = orc.sobel(k1["dpt0"]).astype(np.float32)
+    pose1 = k0["pose1"].copy(); pose1[4] += 0.08; pose1[5] -= 0.03
+    huber = 0.05
+    rows = ref.sparse_geometric(k0["pose0"], pose1, k0["code"], k1["code"], k0["cam"], pts, k0["prx_orig"], k0["prx_jac"], k1["prx_orig"], k1["prx_jac"], dgrad1, huber)
+    zero = ~rows.any(axis=1)
+    assert 0 < zero.sum() < npts
+    code = (k0["code"] + rng.normal(0, 0.05, cs)).astype(np.float32)
+    tgt = (k0["dpt0"] + rng.normal(0, 0.02, k0["dpt0"].shape)).astype(np.float32)
+    d = ref.depth_aligner_step(code, tgt, k0["prx_orig"], k0["prx_jac"])
+    out = dict(cam=k0["cam"], pose0=k0["pose0"], pose1=pose1.astype(np.float32), code0=k0["code"], code1=k1["code"], points=pts, huber=np.float32(huber),
+               prx0=k0["prx_orig"], jac0=k0["prx_jac"], prx1=k1["prx_orig"], jac1=k1["prx_jac"], dgrad1=dgrad1, sg_rows=rows,
+               da_code=code, da_tgt=tgt, da_JtJ=d.JtJ, da_Jtr=d.Jtr, da_residual=np.float64(d.residual), da_inliers=np.int64(d.inliers),
+               sources=np.frombuffer(b"core/gtsam/sparse_geometric_factor.cpp (unmodified, #included); cuda/cu_depthaligner.cpp:32-72 (kernel template, cut out at build time)",
+                                     dtype=np.uint8))
+    np.savez_compressed(OUT_F3, **out)
+    print("wrote", OUT_F3, os.path.getsize(OUT_F3), "bytes")
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--f3-only":   # the first file is left as committed
+        from deepfactors_amd import synth as _synth
+        from oracle import dfx_ref as _ref
+        _ref.build()
+        make_f3(_synth, _ref)
+    else:
+        main()

@@ -80,3 +80,50 @@ def test_hip_path_reproduces_the_reference_vectors(dfx, gold, name):
     out = torch.empty((h, w), dtype=torch.float32, device="cuda")
     dfx.UpdateDepth(g["code"], dev["prx_orig"], dev["prx_jac"], 2.0, out)
     assert np.abs(out.cpu().numpy() - g["dpt"]).max() <= 2e-6 * float(((2.0 + g["dpt"]) ** 2 / 2.0).max())
+
+
+# ---- the reference's SparseGeometricFactor::linearize and DepthAligner kernel on stored inputs (ref_vectors_f3.npz) -----------
+GOLD_F3 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_vectors_f3.npz")
+
+
+@pytest.fixture(scope="module")
+def gold_f3():
+    z = np.load(GOLD_F3)
+    return {k: z[k] for k in z.files}
+
+
+def _check_rows(got, want):
+    zg, zw = ~np.asarray(got, np.float64).any(axis=1), ~want.any(axis=1)
+    assert int((zg != zw).sum()) <= 1 and 0 < zw.sum() < len(want)
+    same = zg == zw
+    scale = np.abs(want).max(axis=0) + 1e-12
+    return float((np.abs(np.asarray(got, np.float64)[same] - want[same]) / scale).max())
+
+
+def test_oracle_reproduces_the_reference_f3_vectors(oracle, gold_f3):
+    g = gold_f3
+    assert b"sparse_geometric_factor.cpp" in bytes(g["sources"]) and g["sg_rows"].shape == (len(g["points"]), 77)
+    rows = oracle.sparse_geometric(g["pose0"], g["pose1"], g["code0"], g["code1"], g["cam"], g["points"], g["prx0"], g["jac0"], g["prx1"], g["jac1"], g["dgrad1"],
+                                   float(g["huber"]), avg_dpt=2.0)
+    assert _check_rows(rows, g["sg_rows"]) <= 2e-5
+    d = oracle.depth_aligner_step(g["da_code"], g["da_tgt"], g["prx0"], g["jac0"], 2.0, accum_f64=True)
+    sj = float(np.abs(g["da_JtJ"]).max())
+    assert d.inliers == int(g["da_inliers"]) and np.abs(d.JtJ - g["da_JtJ"]).max() <= 2e-4 * sj and abs(d.residual - float(g["da_residual"])) <= 2e-4 * float(g["da_residual"])
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_the_reference_f3_vectors(dfx, gold_f3):
+    import torch
+    g = gold_f3
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()   # noqa: E731
+    fac = dfx.SparseGeometricFactor(g["cam"], g["points"], dict(prx_orig=t(g["prx0"]), prx_jac=t(g["jac0"])),
+                                    dict(prx_orig=t(g["prx1"]), prx_jac=t(g["jac1"]), dpt_grad=t(g["dgrad1"])), float(g["huber"]), code_size=32)
+    rows = fac.linearize(g["pose0"], g["pose1"], g["code0"], g["code1"])
+    assert _check_rows(rows, g["sg_rows"]) <= 2e-4
+    da = dfx.DepthAligner(code_size=32)
+    got = da.RunStep(g["da_code"], t(g["da_tgt"]), t(g["prx0"]), t(g["jac0"]), 2.0)
+    sj = float(np.abs(g["da_JtJ"]).max())
+    assert got.inliers == int(g["da_inliers"])
+    assert np.abs(got.JtJ.astype(np.float64) - g["da_JtJ"]).max() <= 2e-4 * sj        # the reference item itself is a float sum over w*h pixels
+    assert np.abs(got.Jtr.astype(np.float64) - g["da_Jtr"]).max() <= 2e-4 * max(float(np.abs(g["da_Jtr"]).max()), float(np.sqrt(sj * float(g["da_residual"]))))
+    assert abs(got.residual - float(g["da_residual"])) <= 2e-4 * float(g["da_residual"])

@@ -52,3 +52,32 @@ def test_se3_tracking_on_the_reference_fixture_matches_the_reference_code(dfx, o
         assert_item_close(got, want, w, h, what=f"SE3 step {it}")
         qt = ref.se3_solve_and_update(got.JtJ, got.Jtr, qt)   # the reference's own update (lucas_kanade_se3.h:85-95)
     assert got.residual / got.inliers <= 1e-3
+
+
+def test_sparse_geometric_and_depth_aligner_match_the_reference_code(dfx, oracle):
+    """SURVEY 8f-3 against oracle/_ref: the reference's SparseGeometricFactor<float,32>::linearize (sparse_geometric_factor.cpp:147-275, compiled
+    unmodified) and its DepthAligner kernel (cu_depthaligner.cpp:32-72) on the inputs the HIP kernels get."""
+    from deepfactors_amd import synth
+    w, h, cs, npts = 256, 192, 32, 1500
+    p0 = synth.to_numpy(synth.make_pair(w, h, cs, seed=501))
+    p1 = synth.to_numpy(synth.make_pair(w, h, cs, seed=502, motion_scale=0.7))
+    rng = np.random.default_rng(9)
+    pts = np.stack([rng.integers(0, w, npts), rng.integers(0, h, npts)], 1).astype(np.int32)
+    dgrad = oracle.sobel(p1["dpt0"])
+    pose1 = p0["pose1"].copy(); pose1[4] += 0.05
+    want = ref.sparse_geometric(p0["pose0"], pose1, p0["code"], p1["code"], p0["cam"], pts, p0["prx_orig"], p0["prx_jac"], p1["prx_orig"], p1["prx_jac"], dgrad, 0.1)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()   # noqa: E731
+    fac = dfx.SparseGeometricFactor(p0["cam"], pts, dict(prx_orig=t(p0["prx_orig"]), prx_jac=t(p0["prx_jac"])),
+                                    dict(prx_orig=t(p1["prx_orig"]), prx_jac=t(p1["prx_jac"]), dpt_grad=t(dgrad)), 0.1, code_size=cs)
+    got = fac.linearize(p0["pose0"], pose1, p0["code"], p1["code"]).astype(np.float64)
+    zg, zw = ~got.any(axis=1), ~want.any(axis=1)
+    assert int((zg != zw).sum()) <= 1 and 0 < zw.sum() < npts
+    same = zg == zw
+    assert (np.abs(got[same] - want[same]) / (np.abs(want).max(axis=0) + 1e-12)).max() <= 2e-4
+    code = (p0["code"] + rng.normal(0, 0.05, cs)).astype(np.float32)
+    tgt = (p0["dpt0"] + rng.normal(0, 0.02, p0["dpt0"].shape)).astype(np.float32)
+    dw = ref.depth_aligner_step(code, tgt, p0["prx_orig"], p0["prx_jac"])
+    dg = dfx.DepthAligner(code_size=cs).RunStep(code, t(tgt), t(p0["prx_orig"]), t(p0["prx_jac"]), 2.0)
+    sj = float(np.abs(dw.JtJ).max())
+    assert dg.inliers == dw.inliers == w * h
+    assert np.abs(dg.JtJ.astype(np.float64) - dw.JtJ).max() <= 3e-4 * sj and abs(dg.residual - dw.residual) <= 3e-4 * dw.residual   # the reference sums w*h floats in order

@@ -168,3 +168,53 @@ def test_camera_pyramid_matches_the_reference_code():
     got = np.stack(synth.camera_pyramid(odd, 3))
     assert np.array_equal(got[:, 4:], want[:, 4:]) and list(want[:, 4]) == [101, 50, 25] and list(want[:, 5]) == [75, 37, 18]
     assert np.allclose(got[:, :4], want[:, :4], rtol=2.5e-7, atol=0)
+
+
+# ---- SparseGeometricFactor::linearize and the DepthAligner kernel, against the reference's own code -------------------
+def _two_keyframes(w, h, seed):
+    from deepfactors_amd import synth
+    p0 = synth.to_numpy(synth.make_pair(w, h, 32, seed=seed, device="cpu"))
+    p1 = synth.to_numpy(synth.make_pair(w, h, 32, seed=seed + 1, device="cpu", motion_scale=0.7))
+    return p0, p1
+
+
+@pytest.mark.parametrize("w,h,npts,seed", [(160, 120, 500, 31), (320, 240, 700, 33), (96, 64, 300, 35)])
+def test_sparse_geometric_oracle_equals_reference_code(oracle, refl, w, h, npts, seed):
+    """core/gtsam/sparse_geometric_factor.cpp:147-275, compiled unmodified (oracle/ref_harness_f3.cpp): every row [pose0 | pose1 | code0 | code1 |
+    err] of the JacobianFactor, incl. the all-zero rows of points without a correspondence, for poses that push a share of the points out
+    of view."""
+    p0, p1 = _two_keyframes(w, h, seed)
+    rng = np.random.default_rng(seed)
+    pts = np.stack([rng.integers(0, w, npts), rng.integers(0, h, npts)], axis=1).astype(np.int32)
+    dgrad1 = oracle.sobel(p1["dpt0"])
+    pose1 = p0["pose1"].copy(); pose1[4] += 0.08; pose1[5] -= 0.03
+    for huber in (0.1, 0.02):
+        want = refl.sparse_geometric(p0["pose0"], pose1, p0["code"], p1["code"], p0["cam"], pts, p0["prx_orig"], p0["prx_jac"], p1["prx_orig"], p1["prx_jac"],
+                                     dgrad1, huber)
+        got = oracle.sparse_geometric(p0["pose0"], pose1, p0["code"], p1["code"], p0["cam"], pts, p0["prx_orig"], p0["prx_jac"], p1["prx_orig"], p1["prx_jac"],
+                                      dgrad1, huber, avg_dpt=2.0)
+        zero_w, zero_g = ~want.any(axis=1), ~got.astype(np.float64).any(axis=1)
+        assert 0 < zero_w.sum() < npts, "the test must exercise both branches"
+        # a point within an ulp of the view border may flip (quaternion vs matrix rotation, see the module docstring)
+        assert int((zero_w != zero_g).sum()) <= 1
+        same = zero_w == zero_g
+        scale = np.abs(want).max(axis=0) + 1e-12
+        assert (np.abs(got[same] - want[same]) / scale).max() <= 2e-5
+
+
+@pytest.mark.parametrize("w,h,seed", [(160, 120, 41), (100, 77, 43)])
+def test_depth_aligner_oracle_equals_reference_code(oracle, refl, w, h, seed):
+    """cuda/cu_depthaligner.cpp:32-72 (the kernel template, cut out at build time and run over all pixels in order)."""
+    from deepfactors_amd import synth
+    n = synth.to_numpy(synth.make_pair(w, h, 32, seed=seed, device="cpu"))
+    rng = np.random.default_rng(seed)
+    code = (n["code"] + rng.normal(0, 0.05, 32)).astype(np.float32)
+    tgt = (n["dpt0"] + rng.normal(0, 0.02, n["dpt0"].shape)).astype(np.float32)
+    want = refl.depth_aligner_step(code, tgt, n["prx_orig"], n["prx_jac"])
+    got = oracle.depth_aligner_step(code, tgt, n["prx_orig"], n["prx_jac"], 2.0, accum_f64=True)
+    assert got.inliers == want.inliers == w * h
+    # the reference accumulates w*h terms in float in pixel order: 1e-4 of the scale is its own rounding
+    sj = float(np.abs(want.JtJ).max())
+    assert np.abs(got.JtJ - want.JtJ).max() <= 2e-4 * sj
+    assert np.abs(got.Jtr - want.Jtr).max() <= 2e-4 * max(float(np.abs(want.Jtr).max()), float(np.sqrt(sj * want.residual)))
+    assert abs(got.residual - want.residual) <= 2e-4 * want.residual
