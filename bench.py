@@ -65,7 +65,7 @@ def parse():
                     help="run the reduction tail of every step (finalize kernel, graph assembly) on a second stream beside the next step's kernel (dfx_set_tail_stream) instead "
                          "of in order on the launch stream.  Measured on MI355X (profiles/r03_bench_tail_modes.txt): the gap between step time and kernel time falls "
                          "from 38 to 27 us, but the 768 finalize workgroups take CU slots from the next step kernel (+15 us): 1.0233 vs 1.0200 ms per step -- so "
-                         "the default stays in order")
+                         "the default stays in order (a higher stream priority for the launch stream does not change that: 1.044 vs 1.038 ms, r03_bench_tail_modes.txt)")
     ap.add_argument("--foreign-valid0", action="store_true", help="keep the valid0 maps in torch tensors (memory the library does not own: the step kernel "
                     "then re-reads the map every step, 4 B/px) instead of library-owned images with a 1-bit shadow")
     ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)

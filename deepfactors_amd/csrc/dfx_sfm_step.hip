@@ -807,7 +807,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     float v = lds[e];
 #pragma unroll
     for (int wv = 1; wv < kWaves; ++wv) v += lds[wv * SLOT + e];
-    out[e] = v;
+    out[e] = v;   // (non-temporal stores here do not shorten the step -> finalize boundary: 39.6 vs 39.5 us between step time and kernel time, round 3)
   }
 #if DFX_TRACE
   __syncthreads();

@@ -151,7 +151,7 @@ class FakeEvent:
 
 
 class FakeStream:
-    def __init__(self, device=None):
+    def __init__(self, device=None, priority=0):
         pass
 
 
@@ -175,6 +175,7 @@ def _run_main(argv, out_path):
                (torch, "device", lambda *a, **k: real_device("cpu")), (deepfactors_amd, "Context", FakeCtx), (deepfactors_amd, "SfmAligner", FakeAligner),
                (tdist, "init_process_group", lambda backend, rank, world_size, device_id=None: real_init("gloo", rank=rank, world_size=world_size)),
                (torch.cuda, "Stream", FakeStream), (torch.cuda, "stream", lambda s: contextlib.nullcontext()), (torch.cuda, "empty_cache", lambda: None),
+               (torch.cuda, "set_stream", lambda s: None),
                (torch.cuda, "Event", FakeEvent), (deepfactors_amd, "SE3Aligner", FakeSE3), (deepfactors_amd, "UpdateDepthBatch", lambda *a, **k: None),
                (synth, "make_pair", small_make_pair)]
     saved = [(o, n, getattr(o, n)) for o, n, _ in patches]
