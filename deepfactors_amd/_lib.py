@@ -132,6 +132,7 @@ _PROTOS = {
     "dfx_graph_destroy": (None, [C.c_void_p]),
     "dfx_graph_system_floats": (C.c_size_t, [C.c_void_p]),
     "dfx_graph_assemble_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "dfx_sfm_step_batch_assemble_async": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SfmParams), C.POINTER(SfmPair), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dfx_comm_get_unique_id": (C.c_int, [C.c_void_p]),
     "dfx_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "dfx_comm_destroy": (None, [C.c_void_p]),

@@ -391,14 +391,23 @@ class SfmAligner:
         check(_lib.lib().dfx_sfm_step_batch_async(self.ctx.handle, self.CS, C.byref(p), pair_array, n,
                                                   C.c_void_p(out_items_dev.data_ptr())))
 
-    def RunStepBatchAssembleAsync(self, pair_array, out_items_dev, neq, first_pair):
-        """RunStepBatchAsync, then the assembly of this rank's items into the keyframe graph's block-sparse normal equations
-        (deepfactors_amd.dist.NormalEquations over a PairGraph; dfx_graph_assemble_async): `pair_array` holds the graph's pairs
-        [first_pair, first_pair + n).  Both enqueue on the context's stream."""
+    def RunStepBatchAssembleAsync(self, pair_array, out_items_dev, neq, first_pair, fused=True):
+        """RunStepBatchAsync plus the assembly of this rank's items into the keyframe graph's block-sparse normal equations
+        (deepfactors_amd.dist.NormalEquations over a PairGraph): `pair_array` holds the graph's pairs [first_pair, first_pair + n).
+        One call (dfx_sfm_step_batch_assemble_async: the assembly runs inside the launch's reduction-tail kernel); `fused=False` issues
+        the two calls dfx_sfm_step_batch_async + dfx_graph_assemble_async instead -- same bits.  Enqueue only."""
         if neq.cs != self.CS:
             raise ValueError("normal-equation buffer has a different code size")
-        self.RunStepBatchAsync(pair_array, out_items_dev)
-        neq.assemble_native(self.ctx, out_items_dev, int(first_pair), len(pair_array))
+        if not fused:
+            self.RunStepBatchAsync(pair_array, out_items_dev)
+            neq.assemble_native(self.ctx, out_items_dev, int(first_pair), len(pair_array))
+            return
+        n = len(pair_array)
+        if out_items_dev.numel() * out_items_dev.element_size() < n * item_size(12 + self.CS):
+            raise ValueError("output buffer too small")
+        p = self._p()
+        check(_lib.lib().dfx_sfm_step_batch_assemble_async(self.ctx.handle, self.CS, C.byref(p), pair_array, n, C.c_void_p(out_items_dev.data_ptr()),
+                                                          neq.native_handle(self.ctx), int(first_pair), C.c_void_p(neq.buf.data_ptr())))
 
     def LinearizeBatch(self, pair_array, prx0_orig, codes0, out_items_dev=None):
         """PhotometricFactor::RunAlignmentStep over a batch (photometric_factor.cpp:225-293): UpdateDepthMaps once per distinct keyframe

@@ -89,6 +89,9 @@ struct dfx_ctx {
   unsigned* qhead = nullptr;   // dynamic schedule: one item-queue head per pair of a batch (rewound by the finalize kernel)
   size_t qhead_cap = 0;
   bool qhead_dirty = false;    // a dynamic launch failed between its step and its finalize kernel: the heads were not rewound
+  unsigned* node_cnt = nullptr;   // graph assembly inside the reduction tail: arrivals per node, zero between launches (k_sfm_tail_b3 rewinds)
+  size_t node_cnt_cap = 0;
+  bool node_cnt_dirty = false;    // a launch failed after the counters were handed out
 
   char* partials_base = nullptr;   // allocation (two halves in deferred-tail mode)
   float* partials = nullptr;   // device scratch for workgroup partials
@@ -545,6 +548,7 @@ DFX_API void dfx_ctx_destroy(dfx_ctx* c) {
   if (c->jobs_dev) (void)hipFree(c->jobs_dev);
   if (c->sdesc_dev) (void)hipFree(c->sdesc_dev);
   if (c->qhead) (void)hipFree(c->qhead);
+  if (c->node_cnt) (void)hipFree(c->node_cnt);
   if (c->track_state_dev) (void)hipFree(c->track_state_dev);
   if (c->sg_dev) (void)hipFree(c->sg_dev);
   for (auto& t : c->ray_tabs) (void)hipFree(t.dev);
@@ -783,7 +787,9 @@ DFX_API int dfx_debug_read_valid0_shadow(dfx_ctx* c, const dfx_img* img, uint64_
 }
 
 // ---- SfmAligner ------------------------------------------------------------------------------------------------
-static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n, void* out_items_dev, bool allow_defer);
+struct dfx_graph;
+static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n, void* out_items_dev, bool allow_defer,
+                               const dfx_graph* graph = nullptr, int first_pair = 0, float* sys_dev = nullptr);
 
 DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
                                      void* out_items_dev) {
@@ -791,7 +797,10 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
 }
 
 // allow_defer = false (the blocking entry points): the finalize kernel runs on the context's stream even in deferred-tail mode
-static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n, void* out_items_dev, bool allow_defer) {
+static int graph_tail(dfx_ctx* c, int cs, const dfx_graph* g, int first_pair, int n, float* sys_dev, dfx::TailGraphDev* tg, int* node_wgs);
+
+static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n, void* out_items_dev, bool allow_defer,
+                               const dfx_graph* graph, int first_pair, float* sys_dev) {
   if (!c || !params || !pairs || !out_items_dev) return fail(DFX_E_INVALID, "dfx_sfm_step_batch: null argument");
   if (!cs_supported(cs)) return fail(DFX_E_INVALID, "unsupported code size %d (16, 32, 64)", cs);
   if (n <= 0 || n > 65535) return fail(DFX_E_INVALID, "batch size %d out of range [1,65535]", n);
@@ -974,10 +983,20 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
     c->qhead_dirty = true;
   }
   hipStream_t const fin_stream = defer ? c->tail_stream : c->stream;
+  // graph assembly: inside the reduction tail where the launch has the one-workgroup-per-pair tail kernel (batched, bf16 split), as a
+  // second kernel behind the finalize kernel otherwise (single pair, fp32 chain) -- the same sums in the same order either way
+  dfx::TailGraphDev tg{};
+  int node_wgs = 0;
+  bool assembled = false;
+  if (graph && (rc = graph_tail(c, cs, graph, first_pair, n, sys_dev, &tg, &node_wgs))) return rc;
   DFX_HIP(dfx::launch_sfm_step(cs, dd, n, (int)W, (int)H, prm, bpp, partials, out_items_dev, dfx_item_size(12 + cs), c->stream,
                                jac_dense, resolve_mfma(c, cs), eb, ee, n == 1 ? &one : nullptr, dyn.qhead ? &dyn : nullptr, dyn_grid, vsh,
-                               fin_stream, defer ? c->ev_mid[par] : nullptr, map_dev, total_blocks));
+                               fin_stream, defer ? c->ev_mid[par] : nullptr, map_dev, total_blocks, graph ? &tg : nullptr, node_wgs, &assembled));
   c->qhead_dirty = false;   // both kernels are enqueued: the finalize kernel rewinds the heads
+  if (graph) {
+    c->node_cnt_dirty = false;   // the tail kernel rewinds the counters it used
+    if (!assembled) DFX_HIP(dfx::launch_graph_assemble(cs, tg.G, out_items_dev, dfx_item_size(12 + cs), first_pair, n, sys_dev, fin_stream));
+  }
   if (defer) {
     DFX_HIP(hipEventRecord(c->ev_tail[par], fin_stream));
     c->tail_busy[par] = true;
@@ -994,8 +1013,10 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
 struct dfx_graph {
   int device = 0;
   int cs = 0, n_nodes = 0, n_pairs = 0;
-  int* dev = nullptr;   // [kf_begin (n_nodes + 1)][fr_begin (n_nodes + 1)][kf_pairs (n_pairs)][fr_pairs (n_pairs)]
+  int* dev = nullptr;   // [kf_begin (n_nodes + 1)][fr_begin (n_nodes + 1)][kf_pairs (n_pairs)][fr_pairs (n_pairs)][pair_nodes (2 n_pairs)]
   dfx::GraphDev view{};
+  const int* pair_nodes_dev = nullptr;
+  bool has_isolated = false;   // a node without any pair: its (zero) blocks need a writer even when every pair is local
 };
 
 DFX_API int dfx_graph_create(dfx_ctx* c, int cs, int n_nodes, int n_pairs, const int32_t* pair_nodes, dfx_graph** out) {
@@ -1012,7 +1033,7 @@ DFX_API int dfx_graph_create(dfx_ctx* c, int cs, int n_nodes, int n_pairs, const
   if ((rc = ensure_device(c))) return rc;
   // CSR by counting sort: pair indices stay ascending inside every node's list (the fixed summation order)
   const size_t nb = (size_t)n_nodes + 1;
-  std::vector<int> h(2 * nb + 2 * (size_t)n_pairs, 0);
+  std::vector<int> h(2 * nb + 4 * (size_t)n_pairs, 0);
   int* kf_begin = h.data();
   int* fr_begin = h.data() + nb;
   int* kf_pairs = h.data() + 2 * nb;
@@ -1021,12 +1042,17 @@ DFX_API int dfx_graph_create(dfx_ctx* c, int cs, int n_nodes, int n_pairs, const
   for (int n = 0; n < n_nodes; ++n) { kf_begin[n + 1] += kf_begin[n]; fr_begin[n + 1] += fr_begin[n]; }
   std::vector<int> kc(kf_begin, kf_begin + n_nodes), fc(fr_begin, fr_begin + n_nodes);
   for (int p = 0; p < n_pairs; ++p) { kf_pairs[kc[pair_nodes[2 * p]]++] = p; fr_pairs[fc[pair_nodes[2 * p + 1]]++] = p; }
+  std::memcpy(fr_pairs + n_pairs, pair_nodes, sizeof(int) * 2 * (size_t)n_pairs);
+  bool isolated = false;
+  for (int n = 0; n < n_nodes; ++n) isolated = isolated || (kf_begin[n + 1] == kf_begin[n] && fr_begin[n + 1] == fr_begin[n]);
   dfx_graph* g = new dfx_graph();
   g->device = c->device; g->cs = cs; g->n_nodes = n_nodes; g->n_pairs = n_pairs;
   hipError_t e = hipMalloc((void**)&g->dev, h.size() * sizeof(int));
   if (e == hipSuccess) e = hipMemcpy(g->dev, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice);
   if (e != hipSuccess) { if (g->dev) (void)hipFree(g->dev); delete g; return fail(DFX_E_HIP, "dfx_graph_create: %s", hipGetErrorString(e)); }
   g->view = dfx::GraphDev{ n_nodes, n_pairs, g->dev, g->dev + 2 * nb, g->dev + nb, g->dev + 2 * nb + n_pairs };
+  g->pair_nodes_dev = g->dev + 2 * nb + 2 * (size_t)n_pairs;
+  g->has_isolated = isolated;
   *out = g;
   return DFX_OK;
 }
@@ -1055,6 +1081,37 @@ DFX_API int dfx_graph_assemble_async(dfx_ctx* c, const dfx_graph* g, const void*
   DFX_HIP(dfx::launch_graph_assemble(g->cs, g->view, items_dev, dfx_item_size(12 + g->cs), first_pair, n_local, sys_dev,
                                      c->tail_stream ? c->tail_stream : c->stream));
   return DFX_OK;
+}
+
+// Arguments of the graph assembly inside the reduction tail: the graph's device view, this rank's pair range, the arrival counters.
+// Node workgroups (zero fill of what no local pair writes) are only launched when this rank does not hold every pair of the graph.
+static int graph_tail(dfx_ctx* c, int cs, const dfx_graph* g, int first_pair, int n, float* sys_dev, dfx::TailGraphDev* tg, int* node_wgs) {
+  if (!sys_dev) return fail(DFX_E_INVALID, "dfx_sfm_step_batch_assemble: null system buffer");
+  if (g->device != c->device) return fail(DFX_E_INVALID, "graph lives on device %d, context on device %d", g->device, c->device);
+  if (g->cs != cs) return fail(DFX_E_INVALID, "graph of code size %d, step of code size %d", g->cs, cs);
+  if (first_pair < 0 || first_pair + n > g->n_pairs)
+    return fail(DFX_E_INVALID, "pairs [%d, %d) are not inside the graph's %d pairs", first_pair, first_pair + n, g->n_pairs);
+  if (c->node_cnt_cap < (size_t)g->n_nodes || c->node_cnt_dirty) {
+    DFX_HIP(hipStreamSynchronize(c->stream));
+    if (c->tail_stream) DFX_HIP(hipStreamSynchronize(c->tail_stream));
+    if (c->node_cnt_cap < (size_t)g->n_nodes) {
+      if (c->node_cnt) DFX_HIP(hipFree(c->node_cnt));
+      c->node_cnt = nullptr; c->node_cnt_cap = 0;
+      DFX_HIP(hipMalloc((void**)&c->node_cnt, sizeof(unsigned) * (size_t)g->n_nodes * 2));
+      c->node_cnt_cap = (size_t)g->n_nodes * 2;
+    }
+    DFX_HIP(hipMemsetAsync(c->node_cnt, 0, sizeof(unsigned) * c->node_cnt_cap, c->stream));
+  }
+  c->node_cnt_dirty = true;   // cleared once the kernel that rewinds them is enqueued
+  *tg = dfx::TailGraphDev{ g->view, g->pair_nodes_dev, first_pair, n, sys_dev, c->node_cnt };
+  *node_wgs = (first_pair == 0 && n == g->n_pairs && !g->has_isolated) ? 0 : g->n_nodes;
+  return DFX_OK;
+}
+
+DFX_API int dfx_sfm_step_batch_assemble_async(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
+                                              void* out_items_dev, const dfx_graph* graph, int first_pair, float* sys_dev) {
+  if (!graph) return fail(DFX_E_INVALID, "dfx_sfm_step_batch_assemble: null graph");
+  return sfm_step_batch_impl(c, cs, params, pairs, n, out_items_dev, true, graph, first_pair, sys_dev);
 }
 
 DFX_API int dfx_sfm_step_batch(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,

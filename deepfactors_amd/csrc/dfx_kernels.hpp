@@ -41,6 +41,15 @@ struct GraphDev {
   const int* fr_pairs;
 };
 
+// Graph assembly inside the reduction tail of a batched step (k_sfm_tail_b3): the last pair to arrive at a node gathers the node
+struct TailGraphDev {
+  GraphDev G;
+  const int* pair_nodes;   // [n_pairs][2] = (keyframe node, frame node)
+  int first_pair, n_local;
+  float* sys;              // null: no assembly
+  unsigned* node_cnt;      // [n_nodes], zero between launches (the assembling workgroup rewinds its counter)
+};
+
 // Dynamic schedule of the batched SfM step (k_sfm_step<..., DYN>): per-pair item queues popped by wave-workers
 struct DynDev {
   unsigned* qhead;      // [npairs] next item of each pair; rewound by k_sfm_finalize
@@ -86,9 +95,11 @@ hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int 
                            const DynDev* dyn = nullptr, int dyn_grid = 0,    // dyn: the dynamic schedule (workgroups = dyn_grid, partials = [pair][team])
                            bool valid0_shadows = false,                      // every non-null valid0 of the batch carries a shadow (SfmPairDev::valid0_shadow)
                            hipStream_t fin_stream = nullptr, hipEvent_t ev_mid = nullptr,   // deferred tail: the finalize kernel runs on fin_stream behind ev_mid
-                           const unsigned* blkmap_dev = nullptr, int total_blocks = 0);   // pairs of several image sizes: 1-D grid, workgroup g serves pair
+                           const unsigned* blkmap_dev = nullptr, int total_blocks = 0,    // pairs of several image sizes: 1-D grid, workgroup g serves pair
                                                                                            // blkmap[g] >> 16 as its block blkmap[g] & 0xffff (of SfmPairDev::nblk);
                                                                                            // W, H = the largest width / height (ray-table LDS); blocks_per_pair unused
+                           const TailGraphDev* tail_graph = nullptr, int node_wgs = 0,    // graph assembly inside the reduction tail (k_sfm_tail_b3) where the
+                           bool* assembled = nullptr);                                    // launch has one: *assembled tells; node_wgs = 0 or the graph's nodes
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair);
 // system layout (floats): Hd [n_nodes][D][D], Ho [n_pairs][D][6], g [n_nodes][D]; contributions of the pairs [first_pair, first_pair + n_local)
 hipError_t launch_graph_assemble(int cs, const GraphDev& G, const void* items_dev, size_t item_stride, int first_pair, int n_local, float* sys_dev,

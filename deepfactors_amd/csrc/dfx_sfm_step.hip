@@ -829,18 +829,32 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 // the shadow bits are recomputed from the map itself: bit p = (valid0[p] == 1.0f).  The pair's finalize workgroups split the words; a map
 // shared by several pairs of the launch is rebuilt by each of them with the same values.  Runs once per change of the inlier set
 // (first step on a fresh map, newly exposed pixels after a pose update) -- never in the steady state.
-__device__ __forceinline__ void rebuild_valid0_shadow(const SfmPairDev& P, int W, int H, unsigned launch_id, int part, int nparts) {
+__device__ __forceinline__ unsigned valid0_shadow_stamp(const SfmPairDev& P, unsigned launch_id) {   // != launch_id: nothing to rebuild
   unsigned long long* const sh = P.valid0_shadow;
-  if (!sh || !P.valid0) return;
+  return (sh && P.valid0) ? gload<unsigned>(reinterpret_cast<const unsigned*>(sh - 1)) : launch_id + 1u;
+}
+__device__ __forceinline__ void rebuild_valid0_shadow(const SfmPairDev& P, int W, int H, unsigned launch_id, int part, int nparts, unsigned stamp) {
+  unsigned long long* const sh = P.valid0_shadow;
+  if (stamp != launch_id) return;
   const unsigned npx = (unsigned)W * (unsigned)H, nwords = (npx + 63u) >> 6;
-  if (gload<unsigned>(reinterpret_cast<const unsigned*>(sh - 1)) != launch_id) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-  for (unsigned wd = (unsigned)(part * nwv + wv); wd < nwords; wd += (unsigned)(nparts * nwv)) {
-    const unsigned p = wd * 64u + (unsigned)lane;
-    const unsigned y = p / (unsigned)W, x = p - y * (unsigned)W;
-    const bool one = p < npx && gload<unsigned>(reinterpret_cast<const char*>(P.valid0) + (size_t)y * P.pitch_valid0 + (size_t)x * 4u) == 0x3f800000u;
-    const unsigned long long bits = __builtin_amdgcn_ballot_w64(one);
-    if (lane == 0) sh[wd] = bits;
+  const unsigned step = (unsigned)(nparts * nwv);
+  // four words of a wave in flight at a time (the tail kernel rebuilds a pair's map with ONE workgroup: 4800 words at 640x480)
+  for (unsigned wd = (unsigned)(part * nwv + wv); wd < nwords; wd += 4u * step) {
+    unsigned val[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned p = (wd + (unsigned)q * step) * 64u + (unsigned)lane;
+      const unsigned pc = p < npx ? p : 0u;
+      const unsigned y = pc / (unsigned)W, x = pc - y * (unsigned)W;
+      val[q] = gload<unsigned>(reinterpret_cast<const char*>(P.valid0) + (size_t)y * P.pitch_valid0 + (size_t)x * 4u);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned w2 = wd + (unsigned)q * step;
+      const unsigned long long bits = __builtin_amdgcn_ballot_w64(w2 * 64u + (unsigned)lane < npx && val[q] == 0x3f800000u);
+      if (lane == 0 && w2 < nwords) sh[w2] = bits;
+    }
   }
 }
 
@@ -868,7 +882,7 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
   const int W = ragged ? (int)PD.w_px : Wk, H = ragged ? (int)PD.h_px : Hk;
   const int nparts = ragged ? (int)PD.nblk : bpp;
   const size_t part0 = ragged ? (size_t)PD.blk0 : (size_t)pair * bpp;
-  if (NPOSE == 12) rebuild_valid0_shadow(PD, W, H, launch_id, blk, (int)gridDim.x);
+  if (NPOSE == 12) rebuild_valid0_shadow(PD, W, H, launch_id, blk, (int)gridDim.x, valid0_shadow_stamp(PD, launch_id));
   if (qhead && blk == 0 && threadIdx.x == 0) qhead[pair] = 0u;   // dynamic schedule: the pair's item queue is rewound for the next launch
   const float* src = partials + part0 * ZDIM + blk * 256 + el;
   red[rg][el] = strided_sum_f64<4, 16>(src, rg, nparts, ZDIM);   // a single pair has 240 partials: 60 rows per group = 4 round trips
@@ -993,77 +1007,55 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__
 
 // ---- finalize of the DFX_MFMA_BF16X3 step: the partials are plain 16x16 tiles S[row][col] (tile 0: P x P; 1 + b: P x C_b; then
 // C_b x C_b', b <= b', row-major), entry i of C_b = code NCB * i + b.  Same reduction (double, fixed order), same T map, same item.
-template <int NCB, int NPOSE, bool BYVAL>
-__global__ __launch_bounds__(1024) void k_sfm_finalize_b3(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs, const SfmPairDev one,
-                                                          char* __restrict__ items, const size_t item_stride, unsigned* __restrict__ qhead,
-                                                          const int Wk, const int Hk, const unsigned launch_id, const int ragged) {
+// Two kernels share the pieces below: k_sfm_finalize_b3 (one workgroup per tile of a pair: single pairs, DepthAligner) and
+// k_sfm_tail_b3 (one workgroup per pair + the graph assembly: every batched launch).
+
+// Block of the partial that holds the N part of tile `blk` (NT3 + d), or -1: d = 0 (P,P): N = P_l x [P_h P_m]; d = 1 + b: (C_b,C_b) with the
+// four-product diagonals: N = hm + hl
+template <int NCB>
+__device__ __forceinline__ int b3_dtile(int blk) {
+  if (blk == 0) return 0;
+  if (b3_diag4(NCB) && blk > NCB) { int q = blk - 1 - NCB; for (int b = 0; b < NCB; ++b) { if (q == 0) return 1 + b; q -= NCB - b; if (q < 0) break; } }
+  return -1;
+}
+
+// d(pose0, pose1) <- d(relative pose): J = gC * T^T; entry (n, i) for n < 12, i < 6
+__device__ __forceinline__ double b3_T_entry(const float* M, const float* HM, int n, int i) {
+  const int j = n % 3, grp = n / 3;   // grp 0: pose0 trs, 1: pose0 rot, 2: pose1 trs, 3: pose1 rot
+  if (grp == 0) return i < 3 ? (double)M[3 * i + j] : 0.0;
+  if (grp == 1) return i >= 3 ? (double)M[3 * (i - 3) + j] : 0.0;
+  if (grp == 2) return i < 3 ? -(double)M[3 * i + j] : 0.0;
+  return i < 3 ? -(double)HM[3 * i + j] : -(double)M[3 * (i - 3) + j];
+}
+
+// Undo the packing of the step kernel for element el = (r, cc) of tile `blk` (same order for every launch: deterministic): S = the tile's
+// 256 sums, Sn = the sums of its N block (dtile >= 0).  `keep` = false: the element stays as summed.
+template <int NCB>
+__device__ __forceinline__ double b3_unpack(int blk, int dtile, int el, const double* S, const double* Sn, bool& keep) {
+  const int r = el >> 4, cc = el & 15;
+  double v = 0.0;
+  keep = true;
+  if (blk == 0) {            // (P,P): quadrants [hh hm ; mh mm] of P stacked as [P_h ; P_m], plus lh + lh^T from the N block's top-left quadrant
+    if (r < 8 && cc < 8) {
+      v = ((S[r * 16 + cc] + S[r * 16 + 8 + cc]) + S[(8 + r) * 16 + cc]) + S[(8 + r) * 16 + 8 + cc];
+      v += Sn[r * 16 + cc] + Sn[cc * 16 + r];
+    }
+  } else if (blk <= NCB) {   // (P,C_b): rows 0..7 = (h + l) pieces, rows 8..15 = m pieces of the same P rows
+    if (r < 8) v = S[r * 16 + cc] + S[(8 + r) * 16 + cc];
+  } else if (dtile >= 0) {   // (C_b,C_b) with four products: Z = S + N + N^T
+    v = S[el] + Sn[el] + Sn[cc * 16 + r];
+  } else {
+    keep = false;
+  }
+  return v;
+}
+
+// Scatter the unpacked tile `blk` (S[row * 16 + col]) into the item; t = 0 .. 255
+template <int NCB, int NPOSE>
+__device__ __forceinline__ void b3_scatter(int blk, int t, const double* S, const double (*T)[6], float* item) {
   constexpr int CS = 16 * NCB;
   constexpr int NP = NPOSE + CS;
-  constexpr int NT3 = b3_tiles(NCB);
-  constexpr int ZDIM = b3_blocks(NCB) * 256;
   constexpr int NT = NP * (NP + 1) / 2;
-  __shared__ double red[4][256];
-  __shared__ double redn[4][256];   // the N part of (P,P) [and of the diagonal tiles (C_b,C_b) with the four-product diagonals]
-  __shared__ double T[12][6];   // d(pose0, pose1) <- d(relative pose): J = gC * T^T
-
-  const int blk = blockIdx.x, pair = blockIdx.y;
-  const int el = threadIdx.x & 255, rg = threadIdx.x >> 8;
-  const SfmPairDev& PD = BYVAL ? one : pairs[pair];
-  const int W = ragged ? (int)PD.w_px : Wk, H = ragged ? (int)PD.h_px : Hk;
-  const int nparts = ragged ? (int)PD.nblk : bpp;
-  const size_t part0 = ragged ? (size_t)PD.blk0 : (size_t)pair * bpp;
-  if (NPOSE == 12) rebuild_valid0_shadow(PD, W, H, launch_id, blk, (int)gridDim.x);
-  if (qhead && blk == 0 && threadIdx.x == 0) qhead[pair] = 0u;
-  const float* src = partials + part0 * ZDIM + blk * 256 + el;
-  red[rg][el] = strided_sum_f64<4, 16>(src, rg, nparts, ZDIM);
-  // blocks with an N part in block NT3 + d: d = 0 (P,P): N = P_l x [P_h P_m]; d = 1 + b (C_b,C_b), four-product diagonals: N = hm + hl
-  int dtile = -1;
-  if (blk == 0) dtile = 0;
-  else if (b3_diag4(NCB) && blk > NCB) { int q = blk - 1 - NCB; for (int b = 0; b < NCB; ++b) { if (q == 0) { dtile = 1 + b; break; } q -= NCB - b; if (q < 0) break; } }
-  if (dtile >= 0) redn[rg][el] = strided_sum_f64<4, 16>(partials + part0 * ZDIM + (NT3 + dtile) * 256 + el, rg, nparts, ZDIM);
-  if (NPOSE == 12 && threadIdx.x < 72) {
-    const int n = threadIdx.x / 6, i = threadIdx.x - n * 6;
-    const float* M = BYVAL ? one.M : pairs[pair].M;
-    const float* HM = BYVAL ? one.HM : pairs[pair].HM;
-    const int j = n % 3, grp = n / 3;   // grp 0: pose0 trs, 1: pose0 rot, 2: pose1 trs, 3: pose1 rot
-    double v = 0.0;
-    if (grp == 0) v = i < 3 ? (double)M[3 * i + j] : 0.0;
-    else if (grp == 1) v = i >= 3 ? (double)M[3 * (i - 3) + j] : 0.0;
-    else if (grp == 2) v = i < 3 ? -(double)M[3 * i + j] : 0.0;
-    else v = i < 3 ? -(double)HM[3 * i + j] : -(double)M[3 * (i - 3) + j];
-    T[n][i] = v;
-  }
-  __syncthreads();
-  if (rg == 0) red[0][el] = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
-  if (dtile >= 0 && rg == 1) redn[0][el] = ((redn[0][el] + redn[1][el]) + redn[2][el]) + redn[3][el];
-  __syncthreads();
-  {
-    // undo the packing of the step kernel (same order for every launch: deterministic)
-    const int r = el >> 4, cc = el & 15;
-    double v = 0.0;
-    bool put_back = false;
-    if (rg == 0) {
-      if (blk == 0) {            // (P,P): quadrants [hh hm ; mh mm] of P stacked as [P_h ; P_m], plus lh + lh^T from the N block's top-left quadrant
-        if (r < 8 && cc < 8) {
-          v = ((red[0][r * 16 + cc] + red[0][r * 16 + 8 + cc]) + red[0][(8 + r) * 16 + cc]) + red[0][(8 + r) * 16 + 8 + cc];
-          v += redn[0][r * 16 + cc] + redn[0][cc * 16 + r];
-        }
-        put_back = true;
-      } else if (blk <= NCB) {   // (P,C_b): rows 0..7 = (h + l) pieces, rows 8..15 = m pieces of the same P rows
-        if (r < 8) v = red[0][r * 16 + cc] + red[0][(8 + r) * 16 + cc];
-        put_back = true;
-      } else if (dtile >= 0) {   // (C_b,C_b) with four products: Z = S + N + N^T
-        v = red[0][el] + redn[0][el] + redn[0][cc * 16 + r];
-        put_back = true;
-      }
-    }
-    __syncthreads();
-    if (put_back) red[0][el] = v;
-    __syncthreads();
-  }
-  const double* S = red[0];   // S[row * 16 + col]
-
-  float* item = reinterpret_cast<float*>(items + (size_t)pair * item_stride);
   auto tri = [](int lo, int hi) { return lo * NP - lo * (lo - 1) / 2 + (hi - lo); };
   auto put = [&](int lo, int hi, float v) { item[tri(lo, hi)] = v; };
   auto put_code = [&](int ca, int cb, float v) {
@@ -1071,7 +1063,6 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize_b3(const float* __restric
     put(n < m ? n : m, n < m ? m : n, v);
   };
   auto put_g = [&](int n, float v) { item[NT + n] = v; };
-  const int t = threadIdx.x;
   if (blk == 0) {
     // P = (gC_0..5, w r, inlier flag); the tile holds both triangles of P P^T, the upper one is used
     auto pp = [&](int p, int q) { return S[p * 16 + q]; };
@@ -1128,6 +1119,245 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize_b3(const float* __restric
   }
 }
 
+template <int NCB, int NPOSE, bool BYVAL>
+__global__ __launch_bounds__(1024) void k_sfm_finalize_b3(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs, const SfmPairDev one,
+                                                          char* __restrict__ items, const size_t item_stride, unsigned* __restrict__ qhead,
+                                                          const int Wk, const int Hk, const unsigned launch_id, const int ragged) {
+  constexpr int NT3 = b3_tiles(NCB);
+  constexpr int ZDIM = b3_blocks(NCB) * 256;
+  __shared__ double red[4][256];
+  __shared__ double redn[4][256];   // the N part of (P,P) [and of the diagonal tiles (C_b,C_b) with the four-product diagonals]
+  __shared__ double T[12][6];
+
+  const int blk = blockIdx.x, pair = blockIdx.y;
+  const int el = threadIdx.x & 255, rg = threadIdx.x >> 8;
+  const SfmPairDev& PD = BYVAL ? one : pairs[pair];
+  const int W = ragged ? (int)PD.w_px : Wk, H = ragged ? (int)PD.h_px : Hk;
+  const int nparts = ragged ? (int)PD.nblk : bpp;
+  const size_t part0 = ragged ? (size_t)PD.blk0 : (size_t)pair * bpp;
+  if (NPOSE == 12) rebuild_valid0_shadow(PD, W, H, launch_id, blk, (int)gridDim.x, valid0_shadow_stamp(PD, launch_id));
+  if (qhead && blk == 0 && threadIdx.x == 0) qhead[pair] = 0u;
+  const float* src = partials + part0 * ZDIM + blk * 256 + el;
+  red[rg][el] = strided_sum_f64<4, 16>(src, rg, nparts, ZDIM);
+  const int dtile = b3_dtile<NCB>(blk);
+  if (dtile >= 0) redn[rg][el] = strided_sum_f64<4, 16>(partials + part0 * ZDIM + (NT3 + dtile) * 256 + el, rg, nparts, ZDIM);
+  if (NPOSE == 12 && threadIdx.x < 72) {
+    const int n = threadIdx.x / 6, i = threadIdx.x - n * 6;
+    T[n][i] = b3_T_entry(BYVAL ? one.M : pairs[pair].M, BYVAL ? one.HM : pairs[pair].HM, n, i);
+  }
+  __syncthreads();
+  if (rg == 0) red[0][el] = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
+  if (dtile >= 0 && rg == 1) redn[0][el] = ((redn[0][el] + redn[1][el]) + redn[2][el]) + redn[3][el];
+  __syncthreads();
+  {
+    bool keep = false;
+    double v = 0.0;
+    if (rg == 0) v = b3_unpack<NCB>(blk, dtile, el, red[0], redn[0], keep);
+    __syncthreads();
+    if (keep) red[0][el] = v;
+    __syncthreads();
+  }
+  float* item = reinterpret_cast<float*>(items + (size_t)pair * item_stride);
+  b3_scatter<NCB, NPOSE>(blk, (int)threadIdx.x, red[0], T, item);
+}
+
+// ---- the reduction tail of a batched bf16-split launch in ONE kernel: workgroup p sums ALL blocks of pair p's partials (same order as
+// k_sfm_finalize_b3: four interleaved groups of partials, folded ((g0 + g1) + g2) + g3 in double), writes the item, and -- when the
+// launch assembles a keyframe graph (dfx_sfm_step_batch_assemble_async) -- the workgroup that completes a node (the last of the
+// node's incident local pairs to arrive, counted in `node_cnt`) gathers that node's diagonal block and gradient exactly as
+// k_graph_assemble does (ascending pair index, double): no second kernel, no launch boundary between finalize and assembly.
+// grid = pairs [+ nodes: workgroups that zero the blocks of nodes / pairs this rank holds no item of], 1024 threads.
+// Round 3, 128 pairs: k_sfm_finalize_b3 (768 workgroups, two rounds) 15.3 us + boundary + k_graph_assemble 6.5 us -> see DESIGN.md 3.7.
+
+template <int CS>
+__device__ __forceinline__ void tail_assemble_node(const TailGraphDev& tg, const char* __restrict__ items, size_t item_stride, int n) {
+  constexpr int NP = 12 + CS, D = 6 + CS, NT = NP * (NP + 1) / 2;
+  const GraphDev& G = tg.G;
+  float* const Hd = tg.sys;
+  float* const gv = tg.sys + (size_t)G.n_nodes * D * D + (size_t)G.n_pairs * D * 6;
+  auto item_of = [&](int p) -> const float* {
+    const int l = p - tg.first_pair;
+    return (l >= 0 && l < tg.n_local) ? reinterpret_cast<const float*>(items + (size_t)l * item_stride) : nullptr;
+  };
+  auto tri = [](int a, int b) { const int lo = a < b ? a : b, hi = a < b ? b : a; return lo * NP - lo * (lo - 1) / 2 + (hi - lo); };
+  const int k0 = G.kf_begin[n], k1 = G.kf_begin[n + 1];
+  const int f0 = G.fr_begin[n], f1 = G.fr_begin[n + 1];
+  for (int e = threadIdx.x; e < D * D + D; e += blockDim.x) {
+    double acc = 0.0;
+    if (e < D * D) {
+      const int r = e / D, c = e - r * D;
+      const int ia = r < 6 ? r : r + 6, ib = c < 6 ? c : c + 6;
+      const int t0 = tri(ia, ib);
+      for (int q = k0; q < k1; ++q) { const float* it = item_of(G.kf_pairs[q]); if (it) acc += (double)it[t0]; }
+      if (r < 6 && c < 6) {
+        const int t1 = tri(6 + r, 6 + c);
+        for (int q = f0; q < f1; ++q) { const float* it = item_of(G.fr_pairs[q]); if (it) acc += (double)it[t1]; }
+      }
+      Hd[(size_t)n * D * D + e] = (float)acc;
+    } else {
+      const int r = e - D * D;
+      const int ia = r < 6 ? r : r + 6;
+      for (int q = k0; q < k1; ++q) { const float* it = item_of(G.kf_pairs[q]); if (it) acc += (double)it[NT + ia]; }
+      if (r < 6) for (int q = f0; q < f1; ++q) { const float* it = item_of(G.fr_pairs[q]); if (it) acc += (double)it[NT + 6 + r]; }
+      gv[(size_t)n * D + r] = (float)acc;
+    }
+  }
+}
+
+// number of node n's incident pairs this rank holds an item of (wave 0 of the workgroup; the result is valid in every lane of wave 0)
+__device__ __forceinline__ int tail_local_degree(const TailGraphDev& tg, int n) {
+  const GraphDev& G = tg.G;
+  const int lane = threadIdx.x & 63;
+  const int k0 = G.kf_begin[n], k1 = G.kf_begin[n + 1], f0 = G.fr_begin[n], f1 = G.fr_begin[n + 1];
+  int cnt = 0;
+  for (int q = k0 + lane; q < k1; q += 64) { const int l = G.kf_pairs[q] - tg.first_pair; cnt += (l >= 0 && l < tg.n_local) ? 1 : 0; }
+  for (int q = f0 + lane; q < f1; q += 64) { const int l = G.fr_pairs[q] - tg.first_pair; cnt += (l >= 0 && l < tg.n_local) ? 1 : 0; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+  return cnt;
+}
+
+template <int NCB>
+__global__ __launch_bounds__(1024) void k_sfm_tail_b3(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs, const int npairs,
+                                                      char* __restrict__ items, const size_t item_stride, unsigned* __restrict__ qhead,
+                                                      const int Wk, const int Hk, const unsigned launch_id, const int ragged, const TailGraphDev tg) {
+  constexpr int CS = 16 * NCB, D = 6 + CS, NP = 12 + CS;
+  constexpr int NT3 = b3_tiles(NCB), NB3 = b3_blocks(NCB);
+  constexpr int ZDIM = NB3 * 256;
+  constexpr int ROWS = NB3 <= 5 ? 8 : (NB3 <= 10 ? 4 : 2);   // partial rows per batch: ROWS * NB3 loads in flight per thread
+  constexpr int MINE = (NT3 + 3) / 4;                         // tiles per thread group in the unpack / scatter stage
+  __shared__ double S[NB3][256];
+  __shared__ double T[12][6];
+  __shared__ int todo[2];
+  const int el = threadIdx.x & 255, rg = threadIdx.x >> 8;
+
+  if ((int)blockIdx.x >= npairs) {
+    // node workgroups (launched only when this rank does not hold every pair, or the graph has isolated nodes): what no local pair
+    // writes is zero -- the diagonal block and gradient of a node without local pairs, the off-diagonal block of every remote pair
+    const int n = (int)blockIdx.x - npairs;
+    if (threadIdx.x < 64) { const int d = tail_local_degree(tg, n); if (threadIdx.x == 0) todo[0] = d; }
+    __syncthreads();
+    float* const Hd = tg.sys;
+    float* const Ho = tg.sys + (size_t)tg.G.n_nodes * D * D;
+    float* const gv = Ho + (size_t)tg.G.n_pairs * D * 6;
+    if (todo[0] == 0) {
+      for (int e = threadIdx.x; e < D * D; e += 1024) Hd[(size_t)n * D * D + e] = 0.f;
+      if (threadIdx.x < D) gv[(size_t)n * D + threadIdx.x] = 0.f;
+    }
+    for (int q = tg.G.kf_begin[n]; q < tg.G.kf_begin[n + 1]; ++q) {
+      const int p = tg.G.kf_pairs[q], l = p - tg.first_pair;
+      if ((l < 0 || l >= tg.n_local) && threadIdx.x < D * 6) Ho[(size_t)p * D * 6 + threadIdx.x] = 0.f;
+    }
+    return;
+  }
+
+  const int pair = blockIdx.x;
+  const SfmPairDev& PD = pairs[pair];
+  const int W = ragged ? (int)PD.w_px : Wk, H = ragged ? (int)PD.h_px : Hk;
+  const int nparts = ragged ? (int)PD.nblk : bpp;
+  const size_t part0 = ragged ? (size_t)PD.blk0 : (size_t)pair * bpp;
+  const unsigned stamp = valid0_shadow_stamp(PD, launch_id);   // read now, used at the very end
+  if (qhead && threadIdx.x == 0) qhead[pair] = 0u;
+  if (threadIdx.x < 72) {
+    const int n = threadIdx.x / 6, i = threadIdx.x - n * 6;
+    T[n][i] = b3_T_entry(PD.M, PD.HM, n, i);
+  }
+  // ---- sums of this thread's group of partials, all blocks at once
+  double s[NB3];
+#pragma unroll
+  for (int a = 0; a < NB3; ++a) s[a] = 0.0;
+  const float* src = partials + part0 * ZDIM + el;
+  for (int b = rg; b < nparts; b += 4 * ROWS) {
+    float v[ROWS][NB3];
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) {
+      const int r = b + 4 * q;
+      const float* row = src + (size_t)(r < nparts ? r : b) * ZDIM;   // unconditional loads of an existing row; +0.0 for the rows past the end
+#pragma unroll
+      for (int a = 0; a < NB3; ++a) { const float t = row[a * 256]; v[q][a] = r < nparts ? t : 0.0f; }
+    }
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q)
+#pragma unroll
+      for (int a = 0; a < NB3; ++a) s[a] += (double)v[q][a];
+  }
+  // ---- ((g0 + g1) + g2) + g3 through one LDS copy of the blocks
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    if (rg == k) {
+#pragma unroll
+      for (int a = 0; a < NB3; ++a) S[a][el] = s[a];
+    }
+    __syncthreads();
+    if (rg == 0) {
+#pragma unroll
+      for (int a = 0; a < NB3; ++a) s[a] += S[a][el];
+    }
+    __syncthreads();
+  }
+  if (rg == 0) {
+#pragma unroll
+    for (int a = 0; a < NB3; ++a) S[a][el] = s[a];
+  }
+  __syncthreads();
+  // ---- unpack: thread group rg owns the tiles rg, rg + 4, ...
+  {
+    double u[MINE];
+    bool keep[MINE];
+#pragma unroll
+    for (int j = 0; j < MINE; ++j) {
+      const int blk = rg + 4 * j;
+      keep[j] = false; u[j] = 0.0;
+      if (blk < NT3) { const int dt = b3_dtile<NCB>(blk); u[j] = b3_unpack<NCB>(blk, dt, el, S[blk], S[NT3 + (dt >= 0 ? dt : 0)], keep[j]); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MINE; ++j) { const int blk = rg + 4 * j; if (blk < NT3 && keep[j]) S[blk][el] = u[j]; }
+    __syncthreads();
+  }
+  float* item = reinterpret_cast<float*>(items + (size_t)pair * item_stride);
+#pragma unroll
+  for (int j = 0; j < MINE; ++j) { const int blk = rg + 4 * j; if (blk < NT3) b3_scatter<NCB, 12>(blk, el, S[blk], T, item); }
+
+  // ---- graph assembly by the last pair to arrive at each of its two nodes
+  if (tg.sys) {
+    __threadfence();   // this thread's part of the item is visible to the device before the arrival is counted
+    __syncthreads();
+    const int gp = tg.first_pair + pair;
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x;
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const int n = tg.pair_nodes[2 * gp + side];
+        const int need = tail_local_degree(tg, n);
+        if (lane == 0) {
+          const unsigned got = atomicAdd(&tg.node_cnt[n], 1u) + 1u;
+          const bool last = got == (unsigned)need;
+          if (last) tg.node_cnt[n] = 0u;   // rewound for the next launch: nobody else counts on this node any more
+          todo[side] = last ? n : -1;
+        }
+      }
+    }
+    __syncthreads();
+    {   // off-diagonal block of this pair: single writer, from the item this workgroup has just written
+      float* const Ho = tg.sys + (size_t)tg.G.n_nodes * D * D;
+      auto tri = [](int a, int b) { const int lo = a < b ? a : b, hi = a < b ? b : a; return lo * NP - lo * (lo - 1) / 2 + (hi - lo); };
+      for (int e = threadIdx.x; e < D * 6; e += 1024) {
+        const int r = e / 6, c = e - r * 6;
+        const int ia = r < 6 ? r : r + 6;
+        Ho[(size_t)gp * D * 6 + e] = item[tri(ia, 6 + c)];
+      }
+    }
+    if (todo[0] >= 0 || todo[1] >= 0) {
+      __threadfence();   // the other pairs' items, published before their arrivals, are read from memory, not from a stale cache line
+      if (todo[0] >= 0) tail_assemble_node<CS>(tg, items, item_stride, todo[0]);
+      if (todo[1] >= 0) tail_assemble_node<CS>(tg, items, item_stride, todo[1]);
+    }
+  }
+  // ---- the pair's valid0 shadow, when a wave of this launch changed the map (never in the steady state)
+  rebuild_valid0_shadow(PD, W, H, launch_id, 0, 1, stamp);
+}
+
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair) {
   // one size for both evaluation modes: the fp32 chain's packed z-space or the bf16 split's tiles (more blocks only with DFX_B3_DIAG4)
   const int zc = sfm_zdim(cs / 16), zb = b3_blocks(cs / 16) * 256;
@@ -1139,7 +1369,10 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
                            float* partials_dev, void* items_dev, size_t item_stride, hipStream_t stream, bool jac_dense, int prec,
                            hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, const SfmPairDev* one_host = nullptr,
                            const DynDev* dyn = nullptr, int dyn_grid = 0, bool vsh = false, hipStream_t fin_stream = nullptr, hipEvent_t ev_mid = nullptr,
-                           const unsigned* blkmap = nullptr, int total_blocks = 0) {
+                           const unsigned* blkmap = nullptr, int total_blocks = 0, const TailGraphDev* tail_graph = nullptr, int node_wgs = 0,
+                           bool* assembled = nullptr) {
+  if (assembled) *assembled = false;
+  const TailGraphDev tg = tail_graph ? *tail_graph : TailGraphDev{};
   constexpr int NACC = NCB * (NCB - 1) / 2 + NCB + 2 * ((NCB + 1) / 2);   // 256-float blocks after block 0 (16x16x4 and 4x4x1 accumulators)
   hipError_t e;
   if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
@@ -1179,9 +1412,11 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
       if (e != hipSuccess) return e;
       if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
       if ((e = to_fin_stream()) != hipSuccess) return e;
-      if (b3) hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, 12, false>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
-                                 (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0);
-      else hipLaunchKernelGGL((k_sfm_finalize<NCB, 12, false>), dim3(1 + NACC, npairs), dim3(1024), 0, fstream,
+      if (b3) {
+        hipLaunchKernelGGL((k_sfm_tail_b3<NCB>), dim3(npairs + (tg.sys ? node_wgs : 0)), dim3(1024), 0, fstream,
+                           (const float*)partials_dev, dyn->team, pairs_dev, npairs, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0, tg);
+        if (assembled) *assembled = tg.sys != nullptr;
+      } else hipLaunchKernelGGL((k_sfm_finalize<NCB, 12, false>), dim3(1 + NACC, npairs), dim3(1024), 0, fstream,
                               (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0);
       return hipGetLastError();
     }
@@ -1210,8 +1445,12 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   if (b3) {
     if (byval) hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, true>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
                                   (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged);
-    else hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, false>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
-                            (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged);
+    else if constexpr (MODE == 0) {   // every batched launch: one workgroup per pair, the graph assembly folded in
+      hipLaunchKernelGGL((k_sfm_tail_b3<NCB>), dim3(npairs + (tg.sys ? node_wgs : 0)), dim3(1024), 0, fstream,
+                         (const float*)partials_dev, bpp, fpairs, npairs, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged, tg);
+      if (assembled) *assembled = tg.sys != nullptr;
+    } else hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, false>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
+                              (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged);
   } else {
     if (byval) hipLaunchKernelGGL((k_sfm_finalize<NCB, NPOSE, true>), dim3(1 + NACC, npairs), dim3(1024), 0, fstream,
                                   (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged);
@@ -1224,11 +1463,12 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
 hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm,
                            int blocks_per_pair, float* partials_dev, void* items_dev, size_t item_stride,
                            hipStream_t stream, bool jac_dense, int prec, hipEvent_t eb, hipEvent_t ee, const SfmPairDev* one_host,
-                           const DynDev* dyn, int dyn_grid, bool vsh, hipStream_t fin_stream, hipEvent_t ev_mid, const unsigned* blkmap_dev, int total_blocks) {
+                           const DynDev* dyn, int dyn_grid, bool vsh, hipStream_t fin_stream, hipEvent_t ev_mid, const unsigned* blkmap_dev, int total_blocks,
+                           const TailGraphDev* tail_graph, int node_wgs, bool* assembled) {
   switch (cs) {
-    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks);
-    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks);
-    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks);
+    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled);
+    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled);
+    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled);
     default: return hipErrorInvalidValue;
   }
 }

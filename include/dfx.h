@@ -329,6 +329,14 @@ DFX_API void dfx_graph_destroy(dfx_graph* graph);
 DFX_API size_t dfx_graph_system_floats(const dfx_graph* graph);
 DFX_API int dfx_graph_assemble_async(dfx_ctx* ctx, const dfx_graph* graph, const void* items_dev, int first_pair, int n_local,
                                      float* sys_dev);
+/* dfx_sfm_step_batch_async + dfx_graph_assemble_async of the same pairs (pairs[l] = pair first_pair + l of the graph) as ONE call:
+ * same items, same system, bit for bit -- but the reduction tail of the launch is one kernel instead of two: the workgroup that sums
+ * a pair's partials writes its item and its off-diagonal block, and the last of a node's pairs to arrive gathers that node's diagonal
+ * block and gradient (ascending pair order, double, as above).  128 pairs of 640x480, CS = 32: 15 + 6.5 us of kernels and one launch
+ * boundary become one kernel.  Launches without that tail kernel (a single pair; the fp32 chain) run the two
+ * kernels one after the other.  Enqueue only. */
+DFX_API int dfx_sfm_step_batch_assemble_async(dfx_ctx* ctx, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
+                                              void* out_items_dev, const dfx_graph* graph, int first_pair, float* sys_dev);
 
 /* ---- multi-GPU exchange (new: SURVEY section 8e; the reference is single-GPU) ---------------------------------------
  * One process per GPU; every rank evaluates a contiguous shard of the pair list (dfx_shard_range) with keyframe pyramids replicated,

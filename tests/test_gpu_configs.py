@@ -262,6 +262,11 @@ def test_dynamic_schedule_matches_the_oracle_and_the_static_schedule(dfx, oracle
     for a, b in zip(valid_dyn, valid_sta):
         assert torch.equal(a, b)
     assert any(float(v.max()) == 1.0 for v in valid_dyn)
+    # a batch of ONE pair never takes the dynamic schedule (its descriptor travels in the kernel arguments, which the wave-worker grid
+    # does not read): the forced context runs the static partition and returns the static bits
+    one_d, one_s = al_d.RunStepBatch(al_d.make_pairs(pairs(valid_dyn)[:1])), al_s.RunStepBatch(al_s.make_pairs(pairs(valid_sta)[:1]))
+    assert not ctx_d.last_schedule_dynamic()
+    assert np.array_equal(one_d[0].raw, one_s[0].raw)
 
 
 @pytest.mark.parametrize("mode", ["auto", "f32"])
