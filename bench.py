@@ -66,6 +66,8 @@ def parse():
                          "of in order on the launch stream.  Measured on MI355X (profiles/r03_bench_tail_modes.txt): the gap between step time and kernel time falls "
                          "from 38 to 27 us, but the 768 finalize workgroups take CU slots from the next step kernel (+15 us): 1.0233 vs 1.0200 ms per step -- so "
                          "the default stays in order (a higher stream priority for the launch stream does not change that: 1.044 vs 1.038 ms, r03_bench_tail_modes.txt)")
+    ap.add_argument("--two-call-tail", action="store_true", help="issue the step and the graph assembly as two library calls (dfx_sfm_step_batch_async + "
+                    "dfx_graph_assemble_async: two tail kernels) instead of dfx_sfm_step_batch_assemble_async (the assembly inside the launch's tail kernel)")
     ap.add_argument("--foreign-valid0", action="store_true", help="keep the valid0 maps in torch tensors (memory the library does not own: the step kernel "
                     "then re-reads the map every step, 4 B/px) instead of library-owned images with a 1-bit shadow")
     ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)
@@ -532,14 +534,16 @@ def main():
     pipe = PipelinedReduce(dist, [NormalEquations(graph, CS, dev) for _ in range(2)], root=0, stream=tail) if world > 1 else None
     neq = NormalEquations(graph, CS, dev) if pipe is None else None
 
+    fused = not a.two_call_tail
+
     def step():
         # hot path: one launch over P pairs (+ its finalize kernel), then this rank's items are summed into the block-sparse
         # normal equations of the graph; for N > 1 the ranks' buffers are reduced onto the rank that solves
         if pipe is not None:
-            al.RunStepBatchAssembleAsync(arr, items, pipe.next(), rank * P)
+            al.RunStepBatchAssembleAsync(arr, items, pipe.next(), rank * P, fused=fused)
             pipe.submit()                                      # RCCL reduce over xGMI, overlapped with the next step's kernels
             return
-        al.RunStepBatchAssembleAsync(arr, items, neq, rank * P)
+        al.RunStepBatchAssembleAsync(arr, items, neq, rank * P, fused=fused)
         if dist is not None:
             if tail is not None:
                 with torch.cuda.stream(tail):

@@ -92,6 +92,9 @@ namespace dfx {
 #define DFX_STREAM_AUX 1     // cache policy of the coalesced img0 / dpt0 loads (read once per launch): 1 = sc0, they bypass the CU's L1 and leave
                              // it to the bilinear taps; -1 % (1055-1059 vs 1067 us, 4 interleaved runs each); nt (2) and sc0+nt (3) are no better
 #endif
+#ifndef DFX_TAIL_KERNEL
+#define DFX_TAIL_KERNEL 1    // batched bf16-split launches: 1 = k_sfm_tail_b3 (a workgroup per pair, graph assembly folded in), 0 = k_sfm_finalize_b3 (a workgroup
+#endif                       // per tile of a pair) and a separate assembly kernel -- the A/B switch of DESIGN.md 3.7
 #ifndef DFX_DYN_ROT
 #define DFX_DYN_ROT 4        // dynamic schedule: member row m of the teams serves the pairs rotated by DFX_DYN_ROT * m (0: a pair's team sits on one XCD)
 #endif
@@ -1412,10 +1415,13 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
       if (e != hipSuccess) return e;
       if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
       if ((e = to_fin_stream()) != hipSuccess) return e;
-      if (b3) {
+      if (b3 && DFX_TAIL_KERNEL) {
         hipLaunchKernelGGL((k_sfm_tail_b3<NCB>), dim3(npairs + (tg.sys ? node_wgs : 0)), dim3(1024), 0, fstream,
                            (const float*)partials_dev, dyn->team, pairs_dev, npairs, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0, tg);
         if (assembled) *assembled = tg.sys != nullptr;
+      } else if (b3) {
+        hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, 12, false>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
+                           (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0);
       } else hipLaunchKernelGGL((k_sfm_finalize<NCB, 12, false>), dim3(1 + NACC, npairs), dim3(1024), 0, fstream,
                               (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0);
       return hipGetLastError();
@@ -1445,7 +1451,7 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   if (b3) {
     if (byval) hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, true>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
                                   (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged);
-    else if constexpr (MODE == 0) {   // every batched launch: one workgroup per pair, the graph assembly folded in
+    else if constexpr (MODE == 0 && DFX_TAIL_KERNEL) {   // every batched launch: one workgroup per pair, the graph assembly folded in
       hipLaunchKernelGGL((k_sfm_tail_b3<NCB>), dim3(npairs + (tg.sys ? node_wgs : 0)), dim3(1024), 0, fstream,
                          (const float*)partials_dev, bpp, fpairs, npairs, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged, tg);
       if (assembled) *assembled = tg.sys != nullptr;

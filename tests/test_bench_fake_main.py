@@ -117,7 +117,7 @@ class FakeAligner:
             items.copy_(it)
         self.ctx.launch()
 
-    def RunStepBatchAssembleAsync(self, arr, items, neq, first_pair):
+    def RunStepBatchAssembleAsync(self, arr, items, neq, first_pair, fused=True):
         from deepfactors_amd import item_size
         self.RunStepBatchAsync(arr, items)
         neq.assemble(items, first_pair, len(arr), item_size(12 + self.CS))
