@@ -834,7 +834,11 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
 // (first step on a fresh map, newly exposed pixels after a pose update) -- never in the steady state.
 __device__ __forceinline__ unsigned valid0_shadow_stamp(const SfmPairDev& P, unsigned launch_id) {   // != launch_id: nothing to rebuild
   unsigned long long* const sh = P.valid0_shadow;
-  return (sh && P.valid0) ? gload<unsigned>(reinterpret_cast<const unsigned*>(sh - 1)) : launch_id + 1u;
+  const bool have = sh && P.valid0;
+  // an unconditional load (of the descriptor itself when there is no shadow): a load inside a branch is waited for at the end of the branch,
+  // which put one memory round trip in front of everything else the finalize kernels do
+  const unsigned v = gload<unsigned>(have ? reinterpret_cast<const unsigned*>(sh - 1) : reinterpret_cast<const unsigned*>(&P.w_px));
+  return have ? v : launch_id + 1u;
 }
 __device__ __forceinline__ void rebuild_valid0_shadow(const SfmPairDev& P, int W, int H, unsigned launch_id, int part, int nparts, unsigned stamp) {
   unsigned long long* const sh = P.valid0_shadow;
@@ -1054,18 +1058,24 @@ __device__ __forceinline__ double b3_unpack(int blk, int dtile, int el, const do
 }
 
 // Scatter the unpacked tile `blk` (S[row * 16 + col]) into the item; t = 0 .. 255
-template <int NCB, int NPOSE>
+// COH: the item is read by OTHER workgroups of the same kernel (graph assembly in k_sfm_tail_b3): device-scope stores (write-through,
+// visible to device-scope loads from any XCD once the store has completed) instead of a cache writeback + invalidate per workgroup
+template <bool COH, typename V>
+__device__ __forceinline__ void coh_store(V* p, V v) {
+  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+template <int NCB, int NPOSE, bool COH = false>
 __device__ __forceinline__ void b3_scatter(int blk, int t, const double* S, const double (*T)[6], float* item) {
   constexpr int CS = 16 * NCB;
   constexpr int NP = NPOSE + CS;
   constexpr int NT = NP * (NP + 1) / 2;
   auto tri = [](int lo, int hi) { return lo * NP - lo * (lo - 1) / 2 + (hi - lo); };
-  auto put = [&](int lo, int hi, float v) { item[tri(lo, hi)] = v; };
+  auto put = [&](int lo, int hi, float v) { coh_store<COH>(&item[tri(lo, hi)], v); };
   auto put_code = [&](int ca, int cb, float v) {
     const int n = NPOSE + ca, m = NPOSE + cb;
     put(n < m ? n : m, n < m ? m : n, v);
   };
-  auto put_g = [&](int n, float v) { item[NT + n] = v; };
+  auto put_g = [&](int n, float v) { coh_store<COH>(&item[NT + n], v); };
   if (blk == 0) {
     // P = (gC_0..5, w r, inlier flag); the tile holds both triangles of P P^T, the upper one is used
     auto pp = [&](int p, int q) { return S[p * 16 + q]; };
@@ -1091,10 +1101,10 @@ __device__ __forceinline__ void b3_scatter(int blk, int t, const double* S, cons
         put_g(n, (float)v);
       }
     }
-    if (t == 160) item[NT + NP] = (float)pp(6, 6);          // residual = sum (w r)^2
+    if (t == 160) coh_store<COH>(&item[NT + NP], (float)pp(6, 6));          // residual = sum (w r)^2
     if (t == 161) {
       const size_t off = (((size_t)(NT + NP + 1)) * 4 + 7) & ~(size_t)7;
-      *reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(item) + off) = (unsigned long long)(pp(7, 7) + 0.5);
+      coh_store<COH>(reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(item) + off), (unsigned long long)(pp(7, 7) + 0.5));
     }
     return;
   }
@@ -1183,6 +1193,8 @@ __device__ __forceinline__ void tail_assemble_node(const TailGraphDev& tg, const
     return (l >= 0 && l < tg.n_local) ? reinterpret_cast<const float*>(items + (size_t)l * item_stride) : nullptr;
   };
   auto tri = [](int a, int b) { const int lo = a < b ? a : b, hi = a < b ? b : a; return lo * NP - lo * (lo - 1) / 2 + (hi - lo); };
+  // items of other workgroups: device-scope loads (they were stored device-scope and had completed before the arrival was counted)
+  auto ld = [](const float* p) { return (double)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   const int k0 = G.kf_begin[n], k1 = G.kf_begin[n + 1];
   const int f0 = G.fr_begin[n], f1 = G.fr_begin[n + 1];
   for (int e = threadIdx.x; e < D * D + D; e += blockDim.x) {
@@ -1191,17 +1203,17 @@ __device__ __forceinline__ void tail_assemble_node(const TailGraphDev& tg, const
       const int r = e / D, c = e - r * D;
       const int ia = r < 6 ? r : r + 6, ib = c < 6 ? c : c + 6;
       const int t0 = tri(ia, ib);
-      for (int q = k0; q < k1; ++q) { const float* it = item_of(G.kf_pairs[q]); if (it) acc += (double)it[t0]; }
+      for (int q = k0; q < k1; ++q) { const float* it = item_of(G.kf_pairs[q]); if (it) acc += ld(it + t0); }
       if (r < 6 && c < 6) {
         const int t1 = tri(6 + r, 6 + c);
-        for (int q = f0; q < f1; ++q) { const float* it = item_of(G.fr_pairs[q]); if (it) acc += (double)it[t1]; }
+        for (int q = f0; q < f1; ++q) { const float* it = item_of(G.fr_pairs[q]); if (it) acc += ld(it + t1); }
       }
       Hd[(size_t)n * D * D + e] = (float)acc;
     } else {
       const int r = e - D * D;
       const int ia = r < 6 ? r : r + 6;
-      for (int q = k0; q < k1; ++q) { const float* it = item_of(G.kf_pairs[q]); if (it) acc += (double)it[NT + ia]; }
-      if (r < 6) for (int q = f0; q < f1; ++q) { const float* it = item_of(G.fr_pairs[q]); if (it) acc += (double)it[NT + 6 + r]; }
+      for (int q = k0; q < k1; ++q) { const float* it = item_of(G.kf_pairs[q]); if (it) acc += ld(it + NT + ia); }
+      if (r < 6) for (int q = f0; q < f1; ++q) { const float* it = item_of(G.fr_pairs[q]); if (it) acc += ld(it + NT + 6 + r); }
       gv[(size_t)n * D + r] = (float)acc;
     }
   }
@@ -1220,21 +1232,24 @@ __device__ __forceinline__ int tail_local_degree(const TailGraphDev& tg, int n) 
   return cnt;
 }
 
-template <int NCB>
+template <int NCB, bool ASM>   // ASM: the launch assembles a graph (tg.sys != null)
 __global__ __launch_bounds__(1024) void k_sfm_tail_b3(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs, const int npairs,
                                                       char* __restrict__ items, const size_t item_stride, unsigned* __restrict__ qhead,
                                                       const int Wk, const int Hk, const unsigned launch_id, const int ragged, const TailGraphDev tg) {
   constexpr int CS = 16 * NCB, D = 6 + CS, NP = 12 + CS;
   constexpr int NT3 = b3_tiles(NCB), NB3 = b3_blocks(NCB);
   constexpr int ZDIM = NB3 * 256;
-  constexpr int ROWS = NB3 <= 5 ? 8 : (NB3 <= 10 ? 4 : 2);   // partial rows per batch: ROWS * NB3 loads in flight per thread
+#ifndef DFX_TAIL_ROWS
+#define DFX_TAIL_ROWS 0
+#endif
+  constexpr int ROWS = DFX_TAIL_ROWS ? DFX_TAIL_ROWS : (NB3 <= 5 ? 8 : (NB3 <= 10 ? 4 : 2));   // partial rows per batch: ROWS * NB3 loads in flight per thread
   constexpr int MINE = (NT3 + 3) / 4;                         // tiles per thread group in the unpack / scatter stage
   __shared__ double S[NB3][256];
   __shared__ double T[12][6];
   __shared__ int todo[2];
   const int el = threadIdx.x & 255, rg = threadIdx.x >> 8;
 
-  if ((int)blockIdx.x >= npairs) {
+  if (ASM && (int)blockIdx.x >= npairs) {
     // node workgroups (launched only when this rank does not hold every pair, or the graph has isolated nodes): what no local pair
     // writes is zero -- the diagonal block and gradient of a node without local pairs, the off-diagonal block of every remote pair
     const int n = (int)blockIdx.x - npairs;
@@ -1261,10 +1276,6 @@ __global__ __launch_bounds__(1024) void k_sfm_tail_b3(const float* __restrict__ 
   const size_t part0 = ragged ? (size_t)PD.blk0 : (size_t)pair * bpp;
   const unsigned stamp = valid0_shadow_stamp(PD, launch_id);   // read now, used at the very end
   if (qhead && threadIdx.x == 0) qhead[pair] = 0u;
-  if (threadIdx.x < 72) {
-    const int n = threadIdx.x / 6, i = threadIdx.x - n * 6;
-    T[n][i] = b3_T_entry(PD.M, PD.HM, n, i);
-  }
   // ---- sums of this thread's group of partials, all blocks at once
   double s[NB3];
 #pragma unroll
@@ -1283,6 +1294,10 @@ __global__ __launch_bounds__(1024) void k_sfm_tail_b3(const float* __restrict__ 
     for (int q = 0; q < ROWS; ++q)
 #pragma unroll
       for (int a = 0; a < NB3; ++a) s[a] += (double)v[q][a];
+  }
+  if (threadIdx.x < 72) {   // (behind the partial loads: its descriptor reads would otherwise be waited for first)
+    const int n = threadIdx.x / 6, i = threadIdx.x - n * 6;
+    T[n][i] = b3_T_entry(PD.M, PD.HM, n, i);
   }
   // ---- ((g0 + g1) + g2) + g3 through one LDS copy of the blocks
 #pragma unroll
@@ -1320,11 +1335,13 @@ __global__ __launch_bounds__(1024) void k_sfm_tail_b3(const float* __restrict__ 
   }
   float* item = reinterpret_cast<float*>(items + (size_t)pair * item_stride);
 #pragma unroll
-  for (int j = 0; j < MINE; ++j) { const int blk = rg + 4 * j; if (blk < NT3) b3_scatter<NCB, 12>(blk, el, S[blk], T, item); }
+  for (int j = 0; j < MINE; ++j) { const int blk = rg + 4 * j; if (blk < NT3) b3_scatter<NCB, 12, ASM>(blk, el, S[blk], T, item); }
 
-  // ---- graph assembly by the last pair to arrive at each of its two nodes
-  if (tg.sys) {
-    __threadfence();   // this thread's part of the item is visible to the device before the arrival is counted
+  // ---- graph assembly by the last pair to arrive at each of its two nodes.  No cache writeback / invalidate (a __threadfence per wave
+  // cost 80 us per launch over the 128 workgroups): the item went out in device-scope stores, every wave waits for its stores to complete,
+  // the barrier collects the waves, and only then one lane counts the arrival; the assembling workgroup reads with device-scope loads.
+  if (ASM) {
+    __builtin_amdgcn_s_waitcnt(0);   // vmcnt = lgkmcnt = expcnt = 0: this wave's stores have completed
     __syncthreads();
     const int gp = tg.first_pair + pair;
     if (threadIdx.x < 64) {
@@ -1351,11 +1368,8 @@ __global__ __launch_bounds__(1024) void k_sfm_tail_b3(const float* __restrict__ 
         Ho[(size_t)gp * D * 6 + e] = item[tri(ia, 6 + c)];
       }
     }
-    if (todo[0] >= 0 || todo[1] >= 0) {
-      __threadfence();   // the other pairs' items, published before their arrivals, are read from memory, not from a stale cache line
-      if (todo[0] >= 0) tail_assemble_node<CS>(tg, items, item_stride, todo[0]);
-      if (todo[1] >= 0) tail_assemble_node<CS>(tg, items, item_stride, todo[1]);
-    }
+    if (todo[0] >= 0) tail_assemble_node<CS>(tg, items, item_stride, todo[0]);
+    if (todo[1] >= 0) tail_assemble_node<CS>(tg, items, item_stride, todo[1]);
   }
   // ---- the pair's valid0 shadow, when a wave of this launch changed the map (never in the steady state)
   rebuild_valid0_shadow(PD, W, H, launch_id, 0, 1, stamp);
@@ -1416,8 +1430,10 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
       if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
       if ((e = to_fin_stream()) != hipSuccess) return e;
       if (b3 && DFX_TAIL_KERNEL) {
-        hipLaunchKernelGGL((k_sfm_tail_b3<NCB>), dim3(npairs + (tg.sys ? node_wgs : 0)), dim3(1024), 0, fstream,
-                           (const float*)partials_dev, dyn->team, pairs_dev, npairs, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0, tg);
+        if (tg.sys) hipLaunchKernelGGL((k_sfm_tail_b3<NCB, true>), dim3(npairs + node_wgs), dim3(1024), 0, fstream,
+                                       (const float*)partials_dev, dyn->team, pairs_dev, npairs, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0, tg);
+        else hipLaunchKernelGGL((k_sfm_tail_b3<NCB, false>), dim3(npairs), dim3(1024), 0, fstream,
+                                (const float*)partials_dev, dyn->team, pairs_dev, npairs, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0, tg);
         if (assembled) *assembled = tg.sys != nullptr;
       } else if (b3) {
         hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, 12, false>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
@@ -1452,8 +1468,10 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
     if (byval) hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, true>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
                                   (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged);
     else if constexpr (MODE == 0 && DFX_TAIL_KERNEL) {   // every batched launch: one workgroup per pair, the graph assembly folded in
-      hipLaunchKernelGGL((k_sfm_tail_b3<NCB>), dim3(npairs + (tg.sys ? node_wgs : 0)), dim3(1024), 0, fstream,
-                         (const float*)partials_dev, bpp, fpairs, npairs, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged, tg);
+      if (tg.sys) hipLaunchKernelGGL((k_sfm_tail_b3<NCB, true>), dim3(npairs + node_wgs), dim3(1024), 0, fstream,
+                                     (const float*)partials_dev, bpp, fpairs, npairs, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged, tg);
+      else hipLaunchKernelGGL((k_sfm_tail_b3<NCB, false>), dim3(npairs), dim3(1024), 0, fstream,
+                              (const float*)partials_dev, bpp, fpairs, npairs, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged, tg);
       if (assembled) *assembled = tg.sys != nullptr;
     } else hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, false>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
                               (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged);
