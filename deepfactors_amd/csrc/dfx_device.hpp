@@ -62,6 +62,9 @@ struct ImgRef {
   __device__ __forceinline__ float at(int x, int y) const { return gload<float>(rowb(y) + (size_t)x * 4); }
 };
 
+#ifndef DFX_DIV_SHARED
+#define DFX_DIV_SHARED 1     // find_correspondence_ray<true>: the three divisions by q.z share one refined reciprocal (0: three compiler divisions everywhere)
+#endif
 // FindCorrespondence (warping.h:204-241): p = d * K^-1 (x,y,1); q = R p + t; pix1 = K q / q.z
 struct Corr {
   float rrx, rry, rrz;   // R * ray            (ray = ReprojectDepthJacobian, pinhole_camera_impl.h:77-86)
@@ -77,6 +80,9 @@ struct Corr {
 // poses (identity) where projected coordinates land exactly on the border.
 // (rx, ry) = K^-1 (x, y, 1) is handed in: the step kernel reads it from a per-camera table (dfx_api.cpp ray_table, the same
 // IEEE expression evaluated once per column / row on the host) instead of paying two divisions per pixel.
+// SD: the shared-reciprocal form of the three divisions (below).  Same bits; it holds the reciprocal across the quotients, which costs the fp32
+// chain of the step kernel its fourth wave per SIMD (126 -> 135 registers), so the caller chooses.
+template <bool SD = false>
 __device__ __forceinline__ Corr find_correspondence_ray(const Geo& g, float rx, float ry, float d, float border, float min_dpt) {
 #pragma clang fp contract(off)
   Corr c;
@@ -90,18 +96,37 @@ __device__ __forceinline__ Corr find_correspondence_ray(const Geo& g, float rx, 
   c.qx = c.vx + g.t[0];
   c.qy = c.vy + g.t[1];
   const float qz = c.vz + g.t[2];
+  if constexpr (SD && DFX_DIV_SHARED) {
+  // The three IEEE quotients by q.z, with the refined reciprocal computed once: the arithmetic of the compiler's own division sequence
+  // (v_rcp_f32, one Newton step, quotient, two residual corrections -- correctly rounded) minus its range scaling (v_div_scale /
+  // v_div_fmas / v_div_fixup), which only acts on operands beyond 2^+-96: 18 instead of 33 vector-ALU instructions per pixel, the same
+  // bits for every depth a camera produces.  (Non-finite or zero q.z: NaN here, a pixel without correspondence either way.)
+    const float r0 = __builtin_amdgcn_rcpf(qz);
+    const float e0 = __builtin_fmaf(-qz, r0, 1.0f);
+    const float r = __builtin_fmaf(e0, r0, r0);
+    auto quot = [&](float a) {
+      const float q0 = a * r;
+      const float q1 = __builtin_fmaf(__builtin_fmaf(-qz, q0, a), r, q0);
+      return __builtin_fmaf(__builtin_fmaf(-qz, q1, a), r, q1);
+    };
+    c.iz = quot(1.0f);
+    c.u = quot(g.fx * c.qx) + g.u0;
+    c.v = quot(g.fy * c.qy) + g.v0;
+  } else {
   c.iz = 1.0f / qz;
   c.u = g.fx * c.qx / qz + g.u0;
   c.v = g.fy * c.qy / qz + g.v0;
+  }
   // PixelValid (pinhole_camera_impl.h:105-108) in float, exactly `x >= b && x < w - b`; NaN -> invalid
   c.valid = (qz > min_dpt) && (c.u >= border) && (c.u < g.w - border) && (c.v >= border) && (c.v < g.h - border);
   return c;
 }
+template <bool SD = false>
 __device__ __forceinline__ Corr find_correspondence(const Geo& g, int x, int y, float d, float border, float min_dpt) {
 #pragma clang fp contract(off)
   const float rx = ((float)x - g.u0) / g.fx;
   const float ry = ((float)y - g.v0) / g.fy;
-  return find_correspondence_ray(g, rx, ry, d, border, min_dpt);
+  return find_correspondence_ray<SD>(g, rx, ry, d, border, min_dpt);
 }
 
 // VisionCore getBilinear convention: floor, lerp in x then y, lerp(a,b,t)=a+t(b-a)

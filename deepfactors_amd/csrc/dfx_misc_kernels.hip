@@ -77,7 +77,7 @@ __device__ __forceinline__ void walk_pixels(const Geo& g, const SimplePairDev& p
     const bool more = inext < npx;
     const int xl = more ? xn : x, yl = more ? yn : y;   // last pixel: a harmless re-load of itself
     const float dn = D0.at(xl, yl), i0n = I0.at(xl, yl);
-    const Corr c = TAB ? find_correspondence_ray(g, rt.tab[x], rt.tab[rt.W + y], d, border, min_dpt) : find_correspondence(g, x, y, d, border, min_dpt);
+    const Corr c = TAB ? find_correspondence_ray<true>(g, rt.tab[x], rt.tab[rt.W + y], d, border, min_dpt) : find_correspondence<true>(g, x, y, d, border, min_dpt);
     body(x, y, d, i0, c);
     if (!more) break;
     i = inext; x = xn; y = yn; d = dn; i0 = i0n;

@@ -154,11 +154,31 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 }
 // Exact three-way split of two fp32 values into packed bf16 pieces (tools/ubench/bf16x3_probe.cpp: 2^20 inputs reconstructed exactly
 // on the hardware).  The subtractions are exact (Sterbenz-like: each remainder fits the fp32 mantissa).
+// The remainders x - h through v_dot2c_f32_bf16: x + (p_lo, p_hi) . (-1, 0) expands the packed piece and subtracts it in ONE instruction per
+// value (exact: the products are exact and the sum is representable) -- 7 instead of 9 vector-ALU instructions per pair of values, and the
+// split is 40 % of the bf16 kernel's vector-ALU work (tools/ubench/bf16x3_probe.cpp section 2b: the same pieces for 2^20 inputs).
+#ifndef DFX_SPLIT_DOT2
+#define DFX_SPLIT_DOT2 1
+#endif
+__device__ __forceinline__ float sub_bf16_lo(float x, unsigned p) {
+#if DFX_SPLIT_DOT2
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, p), __builtin_bit_cast(bf16x2_t, 0x0000bf80u), x, false);
+#else
+  return x - __uint_as_float(p << 16);
+#endif
+}
+__device__ __forceinline__ float sub_bf16_hi(float x, unsigned p) {
+#if DFX_SPLIT_DOT2
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, p), __builtin_bit_cast(bf16x2_t, 0xbf800000u), x, false);
+#else
+  return x - __uint_as_float(p & 0xffff0000u);
+#endif
+}
 __device__ __forceinline__ void split3_bf16(float x0, float x1, unsigned& ph, unsigned& pm, unsigned& pl) {
   ph = cvt_pk_bf16(x0, x1);
-  const float r0 = x0 - __uint_as_float(ph << 16), r1 = x1 - __uint_as_float(ph & 0xffff0000u);
+  const float r0 = sub_bf16_lo(x0, ph), r1 = sub_bf16_hi(x1, ph);
   pm = cvt_pk_bf16(r0, r1);
-  const float s0 = r0 - __uint_as_float(pm << 16), s1 = r1 - __uint_as_float(pm & 0xffff0000u);
+  const float s0 = sub_bf16_lo(r0, pm), s1 = sub_bf16_hi(r1, pm);
   pl = cvt_pk_bf16(s0, s1);
 }
 __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& c) {
@@ -432,7 +452,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   // those may retire ahead of the older ring loads the counted waits of phase B rely on.
   auto issue_gathers = [&](unsigned pbase, Pix& q) {
     if (MODE == 0) {
-      const Corr c = find_correspondence_ray(g, q.rx, q.ry, q.d, prm.border, prm.min_dpt);
+      const Corr c = find_correspondence_ray<B3>(g, q.rx, q.ry, q.d, prm.border, prm.min_dpt);
       const Taps tp = make_taps(c.u, c.v);
       const bool ok = c.valid && (pbase + lane < (unsigned)npx);
       q.c = c; q.ax = tp.ax; q.ay = tp.ay; q.ok = ok;

@@ -53,6 +53,27 @@ __global__ void k_split(const float* x, int n, float* h, float* m, float* lo) {
   lo[t] = bf_lo(pl); lo[t + 1] = bf_hi(pl);
 }
 
+// the same split with the remainders through v_dot2c_f32_bf16: r = x + (h0, h1) . (-1, 0) -- expand + subtract in ONE instruction per value
+// (the step kernel's form since round 3: 7 instead of 9 vector-ALU instructions per pair of values)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_v(float lo, float hi) { const f32x2_t v = { lo, hi }; return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t)); }
+__device__ __forceinline__ float sub_lo(float x, unsigned p) { return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, p), __builtin_bit_cast(bf16x2_t, 0x0000bf80u), x, false); }
+__device__ __forceinline__ float sub_hi(float x, unsigned p) { return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, p), __builtin_bit_cast(bf16x2_t, 0xbf800000u), x, false); }
+__global__ void k_split_dot2(const float* x, int n, float* h, float* m, float* lo) {
+  const int t = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (t + 1 >= n + 1) return;
+  const float x0 = x[t], x1 = x[t + 1];
+  const unsigned ph = cvt_pk_v(x0, x1);
+  const float r0 = sub_lo(x0, ph), r1 = sub_hi(x1, ph);
+  const unsigned pm = cvt_pk_v(r0, r1);
+  const float s0 = sub_lo(r0, pm), s1 = sub_hi(r1, pm);
+  const unsigned pl = cvt_pk_v(s0, s1);
+  h[t] = bf_lo(ph); h[t + 1] = bf_hi(ph);
+  m[t] = bf_lo(pm); m[t + 1] = bf_hi(pm);
+  lo[t] = bf_lo(pl); lo[t + 1] = bf_hi(pl);
+}
+
 // z[32][16] fp32 (pixel k, entry i) -> Z[16][16] by six bf16 MFMAs; lane (i, g) owns pixels 8g .. 8g+7 (any pixel -> (lane group, slot)
 // assignment works as long as A and B use the same one: the sum over k is order-free)
 __global__ void k_gram(const float* z, float* Z) {
@@ -121,6 +142,41 @@ int main() {
   }
   std::printf("2. three-way RNE split through v_cvt_pk_bf16_f32, %d floats in 2^-40 .. 2^41: %ld not reconstructed exactly (worst relative error %.3g), %ld pieces not bf16\n",
               n, inexact, worst, not_bf16);
+
+  // ---- 2b. the same split with v_dot2c_f32_bf16 remainders: identical pieces?  (also on a range that reaches into the denormals)
+  {
+    hipLaunchKernelGGL(k_split_dot2, dim3(n / 2 / 256), dim3(256), 0, 0, dx, n, dh, dm, dl);
+    std::vector<float> h2(n), m2(n), l2(n);
+    hipMemcpy(h2.data(), dh, n * 4, hipMemcpyDeviceToHost); hipMemcpy(m2.data(), dm, n * 4, hipMemcpyDeviceToHost); hipMemcpy(l2.data(), dl, n * 4, hipMemcpyDeviceToHost);
+    long differ = 0, inexact2 = 0;
+    for (int t = 0; t < n; ++t) {
+      if (std::memcmp(&h2[t], &h[t], 4) || std::memcmp(&m2[t], &m[t], 4) || std::memcmp(&l2[t], &lo[t], 4)) ++differ;
+      if ((double)h2[t] + (double)m2[t] + (double)l2[t] != (double)x[t]) ++inexact2;
+    }
+    std::printf("2b. remainders through v_dot2c_f32_bf16: %ld of %d inputs give different pieces than the shift/mask/subtract form, %ld not reconstructed exactly\n", differ, n, inexact2);
+    // pairs with one huge and one tiny member, and values near the bottom of the normal range
+    std::vector<float> y(n);
+    std::uniform_int_distribution<int> exw(-126, 100);
+    for (int t = 0; t < n; ++t) y[t] = std::ldexp(mant(rng), exw(rng)) * (sg(rng) ? 1.f : -1.f);
+    hipMemcpy(dx, y.data(), n * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_split, dim3(n / 2 / 256), dim3(256), 0, 0, dx, n, dh, dm, dl);
+    hipMemcpy(h.data(), dh, n * 4, hipMemcpyDeviceToHost); hipMemcpy(m.data(), dm, n * 4, hipMemcpyDeviceToHost); hipMemcpy(lo.data(), dl, n * 4, hipMemcpyDeviceToHost);
+    hipLaunchKernelGGL(k_split_dot2, dim3(n / 2 / 256), dim3(256), 0, 0, dx, n, dh, dm, dl);
+    hipMemcpy(h2.data(), dh, n * 4, hipMemcpyDeviceToHost); hipMemcpy(m2.data(), dm, n * 4, hipMemcpyDeviceToHost); hipMemcpy(l2.data(), dl, n * 4, hipMemcpyDeviceToHost);
+    long differ_w = 0, inexact_w = 0, inexact_w_small = 0; double worst_w = 0; float smallest_bad = 0.f;
+    for (int t = 0; t < n; ++t) {
+      if (std::memcmp(&h2[t], &h[t], 4) || std::memcmp(&m2[t], &m[t], 4) || std::memcmp(&l2[t], &lo[t], 4)) ++differ_w;
+      const double sum = (double)h2[t] + (double)m2[t] + (double)l2[t];
+      if (sum != (double)y[t]) {
+        ++inexact_w;
+        if (std::fabs(y[t]) < std::ldexp(1.0f, -100)) ++inexact_w_small;
+        const double e = std::fabs(sum - y[t]) / std::fabs(y[t]); if (e > worst_w) { worst_w = e; smallest_bad = y[t]; }
+      }
+    }
+    std::printf("    wide range 2^-126 .. 2^101: %ld different pieces, %ld not exact (%ld of them below 2^-100; worst relative error %.3g at %.3g)\n", differ_w, inexact_w,
+                inexact_w_small, worst_w, (double)smallest_bad);
+    hipMemcpy(dx, x.data(), n * 4, hipMemcpyHostToDevice);
+  }
 
   // ---- 3. Gram matrix of 32 x 16 fp32 values
   std::vector<float> z(32 * 16);
