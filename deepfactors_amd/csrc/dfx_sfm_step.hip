@@ -75,7 +75,7 @@ namespace dfx {
 #define DFX_TRACE 0          // 1: per-wave s_memtime sums of phase A / phase B in the junk row 15 of the (P,P) partial
 #endif
 #ifndef DFX_ABLATE
-#define DFX_ABLATE 0         // diagnosis only (wrong results; fp32 chain only, the bf16 split honours bit 4 alone): 1 = no MFMAs, 2 = no phase-A math/gathers, 4 = no ring loads,
+#define DFX_ABLATE 0         // diagnosis only (wrong results; the bf16 split honours bits 1, 2, 4 and 1024 = matrix instructions replaced by vector-ALU ones): 1 = no MFMAs, 2 = no phase-A math/gathers, 4 = no ring loads,
                              // 16 = no P x P fmas, 32 = no ray-table / valid0 reads, 64 = no operand shuffles, 128 = no tap gathers
 #endif
 
@@ -157,19 +157,22 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 // The remainders x - h through v_dot2c_f32_bf16: x + (p_lo, p_hi) . (-1, 0) expands the packed piece and subtracts it in ONE instruction per
 // value (exact: the products are exact and the sum is representable) -- 7 instead of 9 vector-ALU instructions per pair of values, and the
 // split is 40 % of the bf16 kernel's vector-ALU work (tools/ubench/bf16x3_probe.cpp section 2b: the same pieces for 2^20 inputs).
+// The selector is (-1, -0) / (-0, -1), NOT (-1, 0): the compiler encodes the packed constant 0x0000bf80 as the inline constant "-1.0", which
+// the instruction reads as the fp32 pattern 0xbf800000 = (0, -1) -- the wrong half (found by the probe: every second value wrong).  A
+// pattern that is no inline constant travels as a 32-bit literal; the -0 * piece term only ever adds a signed zero.
 #ifndef DFX_SPLIT_DOT2
 #define DFX_SPLIT_DOT2 1
 #endif
 __device__ __forceinline__ float sub_bf16_lo(float x, unsigned p) {
 #if DFX_SPLIT_DOT2
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, p), __builtin_bit_cast(bf16x2_t, 0x0000bf80u), x, false);
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, p), __builtin_bit_cast(bf16x2_t, 0x8000bf80u), x, false);
 #else
   return x - __uint_as_float(p << 16);
 #endif
 }
 __device__ __forceinline__ float sub_bf16_hi(float x, unsigned p) {
 #if DFX_SPLIT_DOT2
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, p), __builtin_bit_cast(bf16x2_t, 0xbf800000u), x, false);
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, p), __builtin_bit_cast(bf16x2_t, 0xbf808000u), x, false);
 #else
   return x - __uint_as_float(p & 0xffff0000u);
 #endif
@@ -182,7 +185,13 @@ __device__ __forceinline__ void split3_bf16(float x0, float x1, unsigned& ph, un
   pl = cvt_pk_bf16(s0, s1);
 }
 __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& c) {
+#if DFX_ABLATE & 1
+  return c;   // diagnosis: no matrix instructions (and, their operands being dead, no split either)
+#elif DFX_ABLATE & 1024
+  f32x4 r = c; r[0] += __uint_as_float((a[0] ^ b[1]) & 0x3fffffffu) + __uint_as_float((a[2] ^ b[3]) & 0x3fffffffu); return r;   // diagnosis: the split stays, the matrix instruction becomes 5 vector-ALU ones
+#else
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
 }
 
 // MODE 0: SfmAligner::RunStep.  MODE 1: DepthAligner::RunStep (cu_depthaligner.cpp:32-72) -- same rank-1 GEMM with

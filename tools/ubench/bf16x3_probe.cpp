@@ -58,8 +58,8 @@ __global__ void k_split(const float* x, int n, float* h, float* m, float* lo) {
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned cvt_pk_v(float lo, float hi) { const f32x2_t v = { lo, hi }; return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t)); }
-__device__ __forceinline__ float sub_lo(float x, unsigned p) { return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, p), __builtin_bit_cast(bf16x2_t, 0x0000bf80u), x, false); }
-__device__ __forceinline__ float sub_hi(float x, unsigned p) { return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, p), __builtin_bit_cast(bf16x2_t, 0xbf800000u), x, false); }
+__device__ __forceinline__ float sub_lo(float x, unsigned p) { return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, p), __builtin_bit_cast(bf16x2_t, 0x8000bf80u), x, false); }
+__device__ __forceinline__ float sub_hi(float x, unsigned p) { return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, p), __builtin_bit_cast(bf16x2_t, 0xbf808000u), x, false); }
 __global__ void k_split_dot2(const float* x, int n, float* h, float* m, float* lo) {
   const int t = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
   if (t + 1 >= n + 1) return;
