@@ -92,15 +92,10 @@ namespace dfx {
 #define DFX_STREAM_AUX 1     // cache policy of the coalesced img0 / dpt0 loads (read once per launch): 1 = sc0, they bypass the CU's L1 and leave
                              // it to the bilinear taps; -1 % (1055-1059 vs 1067 us, 4 interleaved runs each); nt (2) and sc0+nt (3) are no better
 #endif
-#ifndef DFX_HALF_RING
-#define DFX_HALF_RING 0      // bf16 split: 1 = the operand ring holds HALF a chunk (8 instead of 16 vectors per lane): half h of chunk c is consumed and refilled with
-#endif                       // the other half of the same / the first half of the next chunk -- 16 registers fewer, for a fourth wave per SIMD (DFX_B3_MIN_WAVES)
-#ifndef DFX_B3_EP_PARTS
-#define DFX_B3_EP_PARTS 1    // bf16 split: the workgroup's cross-wave fold stages the accumulators through LDS in this many parts (2: 20 instead of 37 KB of
-#endif                       // LDS per workgroup, so that four workgroups -- four waves per SIMD -- fit a CU beside their ray tables); same sums, same order
-#ifndef DFX_B3_MIN_WAVES
-#define DFX_B3_MIN_WAVES DFX_MIN_WAVES
-#endif
+// Measured in round 3 and removed (profiles/r03_ab_occupancy.txt): a fourth wave per SIMD for the bf16 split (147 -> 128 registers by way of a
+// half-size operand ring and a two-part epilogue fold that brings the workgroup's LDS from 37 to 20 KB): the 16-20 registers that still
+// spill put scratch loads into the in-order vmcnt queue of the pipelined loop: 1367-1415 us against 995-1007 us.  The half-size ring alone
+// (+0.6 %) and the two-part fold alone (+-0) at three waves change nothing.
 #ifndef DFX_TAIL_KERNEL
 #define DFX_TAIL_KERNEL 1    // batched bf16-split launches: 1 = k_sfm_tail_b3 (a workgroup per pair, graph assembly folded in), 0 = k_sfm_finalize_b3 (a workgroup
 #endif                       // per tile of a pair) and a separate assembly kernel -- the A/B switch of DESIGN.md 3.7
@@ -231,7 +226,7 @@ __device__ __forceinline__ float dpp_merge(float old, float src) {
 // VSH: every valid0 map of the launch is library-owned and carries a shadow (1 bit per pixel "known to hold 1.0"): 8 bytes are read per
 // chunk instead of the map's 256.
 template <int NCB, int MODE, bool JDENSE, bool TABLDS, bool BYVAL, bool DYN, bool B3, bool VSH>
-__global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX_B3_MIN_WAVES : DFX_MIN_WAVES)) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmPairDev one, const SfmParamsDev prm,
+__global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_WAVES) void k_sfm_step(const SfmPairDev* __restrict__ pairs, const SfmPairDev one, const SfmParamsDev prm,
                                                        const int Wk, const int Hk, float* __restrict__ partials, const DynDev dyn,
                                                        const unsigned* __restrict__ blkmap) {
   static_assert(!DYN || (MODE == 0 && JDENSE && TABLDS && !BYVAL), "the dynamic schedule exists for the batched dense SfM step");
@@ -241,10 +236,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
   constexpr int NT3 = b3_tiles(NCB);                             // B3: plain 16x16 tiles (P,P), (P,C_b), (C_b,C_b') b <= b'
   constexpr int NB3 = b3_blocks(NCB);                            // B3: accumulators = blocks of the partial
   constexpr int ZDIM = B3 ? NB3 * 256 : (1 + NACC + 2 * ND) * 256;   // block 0: the 29 P x P sums; then X, Pm, (Dd broadcast, Dd plain) per q
-  constexpr int EP = B3 ? DFX_B3_EP_PARTS : 1;                  // parts of the epilogue fold
-  constexpr int NBP = (NB3 + EP - 1) / EP;                      // B3: blocks per part
-  constexpr int ZSTAGE = B3 ? NBP * 256 : ZDIM;
-  constexpr int SLOT = (kUFloats > ZSTAGE) ? kUFloats : ZSTAGE;   // per wave: its P rows in the loop, its accumulators in the epilogue (same place)
+  constexpr int SLOT = (kUFloats > ZDIM) ? kUFloats : ZDIM;   // per wave: its P rows in the loop, its accumulators in the epilogue (same place)
   constexpr int LDS_FLOATS = kWaves * (DYN ? kUFloats : SLOT);   // DYN: no epilogue fold, only the P rows
   typedef typename JV<NCB>::T jv_t;
   // "No next chunk" is handled by re-reading the wave's current chunk (L2-hot, results never consumed), NOT by
@@ -498,8 +490,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
   };
 
   // ---- prologue: ring + state of the first chunk, depth of the second
-  constexpr int RING = (B3 && DFX_HALF_RING) ? 8 : 16;
-  jv_t jv[RING];
+  jv_t jv[16];
   Pix cur, nxt;
   {
     const unsigned base = (chunk < cend) ? (unsigned)chunk << 6 : 0u;   // idle wave: harmless loads of chunk 0
@@ -521,7 +512,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
     __builtin_amdgcn_sched_barrier(0);
     const __amdgpu_buffer_rsrc_t rs0 = ring_rsrc(base);
 #pragma unroll
-    for (int gq = 0; gq < RING; ++gq) jv[gq] = ring_load(rs0, ring_lane_off, base, gq, true);
+    for (int gq = 0; gq < 16; ++gq) jv[gq] = ring_load(rs0, ring_lane_off, base, gq, true);
     __builtin_amdgcn_sched_barrier(0);
   }
 
@@ -672,11 +663,9 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
             const float s = U[13 * kUStride + pp];
             x[0][e] = U[uP_row + pp];
 #pragma unroll
-            for (int b = 0; b < NCB; ++b) x[1 + b][e] = mul_zero_wins(s, jv_get<NCB>(jv[gq % RING], b));
+            for (int b = 0; b < NCB; ++b) x[1 + b][e] = mul_zero_wins(s, jv_get<NCB>(jv[gq], b));
 #if !(DFX_ABLATE & 4)
-            if (RING == 16) jv[gq] = ring_load(nrs, rlo, nbase, gq, has1);
-            else if (h == 0) jv[gq] = ring_load(ring_rsrc((unsigned)base), ring_opaque_off(true), (unsigned)base, gq + 8, true);   // second half of this chunk
-            else jv[gq - 8] = ring_load(nrs, rlo, nbase, gq - 8, has1);                                                          // first half of the next
+            jv[gq] = ring_load(nrs, rlo, nbase, gq, has1);
 #endif
           }
           {
@@ -828,30 +817,14 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
 #endif
     return;
   }
-  float* out = partials + (ragged ? (size_t)P.blk0 + blk_in_pair : (size_t)blockIdx.y * gridDim.x + blockIdx.x) * ZDIM;
-  if constexpr (B3) {   // every tile in the C/D layout of a 16x16 MFMA: [row = 4 (lane >> 4) + r][col = lane & 15]; EP parts of NBP blocks
-    float* mine = lds + wave * SLOT;
-#pragma unroll
-    for (int part = 0; part < EP; ++part) {
-      if (part) __syncthreads();   // the previous part has been read
-#pragma unroll
-      for (int a = part * NBP; a < (part + 1) * NBP && a < NB3; ++a)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mine[(a - part * NBP) * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc3[a][r];
-      __syncthreads();
-      const int nfl = ((part + 1) * NBP < NB3 ? NBP : NB3 - part * NBP) * 256;
-      for (int e = threadIdx.x; e < nfl; e += kThreads) {
-        float v = lds[e];
-#pragma unroll
-        for (int wv = 1; wv < kWaves; ++wv) v += lds[wv * SLOT + e];
-        out[part * NBP * 256 + e] = v;
-      }
-    }
-    return;
-  }
   {
     float* mine = lds + wave * SLOT;
-    {
+    if constexpr (B3) {   // every tile in the C/D layout of a 16x16 MFMA: [row = 4 (lane >> 4) + r][col = lane & 15]
+#pragma unroll
+      for (int a = 0; a < NB3; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[a * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc3[a][r];
+    } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r) mine[ppb * 16 + r * 4 + ppi] = accpp[r];   // block 0: [4x4 block b][row r][column = lane & 3]
 #pragma unroll
@@ -864,6 +837,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : (B3 ? DFX
       for (int r = 0; r < 4; ++r) mine[(1 + NACC + a) * 256 + ppb * 16 + r * 4 + ppi] = accd[a][r];
     }
   }
+  float* out = partials + (ragged ? (size_t)P.blk0 + blk_in_pair : (size_t)blockIdx.y * gridDim.x + blockIdx.x) * ZDIM;
   __syncthreads();
   for (int e = threadIdx.x; e < ZDIM; e += kThreads) {
     float v = lds[e];
