@@ -59,29 +59,95 @@ __device__ __forceinline__ RayLds stage_ray_table(const float* __restrict__ ray_
 }
 constexpr int kRayLdsMax = 4096;   // floats of LDS a simple kernel spends on the table (W + H <= 4096; larger images compute the rays)
 
-template <bool TAB, typename F>
+// Two software-pipeline stages per pixel: `issue` (the warp, then the bilinear tap LOADS of the pixel -- branch-free: a pixel without
+// correspondence reads taps at (0, 0), in range and never used) runs one pixel AHEAD of `consume` (interpolation, Jacobian row, sums), so
+// the taps' memory round trip -- a dependent load behind ~60 vector-ALU instructions of geometry -- hides under the arithmetic of the
+// pixel before instead of stalling every iteration (round 3: 128 pairs of 640x480 262 -> see DESIGN.md 3.4; these operators were
+// latency-bound at one round trip per pixel and wave, not HBM- or ALU-bound).
+#ifndef DFX_WALK_PIPELINED
+#define DFX_WALK_PIPELINED 1
+#endif
+struct TapLoads {       // the four taps of img1 [and of grad1] of one pixel, possibly still in flight
+  f32x2_u ia, ib;       // img1 rows iy, iy + 1: (x, x + 1)
+  f32x4_u8 ga, gb;      // grad1 rows iy, iy + 1: (gx, gy)(x), (gx, gy)(x + 1)
+  float ax, ay;
+};
+template <bool GRAD>
+__device__ __forceinline__ TapLoads issue_taps(const ImgRef& I1, const ImgRef& G1, const Corr& c) {
+  const Taps tp = make_taps(c.u, c.v);
+  const int ix = c.valid ? tp.ix : 0, iy = c.valid ? tp.iy : 0;
+  TapLoads t;
+  t.ax = tp.ax; t.ay = tp.ay;
+  const char* r0 = I1.rowb(iy) + (size_t)ix * 4;
+  t.ia = gload<f32x2_u>(r0);
+  t.ib = gload<f32x2_u>(r0 + I1.pitch);
+  if (GRAD) {
+    const char* q0 = G1.rowb(iy) + (size_t)ix * 8;
+    t.ga = gload<f32x4_u8>(q0);
+    t.gb = gload<f32x4_u8>(q0 + G1.pitch);
+  }
+  return t;
+}
+__device__ __forceinline__ float taps_img(const TapLoads& t) { return lerp1(lerp1(t.ia.x, t.ia.y, t.ax), lerp1(t.ib.x, t.ib.y, t.ax), t.ay); }
+__device__ __forceinline__ void taps_grad(const TapLoads& t, float& gx, float& gy) {
+  gx = lerp1(lerp1(t.ga.x, t.ga.z, t.ax), lerp1(t.gb.x, t.gb.z, t.ax), t.ay);
+  gy = lerp1(lerp1(t.ga.y, t.ga.w, t.ax), lerp1(t.gb.y, t.gb.w, t.ax), t.ay);
+}
+
+template <bool TAB, bool GRAD, typename F>
 __device__ __forceinline__ void walk_pixels(const Geo& g, const SimplePairDev& p, const RayLds& rt, const int W, const int H, const float border,
-                                            const float min_dpt, F&& body) {
+                                            const float min_dpt, F&& consume /* (d, i0, const Corr&, const TapLoads&) */) {
   const ImgRef I0{ (const char*)p.img0, p.pitch_img0 }, D0{ (const char*)p.dpt0, p.pitch_dpt0 };
+  const ImgRef I1{ (const char*)p.img1, p.pitch_img1 }, G1{ (const char*)p.grad1, p.pitch_grad1 };
   const unsigned npx = (unsigned)W * (unsigned)H;
   const unsigned step = gridDim.x * kT;
   unsigned i = blockIdx.x * kT + threadIdx.x;
   if (i >= npx) return;
   int y = (int)(i / (unsigned)W), x = (int)(i - (unsigned)y * (unsigned)W);
   const int sdy = (int)(step / (unsigned)W), sdx = (int)(step - (unsigned)sdy * (unsigned)W);
+  auto corr = [&](int cx, int cy, float cd) {
+    return TAB ? find_correspondence_ray<true>(g, rt.tab[cx], rt.tab[rt.W + cy], cd, border, min_dpt) : find_correspondence<true>(g, cx, cy, cd, border, min_dpt);
+  };
+  // the pixel after (ci, cx, cy) if `have` and there is one -- else the same pixel again (a harmless repeat: in range, never consumed)
+  auto advance = [&](bool have, unsigned ci, int cx, int cy, unsigned& ni, int& nx, int& ny) -> bool {
+    const bool more = have && ci + step < npx;
+    int tx = cx + sdx, ty = cy + sdy;
+    if (tx >= W) { tx -= W; ++ty; }
+    ni = more ? ci + step : ci; nx = more ? tx : cx; ny = more ? ty : cy;
+    return more;
+  };
   float d = D0.at(x, y), i0 = I0.at(x, y);
+#if DFX_WALK_PIPELINED
+  // pixel 0: geometry done, taps issued; pixel 1: depth / intensity in flight
+  unsigned i1; int x1, y1;
+  bool has1 = advance(true, i, x, y, i1, x1, y1);
+  float d1 = D0.at(x1, y1), i01 = I0.at(x1, y1);
+  Corr c = corr(x, y, d);
+  TapLoads t = issue_taps<GRAD>(I1, G1, c);
   while (true) {
-    const unsigned inext = i + step;
-    int xn = x + sdx, yn = y + sdy;
-    if (xn >= W) { xn -= W; ++yn; }
-    const bool more = inext < npx;
-    const int xl = more ? xn : x, yl = more ? yn : y;   // last pixel: a harmless re-load of itself
-    const float dn = D0.at(xl, yl), i0n = I0.at(xl, yl);
-    const Corr c = TAB ? find_correspondence_ray<true>(g, rt.tab[x], rt.tab[rt.W + y], d, border, min_dpt) : find_correspondence<true>(g, x, y, d, border, min_dpt);
-    body(x, y, d, i0, c);
-    if (!more) break;
-    i = inext; x = xn; y = yn; d = dn; i0 = i0n;
+    unsigned i2; int x2, y2;
+    const bool has2 = advance(has1, i1, x1, y1, i2, x2, y2);
+    const float d2 = D0.at(x2, y2), i02 = I0.at(x2, y2);   // depth / intensity of the pixel after next
+    const Corr c1 = corr(x1, y1, d1);                       // stage 1 of the next pixel
+    const TapLoads t1 = issue_taps<GRAD>(I1, G1, c1);
+    consume(d, i0, c, t);                                   // stage 2 of the current one
+    if (!has1) break;
+    d = d1; i0 = i01; c = c1; t = t1;
+    i1 = i2; x1 = x2; y1 = y2; has1 = has2;
+    d1 = d2; i01 = i02;
   }
+#else
+  while (true) {
+    unsigned in; int xn, yn;
+    const bool more = advance(true, i, x, y, in, xn, yn);
+    const float dn = D0.at(xn, yn), i0n = I0.at(xn, yn);
+    const Corr c = corr(x, y, d);
+    const TapLoads t = issue_taps<GRAD>(I1, G1, c);
+    consume(d, i0, c, t);
+    if (!more) break;
+    i = in; x = xn; y = yn; d = dn; i0 = i0n;
+  }
+#endif
 }
 
 // ---- SE3 step: 21 JtJ + 6 Jtr + r^2 + inliers = 29 floats per lane -----------------------------------------
@@ -90,15 +156,14 @@ __device__ __forceinline__ void walk_pixels(const Geo& g, const SimplePairDev& p
 template <bool TAB>
 __device__ __forceinline__ void se3_accumulate(const Geo& g, const SimplePairDev& p, const RayLds& rt, const int W, const int H, const float huber_delta,
                                                float (&acc)[29]) {
-  const ImgRef I1{ (const char*)p.img1, p.pitch_img1 }, G1{ (const char*)p.grad1, p.pitch_grad1 };
+
 #pragma unroll
   for (int q = 0; q < 29; ++q) acc[q] = 0.f;
-  walk_pixels<TAB>(g, p, rt, W, H, 1.0f, 0.0f, [&](int, int, float d, float i0, const Corr& c) {
+  walk_pixels<TAB, true>(g, p, rt, W, H, 1.0f, 0.0f, [&](float d, float i0, const Corr& c, const TapLoads& t) {
     if (c.valid) {
-      const Taps tp = make_taps(c.u, c.v);
       float gx, gy;
-      sample_grad(G1, tp, gx, gy);
-      const float samp = sample_img(I1, tp);
+      taps_grad(t, gx, gy);
+      const float samp = taps_img(t);
       float J[6], D00, D02, D11, D12;
       pose_row(g, c, d, gx, gy, J, D00, D02, D11, D12);
       float r = i0 - samp;
@@ -390,12 +455,11 @@ hipError_t launch_sparse_geometric(int cs, const void* desc_host, const float* c
 template <bool TAB>
 __device__ __forceinline__ void sfm_error_accumulate(const Geo& g, const SimplePairDev& p, const RayLds& rt, const int W, const int H, const float huber_delta,
                                                      float (&acc)[2]) {
-  const ImgRef I1{ (const char*)p.img1, p.pitch_img1 };
+
   acc[0] = acc[1] = 0.f;
-  walk_pixels<TAB>(g, p, rt, W, H, 1.0f, 0.0f, [&](int, int, float, float i0, const Corr& c) {   // dense_sfm.h:91: default border 1, min_dpt 0
+  walk_pixels<TAB, false>(g, p, rt, W, H, 1.0f, 0.0f, [&](float, float i0, const Corr& c, const TapLoads& t) {   // dense_sfm.h:91: default border 1, min_dpt 0
     if (c.valid) {
-      const Taps tp = make_taps(c.u, c.v);
-      float r = i0 - sample_img(I1, tp);
+      float r = i0 - taps_img(t);
       r *= huber_weight(r, huber_delta);
       acc[0] += r * r;
       acc[1] += 1.0f;
