@@ -118,23 +118,33 @@ __device__ __forceinline__ void walk_pixels(const Geo& g, const SimplePairDev& p
   };
   float d = D0.at(x, y), i0 = I0.at(x, y);
 #if DFX_WALK_PIPELINED
-  // pixel 0: geometry done, taps issued; pixel 1: depth / intensity in flight
+  // pixel 0: geometry done, taps issued; pixel 1: depth / intensity in flight.  The loop is written out twice with the two pixel states
+  // (A, B) swapping roles, so that no state is copied from "next" to "current" (the copies were 47 of the SE3 loop's 177 instructions).
   unsigned i1; int x1, y1;
   bool has1 = advance(true, i, x, y, i1, x1, y1);
-  float d1 = D0.at(x1, y1), i01 = I0.at(x1, y1);
-  Corr c = corr(x, y, d);
-  TapLoads t = issue_taps<GRAD>(I1, G1, c);
+  float dB = D0.at(x1, y1), i0B = I0.at(x1, y1);
+  float dA = d, i0A = i0;
+  Corr cA = corr(x, y, dA), cB;
+  TapLoads tA = issue_taps<GRAD>(I1, G1, cA), tB;
   while (true) {
     unsigned i2; int x2, y2;
     const bool has2 = advance(has1, i1, x1, y1, i2, x2, y2);
-    const float d2 = D0.at(x2, y2), i02 = I0.at(x2, y2);   // depth / intensity of the pixel after next
-    const Corr c1 = corr(x1, y1, d1);                       // stage 1 of the next pixel
-    const TapLoads t1 = issue_taps<GRAD>(I1, G1, c1);
-    consume(d, i0, c, t);                                   // stage 2 of the current one
+    const float dN = D0.at(x2, y2), i0N = I0.at(x2, y2);   // depth / intensity of the pixel after next
+    cB = corr(x1, y1, dB);                                  // stage 1 of the next pixel (B)
+    tB = issue_taps<GRAD>(I1, G1, cB);
+    consume(dA, i0A, cA, tA);                               // stage 2 of the current one (A)
     if (!has1) break;
-    d = d1; i0 = i01; c = c1; t = t1;
-    i1 = i2; x1 = x2; y1 = y2; has1 = has2;
-    d1 = d2; i01 = i02;
+    // second half: B is current, A takes the pixel after
+    unsigned i3; int x3, y3;
+    const bool has3 = advance(has2, i2, x2, y2, i3, x3, y3);
+    dA = dN; i0A = i0N;
+    const float dM = D0.at(x3, y3), i0M = I0.at(x3, y3);
+    cA = corr(x2, y2, dA);
+    tA = issue_taps<GRAD>(I1, G1, cA);
+    consume(dB, i0B, cB, tB);
+    if (!has2) break;
+    dB = dM; i0B = i0M;
+    i1 = i3; x1 = x3; y1 = y3; has1 = has3;
   }
 #else
   while (true) {
