@@ -117,7 +117,9 @@ __device__ __forceinline__ void walk_pixels(const Geo& g, const SimplePairDev& p
     return more;
   };
   float d = D0.at(x, y), i0 = I0.at(x, y);
-#if DFX_WALK_PIPELINED
+  // (the SE3 step -- 184 vector-ALU instructions per pixel, its SIMDs 86 % busy with them -- gains nothing from the second stage and pays
+  // for its state: 248 vs 256 us per 128 pairs; EvaluateError, 102 instructions per pixel: 155 -> 129 us.  profiles/r03_small_ops.txt)
+  if constexpr (DFX_WALK_PIPELINED && !GRAD) {
   // pixel 0: geometry done, taps issued; pixel 1: depth / intensity in flight.  The loop is written out twice with the two pixel states
   // (A, B) swapping roles, so that no state is copied from "next" to "current" (the copies were 47 of the SE3 loop's 177 instructions).
   unsigned i1; int x1, y1;
@@ -146,7 +148,7 @@ __device__ __forceinline__ void walk_pixels(const Geo& g, const SimplePairDev& p
     dB = dM; i0B = i0M;
     i1 = i3; x1 = x3; y1 = y3; has1 = has3;
   }
-#else
+  } else {
   while (true) {
     unsigned in; int xn, yn;
     const bool more = advance(true, i, x, y, in, xn, yn);
@@ -157,7 +159,7 @@ __device__ __forceinline__ void walk_pixels(const Geo& g, const SimplePairDev& p
     if (!more) break;
     i = in; x = xn; y = yn; d = dn; i0 = i0n;
   }
-#endif
+  }
 }
 
 // ---- SE3 step: 21 JtJ + 6 Jtr + r^2 + inliers = 29 floats per lane -----------------------------------------
