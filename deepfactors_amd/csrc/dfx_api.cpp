@@ -89,9 +89,6 @@ struct dfx_ctx {
   unsigned* qhead = nullptr;   // dynamic schedule: one item-queue head per pair of a batch (rewound by the finalize kernel)
   size_t qhead_cap = 0;
   bool qhead_dirty = false;    // a dynamic launch failed between its step and its finalize kernel: the heads were not rewound
-  unsigned* fold_cnt = nullptr;   // reduction operators (SE3 step, EvaluateError, Warp, SquaredError, tracker): arrivals per pair for the fold of the second
-  size_t fold_cnt_cap = 0;        // pass into the first (block_reduce_fold); zero between launches
-  bool fold = true;               // DFX_FOLD=0 in the environment: two kernels per operator (k_finalize_rows / k_track_update), for A/B runs
   unsigned* node_cnt = nullptr;   // graph assembly inside the reduction tail: arrivals per node, zero between launches (k_sfm_tail_b3 rewinds)
   size_t node_cnt_cap = 0;
   bool node_cnt_dirty = false;    // a launch failed after the counters were handed out
@@ -385,24 +382,6 @@ int auto_step_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int npairs, int c
   return b < maxb ? b : maxb;
 }
 
-// Arrival counters of the folded reduction operators: n zeroed words (they return to zero with every launch that uses them); *out = null when the
-// fold is switched off.  A launch that failed half-way may have left counts behind: the sticky error of such a launch ends the context's use anyway.
-int fold_counters(dfx_ctx* c, int n, unsigned** out) {
-  *out = nullptr;
-  if (!c->fold) return DFX_OK;
-  if (c->fold_cnt_cap < (size_t)n) {
-    DFX_HIP(hipStreamSynchronize(c->stream));
-    if (c->fold_cnt) DFX_HIP(hipFree(c->fold_cnt));
-    c->fold_cnt = nullptr; c->fold_cnt_cap = 0;
-    const size_t cap = (size_t)n < 256 ? 256 : (size_t)n * 2;
-    DFX_HIP(hipMalloc((void**)&c->fold_cnt, sizeof(unsigned) * cap));
-    DFX_HIP(hipMemsetAsync(c->fold_cnt, 0, sizeof(unsigned) * cap, c->stream));
-    c->fold_cnt_cap = cap;
-  }
-  *out = c->fold_cnt;
-  return DFX_OK;
-}
-
 int simple_blocks(uint32_t W, uint32_t H) {
   int b = (int)(((size_t)W * H + 255) / 256);
   if (b > dfx::kMaxSimpleBlocks) b = dfx::kMaxSimpleBlocks;
@@ -534,11 +513,6 @@ DFX_API int dfx_ctx_create(int device, void* stream, dfx_ctx** out) {
     else if (std::strcmp(ev, "auto") == 0) c->mfma_mode = DFX_MFMA_AUTO;
     else { delete c; return fail(DFX_E_INVALID, "environment DFX_MFMA=%s: expected auto, f32 or bf16x3", ev); }
   }
-  if (const char* ev = std::getenv("DFX_FOLD")) {
-    if (!std::strcmp(ev, "0")) c->fold = false;
-    else if (!std::strcmp(ev, "1")) c->fold = true;
-    else { delete c; return fail(DFX_E_INVALID, "environment DFX_FOLD=%s: expected 0 or 1", ev); }
-  }
   if (const char* ev = std::getenv("DFX_SCHEDULE")) {
     if (std::strcmp(ev, "static") == 0) c->schedule = DFX_SCHEDULE_STATIC;
     else if (std::strcmp(ev, "dynamic") == 0) c->schedule = DFX_SCHEDULE_DYNAMIC;
@@ -575,7 +549,6 @@ DFX_API void dfx_ctx_destroy(dfx_ctx* c) {
   if (c->sdesc_dev) (void)hipFree(c->sdesc_dev);
   if (c->qhead) (void)hipFree(c->qhead);
   if (c->node_cnt) (void)hipFree(c->node_cnt);
-  if (c->fold_cnt) (void)hipFree(c->fold_cnt);
   if (c->track_state_dev) (void)hipFree(c->track_state_dev);
   if (c->sg_dev) (void)hipFree(c->sg_dev);
   for (auto& t : c->ray_tabs) (void)hipFree(t.dev);
@@ -1195,9 +1168,7 @@ DFX_API int dfx_sfm_error(dfx_ctx* c, const dfx_se3* pose0, const dfx_se3* pose1
   if ((rc = grow_partials(c, pbytes))) return rc;
   void* tgt;
   if ((rc = result_target(c, sizeof(dfx_corr_item), &tgt))) return rc;
-  unsigned* fcnt;
-  if ((rc = fold_counters(c, 1, &fcnt))) return rc;
-  DFX_HIP(dfx::launch_sfm_error(d, (int)img0->w, (int)img0->h, params->huber_delta, blocks, c->partials, tgt, c->stream, fcnt));
+  DFX_HIP(dfx::launch_sfm_error(d, (int)img0->w, (int)img0->h, params->huber_delta, blocks, c->partials, tgt, c->stream));
   return finish_result(c, out, sizeof(dfx_corr_item));
 }
 
@@ -1260,9 +1231,7 @@ DFX_API int dfx_sfm_error_batch_async(dfx_ctx* c, const dfx_sfm_params* params, 
   const dfx::SimplePairDev* dd;
   int slot;
   if ((rc = upload_simple(c, descs, &dd, &slot))) return rc;
-  unsigned* fcnt;
-  if ((rc = fold_counters(c, n, &fcnt))) return rc;
-  DFX_HIP(dfx::launch_sfm_error_batch(dd, n, (int)W, (int)H, params->huber_delta, blocks, c->partials, out_items_dev, c->stream, fcnt));
+  DFX_HIP(dfx::launch_sfm_error_batch(dd, n, (int)W, (int)H, params->huber_delta, blocks, c->partials, out_items_dev, c->stream));
   return stage_release(c, slot);
 }
 
@@ -1306,9 +1275,7 @@ DFX_API int dfx_se3_step_batch_async(dfx_ctx* c, const dfx_se3_pair* pairs, int 
   const dfx::SimplePairDev* dd;
   int slot;
   if ((rc = upload_simple(c, descs, &dd, &slot))) return rc;
-  unsigned* fcnt;
-  if ((rc = fold_counters(c, n, &fcnt))) return rc;
-  DFX_HIP(dfx::launch_se3_step_batch(dd, n, (int)W, (int)H, huber_delta, blocks, c->partials, out_items_dev, c->stream, fcnt));
+  DFX_HIP(dfx::launch_se3_step_batch(dd, n, (int)W, (int)H, huber_delta, blocks, c->partials, out_items_dev, c->stream));
   return stage_release(c, slot);
 }
 
@@ -1344,9 +1311,7 @@ DFX_API int dfx_se3_step(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam,
   if ((rc = grow_partials(c, pbytes))) return rc;
   void* tgt;
   if ((rc = result_target(c, dfx_item_size(6), &tgt))) return rc;
-  unsigned* fcnt;
-  if ((rc = fold_counters(c, 1, &fcnt))) return rc;
-  DFX_HIP(dfx::launch_se3_step(d, (int)img0->w, (int)img0->h, huber_delta, blocks, c->partials, tgt, c->stream, fcnt));
+  DFX_HIP(dfx::launch_se3_step(d, (int)img0->w, (int)img0->h, huber_delta, blocks, c->partials, tgt, c->stream));
   return finish_result(c, out_item, dfx_item_size(6));
 }
 
@@ -1364,9 +1329,7 @@ DFX_API int dfx_se3_warp(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam,
   if ((rc = grow_partials(c, pbytes))) return rc;
   void* tgt;
   if ((rc = result_target(c, sizeof(dfx_corr_item), &tgt))) return rc;
-  unsigned* fcnt;
-  if ((rc = fold_counters(c, 1, &fcnt))) return rc;
-  DFX_HIP(dfx::launch_se3_warp(d, (int)img0->w, (int)img0->h, blocks, c->partials, tgt, c->stream, fcnt));
+  DFX_HIP(dfx::launch_se3_warp(d, (int)img0->w, (int)img0->h, blocks, c->partials, tgt, c->stream));
   return finish_result(c, out, sizeof(dfx_corr_item));
 }
 
@@ -1433,13 +1396,11 @@ int track_frames_impl(dfx_ctx* c, int n, const dfx_se3* pose_init, const dfx_tra
   DFX_HIP(hipMemcpyAsync(c->track_state_dev, host, total, hipMemcpyHostToDevice, c->stream));
   if ((rc = stage_release(c, slot))) return rc;
   const dfx::SimplePairDev* ddesc = reinterpret_cast<const dfx::SimplePairDev*>((const char*)c->track_state_dev + off_desc);
-  unsigned* fcnt;   // one launch per iteration: the tracker's last workgroup to arrive sums, solves and moves the pose
-  if ((rc = fold_counters(c, n, &fcnt))) return rc;
   for (int l = n_levels - 1; l >= 0; --l) {
     const int W = (int)levels[l].img0.w, H = (int)levels[l].img0.h;
     const int blocks = simple_blocks(levels[l].img0.w, levels[l].img0.h);
     for (int it = 0; it < levels[l].iterations; ++it)
-      DFX_HIP(dfx::launch_track_iteration(ddesc + (size_t)l * n, n, c->track_state_dev, W, H, huber_delta, blocks, c->partials, c->stream, fcnt));
+      DFX_HIP(dfx::launch_track_iteration(ddesc + (size_t)l * n, n, c->track_state_dev, W, H, huber_delta, blocks, c->partials, c->stream));
   }
   if ((rc = ensure_result_host(c, sbytes * (size_t)n))) return rc;
   DFX_HIP(hipMemcpyAsync(c->result_host, c->track_state_dev, sbytes * (size_t)n, hipMemcpyDeviceToHost, c->stream));
@@ -1725,10 +1686,8 @@ DFX_API int dfx_squared_error(dfx_ctx* c, const dfx_img* a, const dfx_img* b, fl
   if ((rc = grow_partials(c, pbytes))) return rc;
   void* tgt;
   if ((rc = result_target(c, sizeof(float), &tgt))) return rc;
-  unsigned* fcnt;
-  if ((rc = fold_counters(c, 1, &fcnt))) return rc;
   DFX_HIP(dfx::launch_squared_error((const float*)a->ptr, (uint32_t)a->pitch_bytes, (const float*)b->ptr, (uint32_t)b->pitch_bytes,
-                                    (int)a->w, (int)a->h, blocks, c->partials, (float*)tgt, c->stream, fcnt));
+                                    (int)a->w, (int)a->h, blocks, c->partials, (float*)tgt, c->stream));
   return finish_result(c, out, sizeof(float));
 }
 

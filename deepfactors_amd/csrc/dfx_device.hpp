@@ -221,27 +221,13 @@ __device__ __forceinline__ double strided_sum_f64(const float* __restrict__ src,
 
 // Same sum, same order, for n <= STEP * MAXQ: every load of the thread is in flight at once (ONE L2 round trip instead of one per
 // batch of 8 plus one per leftover row).  Rows past n contribute +0.0, which leaves the running double sum unchanged bit for bit.
-// Device-scope ("coherent") accesses: data one workgroup writes and ANOTHER workgroup of the same kernel reads (the last workgroup to arrive
-// folds the others' partial results).  A device-scope store is written through to memory and is visible to device-scope loads from any XCD
-// once it has completed (s_waitcnt vmcnt(0)); the alternative -- a release / acquire fence pair -- writes back and invalidates the XCD's
-// whole L2 per wave (measured: 80 us per launch over 128 workgroups of 16 waves, profiles/r03_tail_kernel.txt).
-template <bool COH, typename V>
-__device__ __forceinline__ void coh_store(V* p, V v) {
-  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
-}
-template <bool COH, typename V>
-__device__ __forceinline__ V coh_load(const V* p) {
-  if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return *p;
-}
-
-template <int STEP, int MAXQ, bool COH = false>
+template <int STEP, int MAXQ>
 __device__ __forceinline__ double strided_sum_f64_wide(const float* __restrict__ src, int first, int n, size_t stride) {
   float v[MAXQ];
 #pragma unroll
   for (int q = 0; q < MAXQ; ++q) {
     const int b = first + q * STEP;
-    const float t = coh_load<COH>(src + (size_t)(b < n ? b : 0) * stride);   // unconditional load of an existing row (a conditional one is a branch + wait each)
+    const float t = src[(size_t)(b < n ? b : 0) * stride];   // unconditional load of an existing row (a conditional one is a branch + wait each)
     v[q] = b < n ? t : 0.0f;
   }
   double s = 0.0;

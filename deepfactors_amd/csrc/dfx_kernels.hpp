@@ -105,19 +105,17 @@ size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair);
 hipError_t launch_graph_assemble(int cs, const GraphDev& G, const void* items_dev, size_t item_stride, int first_pair, int n_local, float* sys_dev,
                                  hipStream_t stream);
 
-// fold_counters (all reduction operators below): one zeroed unsigned per pair -> the pair's last workgroup to arrive writes the result and
-// rewinds its counter (one launch); null -> a second kernel (k_finalize_rows / k_track_update) does.  Same sums, same order either way.
 hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
-                           void* item_dev, hipStream_t stream, unsigned* fold_counters = nullptr);
+                           void* item_dev, hipStream_t stream);
 hipError_t launch_sfm_error(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
-                            void* corr_item_dev, hipStream_t stream, unsigned* fold_counters = nullptr);
+                            void* corr_item_dev, hipStream_t stream);
 // batched forms: descs_dev[n], partials [n][blocks][kSimpleRow], results packed (16 bytes per dfx_corr_item, 120 per JTJJrReductionItem<float,6>)
 hipError_t launch_sfm_error_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
-                                  void* corr_items_dev, hipStream_t stream, unsigned* fold_counters = nullptr);
+                                  void* corr_items_dev, hipStream_t stream);
 hipError_t launch_se3_step_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
-                                 void* items_dev, hipStream_t stream, unsigned* fold_counters = nullptr);
+                                 void* items_dev, hipStream_t stream);
 hipError_t launch_se3_warp(const SimplePairDev& p, int W, int H, int blocks, float* partials_dev, void* corr_item_dev,
-                           hipStream_t stream, unsigned* fold_counters = nullptr);
+                           hipStream_t stream);
 hipError_t launch_update_depth(int cs, const float* code_dev, const float* prx_orig, uint32_t pitch_prx, const float* jac,
                                uint32_t pitch_jac, float avg_dpt, float* dpt_out, uint32_t pitch_out, int W, int H,
                                hipStream_t stream);
@@ -126,7 +124,7 @@ hipError_t launch_sobel(const float* img, uint32_t pitch, float* grad, uint32_t 
 hipError_t launch_blur_down(const float* in, uint32_t pitch, int W, int H, float* out, uint32_t opitch, int OW, int OH,
                             hipStream_t stream);
 hipError_t launch_squared_error(const float* a, uint32_t pitch_a, const float* b, uint32_t pitch_b, int W, int H, int blocks,
-                                float* partials_dev, float* out_dev, hipStream_t stream, unsigned* fold_counters = nullptr);
+                                float* partials_dev, float* out_dev, hipStream_t stream);
 hipError_t launch_depth_aligner_step(int cs, const SfmPairDev* pair_host, int W, int H, float avg_dpt, int blocks,
                                      float* partials_dev, void* item_dev, hipStream_t stream, bool jac_dense, int prec);
 
@@ -136,7 +134,7 @@ void track_state_init(void* host_state, const double* R, const double* t);
 void track_state_read(const void* host_state, double* R, double* t, float* residual, float* inliers, int* failures, int* iters);
 // one Gauss-Newton iteration of `n` independent trackers at one pyramid level: descs_dev[n], states_dev[n], partials [n][blocks][kSimpleRow]
 hipError_t launch_track_iteration(const SimplePairDev* descs_dev, int n, void* states_dev, int W, int H, float huber_delta, int blocks,
-                                  float* partials_dev, hipStream_t stream, unsigned* fold_counters = nullptr);
+                                  float* partials_dev, hipStream_t stream);
 
 // SparseGeometricFactor::linearize
 size_t sparse_geo_desc_bytes();

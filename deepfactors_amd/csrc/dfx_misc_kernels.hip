@@ -13,7 +13,7 @@ namespace dfx {
 
 constexpr int kT = 256;   // threads per workgroup (4 waves)
 
-template <int N, bool COH = false>
+template <int N>
 __device__ __forceinline__ void block_reduce_store(float (&v)[N], float* __restrict__ out_row) {
   static_assert(N <= kSimpleRow, "partial row too small");
   __shared__ float red[kT / 64][kSimpleRow];
@@ -27,80 +27,8 @@ __device__ __forceinline__ void block_reduce_store(float (&v)[N], float* __restr
   if (threadIdx.x < kSimpleRow) {
     float s = 0.f;
     if (threadIdx.x < N) s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-    coh_store<COH>(out_row + threadIdx.x, s);
+    out_row[threadIdx.x] = s;
   }
-}
-
-// ---- the second pass folded into the first: the LAST workgroup of a pair to arrive sums the pair's partial rows (same grouping, same
-// order, same double arithmetic as k_finalize_rows) and writes the result -- one launch per operator instead of two, which is what a
-// blocking single-pair call mostly consists of (SE3Aligner::RunStep: 28 us for an 8 us kernel).  Rounds 1-2 rejected this because the
-// release / acquire fences around the arrival counter cost more than the second launch; the partial rows now travel in device-scope
-// stores and loads instead (dfx_device.hpp, coh_store), which need no cache maintenance.  counters: one per pair, zero between launches.
-struct FoldDev {
-  unsigned* counters;   // null: the caller launches k_finalize_rows / k_track_update behind this kernel
-  char* out;            // result of pair 0; pair g at out + g * out_stride
-  size_t out_stride;
-  int kind;             // FinalKind
-};
-constexpr int kFoldScratchFloats = 2 * (32 * kSimpleRow + kSimpleRow);   // LDS the fold needs, in floats (doubles [32][32] + [32])
-
-// true in every thread of the last workgroup to arrive at `counter` (of `expected`); the caller's device-scope stores are complete first
-__device__ __forceinline__ bool wg_arrive_last(unsigned* counter, unsigned expected) {
-  __shared__ int s_last;
-  __builtin_amdgcn_s_waitcnt(0);   // vmcnt = lgkmcnt = 0: this wave's stores have completed
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned got = atomicAdd(counter, 1u) + 1u;
-    s_last = got == expected ? 1 : 0;
-    if (got == expected) *counter = 0u;   // rewound for the next launch
-  }
-  __syncthreads();
-  return s_last != 0;
-}
-
-enum FinalKind { kFinalItem6 = 0, kFinalCorr = 1, kFinalScalar = 2 };
-
-// sum_b partials[b][e] in double: 32 row groups (rows g, g + 32, ...) summed in ascending order, then the groups in ascending order.
-// THREADS = 1024: one group per thread (k_finalize_rows); 256: four groups per thread, one after the other (the folded form) -- same sums.
-template <int THREADS, bool COH>
-__device__ __forceinline__ double fold_rows(const float* __restrict__ partials, const int nblocks, double* scratch /* [32][kSimpleRow] */) {
-  static_assert(kMaxSimpleBlocks <= 32 * 32, "one load per row group and thread");
-  constexpr int SLOTS = THREADS / 32;
-  double (*red)[kSimpleRow] = reinterpret_cast<double (*)[kSimpleRow]>(scratch);
-  const int e = threadIdx.x & 31, r0 = threadIdx.x >> 5;
-#pragma unroll
-  for (int j = 0; j < 32 / SLOTS; ++j) {
-    const int rg = r0 + SLOTS * j;
-    red[rg][e] = strided_sum_f64_wide<32, 32, COH>(partials + e, rg, nblocks, kSimpleRow);
-  }
-  __syncthreads();
-  double s = 0.0;
-  if (threadIdx.x < 32) for (int q = 0; q < 32; ++q) s += red[q][e];
-  return s;   // valid in threads 0 .. 31 (e = thread)
-}
-
-__device__ __forceinline__ void write_final(const int kind, const int e, const double s, char* __restrict__ out) {
-  if (kind == kFinalItem6) {
-    // JTJJrReductionItem<float,6>: 21 + 6 + 1 floats, then u64 inliers at byte 112
-    if (e < 28) reinterpret_cast<float*>(out)[e] = (float)s;
-    else if (e == 28) *reinterpret_cast<unsigned long long*>(out + 112) = (unsigned long long)(s + 0.5);
-  } else if (kind == kFinalCorr) {
-    if (e == 0) reinterpret_cast<float*>(out)[0] = (float)s;
-    else if (e == 1) *reinterpret_cast<unsigned long long*>(out + 8) = (unsigned long long)(s + 0.5);
-  } else {
-    if (e == 0) reinterpret_cast<float*>(out)[0] = (float)s;
-  }
-}
-
-// epilogue of the reduction kernels: the workgroup's partial row, and -- folded -- the pair's result by the last workgroup to arrive
-template <int N>
-__device__ __forceinline__ void block_reduce_fold(float (&v)[N], float* __restrict__ partials_of_pair, const int nblocks, const int blk, const int pair,
-                                                  const FoldDev& fd, float* lds_scratch /* kFoldScratchFloats, 8-byte aligned */) {
-  if (!fd.counters) { block_reduce_store<N, false>(v, partials_of_pair + (size_t)blk * kSimpleRow); return; }
-  block_reduce_store<N, true>(v, partials_of_pair + (size_t)blk * kSimpleRow);
-  if (!wg_arrive_last(fd.counters + pair, (unsigned)nblocks)) return;
-  const double s = fold_rows<kT, true>(partials_of_pair, nblocks, reinterpret_cast<double*>(lds_scratch));
-  if (threadIdx.x < 32) write_final(fd.kind, (int)threadIdx.x, s, fd.out + (size_t)pair * fd.out_stride);
 }
 
 __device__ __forceinline__ Geo geo_from(const SimplePairDev& p) {
@@ -270,14 +198,13 @@ __device__ __forceinline__ void se3_accumulate(const Geo& g, const SimplePairDev
 
 template <bool TAB>
 __global__ __launch_bounds__(kT) void k_se3_step(const SimplePairDev p, const int W, const int H, const float huber_delta,
-                                                 float* __restrict__ partials, const FoldDev fd) {
-  __shared__ __attribute__((aligned(16))) float ray_lds[TAB ? kRayLdsMax : kFoldScratchFloats];   // the ray table; afterwards the fold's scratch
-  static_assert(kRayLdsMax >= kFoldScratchFloats, "the fold re-uses the ray table's LDS");
+                                                 float* __restrict__ partials) {
+  __shared__ float ray_lds[TAB ? kRayLdsMax : 1];
   const Geo g = geo_from(p);
   const RayLds rt = stage_ray_table<TAB>(p.ray_tab, ray_lds, W, H);
   float acc[29];
   se3_accumulate<TAB>(g, p, rt, W, H, huber_delta, acc);
-  block_reduce_fold<29>(acc, partials, (int)gridDim.x, (int)blockIdx.x, 0, fd, ray_lds);
+  block_reduce_store<29>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
 // ---- device-resident tracker (CameraTracker::TrackFrame, reference core/system/camera_tracker.cpp:42-71) -------------
@@ -292,8 +219,39 @@ struct TrackState {      // device-resident
 
 // blockIdx.y = candidate: Relocalize / the loop-closure geometry checks track ONE live frame against N keyframes
 // (deepfactors.cpp:713-743, loop_detector.cpp:146-167); descriptors, states and partials are arrays over candidates.
-// The solve + pose update of one tracker iteration by thread 0: sum[0..28] = the iteration's sums (double), st = the tracker's state.
-__device__ __forceinline__ void track_solve_update(const double* __restrict__ sum, TrackState* __restrict__ st) {
+template <bool TAB>
+__global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev* __restrict__ descs, const TrackState* __restrict__ states, const int W,
+                                                     const int H, const float huber_delta, float* __restrict__ partials_all) {
+  const SimplePairDev& p = descs[blockIdx.y];
+  const TrackState* st = states + blockIdx.y;
+  float* partials = partials_all + (size_t)blockIdx.y * gridDim.x * kSimpleRow;
+  Geo g = geo_from(p);
+#pragma unroll
+  for (int q = 0; q < 9; ++q) g.R[q] = st->Rf[q];
+  g.t[0] = st->tf[0]; g.t[1] = st->tf[1]; g.t[2] = st->tf[2];
+  __shared__ float ray_lds[TAB ? kRayLdsMax : 1];
+  const RayLds rt = stage_ray_table<TAB>(p.ray_tab, ray_lds, W, H);
+  float acc[29];
+  se3_accumulate<TAB>(g, p, rt, W, H, huber_delta, acc);
+  block_reduce_store<29>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
+}
+
+__global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__ partials_all, const int nblocks, TrackState* __restrict__ states) {
+  const float* partials = partials_all + (size_t)blockIdx.x * nblocks * kSimpleRow;
+  TrackState* st = states + blockIdx.x;
+  __shared__ double red[32][kSimpleRow];
+  __shared__ double sum[kSimpleRow];
+  const int e = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  double s = strided_sum_f64_wide<32, 32>(partials + e, rg, nblocks, kSimpleRow);
+  red[rg][e] = s;
+  __syncthreads();
+  if (rg == 0) {
+    s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) s += red[q][e];
+    sum[e] = s;
+  }
+  __syncthreads();
   if (threadIdx.x != 0) return;
   // Thread 0 solves.  Every loop below is fully unrolled so that the small matrices are REGISTERS (as dynamically indexed private
   // arrays they landed in scratch memory and made this kernel as slow as the step kernel itself; as LDS arrays every dependent
@@ -378,52 +336,14 @@ __device__ __forceinline__ void track_solve_update(const double* __restrict__ su
   for (int i = 0; i < 3; ++i) { st->t[i] -= x[i]; st->tf[i] = (float)st->t[i]; }
 }
 
-__global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__ partials_all, const int nblocks, TrackState* __restrict__ states) {
-  __shared__ double red[32][kSimpleRow];
-  __shared__ double sum[kSimpleRow];
-  const double s = fold_rows<1024, false>(partials_all + (size_t)blockIdx.x * nblocks * kSimpleRow, nblocks, &red[0][0]);
-  if (threadIdx.x < 32) sum[threadIdx.x] = s;
-  __syncthreads();
-  track_solve_update(sum, states + blockIdx.x);
-}
-
-template <bool TAB>
-__global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev* __restrict__ descs, TrackState* __restrict__ states, const int W,
-                                                     const int H, const float huber_delta, float* __restrict__ partials_all, unsigned* __restrict__ fold_counters) {
-  const SimplePairDev& p = descs[blockIdx.y];
-  TrackState* st = states + blockIdx.y;
-  float* partials = partials_all + (size_t)blockIdx.y * gridDim.x * kSimpleRow;
-  Geo g = geo_from(p);
-#pragma unroll
-  for (int q = 0; q < 9; ++q) g.R[q] = st->Rf[q];
-  g.t[0] = st->tf[0]; g.t[1] = st->tf[1]; g.t[2] = st->tf[2];
-  __shared__ __attribute__((aligned(16))) float ray_lds[TAB ? kRayLdsMax : kFoldScratchFloats];   // the ray table; afterwards the fold's scratch
-  static_assert(kRayLdsMax >= kFoldScratchFloats, "the fold re-uses the ray table's LDS");
-  const RayLds rt = stage_ray_table<TAB>(p.ray_tab, ray_lds, W, H);
-  float acc[29];
-  se3_accumulate<TAB>(g, p, rt, W, H, huber_delta, acc);
-  if (!fold_counters) { block_reduce_store<29, false>(acc, partials + (size_t)blockIdx.x * kSimpleRow); return; }
-  // folded: the tracker's last workgroup to arrive sums the partial rows, solves and moves the pose -- no workgroup of this launch reads
-  // the state after that (all of them have arrived), the next iteration's launch does
-  block_reduce_store<29, true>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
-  if (!wg_arrive_last(fold_counters + blockIdx.y, gridDim.x)) return;
-  double* scratch = reinterpret_cast<double*>(ray_lds);
-  const double s = fold_rows<kT, true>(partials, (int)gridDim.x, scratch);
-  double* sum = scratch + 32 * kSimpleRow;
-  if (threadIdx.x < 32) sum[threadIdx.x] = s;
-  __syncthreads();
-  track_solve_update(sum, st);
-}
-
 size_t track_state_bytes() { return sizeof(TrackState); }
 
 hipError_t launch_track_iteration(const SimplePairDev* descs_dev, int n, void* states_dev, int W, int H, float huber_delta, int blocks,
-                                  float* partials_dev, hipStream_t stream, unsigned* fold_counters) {
+                                  float* partials_dev, hipStream_t stream) {
   const bool tab_ok = W + H <= kRayLdsMax;   // the per-camera ray table fits the kernels' LDS budget (every descriptor carries one)
-  if (tab_ok) hipLaunchKernelGGL((k_se3_step_dev<true>), dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (TrackState*)states_dev, W, H, huber_delta, partials_dev, fold_counters);
-  else hipLaunchKernelGGL((k_se3_step_dev<false>), dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (TrackState*)states_dev, W, H, huber_delta, partials_dev, fold_counters);
+  if (tab_ok) hipLaunchKernelGGL((k_se3_step_dev<true>), dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (const TrackState*)states_dev, W, H, huber_delta, partials_dev); else hipLaunchKernelGGL((k_se3_step_dev<false>), dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (const TrackState*)states_dev, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess || fold_counters) return e;
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_track_update, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (TrackState*)states_dev);
   return hipGetLastError();
 }
@@ -561,14 +481,13 @@ __device__ __forceinline__ void sfm_error_accumulate(const Geo& g, const SimpleP
 
 template <bool TAB>
 __global__ __launch_bounds__(kT) void k_sfm_error(const SimplePairDev p, const int W, const int H, const float huber_delta,
-                                                  float* __restrict__ partials, const FoldDev fd) {
-  __shared__ __attribute__((aligned(16))) float ray_lds[TAB ? kRayLdsMax : kFoldScratchFloats];   // the ray table; afterwards the fold's scratch
-  static_assert(kRayLdsMax >= kFoldScratchFloats, "the fold re-uses the ray table's LDS");
+                                                  float* __restrict__ partials) {
+  __shared__ float ray_lds[TAB ? kRayLdsMax : 1];
   const Geo g = geo_from(p);
   const RayLds rt = stage_ray_table<TAB>(p.ray_tab, ray_lds, W, H);
   float acc[2];
   sfm_error_accumulate<TAB>(g, p, rt, W, H, huber_delta, acc);
-  block_reduce_fold<2>(acc, partials, (int)gridDim.x, (int)blockIdx.x, 0, fd, ray_lds);
+  block_reduce_store<2>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
 // ---- batched forms (blockIdx.y = pair): PhotometricFactor::error over a factor set evaluates one pair per blocking call in the reference
@@ -576,33 +495,30 @@ __global__ __launch_bounds__(kT) void k_sfm_error(const SimplePairDev p, const i
 // Same per-pair arithmetic and reduction order as the single-pair kernels launched with the same number of workgroups.
 template <bool TAB>
 __global__ __launch_bounds__(kT) void k_sfm_error_batch(const SimplePairDev* __restrict__ descs, const int W, const int H, const float huber_delta,
-                                                        float* __restrict__ partials_all, const FoldDev fd) {
-  __shared__ __attribute__((aligned(16))) float ray_lds[TAB ? kRayLdsMax : kFoldScratchFloats];   // the ray table; afterwards the fold's scratch
-  static_assert(kRayLdsMax >= kFoldScratchFloats, "the fold re-uses the ray table's LDS");
+                                                        float* __restrict__ partials_all) {
+  __shared__ float ray_lds[TAB ? kRayLdsMax : 1];
   const SimplePairDev& p = descs[blockIdx.y];
   const Geo g = geo_from(p);
   const RayLds rt = stage_ray_table<TAB>(p.ray_tab, ray_lds, W, H);
   float acc[2];
   sfm_error_accumulate<TAB>(g, p, rt, W, H, huber_delta, acc);
-  block_reduce_fold<2>(acc, partials_all + (size_t)blockIdx.y * gridDim.x * kSimpleRow, (int)gridDim.x, (int)blockIdx.x, (int)blockIdx.y, fd, ray_lds);
+  block_reduce_store<2>(acc, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
 }
 
 template <bool TAB>
 __global__ __launch_bounds__(kT) void k_se3_step_batch(const SimplePairDev* __restrict__ descs, const int W, const int H, const float huber_delta,
-                                                       float* __restrict__ partials_all, const FoldDev fd) {
-  __shared__ __attribute__((aligned(16))) float ray_lds[TAB ? kRayLdsMax : kFoldScratchFloats];   // the ray table; afterwards the fold's scratch
-  static_assert(kRayLdsMax >= kFoldScratchFloats, "the fold re-uses the ray table's LDS");
+                                                       float* __restrict__ partials_all) {
+  __shared__ float ray_lds[TAB ? kRayLdsMax : 1];
   const SimplePairDev& p = descs[blockIdx.y];
   const Geo g = geo_from(p);
   const RayLds rt = stage_ray_table<TAB>(p.ray_tab, ray_lds, W, H);
   float acc[29];
   se3_accumulate<TAB>(g, p, rt, W, H, huber_delta, acc);
-  block_reduce_fold<29>(acc, partials_all + (size_t)blockIdx.y * gridDim.x * kSimpleRow, (int)gridDim.x, (int)blockIdx.x, (int)blockIdx.y, fd, ray_lds);
+  block_reduce_store<29>(acc, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
 }
 
 // ---- Warp: render img1 into frame 0, SIGNED residual sum (cu_se3aligner.cpp:106) ----------------------------
-__global__ __launch_bounds__(kT) void k_se3_warp(const SimplePairDev p, const int W, const int H, float* __restrict__ partials, const FoldDev fd) {
-  __shared__ __attribute__((aligned(16))) float fold_lds[kFoldScratchFloats];
+__global__ __launch_bounds__(kT) void k_se3_warp(const SimplePairDev p, const int W, const int H, float* __restrict__ partials) {
   const Geo g = geo_from(p);
   const ImgRef I0{ (const char*)p.img0, p.pitch_img0 }, I1{ (const char*)p.img1, p.pitch_img1 };
   const ImgRef D0{ (const char*)p.dpt0, p.pitch_dpt0 };
@@ -622,13 +538,12 @@ __global__ __launch_bounds__(kT) void k_se3_warp(const SimplePairDev p, const in
     }
     gstore<float>((char*)p.img2 + (size_t)y * p.pitch_img2 + (size_t)x * 4, outv);
   }
-  block_reduce_fold<2>(acc, partials, (int)gridDim.x, (int)blockIdx.x, 0, fd, fold_lds);
+  block_reduce_store<2>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
 // ---- SquaredError ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kT) void k_squared_error(const float* __restrict__ a, const uint32_t pa, const float* __restrict__ b,
-                                                      const uint32_t pb, const int W, const int H, float* __restrict__ partials, const FoldDev fd) {
-  __shared__ __attribute__((aligned(16))) float fold_lds[kFoldScratchFloats];
+                                                      const uint32_t pb, const int W, const int H, float* __restrict__ partials) {
   float acc[1] = { 0.f };
   const int npx = W * H;
   for (int i = blockIdx.x * kT + threadIdx.x; i < npx; i += gridDim.x * kT) {
@@ -637,16 +552,36 @@ __global__ __launch_bounds__(kT) void k_squared_error(const float* __restrict__ 
                     reinterpret_cast<const float*>((const char*)b + (size_t)y * pb)[x];
     acc[0] += d * d;
   }
-  block_reduce_fold<1>(acc, partials, (int)gridDim.x, (int)blockIdx.x, 0, fd, fold_lds);
+  block_reduce_store<1>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
-// ---- finalize: out[e] = sum_b partials[b][e] in double, fixed order; layout-specific scatter (the unfolded form) -----------
+// ---- finalize: out[e] = sum_b partials[b][e] in double, fixed order; layout-specific scatter -------------------
+enum FinalKind { kFinalItem6 = 0, kFinalCorr = 1, kFinalScalar = 2 };
+
 __global__ __launch_bounds__(1024) void k_finalize_rows(const float* __restrict__ partials_all, const int nblocks, const int kind,
                                                         char* __restrict__ out_all, const size_t out_stride) {
   // blockIdx.x = pair of a batched launch (0 for the single-pair operators)
+  const float* partials = partials_all + (size_t)blockIdx.x * nblocks * kSimpleRow;
+  char* out = out_all + (size_t)blockIdx.x * out_stride;
   __shared__ double red[32][kSimpleRow];
-  const double s = fold_rows<1024, false>(partials_all + (size_t)blockIdx.x * nblocks * kSimpleRow, nblocks, &red[0][0]);
-  if (threadIdx.x < 32) write_final(kind, (int)threadIdx.x, s, out_all + (size_t)blockIdx.x * out_stride);
+  const int e = threadIdx.x & 31, rg = threadIdx.x >> 5;   // 32 row groups
+  static_assert(kMaxSimpleBlocks <= 32 * 32, "one load per row group and thread");
+  double s = strided_sum_f64_wide<32, 32>(partials + e, rg, nblocks, kSimpleRow);
+  red[rg][e] = s;
+  __syncthreads();
+  if (rg != 0) return;
+  s = 0.0;
+  for (int q = 0; q < 32; ++q) s += red[q][e];
+  if (kind == kFinalItem6) {
+    // JTJJrReductionItem<float,6>: 21 + 6 + 1 floats, then u64 inliers at byte 112
+    if (e < 28) reinterpret_cast<float*>(out)[e] = (float)s;
+    else if (e == 28) *reinterpret_cast<unsigned long long*>(out + 112) = (unsigned long long)(s + 0.5);
+  } else if (kind == kFinalCorr) {
+    if (e == 0) reinterpret_cast<float*>(out)[0] = (float)s;
+    else if (e == 1) *reinterpret_cast<unsigned long long*>(out + 8) = (unsigned long long)(s + 0.5);
+  } else {
+    if (e == 0) reinterpret_cast<float*>(out)[0] = (float)s;
+  }
 }
 
 // ---- UpdateDepth: dpt = a / (prx0 + jac . code) - a  (the code-Jacobian decoder, GEMV, 8 + 4 CS bytes / pixel) ---
@@ -775,62 +710,63 @@ __global__ __launch_bounds__(kT) void k_blur_down(const float* __restrict__ in, 
 // ---------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------
-// `fold_counters` (one zeroed unsigned per pair; null = off): the pair's last workgroup to arrive writes the result (block_reduce_fold);
-// without them k_finalize_rows runs as a second kernel.
-#define DFX_LAUNCH_TAB(KERNEL, GRID, ...)                                                                  \
-  do {                                                                                                     \
-    if (W + H <= kRayLdsMax) hipLaunchKernelGGL((KERNEL<true>), GRID, dim3(kT), 0, stream, __VA_ARGS__);   \
-    else hipLaunchKernelGGL((KERNEL<false>), GRID, dim3(kT), 0, stream, __VA_ARGS__);                      \
-  } while (0)   // <true>: the per-camera ray table fits the kernels' LDS budget (every descriptor carries one)
-static hipError_t finalize_unless_folded(unsigned* fold_counters, int n, const float* partials_dev, int blocks, int kind, void* out, size_t out_stride, hipStream_t stream) {
+hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
+                           void* item_dev, hipStream_t stream) {
+  const bool tab_ok = W + H <= kRayLdsMax;   // the per-camera ray table fits the kernels' LDS budget (every descriptor carries one)
+  if (tab_ok) hipLaunchKernelGGL((k_se3_step<true>), dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev); else hipLaunchKernelGGL((k_se3_step<false>), dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess || fold_counters) return e;
-  hipLaunchKernelGGL(k_finalize_rows, dim3(n), dim3(1024), 0, stream, partials_dev, blocks, kind, (char*)out, out_stride);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalItem6, (char*)item_dev, (size_t)0);
   return hipGetLastError();
 }
 
-hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
-                           void* item_dev, hipStream_t stream, unsigned* fold_counters) {
-  const FoldDev fd{ fold_counters, (char*)item_dev, 0, (int)kFinalItem6 };
-  DFX_LAUNCH_TAB(k_se3_step, dim3(blocks), p, W, H, huber_delta, partials_dev, fd);
-  return finalize_unless_folded(fold_counters, 1, partials_dev, blocks, kFinalItem6, item_dev, 0, stream);
-}
-
 hipError_t launch_sfm_error(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
-                            void* corr_item_dev, hipStream_t stream, unsigned* fold_counters) {
-  const FoldDev fd{ fold_counters, (char*)corr_item_dev, 0, (int)kFinalCorr };
-  DFX_LAUNCH_TAB(k_sfm_error, dim3(blocks), p, W, H, huber_delta, partials_dev, fd);
-  return finalize_unless_folded(fold_counters, 1, partials_dev, blocks, kFinalCorr, corr_item_dev, 0, stream);
+                            void* corr_item_dev, hipStream_t stream) {
+  const bool tab_ok = W + H <= kRayLdsMax;   // the per-camera ray table fits the kernels' LDS budget (every descriptor carries one)
+  if (tab_ok) hipLaunchKernelGGL((k_sfm_error<true>), dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev); else hipLaunchKernelGGL((k_sfm_error<false>), dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalCorr, (char*)corr_item_dev, (size_t)0);
+  return hipGetLastError();
 }
 
 hipError_t launch_sfm_error_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
-                                  void* corr_items_dev, hipStream_t stream, unsigned* fold_counters) {
-  const FoldDev fd{ fold_counters, (char*)corr_items_dev, 16, (int)kFinalCorr };
-  DFX_LAUNCH_TAB(k_sfm_error_batch, dim3(blocks, n), descs_dev, W, H, huber_delta, partials_dev, fd);
-  return finalize_unless_folded(fold_counters, n, partials_dev, blocks, kFinalCorr, corr_items_dev, 16, stream);
+                                  void* corr_items_dev, hipStream_t stream) {
+  const bool tab_ok = W + H <= kRayLdsMax;   // the per-camera ray table fits the kernels' LDS budget (every descriptor carries one)
+  if (tab_ok) hipLaunchKernelGGL((k_sfm_error_batch<true>), dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev); else hipLaunchKernelGGL((k_sfm_error_batch<false>), dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_finalize_rows, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalCorr, (char*)corr_items_dev, (size_t)16);
+  return hipGetLastError();
 }
 
 hipError_t launch_se3_step_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
-                                 void* items_dev, hipStream_t stream, unsigned* fold_counters) {
-  const FoldDev fd{ fold_counters, (char*)items_dev, 120, (int)kFinalItem6 };
-  DFX_LAUNCH_TAB(k_se3_step_batch, dim3(blocks, n), descs_dev, W, H, huber_delta, partials_dev, fd);
-  return finalize_unless_folded(fold_counters, n, partials_dev, blocks, kFinalItem6, items_dev, 120, stream);
+                                 void* items_dev, hipStream_t stream) {
+  const bool tab_ok = W + H <= kRayLdsMax;   // the per-camera ray table fits the kernels' LDS budget (every descriptor carries one)
+  if (tab_ok) hipLaunchKernelGGL((k_se3_step_batch<true>), dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev); else hipLaunchKernelGGL((k_se3_step_batch<false>), dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_finalize_rows, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalItem6, (char*)items_dev, (size_t)120);
+  return hipGetLastError();
 }
 
 hipError_t launch_se3_warp(const SimplePairDev& p, int W, int H, int blocks, float* partials_dev, void* corr_item_dev,
-                           hipStream_t stream, unsigned* fold_counters) {
-  const FoldDev fd{ fold_counters, (char*)corr_item_dev, 0, (int)kFinalCorr };
-  hipLaunchKernelGGL(k_se3_warp, dim3(blocks), dim3(kT), 0, stream, p, W, H, partials_dev, fd);
-  return finalize_unless_folded(fold_counters, 1, partials_dev, blocks, kFinalCorr, corr_item_dev, 0, stream);
+                           hipStream_t stream) {
+  hipLaunchKernelGGL(k_se3_warp, dim3(blocks), dim3(kT), 0, stream, p, W, H, partials_dev);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalCorr, (char*)corr_item_dev, (size_t)0);
+  return hipGetLastError();
 }
 
 hipError_t launch_squared_error(const float* a, uint32_t pitch_a, const float* b, uint32_t pitch_b, int W, int H, int blocks,
-                                float* partials_dev, float* out_dev, hipStream_t stream, unsigned* fold_counters) {
-  const FoldDev fd{ fold_counters, (char*)out_dev, 0, (int)kFinalScalar };
-  hipLaunchKernelGGL(k_squared_error, dim3(blocks), dim3(kT), 0, stream, a, pitch_a, b, pitch_b, W, H, partials_dev, fd);
-  return finalize_unless_folded(fold_counters, 1, partials_dev, blocks, kFinalScalar, out_dev, 0, stream);
+                                float* partials_dev, float* out_dev, hipStream_t stream) {
+  hipLaunchKernelGGL(k_squared_error, dim3(blocks), dim3(kT), 0, stream, a, pitch_a, b, pitch_b, W, H, partials_dev);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalScalar, (char*)out_dev, (size_t)0);
+  return hipGetLastError();
 }
-#undef DFX_LAUNCH_TAB
 
 hipError_t launch_update_depth(int cs, const float* code_dev, const float* prx_orig, uint32_t pitch_prx, const float* jac,
                                uint32_t pitch_jac, float avg_dpt, float* dpt_out, uint32_t pitch_out, int W, int H,

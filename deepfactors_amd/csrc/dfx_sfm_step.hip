@@ -1091,7 +1091,12 @@ __device__ __forceinline__ double b3_unpack(int blk, int dtile, int el, const do
 }
 
 // Scatter the unpacked tile `blk` (S[row * 16 + col]) into the item; t = 0 .. 255
-// COH: the item is read by OTHER workgroups of the same kernel (graph assembly in k_sfm_tail_b3): device-scope stores (dfx_device.hpp, coh_store)
+// COH: the item is read by OTHER workgroups of the same kernel (graph assembly in k_sfm_tail_b3): device-scope stores (write-through,
+// visible to device-scope loads from any XCD once the store has completed) instead of a cache writeback + invalidate per workgroup
+template <bool COH, typename V>
+__device__ __forceinline__ void coh_store(V* p, V v) {
+  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
 template <int NCB, int NPOSE, bool COH = false>
 __device__ __forceinline__ void b3_scatter(int blk, int t, const double* S, const double (*T)[6], float* item) {
   constexpr int CS = 16 * NCB;
