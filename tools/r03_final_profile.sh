@@ -9,8 +9,9 @@
 #   bench_rccl_1rank_window.json  one rank under torch.distributed.run: RCCL initialised, the exchange step on real streams, configs[3]
 #   latency_cpp.txt, tracker.json, pytest_gpu.log
 set -u
+export OUT
 cd "$(dirname "$0")/.."
-OUT=gpurun_out/r03final; mkdir -p $OUT
+OUT=${OUT:-gpurun_out/r03final}; mkdir -p $OUT
 export TMPDIR=/tmp
 LIB=$PWD/deepfactors_amd/libdfx.so
 t0=$(date +%s); lap() { echo "== $1 @ $(( $(date +%s) - t0 )) s"; }
@@ -26,12 +27,15 @@ timeout 400 tools/profile_sq.sh $OUT/sq32 $LIB --pairs 128 --distinct --steps 3 
 timeout 400 tools/profile_sq.sh $OUT/sq64 $LIB --pairs 16 --width 1280 --height 960 --cs 64 --distinct --steps 3 --preroll 5 --mode 1 > $OUT/pmc_sq_cs64_1280x960_16pairs.txt 2>&1 < /dev/null; echo "sq64 rc=$?"
 timeout 400 tools/profile_traffic.sh $OUT/tr32 $LIB --pairs 128 --distinct --steps 3 --preroll 5 --mode 1 > $OUT/pmc_traffic_cs32_128pairs.txt 2>&1 < /dev/null; echo "tr32 rc=$?"; lap pmc
 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 1 --window --no-cpu-baseline --no-traffic --no-configs > $OUT/bench_rccl_1rank_window.json 2> $OUT/bench_rccl_1rank_window.err < /dev/null; echo "rccl 1-rank rc=$?"; lap rccl
+make -C tests/cpp latency_bench > /dev/null 2>&1
 timeout 120 tests/cpp/latency_bench > $OUT/latency_cpp.txt 2>&1 < /dev/null; tail -12 $OUT/latency_cpp.txt
 timeout 120 python tools/profile_tracker.py > $OUT/tracker.json 2>/dev/null < /dev/null; tail -2 $OUT/tracker.json
+timeout 120 python tools/idle_gap_probe.py --idle-us 0 --seconds 3 > $OUT/clock_power_steady.txt 2>&1 < /dev/null; grep "^idle" $OUT/clock_power_steady.txt
 find $OUT -name "*.csv" -size +300k -delete; find $OUT -name "*.db" -delete; lap done
 python - <<'PY'
 import json
-d=json.loads(open('gpurun_out/r03final/bench.json').read().strip().splitlines()[-1])
+import os
+d=json.loads(open(os.environ.get('OUT','gpurun_out/r03final')+'/bench.json').read().strip().splitlines()[-1])
 r=d['roofline']; print('value',d['value'],'ms',d['ms_per_step'],'kernel',r['kernel_us'],r['kernel_us_min'],r['kernel_us_max'],'frac',r['frac'],'traffic',r['traffic'], r['traffic']/r['algorithmic_bytes_per_launch'] if r['traffic'] else None)
 for k,v in d.get('configs',{}).items(): print(k, json.dumps({a:(round(b,4) if isinstance(b,float) else b) for a,b in v.items() if a!='note'})[:330])
 print('cpu', json.dumps(d.get('cpu_baseline'))[:300])
