@@ -89,10 +89,6 @@ struct dfx_ctx {
   unsigned* qhead = nullptr;   // dynamic schedule: one item-queue head per pair of a batch (rewound by the finalize kernel)
   size_t qhead_cap = 0;
   bool qhead_dirty = false;    // a dynamic launch failed between its step and its finalize kernel: the heads were not rewound
-  unsigned* pair_cnt = nullptr;   // reduction tail folded into the step kernel: arrivals per pair, zero between launches (the folding workgroup rewinds)
-  size_t pair_cnt_cap = 0;
-  bool pair_cnt_dirty = false;
-  bool fold_tail = true;          // DFX_FOLD_TAIL=0 in the environment: a tail kernel behind every batched step instead (A/B runs, tests)
   unsigned* node_cnt = nullptr;   // graph assembly inside the reduction tail: arrivals per node, zero between launches (k_sfm_tail_b3 rewinds)
   size_t node_cnt_cap = 0;
   bool node_cnt_dirty = false;    // a launch failed after the counters were handed out
@@ -517,11 +513,6 @@ DFX_API int dfx_ctx_create(int device, void* stream, dfx_ctx** out) {
     else if (std::strcmp(ev, "auto") == 0) c->mfma_mode = DFX_MFMA_AUTO;
     else { delete c; return fail(DFX_E_INVALID, "environment DFX_MFMA=%s: expected auto, f32 or bf16x3", ev); }
   }
-  if (const char* ev = std::getenv("DFX_FOLD_TAIL")) {
-    if (!std::strcmp(ev, "0")) c->fold_tail = false;
-    else if (!std::strcmp(ev, "1")) c->fold_tail = true;
-    else { delete c; return fail(DFX_E_INVALID, "environment DFX_FOLD_TAIL=%s: expected 0 or 1", ev); }
-  }
   if (const char* ev = std::getenv("DFX_SCHEDULE")) {
     if (std::strcmp(ev, "static") == 0) c->schedule = DFX_SCHEDULE_STATIC;
     else if (std::strcmp(ev, "dynamic") == 0) c->schedule = DFX_SCHEDULE_DYNAMIC;
@@ -558,7 +549,6 @@ DFX_API void dfx_ctx_destroy(dfx_ctx* c) {
   if (c->sdesc_dev) (void)hipFree(c->sdesc_dev);
   if (c->qhead) (void)hipFree(c->qhead);
   if (c->node_cnt) (void)hipFree(c->node_cnt);
-  if (c->pair_cnt) (void)hipFree(c->pair_cnt);
   if (c->track_state_dev) (void)hipFree(c->track_state_dev);
   if (c->sg_dev) (void)hipFree(c->sg_dev);
   for (auto& t : c->ray_tabs) (void)hipFree(t.dev);
@@ -869,34 +859,10 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
   unsigned* map_dev = nullptr;
   int slot = -1;
   const size_t desc_bytes = (sizeof(dfx::SfmPairDev) * (size_t)n + 15) & ~(size_t)15;
-  const size_t map_bytes = (sizeof(unsigned) * (size_t)total_blocks + 15) & ~(size_t)15;
-  // The reduction tail inside the step kernel (k_sfm_step's last workgroup of every pair runs tail_pair): the default for batched launches of
-  // the bf16 split on the static schedule whose results stay on the launch stream.  With a graph, only when this rank holds every pair of
-  // it (the node workgroups that zero what no local pair writes exist in the tail KERNEL only).  The fold's arguments ride behind the
-  // descriptors in the same upload.
-  dfx::TailGraphDev tg{};
-  int node_wgs = 0;
-  if (graph && (rc = graph_tail(c, cs, graph, first_pair, n, sys_dev, &tg, &node_wgs))) return rc;
-  const bool fold = n > 1 && c->fold_tail && resolve_mfma(c, cs) == DFX_MFMA_BF16X3 && c->schedule != DFX_SCHEDULE_DYNAMIC &&
-                    !(allow_defer && c->tail_stream) && (!graph || node_wgs == 0);
-  const size_t fold_bytes = fold ? ((sizeof(dfx::FoldArgsDev) + 15) & ~(size_t)15) : 0;
-  if (fold) {
-    if (c->pair_cnt_cap < (size_t)n || c->pair_cnt_dirty) {
-      DFX_HIP(hipStreamSynchronize(c->stream));
-      if (c->pair_cnt_cap < (size_t)n) {
-        if (c->pair_cnt) DFX_HIP(hipFree(c->pair_cnt));
-        c->pair_cnt = nullptr; c->pair_cnt_cap = 0;
-        const size_t cap = (size_t)n < 256 ? 256 : (size_t)n * 2;
-        DFX_HIP(hipMalloc((void**)&c->pair_cnt, sizeof(unsigned) * cap));
-        c->pair_cnt_cap = cap;
-      }
-      DFX_HIP(hipMemsetAsync(c->pair_cnt, 0, sizeof(unsigned) * c->pair_cnt_cap, c->stream));
-    }
-    c->pair_cnt_dirty = true;   // cleared once the kernel that rewinds them is enqueued
-  }
+  const size_t map_bytes = sizeof(unsigned) * (size_t)total_blocks;
   if (n > 1) {
     char* host;
-    if ((rc = stage_acquire(c, desc_bytes + map_bytes + fold_bytes, &slot, &host))) return rc;
+    if ((rc = stage_acquire(c, desc_bytes + map_bytes, &slot, &host))) return rc;
     hd = reinterpret_cast<dfx::SfmPairDev*>(host);
     unsigned* hm = reinterpret_cast<unsigned*>(host + desc_bytes);
     size_t g = 0;
@@ -912,19 +878,18 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
     hd[p].w_px = q.img0.w; hd[p].h_px = q.img0.h;
     hd[p].nblk = uniform ? 0u : nblk[p];
     hd[p].blk0 = uniform ? 0u : blk0[p];
-    hd[p].fold = nullptr;   // set below when the launch folds its tail into the step kernel
   }
   if (n > 1) {
     // device copy: one region per stage slot so that in-flight launches keep their own.  The upload runs on the context's copy stream,
     // beside the kernels of the previous launches (it used to sit between them on the launch stream: ~10 us per step); the launch
     // stream waits for it, and the copy stream waits for the last kernels that read this slot.
-    if (c->pairs_cap < desc_bytes + map_bytes + fold_bytes) {
+    if (c->pairs_cap < desc_bytes + map_bytes) {
       DFX_HIP(hipStreamSynchronize(c->stream));
       DFX_HIP(hipStreamSynchronize(c->copy_stream));
       if (c->tail_stream) DFX_HIP(hipStreamSynchronize(c->tail_stream));
       if (c->pairs_dev) DFX_HIP(hipFree(c->pairs_dev));
       c->pairs_dev = nullptr;
-      const size_t cap = ((desc_bytes + map_bytes + fold_bytes) * 2 + 255) & ~(size_t)255;
+      const size_t cap = ((desc_bytes + map_bytes) * 2 + 255) & ~(size_t)255;
       DFX_HIP(hipMalloc((void**)&c->pairs_dev, cap * kStageSlots));
       c->pairs_cap = cap;
       for (int i = 0; i < kStageSlots; ++i) c->slot_busy[i] = false;
@@ -932,14 +897,8 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
     char* region = reinterpret_cast<char*>(c->pairs_dev) + (size_t)slot * c->pairs_cap;
     dd = reinterpret_cast<dfx::SfmPairDev*>(region);
     if (!uniform) map_dev = reinterpret_cast<unsigned*>(region + desc_bytes);
-    if (fold) {
-      const dfx::FoldArgsDev* fold_dev = reinterpret_cast<const dfx::FoldArgsDev*>(region + desc_bytes + map_bytes);
-      dfx::FoldArgsDev* fh = reinterpret_cast<dfx::FoldArgsDev*>(reinterpret_cast<char*>(hd) + desc_bytes + map_bytes);
-      *fh = dfx::FoldArgsDev{ (char*)out_items_dev, dfx_item_size(12 + cs), c->pair_cnt, tg };
-      for (int p = 0; p < n; ++p) hd[p].fold = fold_dev;
-    }
     if (c->slot_busy[slot]) DFX_HIP(hipStreamWaitEvent(c->copy_stream, c->slot_done[slot], 0));
-    DFX_HIP(hipMemcpyAsync(region, hd, desc_bytes + map_bytes + fold_bytes, hipMemcpyHostToDevice, c->copy_stream));
+    DFX_HIP(hipMemcpyAsync(region, hd, desc_bytes + map_bytes, hipMemcpyHostToDevice, c->copy_stream));
     DFX_HIP(hipEventRecord(c->stage_ev[slot], c->copy_stream));
     c->stage_used[slot] = true;
     DFX_HIP(hipStreamWaitEvent(c->stream, c->stage_ev[slot], 0));
@@ -1026,12 +985,14 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
   hipStream_t const fin_stream = defer ? c->tail_stream : c->stream;
   // graph assembly: inside the reduction tail where the launch has the one-workgroup-per-pair tail kernel (batched, bf16 split), as a
   // second kernel behind the finalize kernel otherwise (single pair, fp32 chain) -- the same sums in the same order either way
+  dfx::TailGraphDev tg{};
+  int node_wgs = 0;
   bool assembled = false;
+  if (graph && (rc = graph_tail(c, cs, graph, first_pair, n, sys_dev, &tg, &node_wgs))) return rc;
   DFX_HIP(dfx::launch_sfm_step(cs, dd, n, (int)W, (int)H, prm, bpp, partials, out_items_dev, dfx_item_size(12 + cs), c->stream,
                                jac_dense, resolve_mfma(c, cs), eb, ee, n == 1 ? &one : nullptr, dyn.qhead ? &dyn : nullptr, dyn_grid, vsh,
-                               fin_stream, defer ? c->ev_mid[par] : nullptr, map_dev, total_blocks, graph ? &tg : nullptr, node_wgs, &assembled, fold));
+                               fin_stream, defer ? c->ev_mid[par] : nullptr, map_dev, total_blocks, graph ? &tg : nullptr, node_wgs, &assembled));
   c->qhead_dirty = false;   // both kernels are enqueued: the finalize kernel rewinds the heads
-  if (fold) c->pair_cnt_dirty = false;
   if (graph) {
     c->node_cnt_dirty = false;   // the tail kernel rewinds the counters it used
     if (!assembled) DFX_HIP(dfx::launch_graph_assemble(cs, tg.G, out_items_dev, dfx_item_size(12 + cs), first_pair, n, sys_dev, fin_stream));

@@ -5,7 +5,6 @@
 
 namespace dfx {
 
-struct FoldArgsDev;
 // Device-side descriptor of one keyframe->frame pair (argument list of SfmAligner::RunStep,
 // cu_sfmaligner.h:76-86, after the host has folded RelativePose + its Jacobians, cu_sfmaligner.cpp:166).
 struct SfmPairDev {
@@ -25,10 +24,6 @@ struct SfmPairDev {
   // batches whose pairs differ in image size (several pyramid levels in ONE launch): the pair's own size, its share of the 1-D grid and
   // the index of its first workgroup partial (`blkmap` of launch_sfm_step); unused (0) by launches of one image size
   uint32_t w_px, h_px, nblk, blk0;
-  // the launch's reduction tail folded into the step kernel (null: a tail kernel follows).  Carried per pair, not as a kernel argument: it is
-  // read once, at the end of the kernel, through the descriptor pointer the kernel holds anyway (a kernel argument would occupy two of the
-  // pipelined loop's scalar registers, which spill into vector-register lanes).
-  const FoldArgsDev* fold;
 };
 constexpr int kRayTabSlack = 80;   // rows a lane past the last pixel may index (<= 64 / W + 1), zero-filled
 
@@ -53,16 +48,6 @@ struct TailGraphDev {
   int first_pair, n_local;
   float* sys;              // null: no assembly
   unsigned* node_cnt;      // [n_nodes], zero between launches (the assembling workgroup rewinds its counter)
-};
-
-// The reduction tail folded into the step kernel (static schedule, bf16 split, batched): the last workgroup of a pair to arrive runs the
-// pair's tail (tail_pair) itself -- no second kernel, no launch boundary behind the step kernel.  Lives in device memory (one read at the
-// end of the kernel; kernel arguments would sit in scalar registers through the pipelined loop, which has none to spare).
-struct FoldArgsDev {
-  char* items;            // result items of the launch
-  size_t item_stride;
-  unsigned* pair_cnt;     // [npairs] arrivals per pair, zero between launches (the folding workgroup rewinds its counter)
-  TailGraphDev tg;        // tg.sys == null: no graph assembly
 };
 
 // Dynamic schedule of the batched SfM step (k_sfm_step<..., DYN>): per-pair item queues popped by wave-workers
@@ -114,9 +99,7 @@ hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int 
                                                                                            // blkmap[g] >> 16 as its block blkmap[g] & 0xffff (of SfmPairDev::nblk);
                                                                                            // W, H = the largest width / height (ray-table LDS); blocks_per_pair unused
                            const TailGraphDev* tail_graph = nullptr, int node_wgs = 0,    // graph assembly inside the reduction tail (k_sfm_tail_b3) where the
-                           bool* assembled = nullptr,                                     // launch has one: *assembled tells; node_wgs = 0 or the graph's nodes
-                           bool folded = false);                                          // the pairs' descriptors carry SfmPairDev::fold: the tail runs inside the step
-                                                                                           // kernel (bf16 split, static schedule, descriptors in device memory), no tail kernel
+                           bool* assembled = nullptr);                                    // launch has one: *assembled tells; node_wgs = 0 or the graph's nodes
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair);
 // system layout (floats): Hd [n_nodes][D][D], Ho [n_pairs][D][6], g [n_nodes][D]; contributions of the pairs [first_pair, first_pair + n_local)
 hipError_t launch_graph_assemble(int cs, const GraphDev& G, const void* items_dev, size_t item_stride, int first_pair, int n_local, float* sys_dev,

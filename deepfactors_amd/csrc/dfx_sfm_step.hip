@@ -105,25 +105,6 @@ namespace dfx {
 #ifndef DFX_WAVES
 #define DFX_WAVES 4
 #endif
-// Device-scope ("coherent") accesses for data one workgroup writes and ANOTHER workgroup of the same kernel reads (a pair's partials and items
-// in the folded reduction tail): written through to memory and visible to device-scope loads from any XCD once the store has completed
-// (s_waitcnt vmcnt(0)) -- instead of a release / acquire fence pair, which writes back and invalidates the XCD's whole L2 per wave
-// (80 us per launch over 128 workgroups of 16 waves, profiles/r03_tail_kernel.txt).
-template <bool COH, typename V>
-__device__ __forceinline__ void coh_store(V* p, V v) {
-  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
-}
-template <bool COH, typename V>
-__device__ __forceinline__ V coh_load(const V* p) {
-  if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return *p;
-}
-// the reduction tail of one pair (defined with the finalize kernels below; the step kernel's last workgroup of a pair runs it when the tail is folded in)
-template <int NCB, bool ASM, int THREADS, bool COHP>
-__device__ __forceinline__ void tail_pair(const float* __restrict__ partials, const int nparts, const size_t part0, const SfmPairDev& PD, const int pair,
-                                          const int W, const int H, char* __restrict__ items, const size_t item_stride, const unsigned launch_id,
-                                          const TailGraphDev& tg, double (*S)[256], double (*T)[6], int* todo);
-
 constexpr int kWaves = DFX_WAVES;         // waves per workgroup
 constexpr int kThreads = kWaves * 64;
 #ifndef DFX_USTRIDE
@@ -856,49 +837,13 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
       for (int r = 0; r < 4; ++r) mine[(1 + NACC + a) * 256 + ppb * 16 + r * 4 + ppi] = accd[a][r];
     }
   }
-  const size_t part0 = ragged ? (size_t)P.blk0 : (size_t)blockIdx.y * gridDim.x;
-  float* out = partials + (part0 + blk_in_pair) * ZDIM;
-  constexpr bool CAN_FOLD = B3 && MODE == 0 && !BYVAL && !DYN && !DFX_TRACE;
-  const FoldArgsDev* const fold = CAN_FOLD ? P.fold : nullptr;
-  const bool folding = fold != nullptr;   // kernel-uniform
+  float* out = partials + (ragged ? (size_t)P.blk0 + blk_in_pair : (size_t)blockIdx.y * gridDim.x + blockIdx.x) * ZDIM;
   __syncthreads();
   for (int e = threadIdx.x; e < ZDIM; e += kThreads) {
     float v = lds[e];
 #pragma unroll
     for (int wv = 1; wv < kWaves; ++wv) v += lds[wv * SLOT + e];
-    // (non-temporal stores here do not shorten the step -> finalize boundary: 39.6 vs 39.5 us between step time and kernel time, round 3)
-    if (CAN_FOLD && folding) coh_store<true>(out + e, v); else out[e] = v;   // folding: another workgroup of THIS kernel reads the partial
-  }
-  // ---- the reduction tail folded in: the pair's last workgroup to arrive sums the pair's partials, writes the item and takes part in the
-  // graph assembly (tail_pair, the body of k_sfm_tail_b3 on 256 threads) -- what used to be a second kernel behind a launch boundary.
-  // Hand-over without fences: device-scope partial stores above, every wave waits for its own, the barrier collects the waves, one lane
-  // counts the arrival.  The workgroup's LDS is free by now and holds the tail's tiles.
-  if constexpr (CAN_FOLD) {
-    if (folding) {
-      int* const s_last = reinterpret_cast<int*>(lds);   // (no LDS of its own: CS = 64 fits two workgroups per CU to the byte)
-      __builtin_amdgcn_s_waitcnt(0);
-      __syncthreads();
-      const int pair_idx = ragged ? (int)(bm >> 16) : (int)blockIdx.y;
-      if (threadIdx.x == 0) {
-        unsigned* cnt = fold->pair_cnt + pair_idx;
-        const unsigned got = atomicAdd(cnt, 1u) + 1u;
-        const bool last = got == (unsigned)blks_of_pair;
-        if (last) *cnt = 0u;
-        *s_last = last ? 1 : 0;
-      }
-      __syncthreads();
-      const bool last_wg = *s_last != 0;
-      __syncthreads();   // everybody has read the flag: the LDS now belongs to the tail
-      if (last_wg) {
-        static_assert((size_t)LDS_FLOATS * 4 >= (size_t)NB3 * 256 * 8 + 12 * 6 * 8 + 16, "the tail's tiles fit the workgroup's LDS");
-        double (*S)[256] = reinterpret_cast<double (*)[256]>(lds);
-        double (*T)[6] = reinterpret_cast<double (*)[6]>(lds + NB3 * 512);
-        int* todo = reinterpret_cast<int*>(lds + NB3 * 512 + 144);
-        const TailGraphDev tg = fold->tg;
-        if (tg.sys) tail_pair<NCB, true, kThreads, true>(partials, blks_of_pair, part0, P, pair_idx, W, H, fold->items, fold->item_stride, prm.launch_id, tg, S, T, todo);
-        else tail_pair<NCB, false, kThreads, true>(partials, blks_of_pair, part0, P, pair_idx, W, H, fold->items, fold->item_stride, prm.launch_id, tg, S, T, todo);
-      }
-    }
+    out[e] = v;   // (non-temporal stores here do not shorten the step -> finalize boundary: 39.6 vs 39.5 us between step time and kernel time, round 3)
   }
 #if DFX_TRACE
   __syncthreads();
@@ -1146,7 +1091,12 @@ __device__ __forceinline__ double b3_unpack(int blk, int dtile, int el, const do
 }
 
 // Scatter the unpacked tile `blk` (S[row * 16 + col]) into the item; t = 0 .. 255
-// COH: the item is read by OTHER workgroups of the same kernel (graph assembly): device-scope stores (coh_store, top of this file)
+// COH: the item is read by OTHER workgroups of the same kernel (graph assembly in k_sfm_tail_b3): device-scope stores (write-through,
+// visible to device-scope loads from any XCD once the store has completed) instead of a cache writeback + invalidate per workgroup
+template <bool COH, typename V>
+__device__ __forceinline__ void coh_store(V* p, V v) {
+  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
 template <int NCB, int NPOSE, bool COH = false>
 __device__ __forceinline__ void b3_scatter(int blk, int t, const double* S, const double (*T)[6], float* item) {
   constexpr int CS = 16 * NCB;
@@ -1315,142 +1265,22 @@ __device__ __forceinline__ int tail_local_degree(const TailGraphDev& tg, int n) 
   return cnt;
 }
 
-#ifndef DFX_TAIL_ROWS
-#define DFX_TAIL_ROWS 0
-#endif
-// The reduction tail of ONE pair by the calling workgroup of THREADS threads: 1024 (k_sfm_tail_b3: the four groups of partials side by
-// side) or 256 (the fold at the end of the step kernel: one group after the other) -- the same sums in the same order.  COHP: the
-// partials were written by other workgroups of the SAME kernel (device-scope loads).  S: [b3_blocks][256] doubles, T: [12][6], todo: [2].
-template <int NCB, bool ASM, int THREADS, bool COHP>
-__device__ __forceinline__ void tail_pair(const float* __restrict__ partials, const int nparts, const size_t part0, const SfmPairDev& PD, const int pair,
-                                          const int W, const int H, char* __restrict__ items, const size_t item_stride, const unsigned launch_id,
-                                          const TailGraphDev& tg, double (*S)[256], double (*T)[6], int* todo) {
-  constexpr int CS = 16 * NCB, D = 6 + CS, NP = 12 + CS;
-  constexpr int NT3 = b3_tiles(NCB), NB3 = b3_blocks(NCB);
-  constexpr int ZDIM = NB3 * 256;
-  constexpr int ROWS = DFX_TAIL_ROWS ? DFX_TAIL_ROWS : (NB3 <= 5 ? 8 : (NB3 <= 10 ? (THREADS == 1024 ? 4 : 5) : 2));   // partial rows per batch: ROWS * NB3 loads in flight per thread
-  constexpr int G = THREADS / 256;                            // groups of partials summed side by side
-  constexpr int MINE = (NT3 + G - 1) / G;                     // tiles per thread group in the unpack / scatter stage
-  static_assert(G == 4 || G == 1, "1024 or 256 threads");
-  const int el = threadIdx.x & 255, rg0 = threadIdx.x >> 8;
-  const unsigned stamp = valid0_shadow_stamp(PD, launch_id);   // read now, used at the very end
-  // ---- sums of this thread's group(s) of partials, all blocks at once; groups are folded ((g0 + g1) + g2) + g3
-  const float* src = partials + part0 * ZDIM + el;
-  double s[NB3];
-#pragma unroll
-  for (int gi = 0; gi < 4 / G; ++gi) {
-    const int rg = G == 4 ? rg0 : gi;
-#pragma unroll
-    for (int a = 0; a < NB3; ++a) s[a] = 0.0;
-    for (int b = rg; b < nparts; b += 4 * ROWS) {
-      float v[ROWS][NB3];
-#pragma unroll
-      for (int q = 0; q < ROWS; ++q) {
-        const int r = b + 4 * q;
-        const float* row = src + (size_t)(r < nparts ? r : b) * ZDIM;   // unconditional loads of an existing row; +0.0 for the rows past the end
-#pragma unroll
-        for (int a = 0; a < NB3; ++a) { const float t = coh_load<COHP>(row + a * 256); v[q][a] = r < nparts ? t : 0.0f; }
-      }
-#pragma unroll
-      for (int q = 0; q < ROWS; ++q)
-#pragma unroll
-        for (int a = 0; a < NB3; ++a) s[a] += (double)v[q][a];
-    }
-    if (G == 1) {   // one group after the other: every thread folds into its own elements, no barrier in between
-#pragma unroll
-      for (int a = 0; a < NB3; ++a) S[a][el] = gi == 0 ? s[a] : S[a][el] + s[a];
-    }
-  }
-  if (threadIdx.x < 72) {   // (behind the partial loads: its descriptor reads would otherwise be waited for first)
-    const int n = threadIdx.x / 6, i = threadIdx.x - n * 6;
-    T[n][i] = b3_T_entry(PD.M, PD.HM, n, i);
-  }
-  if (G == 4) {   // through one LDS copy of the blocks
-#pragma unroll
-    for (int k = 1; k < 4; ++k) {
-      if (rg0 == k) {
-#pragma unroll
-        for (int a = 0; a < NB3; ++a) S[a][el] = s[a];
-      }
-      __syncthreads();
-      if (rg0 == 0) {
-#pragma unroll
-        for (int a = 0; a < NB3; ++a) s[a] += S[a][el];
-      }
-      __syncthreads();
-    }
-    if (rg0 == 0) {
-#pragma unroll
-      for (int a = 0; a < NB3; ++a) S[a][el] = s[a];
-    }
-  }
-  __syncthreads();
-  // ---- unpack: thread group rg owns the tiles rg, rg + G, ...
-  {
-    double u[MINE];
-    bool keep[MINE];
-#pragma unroll
-    for (int j = 0; j < MINE; ++j) {
-      const int blk = rg0 + G * j;
-      keep[j] = false; u[j] = 0.0;
-      if (blk < NT3) { const int dt = b3_dtile<NCB>(blk); u[j] = b3_unpack<NCB>(blk, dt, el, S[blk], S[NT3 + (dt >= 0 ? dt : 0)], keep[j]); }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < MINE; ++j) { const int blk = rg0 + G * j; if (blk < NT3 && keep[j]) S[blk][el] = u[j]; }
-    __syncthreads();
-  }
-  float* item = reinterpret_cast<float*>(items + (size_t)pair * item_stride);
-#pragma unroll
-  for (int j = 0; j < MINE; ++j) { const int blk = rg0 + G * j; if (blk < NT3) b3_scatter<NCB, 12, ASM>(blk, el, S[blk], T, item); }
-
-  // ---- graph assembly by the last pair to arrive at each of its two nodes.  No cache writeback / invalidate (a __threadfence per wave
-  // cost 80 us per launch over the 128 workgroups): the item went out in device-scope stores, every wave waits for its stores to complete,
-  // the barrier collects the waves, and only then one lane counts the arrival; the assembling workgroup reads with device-scope loads.
-  if (ASM) {
-    __builtin_amdgcn_s_waitcnt(0);   // vmcnt = lgkmcnt = expcnt = 0: this wave's stores have completed
-    __syncthreads();
-    const int gp = tg.first_pair + pair;
-    if (threadIdx.x < 64) {
-      const int lane = threadIdx.x;
-#pragma unroll
-      for (int side = 0; side < 2; ++side) {
-        const int n = tg.pair_nodes[2 * gp + side];
-        const int need = tail_local_degree(tg, n);
-        if (lane == 0) {
-          const unsigned got = atomicAdd(&tg.node_cnt[n], 1u) + 1u;
-          const bool last = got == (unsigned)need;
-          if (last) tg.node_cnt[n] = 0u;   // rewound for the next launch: nobody else counts on this node any more
-          todo[side] = last ? n : -1;
-        }
-      }
-    }
-    __syncthreads();
-    {   // off-diagonal block of this pair: single writer, from the item this workgroup has just written
-      float* const Ho = tg.sys + (size_t)tg.G.n_nodes * D * D;
-      auto tri = [](int a, int b) { const int lo = a < b ? a : b, hi = a < b ? b : a; return lo * NP - lo * (lo - 1) / 2 + (hi - lo); };
-      for (int e = threadIdx.x; e < D * 6; e += THREADS) {
-        const int r = e / 6, c = e - r * 6;
-        const int ia = r < 6 ? r : r + 6;
-        Ho[(size_t)gp * D * 6 + e] = item[tri(ia, 6 + c)];
-      }
-    }
-    if (todo[0] >= 0) tail_assemble_node<CS>(tg, items, item_stride, todo[0]);
-    if (todo[1] >= 0) tail_assemble_node<CS>(tg, items, item_stride, todo[1]);
-  }
-  // ---- the pair's valid0 shadow, when a wave of this launch changed the map (never in the steady state)
-  rebuild_valid0_shadow(PD, W, H, launch_id, 0, 1, stamp);
-}
-
 template <int NCB, bool ASM>   // ASM: the launch assembles a graph (tg.sys != null)
 __global__ __launch_bounds__(1024) void k_sfm_tail_b3(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs, const int npairs,
                                                       char* __restrict__ items, const size_t item_stride, unsigned* __restrict__ qhead,
                                                       const int Wk, const int Hk, const unsigned launch_id, const int ragged, const TailGraphDev tg) {
-  constexpr int CS = 16 * NCB, D = 6 + CS;
-  constexpr int NB3 = b3_blocks(NCB);
+  constexpr int CS = 16 * NCB, D = 6 + CS, NP = 12 + CS;
+  constexpr int NT3 = b3_tiles(NCB), NB3 = b3_blocks(NCB);
+  constexpr int ZDIM = NB3 * 256;
+#ifndef DFX_TAIL_ROWS
+#define DFX_TAIL_ROWS 0
+#endif
+  constexpr int ROWS = DFX_TAIL_ROWS ? DFX_TAIL_ROWS : (NB3 <= 5 ? 8 : (NB3 <= 10 ? 4 : 2));   // partial rows per batch: ROWS * NB3 loads in flight per thread
+  constexpr int MINE = (NT3 + 3) / 4;                         // tiles per thread group in the unpack / scatter stage
   __shared__ double S[NB3][256];
   __shared__ double T[12][6];
   __shared__ int todo[2];
+  const int el = threadIdx.x & 255, rg = threadIdx.x >> 8;
 
   if (ASM && (int)blockIdx.x >= npairs) {
     // node workgroups (launched only when this rank does not hold every pair, or the graph has isolated nodes): what no local pair
@@ -1477,8 +1307,105 @@ __global__ __launch_bounds__(1024) void k_sfm_tail_b3(const float* __restrict__ 
   const int W = ragged ? (int)PD.w_px : Wk, H = ragged ? (int)PD.h_px : Hk;
   const int nparts = ragged ? (int)PD.nblk : bpp;
   const size_t part0 = ragged ? (size_t)PD.blk0 : (size_t)pair * bpp;
+  const unsigned stamp = valid0_shadow_stamp(PD, launch_id);   // read now, used at the very end
   if (qhead && threadIdx.x == 0) qhead[pair] = 0u;
-  tail_pair<NCB, ASM, 1024, false>(partials, nparts, part0, PD, pair, W, H, items, item_stride, launch_id, tg, S, T, todo);
+  // ---- sums of this thread's group of partials, all blocks at once
+  double s[NB3];
+#pragma unroll
+  for (int a = 0; a < NB3; ++a) s[a] = 0.0;
+  const float* src = partials + part0 * ZDIM + el;
+  for (int b = rg; b < nparts; b += 4 * ROWS) {
+    float v[ROWS][NB3];
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) {
+      const int r = b + 4 * q;
+      const float* row = src + (size_t)(r < nparts ? r : b) * ZDIM;   // unconditional loads of an existing row; +0.0 for the rows past the end
+#pragma unroll
+      for (int a = 0; a < NB3; ++a) { const float t = row[a * 256]; v[q][a] = r < nparts ? t : 0.0f; }
+    }
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q)
+#pragma unroll
+      for (int a = 0; a < NB3; ++a) s[a] += (double)v[q][a];
+  }
+  if (threadIdx.x < 72) {   // (behind the partial loads: its descriptor reads would otherwise be waited for first)
+    const int n = threadIdx.x / 6, i = threadIdx.x - n * 6;
+    T[n][i] = b3_T_entry(PD.M, PD.HM, n, i);
+  }
+  // ---- ((g0 + g1) + g2) + g3 through one LDS copy of the blocks
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    if (rg == k) {
+#pragma unroll
+      for (int a = 0; a < NB3; ++a) S[a][el] = s[a];
+    }
+    __syncthreads();
+    if (rg == 0) {
+#pragma unroll
+      for (int a = 0; a < NB3; ++a) s[a] += S[a][el];
+    }
+    __syncthreads();
+  }
+  if (rg == 0) {
+#pragma unroll
+    for (int a = 0; a < NB3; ++a) S[a][el] = s[a];
+  }
+  __syncthreads();
+  // ---- unpack: thread group rg owns the tiles rg, rg + 4, ...
+  {
+    double u[MINE];
+    bool keep[MINE];
+#pragma unroll
+    for (int j = 0; j < MINE; ++j) {
+      const int blk = rg + 4 * j;
+      keep[j] = false; u[j] = 0.0;
+      if (blk < NT3) { const int dt = b3_dtile<NCB>(blk); u[j] = b3_unpack<NCB>(blk, dt, el, S[blk], S[NT3 + (dt >= 0 ? dt : 0)], keep[j]); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MINE; ++j) { const int blk = rg + 4 * j; if (blk < NT3 && keep[j]) S[blk][el] = u[j]; }
+    __syncthreads();
+  }
+  float* item = reinterpret_cast<float*>(items + (size_t)pair * item_stride);
+#pragma unroll
+  for (int j = 0; j < MINE; ++j) { const int blk = rg + 4 * j; if (blk < NT3) b3_scatter<NCB, 12, ASM>(blk, el, S[blk], T, item); }
+
+  // ---- graph assembly by the last pair to arrive at each of its two nodes.  No cache writeback / invalidate (a __threadfence per wave
+  // cost 80 us per launch over the 128 workgroups): the item went out in device-scope stores, every wave waits for its stores to complete,
+  // the barrier collects the waves, and only then one lane counts the arrival; the assembling workgroup reads with device-scope loads.
+  if (ASM) {
+    __builtin_amdgcn_s_waitcnt(0);   // vmcnt = lgkmcnt = expcnt = 0: this wave's stores have completed
+    __syncthreads();
+    const int gp = tg.first_pair + pair;
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x;
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const int n = tg.pair_nodes[2 * gp + side];
+        const int need = tail_local_degree(tg, n);
+        if (lane == 0) {
+          const unsigned got = atomicAdd(&tg.node_cnt[n], 1u) + 1u;
+          const bool last = got == (unsigned)need;
+          if (last) tg.node_cnt[n] = 0u;   // rewound for the next launch: nobody else counts on this node any more
+          todo[side] = last ? n : -1;
+        }
+      }
+    }
+    __syncthreads();
+    {   // off-diagonal block of this pair: single writer, from the item this workgroup has just written
+      float* const Ho = tg.sys + (size_t)tg.G.n_nodes * D * D;
+      auto tri = [](int a, int b) { const int lo = a < b ? a : b, hi = a < b ? b : a; return lo * NP - lo * (lo - 1) / 2 + (hi - lo); };
+      for (int e = threadIdx.x; e < D * 6; e += 1024) {
+        const int r = e / 6, c = e - r * 6;
+        const int ia = r < 6 ? r : r + 6;
+        Ho[(size_t)gp * D * 6 + e] = item[tri(ia, 6 + c)];
+      }
+    }
+    if (todo[0] >= 0) tail_assemble_node<CS>(tg, items, item_stride, todo[0]);
+    if (todo[1] >= 0) tail_assemble_node<CS>(tg, items, item_stride, todo[1]);
+  }
+  // ---- the pair's valid0 shadow, when a wave of this launch changed the map (never in the steady state)
+  rebuild_valid0_shadow(PD, W, H, launch_id, 0, 1, stamp);
 }
 
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair) {
@@ -1493,7 +1420,7 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
                            hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, const SfmPairDev* one_host = nullptr,
                            const DynDev* dyn = nullptr, int dyn_grid = 0, bool vsh = false, hipStream_t fin_stream = nullptr, hipEvent_t ev_mid = nullptr,
                            const unsigned* blkmap = nullptr, int total_blocks = 0, const TailGraphDev* tail_graph = nullptr, int node_wgs = 0,
-                           bool* assembled = nullptr, bool folded_req = false) {
+                           bool* assembled = nullptr) {
   if (assembled) *assembled = false;
   const TailGraphDev tg = tail_graph ? *tail_graph : TailGraphDev{};
   constexpr int NACC = NCB * (NCB - 1) / 2 + NCB + 2 * ((NCB + 1) / 2);   // 256-float blocks after block 0 (16x16x4 and 4x4x1 accumulators)
@@ -1512,8 +1439,6 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   const bool tab_lds = MODE == 0 && kStaticLds + tab_bytes + DFX_EXTRA_LDS <= 64 * 1024;
   const size_t dyn_lds = DFX_EXTRA_LDS + (tab_lds ? tab_bytes : 0);
   const bool byval = one_host != nullptr && npairs == 1;
-  // the reduction tail inside the step kernel: bf16 split, static schedule, descriptors in device memory, SfM step
-  const bool folded = folded_req && prec == 1 && MODE == 0 && !byval && !(dyn && dyn->qhead) && DFX_TAIL_KERNEL;   // (the caller asks only when all of this holds)
   const SfmPairDev one = byval ? *one_host : SfmPairDev{};
   const DynDev nodyn{ nullptr, 0, 0, 0, 0, 0u };
   // deferred tail: the finalize kernel runs on `fin_stream`, behind an event recorded after the step kernel
@@ -1569,7 +1494,6 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
-  if (folded) { if (assembled) *assembled = tg.sys != nullptr; return hipSuccess; }   // items (and system) are complete behind the step kernel
   if ((e = to_fin_stream()) != hipSuccess) return e;
   constexpr int NPOSE = MODE == 0 ? 12 : 0;
   const SfmPairDev* fpairs = byval ? (const SfmPairDev*)nullptr : pairs_dev;
@@ -1597,11 +1521,11 @@ hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int 
                            int blocks_per_pair, float* partials_dev, void* items_dev, size_t item_stride,
                            hipStream_t stream, bool jac_dense, int prec, hipEvent_t eb, hipEvent_t ee, const SfmPairDev* one_host,
                            const DynDev* dyn, int dyn_grid, bool vsh, hipStream_t fin_stream, hipEvent_t ev_mid, const unsigned* blkmap_dev, int total_blocks,
-                           const TailGraphDev* tail_graph, int node_wgs, bool* assembled, bool folded) {
+                           const TailGraphDev* tail_graph, int node_wgs, bool* assembled) {
   switch (cs) {
-    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled, folded);
-    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled, folded);
-    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled, folded);
+    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled);
+    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled);
+    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled);
     default: return hipErrorInvalidValue;
   }
 }

@@ -151,47 +151,3 @@ def test_a_changed_valid0_map_is_rebuilt_by_the_tail_kernel(dfx):
     again = al.RunStepBatch(arr)
     for a, b in zip(first, again):
         assert np.array_equal(a.raw, b.raw)
-
-
-def test_tail_inside_the_step_kernel_equals_the_tail_kernel(dfx):
-    """Batched launches of the bf16 split on the static schedule run their reduction tail INSIDE the step kernel (the pair's last workgroup to
-    arrive: tail_pair on 256 threads); DFX_FOLD_TAIL=0 keeps the tail kernel (1024 threads per pair).  Same items, same systems, bit for
-    bit -- one image size and several, with and without a graph, CS 16 / 32 / 64, launch after launch."""
-    import os
-    from deepfactors_amd.dist import NormalEquations, PairGraph
-    old = os.environ.pop("DFX_FOLD_TAIL", None)
-    try:
-        ctx_f = dfx.Context(0)
-        os.environ["DFX_FOLD_TAIL"] = "0"
-        ctx_k = dfx.Context(0)
-    finally:
-        os.environ.pop("DFX_FOLD_TAIL", None)
-        if old is not None:
-            os.environ["DFX_FOLD_TAIL"] = old
-    for cs, sizes in ((32, [(320, 240)] * 10), (16, [(256, 192), (128, 96), (64, 48)] * 4), (64, [(192, 128)] * 5), (32, [(640, 480)] * 3)):
-        n = len(sizes)
-        graph = PairGraph.chain(n)
-        isz = dfx.item_size(12 + cs)
-        res = []
-        for ctx in (ctx_f, ctx_k):
-            al = dfx.SfmAligner(code_size=cs, ctx=ctx)
-            plist, keep = _plist(dfx, al, ctx, sizes, cs, 0x5700 + cs)
-            arr = al.make_pairs(plist)
-            items = torch.zeros(n * isz, dtype=torch.uint8, device="cuda")
-            neq = NormalEquations(graph, cs, "cuda")
-            snaps = []
-            for rep in range(3):
-                al.RunStepBatchAssembleAsync(arr, items, neq, 0)
-                snaps.append((items.clone(), neq.buf.clone()))
-            plain = al.RunStepBatch(arr)          # no graph: blocking entry
-            ctx.sync()
-            res.append(([(a.cpu().numpy(), b.cpu().numpy()) for a, b in snaps], np.concatenate([p.raw for p in plain]),
-                        [k["valid0"].download() for k in keep], [k["valid0"].valid0_shadow() for k in keep]))
-        (sf, pf, vf, shf), (sk, pk, vk, shk) = res
-        for rep in range(3):
-            assert np.array_equal(sf[rep][0], sk[rep][0]), (cs, rep)
-            assert np.array_equal(sf[rep][1], sk[rep][1]), (cs, rep)
-        assert np.array_equal(pf, pk) and np.array_equal(pf, sf[0][0])
-        assert np.abs(sf[0][1]).max() > 0
-        for a, b, c_, d in zip(vf, vk, shf, shk):
-            assert np.array_equal(a, b) and np.array_equal(c_, d) and np.array_equal(c_, a == 1.0)
