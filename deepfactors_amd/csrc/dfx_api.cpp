@@ -807,6 +807,12 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
   int rc;
   if ((rc = ensure_device(c))) return rc;
   if (params->step_blocks < 0 || params->step_blocks > 65535) return fail(DFX_E_INVALID, "step_blocks %d out of range [0,65535]", params->step_blocks);
+  // graph assembly: inside the reduction tail where the launch has the one-workgroup-per-pair tail kernel (batched, bf16 split), as a
+  // second kernel behind the finalize kernel otherwise (single pair, fp32 chain) -- the same sums in the same order either way.
+  // Checked first: an inconsistent graph fails the call before anything is enqueued.
+  dfx::TailGraphDev tg{};
+  int node_wgs = 0;
+  if (graph && (rc = graph_tail(c, cs, graph, first_pair, n, sys_dev, &tg, &node_wgs))) return rc;
   // Image sizes: a batch may mix pyramid levels (the reference walks all levels of a factor set per relinearisation,
   // core/mapping/df_work.cpp:118-136, tools/kernel_benchmark.cpp:192-203).  W, H = the largest width / height (ray-table LDS).
   uint32_t W = 0, H = 0;
@@ -983,12 +989,7 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
     c->qhead_dirty = true;
   }
   hipStream_t const fin_stream = defer ? c->tail_stream : c->stream;
-  // graph assembly: inside the reduction tail where the launch has the one-workgroup-per-pair tail kernel (batched, bf16 split), as a
-  // second kernel behind the finalize kernel otherwise (single pair, fp32 chain) -- the same sums in the same order either way
-  dfx::TailGraphDev tg{};
-  int node_wgs = 0;
   bool assembled = false;
-  if (graph && (rc = graph_tail(c, cs, graph, first_pair, n, sys_dev, &tg, &node_wgs))) return rc;
   DFX_HIP(dfx::launch_sfm_step(cs, dd, n, (int)W, (int)H, prm, bpp, partials, out_items_dev, dfx_item_size(12 + cs), c->stream,
                                jac_dense, resolve_mfma(c, cs), eb, ee, n == 1 ? &one : nullptr, dyn.qhead ? &dyn : nullptr, dyn_grid, vsh,
                                fin_stream, defer ? c->ev_mid[par] : nullptr, map_dev, total_blocks, graph ? &tg : nullptr, node_wgs, &assembled));

@@ -151,3 +151,40 @@ def test_a_changed_valid0_map_is_rebuilt_by_the_tail_kernel(dfx):
     again = al.RunStepBatch(arr)
     for a, b in zip(first, again):
         assert np.array_equal(a.raw, b.raw)
+
+
+def test_step_batch_assemble_rejects_inconsistent_arguments(dfx):
+    """dfx_sfm_step_batch_assemble_async fails loudly on a graph of another code size, a pair range outside the graph, a null system --
+    and leaves the context usable (the next launch gives the usual result)."""
+    import ctypes as C
+    from deepfactors_amd import _lib
+    from deepfactors_amd.dist import NormalEquations, PairGraph
+    cs = 16
+    ctx = dfx.Context(0)
+    al = dfx.SfmAligner(code_size=cs, ctx=ctx)
+    plist, keep = _plist(dfx, al, ctx, [(96, 64)] * 4, cs, 0x5800)
+    arr = al.make_pairs(plist)
+    isz = dfx.item_size(12 + cs)
+    items = torch.zeros(4 * isz, dtype=torch.uint8, device="cuda")
+    graph = PairGraph.chain(4)
+    neq = NormalEquations(graph, cs, "cuda")
+    al.RunStepBatchAssembleAsync(arr, items, neq, 0)
+    ctx.sync()
+    want_items, want_sys = items.cpu().numpy().copy(), neq.buf.cpu().numpy().copy()
+    other = NormalEquations(graph, 32, "cuda")
+    with pytest.raises(ValueError, match="code size"):
+        al.RunStepBatchAssembleAsync(arr, items, other, 0)
+    p = al._p()
+    rc = _lib.lib().dfx_sfm_step_batch_assemble_async(ctx.handle, cs, C.byref(p), arr, 4, C.c_void_p(items.data_ptr()), other.native_handle(ctx), 0,
+                                                      C.c_void_p(other.buf.data_ptr()))
+    assert rc == _lib.DFX_E_INVALID and "code size" in _lib.lib().dfx_last_error().decode()
+    with pytest.raises(dfx.DfxError, match="not inside the graph"):
+        al.RunStepBatchAssembleAsync(arr, items, neq, 2)
+    rc = _lib.lib().dfx_sfm_step_batch_assemble_async(ctx.handle, cs, C.byref(p), arr, 4, C.c_void_p(items.data_ptr()), neq.native_handle(ctx), 0, None)
+    assert rc == _lib.DFX_E_INVALID
+    rc = _lib.lib().dfx_sfm_step_batch_assemble_async(ctx.handle, cs, C.byref(p), arr, 4, C.c_void_p(items.data_ptr()), None, 0, C.c_void_p(neq.buf.data_ptr()))
+    assert rc == _lib.DFX_E_INVALID
+    items.zero_(); neq.buf.fill_(3.0)
+    al.RunStepBatchAssembleAsync(arr, items, neq, 0)
+    ctx.sync()
+    assert np.array_equal(items.cpu().numpy(), want_items) and np.array_equal(neq.buf.cpu().numpy(), want_sys)
