@@ -360,7 +360,17 @@ int fill_sfm_pair(dfx_ctx* c, int cs, const dfx_se3* pose0, const dfx_se3* pose1
 // much as two chunks, so waves should be long: 5 chunks per wave while the batch is small (1 / 2 / 4 pairs of 640x480: 240
 // workgroups per pair is best), then as many as leave ~1.25 rounds of the 16 * CUs resident waves, up to 30:
 //   8 pairs 78 -> 74 us, 16 pairs 148 -> 138 us, 32 pairs 294 -> 258 us, 64 pairs 550 -> 533 us against the old five-round rule.
-int auto_step_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int npairs, int cs, int requested = 0) {
+// Longest wave (chunks) the launch shape hands out.  30 for the fp32 chain (four workgroups per CU: 40 workgroups per 640x480 pair x 128 pairs =
+// 5.0 rounds of 1024).  The bf16 split runs three workgroups per CU (147 registers), and with it 40 chunks per wave -- 30 workgroups per pair
+// -- measured the same or better at every batch size tried (round 3, profiles/r03_ab_launch_shape.txt: 48 pairs -2.3 %, 128 pairs -0.5 % and
+// 3 us less reduction tail, 256 pairs -0.5 %, 64 pairs and CS = 16 +-0); CS = 64 keeps 30.  DFX_CPW_MAX overrides (tuning aid).
+int chunks_per_wave_max(int cs, bool b3) {
+  static const int env = [] { const char* ev = std::getenv("DFX_CPW_MAX"); const int v = ev ? std::atoi(ev) : 0; return v > 0 && v <= 1000 ? v : 0; }();
+  if (env) return env;
+  return (b3 && cs < 64) ? 40 : 30;
+}
+
+int auto_step_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int npairs, int cs, int requested = 0, bool b3 = false) {
   const int nchunks = (int)(((size_t)W * H + 63) / 64);
   int maxb = (nchunks + 3) / 4;   // one chunk per wave at most
   if (maxb < 1) maxb = 1;
@@ -371,7 +381,7 @@ int auto_step_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int npairs, int c
     // measured best (4 pairs 1280x960: 309 us at 15 chunks per wave vs 330 at 5; 16 pairs: 1204 us at 30 vs 1245 at 10)
     const long long resident_waves = (cs >= 64 ? 8LL : 16LL) * c->cu_count;
     int cpw = cs >= 64 ? (int)(2 * total_chunks / (5 * resident_waves)) : (int)(4 * total_chunks / (5 * resident_waves));
-    const int cpw_max = 30;
+    const int cpw_max = chunks_per_wave_max(cs, b3);
     if (cpw < 5) cpw = 5;
     if (cpw > cpw_max) cpw = cpw_max;
     b = (nchunks + 4 * cpw - 1) / (4 * cpw);
@@ -835,7 +845,7 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
     const long long resident_waves = (cs >= 64 ? 8LL : 12LL) * c->cu_count;
     int cpw = (int)(4 * total_chunks / (5 * resident_waves));
     if (cpw < 5) cpw = 5;
-    if (cpw > 30) cpw = 30;
+    if (cpw > chunks_per_wave_max(cs, resolve_mfma(c, cs) == DFX_MFMA_BF16X3)) cpw = chunks_per_wave_max(cs, resolve_mfma(c, cs) == DFX_MFMA_BF16X3);
     if (params->step_blocks > 0 || c->step_blocks > 0) {   // an explicit request is read as "workgroups of a pair of the LARGEST size"
       const int req = params->step_blocks > 0 ? params->step_blocks : c->step_blocks;
       const long long big = ((long long)W * H + 63) / 64;
@@ -957,7 +967,7 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
     }
   }
   c->last_dynamic = dyn.qhead ? 1 : 0;
-  const int bpp = dyn.qhead ? dyn.team : (uniform ? auto_step_blocks(c, W, H, n, cs, params->step_blocks) : 0);
+  const int bpp = dyn.qhead ? dyn.team : (uniform ? auto_step_blocks(c, W, H, n, cs, params->step_blocks, resolve_mfma(c, cs) == DFX_MFMA_BF16X3) : 0);
   const size_t pbytes = uniform ? dfx::sfm_step_partials_bytes(cs, n, bpp) : dfx::sfm_step_partials_bytes(cs, 1, total_blocks);
   if ((rc = grow_partials(c, pbytes, true))) return rc;
   // Deferred tail: this launch's finalize kernel goes to the tail stream and runs beside the NEXT launch's step kernel; the two halves of
