@@ -362,15 +362,18 @@ int fill_sfm_pair(dfx_ctx* c, int cs, const dfx_se3* pose0, const dfx_se3* pose1
 //   8 pairs 78 -> 74 us, 16 pairs 148 -> 138 us, 32 pairs 294 -> 258 us, 64 pairs 550 -> 533 us against the old five-round rule.
 // Longest wave (chunks) the launch shape hands out.  30 for the fp32 chain (four workgroups per CU: 40 workgroups per 640x480 pair x 128 pairs =
 // 5.0 rounds of 1024).  The bf16 split runs three workgroups per CU (147 registers), and with it 40 chunks per wave -- 30 workgroups per pair
-// -- measured the same or better at every batch size tried (round 3, profiles/r03_ab_launch_shape.txt: 48 pairs -2.3 %, 128 pairs -0.5 % and
-// 3 us less reduction tail, 256 pairs -0.5 %, 64 pairs and CS = 16 +-0); CS = 64 keeps 30.  DFX_CPW_MAX overrides (tuning aid).
-int chunks_per_wave_max(int cs, bool b3) {
+// -- measured the same or better at every batch size tried when every pair streams its OWN Jacobian (round 3, profiles/r03_ab_launch_shape.txt:
+// 48 pairs -2.3 %, 128 pairs -1.0 % incl. 3 us less reduction tail, 256 pairs -0.5 %, three pyramid levels in one launch -0.5 %, 64 pairs and
+// CS = 16 +-0).  Batches whose pairs SHARE a keyframe's Jacobian (a relinearisation round: 120 pairs of 16 keyframes) live on the pairs of a
+// keyframe running side by side through the L2 / Infinity Cache, and there the shorter waves are 8 % faster (917 vs 990 us): they keep 30,
+// and so does CS = 64.  DFX_CPW_MAX overrides (tuning aid).
+int chunks_per_wave_max(int cs, bool b3, bool distinct_jacobians) {
   static const int env = [] { const char* ev = std::getenv("DFX_CPW_MAX"); const int v = ev ? std::atoi(ev) : 0; return v > 0 && v <= 1000 ? v : 0; }();
   if (env) return env;
-  return (b3 && cs < 64) ? 40 : 30;
+  return (b3 && cs < 64 && distinct_jacobians) ? 40 : 30;
 }
 
-int auto_step_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int npairs, int cs, int requested = 0, bool b3 = false) {
+int auto_step_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int npairs, int cs, int requested = 0, bool b3 = false, bool distinct_jacobians = false) {
   const int nchunks = (int)(((size_t)W * H + 63) / 64);
   int maxb = (nchunks + 3) / 4;   // one chunk per wave at most
   if (maxb < 1) maxb = 1;
@@ -381,7 +384,7 @@ int auto_step_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int npairs, int c
     // measured best (4 pairs 1280x960: 309 us at 15 chunks per wave vs 330 at 5; 16 pairs: 1204 us at 30 vs 1245 at 10)
     const long long resident_waves = (cs >= 64 ? 8LL : 16LL) * c->cu_count;
     int cpw = cs >= 64 ? (int)(2 * total_chunks / (5 * resident_waves)) : (int)(4 * total_chunks / (5 * resident_waves));
-    const int cpw_max = chunks_per_wave_max(cs, b3);
+    const int cpw_max = chunks_per_wave_max(cs, b3, distinct_jacobians);
     if (cpw < 5) cpw = 5;
     if (cpw > cpw_max) cpw = cpw_max;
     b = (nchunks + 4 * cpw - 1) / (4 * cpw);
@@ -834,6 +837,14 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
     uniform = uniform && w == pairs[0].img0.w && h == pairs[0].img0.h;
     W = w > W ? w : W; H = h > H ? h : H;
   }
+  // does every pair stream its own Jacobian image?  (decides how long the waves may be: chunks_per_wave_max)
+  bool distinct_jac = true;
+  {
+    std::vector<const void*> jp((size_t)n);
+    for (int p = 0; p < n; ++p) jp[(size_t)p] = pairs[p].prx0_jac.ptr;
+    std::sort(jp.begin(), jp.end());
+    distinct_jac = std::adjacent_find(jp.begin(), jp.end()) == jp.end();
+  }
   // Launch shape of a mixed batch: one chunks-per-wave figure for all pairs (so that a 160x120 pair gets 1/16 of the workgroups of a
   // 640x480 one instead of the same number of much shorter ones), a 1-D grid, the large pairs first: the small levels fill the tail.
   std::vector<uint32_t> nblk, blk0;
@@ -845,7 +856,8 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
     const long long resident_waves = (cs >= 64 ? 8LL : 12LL) * c->cu_count;
     int cpw = (int)(4 * total_chunks / (5 * resident_waves));
     if (cpw < 5) cpw = 5;
-    if (cpw > chunks_per_wave_max(cs, resolve_mfma(c, cs) == DFX_MFMA_BF16X3)) cpw = chunks_per_wave_max(cs, resolve_mfma(c, cs) == DFX_MFMA_BF16X3);
+    const int cpw_cap = chunks_per_wave_max(cs, resolve_mfma(c, cs) == DFX_MFMA_BF16X3, distinct_jac);
+    if (cpw > cpw_cap) cpw = cpw_cap;
     if (params->step_blocks > 0 || c->step_blocks > 0) {   // an explicit request is read as "workgroups of a pair of the LARGEST size"
       const int req = params->step_blocks > 0 ? params->step_blocks : c->step_blocks;
       const long long big = ((long long)W * H + 63) / 64;
@@ -967,7 +979,7 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
     }
   }
   c->last_dynamic = dyn.qhead ? 1 : 0;
-  const int bpp = dyn.qhead ? dyn.team : (uniform ? auto_step_blocks(c, W, H, n, cs, params->step_blocks, resolve_mfma(c, cs) == DFX_MFMA_BF16X3) : 0);
+  const int bpp = dyn.qhead ? dyn.team : (uniform ? auto_step_blocks(c, W, H, n, cs, params->step_blocks, resolve_mfma(c, cs) == DFX_MFMA_BF16X3, distinct_jac) : 0);
   const size_t pbytes = uniform ? dfx::sfm_step_partials_bytes(cs, n, bpp) : dfx::sfm_step_partials_bytes(cs, 1, total_blocks);
   if ((rc = grow_partials(c, pbytes, true))) return rc;
   // Deferred tail: this launch's finalize kernel goes to the tail stream and runs beside the NEXT launch's step kernel; the two halves of
