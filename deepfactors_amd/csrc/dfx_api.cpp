@@ -979,7 +979,8 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
     }
   }
   c->last_dynamic = dyn.qhead ? 1 : 0;
-  const int bpp = dyn.qhead ? dyn.team : (uniform ? auto_step_blocks(c, W, H, n, cs, params->step_blocks, resolve_mfma(c, cs) == DFX_MFMA_BF16X3, distinct_jac) : 0);
+  int bpp = dyn.qhead ? dyn.team : (uniform ? auto_step_blocks(c, W, H, n, cs, params->step_blocks, resolve_mfma(c, cs) == DFX_MFMA_BF16X3, distinct_jac) : 0);
+  if (!uniform) for (int p = 0; p < n; ++p) bpp = std::max(bpp, (int)nblk[(size_t)p]);   // mixed sizes: the partials of the largest pair (the launcher picks the tail kernel by it)
   const size_t pbytes = uniform ? dfx::sfm_step_partials_bytes(cs, n, bpp) : dfx::sfm_step_partials_bytes(cs, 1, total_blocks);
   if ((rc = grow_partials(c, pbytes, true))) return rc;
   // Deferred tail: this launch's finalize kernel goes to the tail stream and runs beside the NEXT launch's step kernel; the two halves of

@@ -99,6 +99,10 @@ namespace dfx {
 #ifndef DFX_TAIL_KERNEL
 #define DFX_TAIL_KERNEL 1    // batched bf16-split launches: 1 = k_sfm_tail_b3 (a workgroup per pair, graph assembly folded in), 0 = k_sfm_finalize_b3 (a workgroup
 #endif                       // per tile of a pair) and a separate assembly kernel -- the A/B switch of DESIGN.md 3.7
+#ifndef DFX_TAIL_MAX_KB
+#define DFX_TAIL_MAX_KB 512  // ... while a pair's partials are at most this many KB: the tail kernel reads a pair with ONE workgroup, the per-tile kernel with one per tile.
+#endif                       // 128 pairs x 30 partials x 9 KB = 270 KB per pair: 16 us against 15 + 6.5 us in two kernels; 16 pairs of 1280x960 at CS = 64 (160 x 20 KB
+                             // = 3.2 MB per pair, 16 workgroups in all): 90 us against 45 us (profiles/r03_ab_launch_shape.txt, call 24) -- those take the per-tile kernel
 #ifndef DFX_DYN_ROT
 #define DFX_DYN_ROT 4        // dynamic schedule: member row m of the teams serves the pairs rotated by DFX_DYN_ROT * m (0: a pair's team sits on one XCD)
 #endif
@@ -1439,6 +1443,9 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   const bool tab_lds = MODE == 0 && kStaticLds + tab_bytes + DFX_EXTRA_LDS <= 64 * 1024;
   const size_t dyn_lds = DFX_EXTRA_LDS + (tab_lds ? tab_bytes : 0);
   const bool byval = one_host != nullptr && npairs == 1;
+  // one workgroup per pair (k_sfm_tail_b3) or one per tile of a pair (k_sfm_finalize_b3)?  bpp = the partials of the largest pair
+  const long long tail_kb = (long long)((dyn && dyn->qhead) ? dyn->team : bpp) * b3_blocks(NCB);
+  const bool use_tail = DFX_TAIL_KERNEL && MODE == 0 && tail_kb <= DFX_TAIL_MAX_KB;
   const SfmPairDev one = byval ? *one_host : SfmPairDev{};
   const DynDev nodyn{ nullptr, 0, 0, 0, 0, 0u };
   // deferred tail: the finalize kernel runs on `fin_stream`, behind an event recorded after the step kernel
@@ -1462,7 +1469,7 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
       if (e != hipSuccess) return e;
       if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
       if ((e = to_fin_stream()) != hipSuccess) return e;
-      if (b3 && DFX_TAIL_KERNEL) {
+      if (b3 && use_tail) {
         if (tg.sys) hipLaunchKernelGGL((k_sfm_tail_b3<NCB, true>), dim3(npairs + node_wgs), dim3(1024), 0, fstream,
                                        (const float*)partials_dev, dyn->team, pairs_dev, npairs, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0, tg);
         else hipLaunchKernelGGL((k_sfm_tail_b3<NCB, false>), dim3(npairs), dim3(1024), 0, fstream,
@@ -1500,7 +1507,7 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   if (b3) {
     if (byval) hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, true>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
                                   (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged);
-    else if constexpr (MODE == 0 && DFX_TAIL_KERNEL) {   // every batched launch: one workgroup per pair, the graph assembly folded in
+    else if (MODE == 0 && use_tail) {   // batched launches: one workgroup per pair, the graph assembly folded in
       if (tg.sys) hipLaunchKernelGGL((k_sfm_tail_b3<NCB, true>), dim3(npairs + node_wgs), dim3(1024), 0, fstream,
                                      (const float*)partials_dev, bpp, fpairs, npairs, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged, tg);
       else hipLaunchKernelGGL((k_sfm_tail_b3<NCB, false>), dim3(npairs), dim3(1024), 0, fstream,

@@ -93,23 +93,26 @@ def test_mixed_sizes_both_schedules_and_the_launches_without_a_tail_kernel(dfx):
     (i0, s0, _), (i1, s1, _) = _both(al, arr, graph, cs, 12, 0)
     assert np.array_equal(i0, i1) and np.array_equal(s0, s1)
     # one size, dynamic schedule: the items differ from the static ones by re-association only, and the one-call system is the gather of ITS items
-    plist, keep = _plist(dfx, al, ctx, [(320, 240)] * 8, cs, 0x5400)
-    arr = al.make_pairs(plist)
-    graph = PairGraph.chain(8)
-    ctx.set_schedule(_lib.DFX_SCHEDULE_DYNAMIC)
+    # (80 pairs: teams of 51 waves = 51 partials per pair -- few enough for the one-workgroup-per-pair tail kernel; the 8-pair batch below
+    # has teams of 512 and takes the per-tile finalize + k_graph_assemble)
     from deepfactors_amd.dist import NormalEquations
     isz = dfx.item_size(12 + cs)
-    items = torch.zeros(8 * isz, dtype=torch.uint8, device="cuda")
-    neq = NormalEquations(graph, cs, "cuda")
-    for _ in range(3):
-        al.RunStepBatchAssembleAsync(arr, items, neq, 0)
-    ctx.sync()
-    assert ctx.last_schedule_dynamic()
-    want = NormalEquations(graph, cs, "cuda")
-    want.assemble_native(ctx, items, 0, 8)
-    ctx.sync()
-    assert torch.equal(want.buf, neq.buf)
-    ctx.set_schedule(_lib.DFX_SCHEDULE_STATIC)
+    for npr, (w_, h_) in ((80, (128, 96)), (8, (320, 240))):
+        plist, keep = _plist(dfx, al, ctx, [(w_, h_)] * npr, cs, 0x5400)
+        arr = al.make_pairs(plist)
+        graph = PairGraph.chain(npr)
+        ctx.set_schedule(_lib.DFX_SCHEDULE_DYNAMIC)
+        items = torch.zeros(npr * isz, dtype=torch.uint8, device="cuda")
+        neq = NormalEquations(graph, cs, "cuda")
+        for _ in range(3):
+            al.RunStepBatchAssembleAsync(arr, items, neq, 0)
+        ctx.sync()
+        assert ctx.last_schedule_dynamic()
+        want = NormalEquations(graph, cs, "cuda")
+        want.assemble_native(ctx, items, 0, npr)
+        ctx.sync()
+        assert torch.equal(want.buf, neq.buf)
+        ctx.set_schedule(_lib.DFX_SCHEDULE_STATIC)
     # the fp32 chain has no tail kernel: the call runs finalize + assembly as two kernels
     ctx.set_mfma_mode(_lib.DFX_MFMA_F32_CHAIN)
     (i0, s0, _), (i1, s1, _) = _both(al, arr, graph, cs, 8, 0)
