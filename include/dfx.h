@@ -161,7 +161,9 @@ DFX_API int dfx_set_mfma_mode(dfx_ctx* ctx, int mode);
 /* *mode = the evaluation mode (DFX_MFMA_F32_CHAIN / DFX_MFMA_BF16X3) the context's last SfM / DepthAligner step resolved to. */
 DFX_API int dfx_last_mfma_mode(dfx_ctx* ctx, int* mode);
 /* Testing aids: the environment variables DFX_MFMA = auto | f32 | bf16x3 and DFX_SCHEDULE = auto | static | dynamic set the INITIAL mode of
- * every context this process creates (e.g. to run a whole test suite in one mode); any other value makes dfx_ctx_create fail. */
+ * every context this process creates (e.g. to run a whole test suite in one mode); any other value makes dfx_ctx_create fail.
+ * Tuning aid: DFX_CPW_MAX = n overrides the longest wave (64-pixel chunks) the launch shape of a batched step hands out -- 30, or 40 for the
+ * bf16 split at CS < 64 when every pair of the batch streams its own Jacobian image; results stay bit-reproducible for a given shape. */
 /* Launch schedule of the batched SfM step (no reference counterpart: the reference has one fixed 11 x 32 grid, cu_sfmaligner.cpp:60).
  *  DFX_SCHEDULE_AUTO     (default) the library's choice -- today always the static partition.
  *  DFX_SCHEDULE_STATIC   the static partition: bit-reproducible for a given launch shape, like the reference's fixed grid.
