@@ -47,12 +47,16 @@
 //   Epilogue: waves fold their accumulators through LDS in fixed order; each workgroup writes one z-space partial;
 //     k_sfm_finalize sums the partials of a pair in double, in fixed order (bit-reproducible for a given launch
 //     shape), and scatters into the reference's JTJJrReductionItem layout (reduction_items.h:77-143).
-//   Second evaluation mode (DFX_MFMA_BF16X3, opt-in, template flag B3): the fp32 MFMA above runs at the vector ALU's rate, the bf16 MFMA
-//     at 16x that.  Every fp32 entry of z is split EXACTLY into three bf16 pieces (x = h + m + l, round-to-nearest-even through
-//     v_cvt_pk_bf16_f32, 11 VALU instructions per pair of values) and z z^T is summed as hh + hm + mh + hl + lh + mm on
-//     v_mfma_f32_16x16x32_bf16 (fp32 accumulate; the dropped terms are < 2^-26 of a product).  Plain 16x16 tiles (P,P), (P,C_b),
-//     (C_b,C_b'), b <= b'; the operand ring, phase A, the pipeline, both schedules and the epilogue are shared; k_sfm_finalize_b3 scatters.
-//     Measured on MI355X: CS = 64 at 1280x960 1202 -> 997 us per 16 pairs, CS = 32 at 640x480 1055 -> 1041 us per 128 pairs.
+//   The DEFAULT evaluation mode since round 3 (DFX_MFMA_BF16X3, template flag B3; the chain above is DFX_MFMA_F32_CHAIN): the fp32 MFMA runs at the
+//     vector ALU's rate, the bf16 MFMA at 16x that.  Every fp32 entry of z is split EXACTLY into three bf16 pieces (x = h + m + l, round-to-nearest-
+//     even through v_cvt_pk_bf16_f32, remainders through v_dot2c_f32_bf16: 7 VALU instructions per pair of values) and z z^T is summed as
+//     hh + hm + mh + hl + lh + mm on v_mfma_f32_16x16x32_bf16 (fp32 accumulate; the dropped terms are < 2^-26 of a product).  16x16 tiles (P,P),
+//     (P,C_b), (C_b,C_b'), b <= b', with the P block stacked as [P_h ; P_m] and four-product diagonal tiles: 48 MFMAs per chunk at CS = 32.  The
+//     operand ring, phase A, the pipeline, both schedules and the epilogue are shared.  Reduction tail: k_sfm_tail_b3 (a workgroup per pair, the
+//     keyframe graph's assembly folded in) for batches, k_sfm_finalize_b3 (a workgroup per tile) for single pairs and pairs with > 512 KB of partials.
+//     Measured on MI355X: CS = 32 at 640x480 956 us per 128 pairs (chain 1037), CS = 64 at 1280x960 883-922 us per 16 pairs (1148).
+//     On this part the kernel runs at the package's power cap (shader clock 1.65-1.8 GHz), where its vector-ALU + matrix issue time is 95 % of
+//     the kernel time and the memory system delivers what it can sustain: both terms above still count one to one.
 #include "dfx_device.hpp"
 #include "dfx_kernels.hpp"
 
