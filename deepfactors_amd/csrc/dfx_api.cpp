@@ -1223,7 +1223,8 @@ int upload_simple(dfx_ctx* c, const std::vector<dfx::SimplePairDev>& descs, cons
 // workgroups per pair of a batched simple kernel: ~24 per CU over the whole batch, at least one wave-row of pixels each
 int batch_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int n) {
   int b = simple_blocks(W, H);
-  const int cap = (24 * c->cu_count + n - 1) / n;
+  static const int k_env = [] { const char* ev = std::getenv("DFX_BATCH_WGS_PER_CU"); const int v = ev ? std::atoi(ev) : 0; return v > 0 && v <= 256 ? v : 0; }();   // tuning aid
+  const int cap = ((k_env ? k_env : 24) * c->cu_count + n - 1) / n;
   if (b > cap) b = cap;
   return b < 1 ? 1 : b;
 }

@@ -1283,7 +1283,7 @@ __global__ __launch_bounds__(1024) void k_sfm_tail_b3(const float* __restrict__ 
 #ifndef DFX_TAIL_ROWS
 #define DFX_TAIL_ROWS 0
 #endif
-  constexpr int ROWS = DFX_TAIL_ROWS ? DFX_TAIL_ROWS : (NB3 <= 5 ? 8 : (NB3 <= 10 ? 4 : 2));   // partial rows per batch: ROWS * NB3 loads in flight per thread
+  constexpr int ROWS = DFX_TAIL_ROWS ? DFX_TAIL_ROWS : (NB3 <= 10 ? 8 : 2);   // partial rows per batch: ROWS * NB3 loads in flight per thread (CS = 32: a pair's 30 partials in ONE batch per group of rows, 101 registers)
   constexpr int MINE = (NT3 + 3) / 4;                         // tiles per thread group in the unpack / scatter stage
   __shared__ double S[NB3][256];
   __shared__ double T[12][6];
