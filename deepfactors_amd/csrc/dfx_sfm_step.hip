@@ -79,7 +79,7 @@ namespace dfx {
 #define DFX_TRACE 0          // 1: per-wave s_memtime sums of phase A / phase B in the junk row 15 of the (P,P) partial
 #endif
 #ifndef DFX_ABLATE
-#define DFX_ABLATE 0         // diagnosis only (wrong results; the bf16 split honours bits 1, 2, 4 and 1024 = matrix instructions replaced by vector-ALU ones): 1 = no MFMAs, 2 = no phase-A math/gathers, 4 = no ring loads,
+#define DFX_ABLATE 0         // diagnosis only (wrong results; the bf16 split honours bits 1, 2, 4, 1024 = matrix instructions replaced by vector-ALU ones, 2048 = phase B reduced to the operand stream): 1 = no MFMAs, 2 = no phase-A math/gathers, 4 = no ring loads,
                              // 16 = no P x P fmas, 32 = no ray-table / valid0 reads, 64 = no operand shuffles, 128 = no tap gathers
 #endif
 
@@ -657,6 +657,19 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
       //   (P,P)  :  Pa x Pa  = [hh hm ; mh mm]   and   Pl0 x Pa = [lh (lm) ; 0 0] in a second accumulator             2 instead of 6
       // (terms in parentheses are of the dropped 2^-24 class: harmless).  The finalize kernel adds the row halves / quadrants and
       // symmetrises lh (P P^T = sum of p p^T: hl = lh^T).  CS = 32 with the four-product diagonal tiles: 48 MFMAs per chunk (72 plain).
+#if DFX_ABLATE & 2048
+      // diagnosis: the operand stream alone -- every ring vector is consumed by ONE xor (no scaling, no split, no matrix instruction) and refilled
+      {
+        unsigned sink = 0;
+#pragma unroll
+        for (int gq = 0; gq < 16; ++gq) {
+#pragma unroll
+          for (int b = 0; b < NCB; ++b) sink ^= __float_as_uint(jv_get<NCB>(jv[gq], b));
+          jv[gq] = ring_load(nrs, rlo, nbase, gq, has1);
+        }
+        acc3[0][0] += __uint_as_float(sink & 0x007fffffu);
+      }
+#else
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         u32x4 oh[1 + NCB], om[1 + NCB], ol[1 + NCB];   // packed bf16 pairs (slots 2 jp, 2 jp + 1) of the three pieces of the code blocks (index 0 unused)
@@ -727,6 +740,7 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
           acc3[0] = mfma_bf16(pa, pa, acc3[0]);
         }
       }
+#endif
     } else {
 #if !(DFX_ABLATE & 16)
 #pragma unroll
