@@ -401,8 +401,10 @@ int simple_blocks(uint32_t W, uint32_t H) {
   return b < 1 ? 1 : b;
 }
 
+// R10 (optional): the rotation of pose_10 as nine floats -- the callers that get it from relative_pose() (the quaternion of pose_10 is then
+// ignored); the constants of the kernels' fast geometry are derived from the rotation the kernels will see.
 int fill_simple(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam, const dfx_img* img0, const dfx_img* img1, const dfx_img* dpt0,
-                const dfx_img* grad1, const dfx_img* img2, dfx::SimplePairDev* d) {
+                const dfx_img* grad1, const dfx_img* img2, dfx::SimplePairDev* d, const float* R10 = nullptr) {
   if (!pose_10 || !cam) return fail(DFX_E_INVALID, "null pose/camera");
   if (!img_ok(img0)) return fail(DFX_E_INVALID, "img0: null or empty image view");
   const uint32_t W = img0->w, H = img0->h;
@@ -412,9 +414,17 @@ int fill_simple(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam, const df
   if ((rc = check_img(dpt0, "dpt0", W, H, 4))) return rc;
   double R[9];
   quat_to_R(pose_10->q, R);
-  for (int i = 0; i < 9; ++i) d->R[i] = (float)R[i];
+  for (int i = 0; i < 9; ++i) d->R[i] = R10 ? R10[i] : (float)R[i];
   d->t[0] = pose_10->t[0]; d->t[1] = pose_10->t[1]; d->t[2] = pose_10->t[2];
   d->fx = cam->fx; d->fy = cam->fy; d->u0 = cam->u0; d->v0 = cam->v0; d->w = cam->w; d->h = cam->h;
+  {
+    // constants of the fast geometry of the pixel reductions (dfx_kernels.hpp FastGeo), of the fp32 pose the kernels see
+    double Rf[9], tf[3];
+    for (int i = 0; i < 9; ++i) Rf[i] = (double)d->R[i];
+    for (int i = 0; i < 3; ++i) tf[i] = (double)d->t[i];
+    dfx::derive_fast_cam(cam->fx, cam->fy, cam->u0, cam->v0, cam->w, cam->h, (int)W, (int)H, &d->fc);
+    dfx::derive_fast_geo(Rf, tf, cam->fx, cam->fy, cam->u0, cam->v0, cam->w, cam->h, d->fc, &d->fg);
+  }
   d->img0 = (const float*)img0->ptr; d->img1 = (const float*)img1->ptr; d->dpt0 = (const float*)dpt0->ptr;
   d->pitch_img0 = (uint32_t)img0->pitch_bytes; d->pitch_img1 = (uint32_t)img1->pitch_bytes;
   d->pitch_dpt0 = (uint32_t)dpt0->pitch_bytes;
@@ -1185,8 +1195,7 @@ DFX_API int dfx_sfm_error(dfx_ctx* c, const dfx_se3* pose0, const dfx_se3* pose1
   relative_pose(*pose0, *pose1, R10, p10.t, nullptr, HM);
   dfx::SimplePairDev d;
   p10.q[0] = p10.q[1] = p10.q[2] = 0; p10.q[3] = 1;
-  if ((rc = fill_simple(c, &p10, cam, img0, img1, dpt0, nullptr, nullptr, &d))) return rc;
-  for (int i = 0; i < 9; ++i) d.R[i] = R10[i];
+  if ((rc = fill_simple(c, &p10, cam, img0, img1, dpt0, nullptr, nullptr, &d, R10))) return rc;
   const int blocks = simple_blocks(img0->w, img0->h);
   const size_t pbytes = (size_t)blocks * dfx::kSimpleRow * sizeof(float);
   if ((rc = grow_partials(c, pbytes))) return rc;
@@ -1245,11 +1254,10 @@ DFX_API int dfx_sfm_error_batch_async(dfx_ctx* c, const dfx_sfm_params* params, 
     relative_pose(pairs[p].pose0, pairs[p].pose1, R10, p10.t, nullptr, HM);
     p10.q[0] = p10.q[1] = p10.q[2] = 0; p10.q[3] = 1;
     if (pairs[p].img0.w != W || pairs[p].img0.h != H) return fail(DFX_E_INVALID, "pair %d: image size differs from pair 0 (one pyramid level per batch)", p);
-    if ((rc = fill_simple(c, &p10, &pairs[p].cam, &pairs[p].img0, &pairs[p].img1, &pairs[p].dpt0, nullptr, nullptr, &descs[p]))) {
+    if ((rc = fill_simple(c, &p10, &pairs[p].cam, &pairs[p].img0, &pairs[p].img1, &pairs[p].dpt0, nullptr, nullptr, &descs[p], R10))) {
       g_last_error = "pair " + std::to_string(p) + ": " + g_last_error;
       return rc;
     }
-    for (int i = 0; i < 9; ++i) descs[p].R[i] = R10[i];
   }
   const int blocks = batch_blocks(c, W, H, n);
   if ((rc = grow_partials(c, (size_t)n * blocks * dfx::kSimpleRow * sizeof(float)))) return rc;

@@ -69,9 +69,78 @@ struct alignas(16) DepthJobDev {   // one UpdateDepth of a batch (k_update_depth
 };
 static_assert(sizeof(DepthJobDev) % 16 == 0 && alignof(DepthJobDev) == 16, "float4 loads of DepthJobDev::code need 16-byte slots");
 
+// Wave-uniform constants of the FAST geometry of the pixel reductions (SE3 step, EvaluateError; dfx_misc_kernels.hip `row_walk`), derived
+// once per pair from (R, t, camera) -- on the host when a descriptor is filled, by k_track_update when the pose lives on the device.
+// Image coordinates are centred on (w/2, h/2) so that PixelValid(border = 1) is the symmetric test |u_c| < w/2 - 1, evaluated without a
+// division as  m = |X| - hw * Z < 0  with  X = fx q.x + (u0 - w/2) q.z,  Z = q.z.  The inlier set stays EXACTLY the reference's
+// (pinhole_camera_impl.h:105-108 on the values of warping.h:204-241): a pixel whose margin lies within E = e1 |d| + e2 of zero -- a
+// rigorous bound on the difference between the fast and the reference-order arithmetic -- is re-evaluated in the reference's
+// operation order (find_correspondence_ray), wave-uniformly and rarely (a band of ~1e-3 pixels along the view border).
+struct FastGeo {
+  float KR[9];      // rows: fx R_0 + cu R_2, fy R_1 + cv R_2, R_2        (cu = u0 - w/2, cv = v0 - h/2)
+  float Kt[3];      // fx t_0 + cu t_2, fy t_1 + cv t_2, t_2
+  float cu, cv;
+  float hw, hh;     // w/2 - 1, h/2 - 1
+  float fcx, fcy;   // w/2 - floor(w/2), h/2 - floor(h/2): tap coordinate = centred coordinate + fc, relative to pixel (icx, icy)
+  float du, dv;     // w/2 - u0, h/2 - v0: u - u0 = u_c + du
+  int icx, icy;     // floor(w/2), floor(h/2)
+  float e1, e2;     // ambiguity band of the margin: E = e1 |d| + e2
+};
+// Camera-only part: what a kernel needs to rebuild (KR, Kt, e1, e2) when the pose changes on the device.
+struct FastCam {
+  float rxmax, rymax;   // max |K^-1 (x, y, 1)| over the image
+  float gscale;         // 32 * 2^-24 * (fx + fy + 2 (w + h) + 2 (|u0| + |v0|)): see derive_fast_geo
+};
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define DFX_HD __host__ __device__
+#else
+#define DFX_HD
+#endif
+DFX_HD inline double dfx_absd(double v) { return v < 0 ? -v : v; }
+DFX_HD inline double dfx_maxd(double a, double b) { return a > b ? a : b; }
+DFX_HD inline double dfx_floord(double v) { const long long i = (long long)v; return (double)(i > v ? i - 1 : i); }
+DFX_HD inline void derive_fast_cam(float fx, float fy, float u0, float v0, float w, float h, int W, int H, FastCam* c) {
+  const double rx = dfx_maxd(dfx_absd(0.0 - u0), dfx_absd((double)(W - 1) - u0)) / dfx_absd((double)fx);
+  const double ry = dfx_maxd(dfx_absd(0.0 - v0), dfx_absd((double)(H - 1) - v0)) / dfx_absd((double)fy);
+  c->rxmax = (float)(rx * 1.000001);
+  c->rymax = (float)(ry * 1.000001);
+  // Error budget of the margin (homogeneous units): both evaluations of fx q.x + (u0 - bound) q.z differ from the real value by at most
+  // ~8 * 2^-24 * (fx + |u0| + w) * S, S = sum of the absolute terms of a component of q = R p + t (<= rho |d| + tau); the division and
+  // the rounded "+ u0" of the reference order add 3 * 2^-24 * (2 w + |u0|) * S.  32 * 2^-24 * G * S with G below is > 2x that sum.
+  const double G = dfx_absd((double)fx) + dfx_absd((double)fy) + 2.0 * ((double)w + (double)h) + 2.0 * (dfx_absd((double)u0) + dfx_absd((double)v0));
+  c->gscale = (float)(32.0 * 5.9604644775390625e-08 * G * 1.000001);
+}
+DFX_HD inline void derive_fast_geo(const double* R, const double* t, float fx, float fy, float u0, float v0, float w, float h,
+                                   const FastCam& c, FastGeo* g) {
+  const double cu = (double)u0 - 0.5 * (double)w, cv = (double)v0 - 0.5 * (double)h;
+  for (int j = 0; j < 3; ++j) {
+    g->KR[j] = (float)((double)fx * R[j] + cu * R[6 + j]);
+    g->KR[3 + j] = (float)((double)fy * R[3 + j] + cv * R[6 + j]);
+    g->KR[6 + j] = (float)R[6 + j];
+  }
+  g->Kt[0] = (float)((double)fx * t[0] + cu * t[2]);
+  g->Kt[1] = (float)((double)fy * t[1] + cv * t[2]);
+  g->Kt[2] = (float)t[2];
+  g->cu = (float)cu; g->cv = (float)cv;
+  g->hw = (float)(0.5 * (double)w - 1.0); g->hh = (float)(0.5 * (double)h - 1.0);
+  const double fw = dfx_floord(0.5 * (double)w), fh = dfx_floord(0.5 * (double)h);
+  g->fcx = (float)(0.5 * (double)w - fw); g->fcy = (float)(0.5 * (double)h - fh);
+  g->icx = (int)fw; g->icy = (int)fh;
+  g->du = (float)(-cu); g->dv = (float)(-cv);
+  double rho = 0.0, tau = 0.0;
+  for (int i = 0; i < 3; ++i) {
+    rho = dfx_maxd(rho, dfx_absd(R[3 * i]) * c.rxmax + dfx_absd(R[3 * i + 1]) * c.rymax + dfx_absd(R[3 * i + 2]));
+    tau = dfx_maxd(tau, dfx_absd(t[i]));
+  }
+  g->e1 = (float)((double)c.gscale * rho * 1.000001);
+  g->e2 = (float)((double)c.gscale * tau * 1.000001);
+}
+
 struct SimplePairDev {   // SE3Aligner / EvaluateError / Warp
   float R[9], t[3];
   float fx, fy, u0, v0, w, h;
+  FastGeo fg;           // of (R, t): SE3 step / EvaluateError; the device-resident tracker keeps its own copy beside the pose
+  FastCam fc;
   const float* img0;
   const float* img1;
   const float* dpt0;

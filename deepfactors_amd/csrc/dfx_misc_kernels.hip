@@ -40,171 +40,276 @@ __device__ __forceinline__ Geo geo_from(const SimplePairDev& p) {
   return g;
 }
 
-// ---- the per-thread pixel walk shared by the reductions below -------------------------------------------------------
-// Thread t of workgroup b visits pixels b * kT + t, + gridDim.x * kT, ...: (x, y) advance by a fixed step (no division per pixel), the
-// depth / intensity of the NEXT pixel are loaded before the current one is processed (their latency hides under the warp + taps + sums
-// of the current pixel), and K^-1 (x, y, 1) comes from the per-camera ray table staged in LDS (the same IEEE expressions the reference
-// evaluates per pixel, pinhole_camera_impl.h:77-86, evaluated once per column / row on the host: dfx_api.cpp ray_table) instead of two
-// IEEE divisions per pixel.  These operators are vector-ALU bound (exact-IEEE geometry: ~150-200 instructions per pixel), not HBM bound.
-struct RayLds {
-  const float* tab;   // LDS: [W] x rays, [H] y rays; null -> compute
-  int W;
-};
-template <bool TAB>
-__device__ __forceinline__ RayLds stage_ray_table(const float* __restrict__ ray_tab, float* lds_tab, int W, int H) {
-  if (!TAB) return RayLds{ nullptr, W };
-  for (int e = threadIdx.x; e < W + H; e += kT) lds_tab[e] = ray_tab[e];
-  __syncthreads();
-  return RayLds{ lds_tab, W };
-}
-constexpr int kRayLdsMax = 4096;   // floats of LDS a simple kernel spends on the table (W + H <= 4096; larger images compute the rays)
+// ---- the row walk shared by the pixel reductions (SE3 step, EvaluateError) --------------------------------------------------------------
+// Round 4.  Rounds 1-3 walked pixels thread by thread (lane = pixel, grid stride) with the reference-order IEEE geometry for every pixel:
+// 195 / 108 vector-ALU instructions per pixel and two dependent memory round trips per iteration; the batched kernels sat at 0.43 / 0.46
+// of the HBM roofline.  Now:
+//  * a wave owns a 64-pixel-wide column BAND and walks down a segment of its rows: x (and the ray K^-1 x) is loop-invariant per lane, the
+//    row is wave-uniform, so every streaming load is `buffer_load  voffset = x * 4 (constant), soffset = y * pitch (scalar unit)` -- no
+//    vector-ALU address arithmetic at all, 256 contiguous bytes per wave-load, adjacent waves of a workgroup take adjacent bands;
+//  * three rows are in flight per wave: the depth / intensity / ray of row y + 2 are loaded, the geometry of row y + 1 is evaluated and its
+//    bilinear taps are issued, row y is consumed (the compiler counts the `vmcnt` waits: loads return in order);
+//  * FAST geometry (FastGeo, dfx_kernels.hpp): fused multiply-adds, one v_rcp_f32, validity as a margin in homogeneous coordinates.  The
+//    inlier set is still EXACTLY the reference's: a wave with a pixel whose margin is within the error bound E of zero re-evaluates those
+//    pixels in the reference's operation order (find_correspondence_ray<true>) -- a wave-uniform branch taken for a ~1e-3-pixel band
+//    along the view border.  The sums are within a few ulp per pixel of the reference-order arithmetic (the parity tests' tolerance is
+//    1e-4 of the block scale against the fp64 oracle);
+//  * the Huber weight is folded into 1 / q.z before the pose row (J = [a | (R p) x a], a = -w grad D: warping.h:156-164 restated), the
+//    inlier count rides the scalar unit (s_bcnt1 of the validity mask), and the 28 + 1 sums of a wave are folded with
+//    v_permlane32_swap / v_permlane16_swap + four DPP row shifts (70 vector-ALU instructions instead of 29 64-lane shuffle ladders).
+constexpr int kBand = 64;
 
-// Two software-pipeline stages per pixel: `issue` (the warp, then the bilinear tap LOADS of the pixel -- branch-free: a pixel without
-// correspondence reads taps at (0, 0), in range and never used) runs one pixel AHEAD of `consume` (interpolation, Jacobian row, sums), so
-// the taps' memory round trip -- a dependent load behind ~60 vector-ALU instructions of geometry -- hides under the arithmetic of the
-// pixel before instead of stalling every iteration (round 3: 128 pairs of 640x480 262 -> see DESIGN.md 3.4; these operators were
-// latency-bound at one round trip per pixel and wave, not HBM- or ALU-bound).
-#ifndef DFX_WALK_PIPELINED
-#define DFX_WALK_PIPELINED 1
-#endif
-struct TapLoads {       // the four taps of img1 [and of grad1] of one pixel, possibly still in flight
-  f32x2_u ia, ib;       // img1 rows iy, iy + 1: (x, x + 1)
-  f32x4_u8 ga, gb;      // grad1 rows iy, iy + 1: (gx, gy)(x), (gx, gy)(x + 1)
-  float ax, ay;
-};
+__device__ __forceinline__ float rfl(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ f32x2 bload2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
+struct RowIn { float d, i0, ry; };   // loads of one row of the band: depth, intensity (per lane), (y - v0) / fy (wave-uniform)
 template <bool GRAD>
-__device__ __forceinline__ TapLoads issue_taps(const ImgRef& I1, const ImgRef& G1, const Corr& c) {
-  const Taps tp = make_taps(c.u, c.v);
-  const int ix = c.valid ? tp.ix : 0, iy = c.valid ? tp.iy : 0;
-  TapLoads t;
-  t.ax = tp.ax; t.ay = tp.ay;
-  const char* r0 = I1.rowb(iy) + (size_t)ix * 4;
-  t.ia = gload<f32x2_u>(r0);
-  t.ib = gload<f32x2_u>(r0 + I1.pitch);
-  if (GRAD) {
-    const char* q0 = G1.rowb(iy) + (size_t)ix * 8;
-    t.ga = gload<f32x4_u8>(q0);
-    t.gb = gload<f32x4_u8>(q0 + G1.pitch);
-  }
-  return t;
-}
-__device__ __forceinline__ float taps_img(const TapLoads& t) { return lerp1(lerp1(t.ia.x, t.ia.y, t.ax), lerp1(t.ib.x, t.ib.y, t.ax), t.ay); }
-__device__ __forceinline__ void taps_grad(const TapLoads& t, float& gx, float& gy) {
-  gx = lerp1(lerp1(t.ga.x, t.ga.z, t.ax), lerp1(t.gb.x, t.gb.z, t.ax), t.ay);
-  gy = lerp1(lerp1(t.ga.y, t.ga.w, t.ax), lerp1(t.gb.y, t.gb.w, t.ax), t.ay);
-}
+struct RowPix {                       // geometry of one row + its taps (possibly still in flight)
+  float i0, ax, ay;
+  float iz, U, V, vx, vy, vz;         // GRAD (SE3 step) only: 1 / q.z, u - u0, v - v0, R p
+  bool valid;
+  f32x2 ia, ib;                       // img1 rows iy, iy + 1: (x, x + 1)
+  f32x4 ga, gb;                       // grad1 rows iy, iy + 1: (gx, gy)(x), (gx, gy)(x + 1)
+};
 
-template <bool TAB, bool GRAD, typename F>
-__device__ __forceinline__ void walk_pixels(const Geo& g, const SimplePairDev& p, const RayLds& rt, const int W, const int H, const float border,
-                                            const float min_dpt, F&& consume /* (d, i0, const Corr&, const TapLoads&) */) {
-  const ImgRef I0{ (const char*)p.img0, p.pitch_img0 }, D0{ (const char*)p.dpt0, p.pitch_dpt0 };
-  const ImgRef I1{ (const char*)p.img1, p.pitch_img1 }, G1{ (const char*)p.grad1, p.pitch_grad1 };
-  const unsigned npx = (unsigned)W * (unsigned)H;
-  const unsigned step = gridDim.x * kT;
-  unsigned i = blockIdx.x * kT + threadIdx.x;
-  if (i >= npx) return;
-  int y = (int)(i / (unsigned)W), x = (int)(i - (unsigned)y * (unsigned)W);
-  const int sdy = (int)(step / (unsigned)W), sdx = (int)(step - (unsigned)sdy * (unsigned)W);
-  auto corr = [&](int cx, int cy, float cd) {
-    return TAB ? find_correspondence_ray<true>(g, rt.tab[cx], rt.tab[rt.W + cy], cd, border, min_dpt) : find_correspondence<true>(g, cx, cy, cd, border, min_dpt);
-  };
-  // the pixel after (ci, cx, cy) if `have` and there is one -- else the same pixel again (a harmless repeat: in range, never consumed)
-  auto advance = [&](bool have, unsigned ci, int cx, int cy, unsigned& ni, int& nx, int& ny) -> bool {
-    const bool more = have && ci + step < npx;
-    int tx = cx + sdx, ty = cy + sdy;
-    if (tx >= W) { tx -= W; ++ty; }
-    ni = more ? ci + step : ci; nx = more ? tx : cx; ny = more ? ty : cy;
-    return more;
-  };
-  float d = D0.at(x, y), i0 = I0.at(x, y);
-  // (the SE3 step -- 184 vector-ALU instructions per pixel, its SIMDs 86 % busy with them -- gains nothing from the second stage and pays
-  // for its state: 248 vs 256 us per 128 pairs; EvaluateError, 102 instructions per pixel: 155 -> 129 us.  profiles/r03_small_ops.txt)
-  if constexpr (DFX_WALK_PIPELINED && !GRAD) {
-  // pixel 0: geometry done, taps issued; pixel 1: depth / intensity in flight.  The loop is written out twice with the two pixel states
-  // (A, B) swapping roles, so that no state is copied from "next" to "current" (the copies were 47 of the SE3 loop's 177 instructions).
-  unsigned i1; int x1, y1;
-  bool has1 = advance(true, i, x, y, i1, x1, y1);
-  float dB = D0.at(x1, y1), i0B = I0.at(x1, y1);
-  float dA = d, i0A = i0;
-  Corr cA = corr(x, y, dA), cB;
-  TapLoads tA = issue_taps<GRAD>(I1, G1, cA), tB;
-  while (true) {
-    unsigned i2; int x2, y2;
-    const bool has2 = advance(has1, i1, x1, y1, i2, x2, y2);
-    const float dN = D0.at(x2, y2), i0N = I0.at(x2, y2);   // depth / intensity of the pixel after next
-    cB = corr(x1, y1, dB);                                  // stage 1 of the next pixel (B)
-    tB = issue_taps<GRAD>(I1, G1, cB);
-    consume(dA, i0A, cA, tA);                               // stage 2 of the current one (A)
-    if (!has1) break;
-    // second half: B is current, A takes the pixel after
-    unsigned i3; int x3, y3;
-    const bool has3 = advance(has2, i2, x2, y2, i3, x3, y3);
-    dA = dN; i0A = i0N;
-    const float dM = D0.at(x3, y3), i0M = I0.at(x3, y3);
-    cA = corr(x2, y2, dA);
-    tA = issue_taps<GRAD>(I1, G1, cA);
-    consume(dB, i0B, cB, tB);
-    if (!has2) break;
-    dB = dM; i0B = i0M;
-    i1 = i3; x1 = x3; y1 = y3; has1 = has3;
+// pose-dependent part of the ambiguity band on the device (the tracker's pose lives in device memory): E = e1 |d| + e2, derive_fast_geo
+__device__ __forceinline__ void fast_band(const float (&R)[9], const float (&t)[3], const FastCam& c, float& e1, float& e2) {
+  float rho = 0.f, tau = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    rho = fmaxf(rho, fabsf(R[3 * i]) * c.rxmax + fabsf(R[3 * i + 1]) * c.rymax + fabsf(R[3 * i + 2]));
+    tau = fmaxf(tau, fabsf(t[i]));
   }
-  } else {
-  while (true) {
-    unsigned in; int xn, yn;
-    const bool more = advance(true, i, x, y, in, xn, yn);
-    const float dn = D0.at(xn, yn), i0n = I0.at(xn, yn);
-    const Corr c = corr(x, y, d);
-    const TapLoads t = issue_taps<GRAD>(I1, G1, c);
-    consume(d, i0, c, t);
-    if (!more) break;
-    i = in; x = xn; y = yn; d = dn; i0 = i0n;
-  }
-  }
+  e1 = rfl(c.gscale * rho * 1.00001f);
+  e2 = rfl(c.gscale * tau * 1.00001f);
 }
 
-// ---- SE3 step: 21 JtJ + 6 Jtr + r^2 + inliers = 29 floats per lane -----------------------------------------
-// Per-lane sums of one SE3 Gauss-Newton step over this thread's pixels (lucas_kanade_se3.h:41-77): shared by the blocking
-// operator and by the device-resident tracker.
-template <bool TAB>
-__device__ __forceinline__ void se3_accumulate(const Geo& g, const SimplePairDev& p, const RayLds& rt, const int W, const int H, const float huber_delta,
-                                               float (&acc)[29]) {
+// Walks the calling wave's share of the image; `consume(const RowPix<GRAD>&)` is called once per row with exec = the row's inliers.
+// Returns the wave's inlier count (wave-uniform).
+template <bool GRAD, typename F>
+__device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float (&R)[9], const float (&t)[3], const float e1, const float e2,
+                                             const int W, const int H, F&& consume) {
+  const FastGeo& fg = p.fg;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned HB = (unsigned)H;
+  const __amdgpu_buffer_rsrc_t rI0 = make_rsrc(p.img0, p.pitch_img0 * HB), rD0 = make_rsrc(p.dpt0, p.pitch_dpt0 * HB);
+  const __amdgpu_buffer_rsrc_t rI1 = make_rsrc(p.img1, p.pitch_img1 * HB);
+  const __amdgpu_buffer_rsrc_t rG1 = make_rsrc(GRAD ? p.grad1 : p.img1, (GRAD ? p.pitch_grad1 : p.pitch_img1) * HB);
+  const __amdgpu_buffer_rsrc_t rRay = make_rsrc(p.ray_tab, (unsigned)(W + H) * 4u);
+  // tap offsets are relative to pixel (icx, icy): fold it into a scalar
+  const unsigned c1 = (unsigned)fg.icy * p.pitch_img1 + (unsigned)fg.icx * 4u;
+  const unsigned cg = GRAD ? (unsigned)fg.icy * p.pitch_grad1 + (unsigned)fg.icx * 8u : 0u;
+  Geo g;   // the reference-order fall-back
+#pragma unroll
+  for (int q = 0; q < 9; ++q) g.R[q] = R[q];
+  g.t[0] = t[0]; g.t[1] = t[1]; g.t[2] = t[2];
+  g.fx = p.fx; g.fy = p.fy; g.u0 = p.u0; g.v0 = p.v0; g.w = p.w; g.h = p.h;
 
-#pragma unroll
-  for (int q = 0; q < 29; ++q) acc[q] = 0.f;
-  walk_pixels<TAB, true>(g, p, rt, W, H, 1.0f, 0.0f, [&](float d, float i0, const Corr& c, const TapLoads& t) {
-    if (c.valid) {
-      float gx, gy;
-      taps_grad(t, gx, gy);
-      const float samp = taps_img(t);
-      float J[6], D00, D02, D11, D12;
-      pose_row(g, c, d, gx, gy, J, D00, D02, D11, D12);
-      float r = i0 - samp;
-      const float wgt = huber_weight(r, huber_delta);
-      r *= wgt;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) J[j] *= wgt;
-      int k = 0;
-#pragma unroll
-      for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int b = a; b < 6; ++b) acc[k++] += J[a] * J[b];
-#pragma unroll
-      for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;
-      acc[27] += r * r;
-      acc[28] += 1.0f;
+  // items = (band, row segment): all bands of a segment are adjacent items, so the waves of a workgroup read adjacent 256-byte runs
+  const unsigned nb = ((unsigned)W + kBand - 1) / kBand;
+  const unsigned waves = gridDim.x * (kT / 64);
+  unsigned nseg = waves / nb;
+  nseg = nseg > HB ? HB : nseg;
+  nseg = nseg < 1 ? 1 : nseg;
+  const unsigned rps = (HB + nseg - 1) / nseg;          // rows per segment
+  const unsigned nitems = nb * ((HB + rps - 1) / rps);
+  unsigned inliers = 0;
+  for (unsigned item = blockIdx.x * (kT / 64) + (unsigned)wave; item < nitems; item += waves) {
+    const unsigned seg = item / nb, band = item - seg * nb;
+    const int y0 = (int)(seg * rps), y1 = (int)(seg * rps + rps < HB ? seg * rps + rps : HB);
+    const int x = (int)band * kBand + lane;
+    const bool lane_ok = x < W;
+    const unsigned voff = (unsigned)(lane_ok ? x : W - 1) * 4u;   // lanes past the last column repeat it (never consumed)
+    const float rx = bload1(rRay, voff, 0);
+    auto load_row = [&](int y) {
+      const unsigned yc = (unsigned)(y < y1 ? y : y1 - 1);        // rows past the segment repeat its last row (never consumed)
+      RowIn L;
+      L.d = bload1(rD0, voff, yc * p.pitch_dpt0);
+      L.i0 = bload1(rI0, voff, yc * p.pitch_img0);
+      L.ry = bload1(rRay, 0, ((unsigned)W + yc) * 4u);
+      return L;
+    };
+    auto geom = [&](const RowIn& L, RowPix<GRAD>& S) {
+      const float d = L.d, ry = L.ry;
+      S.i0 = L.i0;
+      float X, Y, Z;
+      if constexpr (GRAD) {
+        const float rrx = __builtin_fmaf(R[0], rx, __builtin_fmaf(R[1], ry, R[2]));
+        const float rry = __builtin_fmaf(R[3], rx, __builtin_fmaf(R[4], ry, R[5]));
+        const float rrz = __builtin_fmaf(R[6], rx, __builtin_fmaf(R[7], ry, R[8]));
+        S.vx = rrx * d; S.vy = rry * d; S.vz = rrz * d;
+        Z = S.vz + t[2];
+        X = __builtin_fmaf(p.fx, S.vx + t[0], fg.cu * Z);
+        Y = __builtin_fmaf(p.fy, S.vy + t[1], fg.cv * Z);
+      } else {
+        X = __builtin_fmaf(__builtin_fmaf(fg.KR[0], rx, __builtin_fmaf(fg.KR[1], ry, fg.KR[2])), d, fg.Kt[0]);
+        Y = __builtin_fmaf(__builtin_fmaf(fg.KR[3], rx, __builtin_fmaf(fg.KR[4], ry, fg.KR[5])), d, fg.Kt[1]);
+        Z = __builtin_fmaf(__builtin_fmaf(fg.KR[6], rx, __builtin_fmaf(fg.KR[7], ry, fg.KR[8])), d, fg.Kt[2]);
+      }
+      float iz = __builtin_amdgcn_rcpf(Z);
+      // |u_c| < hw and |v_c| < hh and q.z > 0  <=>  max(|X| - hw Z, |Y| - hh Z) < 0
+      const float mu = __builtin_fmaf(-fg.hw, Z, fabsf(X)), mv = __builtin_fmaf(-fg.hh, Z, fabsf(Y));
+      const float E = __builtin_fmaf(e1, fabsf(d), e2);
+      bool valid = (mu < -E) && (mv < -E);                 // NaN anywhere -> false
+      const bool amb = fabsf(fmaxf(mu, mv)) < E;
+      float tu = __builtin_fmaf(X, iz, fg.fcx), tv = __builtin_fmaf(Y, iz, fg.fcy);   // tap coordinates relative to pixel (icx, icy)
+      float U = 0.f, V = 0.f;
+      if constexpr (GRAD) { U = __builtin_fmaf(X, iz, fg.du); V = __builtin_fmaf(Y, iz, fg.dv); }
+      if (__builtin_amdgcn_ballot_w64(amb) != 0) {         // wave-uniform and rare: the reference's operation order decides
+        const Corr c = find_correspondence_ray<true>(g, rx, ry, d, 1.0f, 0.0f);
+        valid = amb ? c.valid : valid;
+        tu = amb ? c.u - (float)fg.icx : tu;               // and supplies the coordinates: its taps are in range where it says valid
+        tv = amb ? c.v - (float)fg.icy : tv;
+        if constexpr (GRAD) { U = amb ? c.u - p.u0 : U; V = amb ? c.v - p.v0 : V; iz = amb ? c.iz : iz; }
+      }
+      valid = valid && lane_ok;
+      if constexpr (GRAD) { S.iz = iz; S.U = U; S.V = V; }
+      const float fu = floorf(tu), fv = floorf(tv);
+      S.ax = tu - fu; S.ay = tv - fv;
+      const int ix = (int)fu, iy = (int)fv;
+      // a lane without correspondence reads offset 0: in range, never used (and no wave-load is ever entirely out of range)
+      const unsigned o1 = valid ? (unsigned)(__mul24(iy, (int)p.pitch_img1) + ((ix << 2) + (int)c1)) : 0u;
+      S.ia = bload2(rI1, o1, 0);
+      S.ib = bload2(rI1, o1, p.pitch_img1);
+      if constexpr (GRAD) {
+        const unsigned og = valid ? (unsigned)(__mul24(iy, (int)p.pitch_grad1) + ((ix << 3) + (int)cg)) : 0u;
+        S.ga = bload4(rG1, og, 0);
+        S.gb = bload4(rG1, og, p.pitch_grad1);
+      }
+      S.valid = valid;
+    };
+    auto eat = [&](const RowPix<GRAD>& S) {
+      inliers += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(S.valid));
+      if (S.valid) consume(S);
+    };
+    // rows y (consume), y + 1 (geometry, taps issued), y + 2 (loads issued); the two row states swap roles, so nothing is copied
+    RowIn LA = load_row(y0), LB = load_row(y0 + 1);
+    RowPix<GRAD> P, Q;
+    geom(LA, P);
+    int y = y0;
+    while (true) {
+      LA = load_row(y + 2);
+      geom(LB, Q);
+      eat(P);
+      if (++y >= y1) break;
+      LB = load_row(y + 2);
+      geom(LA, P);
+      eat(Q);
+      if (++y >= y1) break;
     }
-  });
+  }
+  return inliers;
 }
 
-template <bool TAB>
+__device__ __forceinline__ float lerpf(float a, float b, float t) { return __builtin_fmaf(t, b - a, a); }
+template <bool GRAD>
+__device__ __forceinline__ float pix_img(const RowPix<GRAD>& S) { return lerpf(lerpf(S.ia.x, S.ia.y, S.ax), lerpf(S.ib.x, S.ib.y, S.ax), S.ay); }
+
+// v + (v shifted right by N lanes inside its 16-lane row); lanes without a source add 0
+template <int CTRL>
+__device__ __forceinline__ float row_shr_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// Sum over the 64 lanes of NV = 4 * NQ per-lane values: v_permlane32_swap folds the wave's halves of two values into one register
+// (A, B -> [A.lo + A.hi | B.lo + B.hi]), v_permlane16_swap the 16-lane rows of two such registers ([A A B B], [C C D D] -> rows A C B D),
+// four DPP row shifts finish inside the rows.  out[j], lane 16 r + 15, then holds the total of value 4 j + {0, 2, 1, 3}[r].
+// hipcc (ROCm 7.2, clang 22) turns `s[0] + s[1]` of a permlane swap's two results into `s[0] + s[0]` (tools/ubench/wave_fold_probe.cpp,
+// profiles/r04_wave_fold_probe.txt: found there, pinned there): the second result goes through an empty asm so that it stays a value of
+// its own.  The asm holds no instruction, so no hazard can hide in it.
+__device__ __forceinline__ float swap_sum(unsigned a, unsigned b) {
+  float fb = __builtin_bit_cast(float, b);
+  asm volatile("" : "+v"(fb));
+  return __builtin_bit_cast(float, a) + fb;
+}
+template <int NQ>
+__device__ __forceinline__ void wave_fold4(const float (&v)[4 * NQ], float (&out)[NQ]) {
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    float w[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const auto s = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v[4 * j + 2 * h]), __builtin_bit_cast(unsigned, v[4 * j + 2 * h + 1]), false, false);
+      w[h] = swap_sum(s[0], s[1]);
+    }
+    const auto s = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, w[0]), __builtin_bit_cast(unsigned, w[1]), false, false);
+    float r = swap_sum(s[0], s[1]);
+    r = row_shr_add<0x118>(r);   // row_shr:8
+    r = row_shr_add<0x114>(r);   // row_shr:4
+    r = row_shr_add<0x112>(r);   // row_shr:2
+    r = row_shr_add<0x111>(r);   // row_shr:1
+    out[j] = r;
+  }
+}
+
+// the workgroup's partial row from per-wave rows in LDS: ((w0 + w1) + w2) + w3, fixed order
+__device__ __forceinline__ void fold_waves_store(float (&red)[kT / 64][kSimpleRow], const int nvals, float* __restrict__ out_row) {
+  __syncthreads();
+  if (threadIdx.x < kSimpleRow) {
+    float s = 0.f;
+    if ((int)threadIdx.x < nvals) s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    out_row[threadIdx.x] = s;
+  }
+}
+
+// ---- SE3 step: 21 JtJ + 6 Jtr + r^2 + inliers = 29 floats per workgroup row ---------------------------------------------------------
+// One SE3 Gauss-Newton step (lucas_kanade_se3.h:41-77) over this workgroup's share of the pair; shared by the blocking operator, the
+// batched form and the device-resident tracker (R, t = the pose the step is evaluated at).
+__device__ __forceinline__ void se3_step_body(const SimplePairDev& p, const float (&R)[9], const float (&t)[3], const float e1, const float e2,
+                                              const int W, const int H, const float huber_delta, float* __restrict__ out_row) {
+  __shared__ float red[kT / 64][kSimpleRow];
+  float acc[28];
+#pragma unroll
+  for (int q = 0; q < 28; ++q) acc[q] = 0.f;
+  const float fx = p.fx, fy = p.fy;
+  const unsigned inl = row_walk<true>(p, R, t, e1, e2, W, H, [&](const RowPix<true>& S) {
+    const float gx = lerpf(lerpf(S.ga.x, S.ga.z, S.ax), lerpf(S.gb.x, S.gb.z, S.ax), S.ay);
+    const float gy = lerpf(lerpf(S.ga.y, S.ga.w, S.ax), lerpf(S.gb.y, S.gb.w, S.ax), S.ay);
+    float r = S.i0 - pix_img(S);
+    const float wgt = huber_weight(r, huber_delta);
+    r *= wgt;
+    // J = -w grad D [I | -hat(R p)] = [a | (R p) x a],  a = -w grad D,  D = ProjectPointJacobian(q)  (pinhole_camera_impl.h:91-97)
+    const float wz = wgt * S.iz;
+    float J[6];
+    J[0] = -(gx * fx) * wz;
+    J[1] = -(gy * fy) * wz;
+    J[2] = __builtin_fmaf(gx, S.U, gy * S.V) * wz;
+    J[3] = S.vy * J[2] - S.vz * J[1];
+    J[4] = S.vz * J[0] - S.vx * J[2];
+    J[5] = S.vx * J[1] - S.vy * J[0];
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = a; b < 6; ++b) { acc[k] = __builtin_fmaf(J[a], J[b], acc[k]); ++k; }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) acc[21 + a] = __builtin_fmaf(J[a], r, acc[21 + a]);
+    acc[27] = __builtin_fmaf(r, r, acc[27]);
+  });
+  float f[7];
+  wave_fold4<7>(acc, f);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((lane & 15) == 15) {
+    const int r = lane >> 4;
+    const int slot = ((r & 1) << 1) | (r >> 1);   // rows hold values {0, 2, 1, 3} of their group of four
+#pragma unroll
+    for (int j = 0; j < 7; ++j) red[wave][4 * j + slot] = f[j];
+  }
+  if (lane == 0) red[wave][28] = (float)inl;      // exact: < 2^24 pixels per wave
+  fold_waves_store(red, 29, out_row);
+}
+
 __global__ __launch_bounds__(kT) void k_se3_step(const SimplePairDev p, const int W, const int H, const float huber_delta,
                                                  float* __restrict__ partials) {
-  __shared__ float ray_lds[TAB ? kRayLdsMax : 1];
-  const Geo g = geo_from(p);
-  const RayLds rt = stage_ray_table<TAB>(p.ray_tab, ray_lds, W, H);
-  float acc[29];
-  se3_accumulate<TAB>(g, p, rt, W, H, huber_delta, acc);
-  block_reduce_store<29>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
+  se3_step_body(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
 // ---- device-resident tracker (CameraTracker::TrackFrame, reference core/system/camera_tracker.cpp:42-71) -------------
@@ -219,21 +324,17 @@ struct TrackState {      // device-resident
 
 // blockIdx.y = candidate: Relocalize / the loop-closure geometry checks track ONE live frame against N keyframes
 // (deepfactors.cpp:713-743, loop_detector.cpp:146-167); descriptors, states and partials are arrays over candidates.
-template <bool TAB>
 __global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev* __restrict__ descs, const TrackState* __restrict__ states, const int W,
                                                      const int H, const float huber_delta, float* __restrict__ partials_all) {
   const SimplePairDev& p = descs[blockIdx.y];
   const TrackState* st = states + blockIdx.y;
   float* partials = partials_all + (size_t)blockIdx.y * gridDim.x * kSimpleRow;
-  Geo g = geo_from(p);
+  float R[9], t[3], e1, e2;
 #pragma unroll
-  for (int q = 0; q < 9; ++q) g.R[q] = st->Rf[q];
-  g.t[0] = st->tf[0]; g.t[1] = st->tf[1]; g.t[2] = st->tf[2];
-  __shared__ float ray_lds[TAB ? kRayLdsMax : 1];
-  const RayLds rt = stage_ray_table<TAB>(p.ray_tab, ray_lds, W, H);
-  float acc[29];
-  se3_accumulate<TAB>(g, p, rt, W, H, huber_delta, acc);
-  block_reduce_store<29>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
+  for (int q = 0; q < 9; ++q) R[q] = st->Rf[q];
+  t[0] = st->tf[0]; t[1] = st->tf[1]; t[2] = st->tf[2];
+  fast_band(R, t, p.fc, e1, e2);   // the descriptor's band belongs to the pose it was filled with, not to the state's
+  se3_step_body(p, R, t, e1, e2, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
 __global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__ partials_all, const int nblocks, TrackState* __restrict__ states) {
@@ -340,8 +441,7 @@ size_t track_state_bytes() { return sizeof(TrackState); }
 
 hipError_t launch_track_iteration(const SimplePairDev* descs_dev, int n, void* states_dev, int W, int H, float huber_delta, int blocks,
                                   float* partials_dev, hipStream_t stream) {
-  const bool tab_ok = W + H <= kRayLdsMax;   // the per-camera ray table fits the kernels' LDS budget (every descriptor carries one)
-  if (tab_ok) hipLaunchKernelGGL((k_se3_step_dev<true>), dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (const TrackState*)states_dev, W, H, huber_delta, partials_dev); else hipLaunchKernelGGL((k_se3_step_dev<false>), dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (const TrackState*)states_dev, W, H, huber_delta, partials_dev);
+  hipLaunchKernelGGL(k_se3_step_dev, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (const TrackState*)states_dev, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_track_update, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (TrackState*)states_dev);
@@ -463,58 +563,38 @@ hipError_t launch_sparse_geometric(int cs, const void* desc_host, const float* c
   return hipGetLastError();
 }
 
-// ---- SfM error: sum (w r)^2, inliers -----------------------------------------------------------------------
-template <bool TAB>
-__device__ __forceinline__ void sfm_error_accumulate(const Geo& g, const SimplePairDev& p, const RayLds& rt, const int W, const int H, const float huber_delta,
-                                                     float (&acc)[2]) {
-
-  acc[0] = acc[1] = 0.f;
-  walk_pixels<TAB, false>(g, p, rt, W, H, 1.0f, 0.0f, [&](float, float i0, const Corr& c, const TapLoads& t) {   // dense_sfm.h:91: default border 1, min_dpt 0
-    if (c.valid) {
-      float r = i0 - taps_img(t);
-      r *= huber_weight(r, huber_delta);
-      acc[0] += r * r;
-      acc[1] += 1.0f;
-    }
+// ---- SfM error: sum (w r)^2, inliers (dense_sfm.h:79-119: default border 1, min_dpt 0) -------------------------------------------------
+__device__ __forceinline__ void sfm_error_body(const SimplePairDev& p, const int W, const int H, const float huber_delta, float* __restrict__ out_row) {
+  __shared__ float red[kT / 64][kSimpleRow];
+  float acc = 0.f;
+  const unsigned inl = row_walk<false>(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, [&](const RowPix<false>& S) {
+    float r = S.i0 - pix_img(S);
+    r *= huber_weight(r, huber_delta);
+    acc = __builtin_fmaf(r, r, acc);
   });
+  const float s = wave_sum(acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[wave][0] = s; red[wave][1] = (float)inl; }
+  fold_waves_store(red, 2, out_row);
 }
 
-template <bool TAB>
 __global__ __launch_bounds__(kT) void k_sfm_error(const SimplePairDev p, const int W, const int H, const float huber_delta,
                                                   float* __restrict__ partials) {
-  __shared__ float ray_lds[TAB ? kRayLdsMax : 1];
-  const Geo g = geo_from(p);
-  const RayLds rt = stage_ray_table<TAB>(p.ray_tab, ray_lds, W, H);
-  float acc[2];
-  sfm_error_accumulate<TAB>(g, p, rt, W, H, huber_delta, acc);
-  block_reduce_store<2>(acc, partials + (size_t)blockIdx.x * kSimpleRow);
+  sfm_error_body(p, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
 // ---- batched forms (blockIdx.y = pair): PhotometricFactor::error over a factor set evaluates one pair per blocking call in the reference
 // (core/gtsam/photometric_factor.cpp:61-81,197-216); a relocalisation / loop-closure check steps one live frame against many keyframes.
 // Same per-pair arithmetic and reduction order as the single-pair kernels launched with the same number of workgroups.
-template <bool TAB>
 __global__ __launch_bounds__(kT) void k_sfm_error_batch(const SimplePairDev* __restrict__ descs, const int W, const int H, const float huber_delta,
                                                         float* __restrict__ partials_all) {
-  __shared__ float ray_lds[TAB ? kRayLdsMax : 1];
-  const SimplePairDev& p = descs[blockIdx.y];
-  const Geo g = geo_from(p);
-  const RayLds rt = stage_ray_table<TAB>(p.ray_tab, ray_lds, W, H);
-  float acc[2];
-  sfm_error_accumulate<TAB>(g, p, rt, W, H, huber_delta, acc);
-  block_reduce_store<2>(acc, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
+  sfm_error_body(descs[blockIdx.y], W, H, huber_delta, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
 }
 
-template <bool TAB>
 __global__ __launch_bounds__(kT) void k_se3_step_batch(const SimplePairDev* __restrict__ descs, const int W, const int H, const float huber_delta,
                                                        float* __restrict__ partials_all) {
-  __shared__ float ray_lds[TAB ? kRayLdsMax : 1];
   const SimplePairDev& p = descs[blockIdx.y];
-  const Geo g = geo_from(p);
-  const RayLds rt = stage_ray_table<TAB>(p.ray_tab, ray_lds, W, H);
-  float acc[29];
-  se3_accumulate<TAB>(g, p, rt, W, H, huber_delta, acc);
-  block_reduce_store<29>(acc, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
+  se3_step_body(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, huber_delta, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
 }
 
 // ---- Warp: render img1 into frame 0, SIGNED residual sum (cu_se3aligner.cpp:106) ----------------------------
@@ -712,8 +792,7 @@ __global__ __launch_bounds__(kT) void k_blur_down(const float* __restrict__ in, 
 // ---------------------------------------------------------------------------------------------------------------
 hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
                            void* item_dev, hipStream_t stream) {
-  const bool tab_ok = W + H <= kRayLdsMax;   // the per-camera ray table fits the kernels' LDS budget (every descriptor carries one)
-  if (tab_ok) hipLaunchKernelGGL((k_se3_step<true>), dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev); else hipLaunchKernelGGL((k_se3_step<false>), dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
+  hipLaunchKernelGGL(k_se3_step, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalItem6, (char*)item_dev, (size_t)0);
@@ -722,8 +801,7 @@ hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_del
 
 hipError_t launch_sfm_error(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
                             void* corr_item_dev, hipStream_t stream) {
-  const bool tab_ok = W + H <= kRayLdsMax;   // the per-camera ray table fits the kernels' LDS budget (every descriptor carries one)
-  if (tab_ok) hipLaunchKernelGGL((k_sfm_error<true>), dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev); else hipLaunchKernelGGL((k_sfm_error<false>), dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
+  hipLaunchKernelGGL(k_sfm_error, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalCorr, (char*)corr_item_dev, (size_t)0);
@@ -732,8 +810,7 @@ hipError_t launch_sfm_error(const SimplePairDev& p, int W, int H, float huber_de
 
 hipError_t launch_sfm_error_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
                                   void* corr_items_dev, hipStream_t stream) {
-  const bool tab_ok = W + H <= kRayLdsMax;   // the per-camera ray table fits the kernels' LDS budget (every descriptor carries one)
-  if (tab_ok) hipLaunchKernelGGL((k_sfm_error_batch<true>), dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev); else hipLaunchKernelGGL((k_sfm_error_batch<false>), dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
+  hipLaunchKernelGGL(k_sfm_error_batch, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_finalize_rows, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalCorr, (char*)corr_items_dev, (size_t)16);
@@ -742,8 +819,7 @@ hipError_t launch_sfm_error_batch(const SimplePairDev* descs_dev, int n, int W, 
 
 hipError_t launch_se3_step_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
                                  void* items_dev, hipStream_t stream) {
-  const bool tab_ok = W + H <= kRayLdsMax;   // the per-camera ray table fits the kernels' LDS budget (every descriptor carries one)
-  if (tab_ok) hipLaunchKernelGGL((k_se3_step_batch<true>), dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev); else hipLaunchKernelGGL((k_se3_step_batch<false>), dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
+  hipLaunchKernelGGL(k_se3_step_batch, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_finalize_rows, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalItem6, (char*)items_dev, (size_t)120);
