@@ -58,6 +58,17 @@ __device__ __forceinline__ Geo geo_from(const SimplePairDev& p) {
 //    inlier count rides the scalar unit (s_bcnt1 of the validity mask), and the 28 + 1 sums of a wave are folded with
 //    v_permlane32_swap / v_permlane16_swap + four DPP row shifts (70 vector-ALU instructions instead of 29 64-lane shuffle ladders).
 constexpr int kBand = 64;
+#ifndef DFX_RW_UNROLL
+#define DFX_RW_UNROLL 1   // rotations of the row states per loop iteration
+#endif
+// rows between the issue of a row's bilinear taps and their use (the depth of the software pipeline, see row_walk), per operator: the
+// SE3 step carries 21 registers of row state per stage (4 waves per SIMD at depth 2), EvaluateError 8
+#ifndef DFX_TAP_DIST_SE3
+#define DFX_TAP_DIST_SE3 1
+#endif
+#ifndef DFX_TAP_DIST_ERR
+#define DFX_TAP_DIST_ERR 1
+#endif
 
 __device__ __forceinline__ float rfl(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -75,7 +86,7 @@ template <bool GRAD>
 struct RowPix {                       // geometry of one row + its taps (possibly still in flight)
   float i0, ax, ay;
   float iz, U, V, vx, vy, vz;         // GRAD (SE3 step) only: 1 / q.z, u - u0, v - v0, R p
-  bool valid;
+  unsigned vmask;                     // all ones: the pixel has a correspondence (and belongs to the wave's share)
   f32x2 ia, ib;                       // img1 rows iy, iy + 1: (x, x + 1)
   f32x4 ga, gb;                       // grad1 rows iy, iy + 1: (gx, gy)(x), (gx, gy)(x + 1)
 };
@@ -94,7 +105,7 @@ __device__ __forceinline__ void fast_band(const float (&R)[9], const float (&t)[
 
 // Walks the calling wave's share of the image; `consume(const RowPix<GRAD>&)` is called once per row with exec = the row's inliers.
 // Returns the wave's inlier count (wave-uniform).
-template <bool GRAD, typename F>
+template <bool GRAD, int DT, typename F>
 __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float (&R)[9], const float (&t)[3], const float e1, const float e2,
                                              const int W, const int H, F&& consume) {
   const FastGeo& fg = p.fg;
@@ -120,7 +131,9 @@ __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float
   unsigned nseg = waves / nb;
   nseg = nseg > HB ? HB : nseg;
   nseg = nseg < 1 ? 1 : nseg;
-  const unsigned rps = (HB + nseg - 1) / nseg;          // rows per segment
+  unsigned rps = (HB + nseg - 1) / nseg;                // rows per segment ...
+  constexpr unsigned kUnr = (unsigned)((DT + 1) * DFX_RW_UNROLL);
+  rps = (rps + 2 * DT + kUnr - 1) / kUnr * kUnr - 2 * DT;   // ... such that the warm-up + the rows are whole groups of the unrolled loop
   const unsigned nitems = nb * ((HB + rps - 1) / rps);
   unsigned inliers = 0;
   for (unsigned item = blockIdx.x * (kT / 64) + (unsigned)wave; item < nitems; item += waves) {
@@ -130,81 +143,106 @@ __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float
     const bool lane_ok = x < W;
     const unsigned voff = (unsigned)(lane_ok ? x : W - 1) * 4u;   // lanes past the last column repeat it (never consumed)
     const float rx = bload1(rRay, voff, 0);
+    // loop-invariant per lane: the column part of (K) R ray, so that a row's (K) R ray is ONE fma per component (an fma reads one scalar
+    // register: `R1 * ry + R2` with two of them costs a move)
+    const float* M = GRAD ? R : fg.KR;
+    const float cx = __builtin_fmaf(M[0], rx, M[2]), cy = __builtin_fmaf(M[3], rx, M[5]), cz = __builtin_fmaf(M[6], rx, M[8]);
+    float e2v = e2;
+    asm volatile("" : "+v"(e2v));   // keep it in a vector register: as a second scalar operand of the fma below it costs a move per row
+    const unsigned lanemask = lane_ok ? ~0u : 0u;
     auto load_row = [&](int y) {
-      const unsigned yc = (unsigned)(y < y1 ? y : y1 - 1);        // rows past the segment repeat its last row (never consumed)
+      const unsigned yc = (unsigned)(y < y1 ? y : y1 - 1);        // rows past the segment repeat its last row (masked)
       RowIn L;
       L.d = bload1(rD0, voff, yc * p.pitch_dpt0);
       L.i0 = bload1(rI0, voff, yc * p.pitch_img0);
       L.ry = bload1(rRay, 0, ((unsigned)W + yc) * 4u);
       return L;
     };
-    auto geom = [&](const RowIn& L, RowPix<GRAD>& S) {
+    // geometry of one row + issue of its taps.  `rowmask` (scalar): all ones if the row belongs to the segment
+    auto geom = [&](const RowIn& L, RowPix<GRAD>& S, const unsigned rowmask) {
       const float d = L.d, ry = L.ry;
       S.i0 = L.i0;
       float X, Y, Z;
+      const float rrx = __builtin_fmaf(M[1], ry, cx), rry = __builtin_fmaf(M[4], ry, cy), rrz = __builtin_fmaf(M[7], ry, cz);
       if constexpr (GRAD) {
-        const float rrx = __builtin_fmaf(R[0], rx, __builtin_fmaf(R[1], ry, R[2]));
-        const float rry = __builtin_fmaf(R[3], rx, __builtin_fmaf(R[4], ry, R[5]));
-        const float rrz = __builtin_fmaf(R[6], rx, __builtin_fmaf(R[7], ry, R[8]));
         S.vx = rrx * d; S.vy = rry * d; S.vz = rrz * d;
         Z = S.vz + t[2];
         X = __builtin_fmaf(p.fx, S.vx + t[0], fg.cu * Z);
         Y = __builtin_fmaf(p.fy, S.vy + t[1], fg.cv * Z);
       } else {
-        X = __builtin_fmaf(__builtin_fmaf(fg.KR[0], rx, __builtin_fmaf(fg.KR[1], ry, fg.KR[2])), d, fg.Kt[0]);
-        Y = __builtin_fmaf(__builtin_fmaf(fg.KR[3], rx, __builtin_fmaf(fg.KR[4], ry, fg.KR[5])), d, fg.Kt[1]);
-        Z = __builtin_fmaf(__builtin_fmaf(fg.KR[6], rx, __builtin_fmaf(fg.KR[7], ry, fg.KR[8])), d, fg.Kt[2]);
+        X = __builtin_fmaf(rrx, d, fg.Kt[0]);
+        Y = __builtin_fmaf(rry, d, fg.Kt[1]);
+        Z = __builtin_fmaf(rrz, d, fg.Kt[2]);
       }
       float iz = __builtin_amdgcn_rcpf(Z);
       // |u_c| < hw and |v_c| < hh and q.z > 0  <=>  max(|X| - hw Z, |Y| - hh Z) < 0
       const float mu = __builtin_fmaf(-fg.hw, Z, fabsf(X)), mv = __builtin_fmaf(-fg.hh, Z, fabsf(Y));
-      const float E = __builtin_fmaf(e1, fabsf(d), e2);
+      const float E = __builtin_fmaf(e1, fabsf(d), e2v);
       bool valid = (mu < -E) && (mv < -E);                 // NaN anywhere -> false
       const bool amb = fabsf(fmaxf(mu, mv)) < E;
       float tu = __builtin_fmaf(X, iz, fg.fcx), tv = __builtin_fmaf(Y, iz, fg.fcy);   // tap coordinates relative to pixel (icx, icy)
       float U = 0.f, V = 0.f;
       if constexpr (GRAD) { U = __builtin_fmaf(X, iz, fg.du); V = __builtin_fmaf(Y, iz, fg.dv); }
-      if (__builtin_amdgcn_ballot_w64(amb) != 0) {         // wave-uniform and rare: the reference's operation order decides
+      if (amb) {   // rare (a ~1e-3-pixel band along the view border): the reference's operation order decides, for these lanes only
         const Corr c = find_correspondence_ray<true>(g, rx, ry, d, 1.0f, 0.0f);
-        valid = amb ? c.valid : valid;
-        tu = amb ? c.u - (float)fg.icx : tu;               // and supplies the coordinates: its taps are in range where it says valid
-        tv = amb ? c.v - (float)fg.icy : tv;
-        if constexpr (GRAD) { U = amb ? c.u - p.u0 : U; V = amb ? c.v - p.v0 : V; iz = amb ? c.iz : iz; }
+        valid = c.valid;
+        tu = c.u - (float)fg.icx;                          // and supplies the coordinates: its taps are in range where it says valid
+        tv = c.v - (float)fg.icy;
+        if constexpr (GRAD) { U = c.u - p.u0; V = c.v - p.v0; iz = c.iz; }
       }
-      valid = valid && lane_ok;
+      // validity travels to the consuming step as a lane value (a carried bool costs three scalar mask instructions per step and stage)
+      const unsigned vm = (valid ? lanemask : 0u) & rowmask;
+      S.vmask = vm;
       if constexpr (GRAD) { S.iz = iz; S.U = U; S.V = V; }
       const float fu = floorf(tu), fv = floorf(tv);
       S.ax = tu - fu; S.ay = tv - fv;
       const int ix = (int)fu, iy = (int)fv;
       // a lane without correspondence reads offset 0: in range, never used (and no wave-load is ever entirely out of range)
-      const unsigned o1 = valid ? (unsigned)(__mul24(iy, (int)p.pitch_img1) + ((ix << 2) + (int)c1)) : 0u;
+      const unsigned o1 = (unsigned)(__mul24(iy, (int)p.pitch_img1) + ((ix << 2) + (int)c1)) & vm;
       S.ia = bload2(rI1, o1, 0);
       S.ib = bload2(rI1, o1, p.pitch_img1);
       if constexpr (GRAD) {
-        const unsigned og = valid ? (unsigned)(__mul24(iy, (int)p.pitch_grad1) + ((ix << 3) + (int)cg)) : 0u;
+        const unsigned og = (unsigned)(__mul24(iy, (int)p.pitch_grad1) + ((ix << 3) + (int)cg)) & vm;
         S.ga = bload4(rG1, og, 0);
         S.gb = bload4(rG1, og, p.pitch_grad1);
       }
-      S.valid = valid;
     };
     auto eat = [&](const RowPix<GRAD>& S) {
-      inliers += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(S.valid));
-      if (S.valid) consume(S);
+      const bool v = S.vmask != 0;
+      inliers += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(v));
+      if (v) consume(S);
     };
-    // rows y (consume), y + 1 (geometry, taps issued), y + 2 (loads issued); the two row states swap roles, so nothing is copied
-    RowIn LA = load_row(y0), LB = load_row(y0 + 1);
-    RowPix<GRAD> P, Q;
-    geom(LA, P);
-    int y = y0;
-    while (true) {
-      LA = load_row(y + 2);
-      geom(LB, Q);
-      eat(P);
-      if (++y >= y1) break;
-      LB = load_row(y + 2);
-      geom(LA, P);
-      eat(Q);
-      if (++y >= y1) break;
+    // Software pipeline, DT rows deep: at step y the loads of row y + 2 DT are issued, the geometry of row y + DT is evaluated and its
+    // taps are issued, row y is consumed.  The DT + 1 row states rotate through the unrolled steps, so nothing is copied.  The warm-up
+    // runs INSIDE the loop and without branches: steps y0 - 2 DT .. y0 - 1 run every stage on zero-initialised / repeated rows whose
+    // lanes are masked (`rowmask`), so the loop header sees the same queue of outstanding loads from the preheader and from the back
+    // edge (the compiler's vmcnt counts stay exact; a separate prologue made the header wait for all but 4 loads) and a step holds no
+    // scalar control flow but the loop itself and the rare border branch.
+    constexpr int NS = DT + 1;
+    RowIn L[NS];
+    RowPix<GRAD> S[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      L[j].d = 0.f; L[j].i0 = 0.f; L[j].ry = 0.f;
+      S[j].i0 = S[j].ax = S[j].ay = 0.f; S[j].vmask = 0u;
+      S[j].ia = S[j].ib = f32x2{ 0.f, 0.f };
+      if constexpr (GRAD) { S[j].iz = S[j].U = S[j].V = S[j].vx = S[j].vy = S[j].vz = 0.f; S[j].ga = S[j].gb = f32x4{ 0.f, 0.f, 0.f, 0.f }; }
+    }
+    // UNR steps per loop iteration and no exit inside: the steps past the segment's last row are masked like the warm-up's (the
+    // segments are sized so that only a wave's last group of a short last segment has any), and the compiler's conservative vmcnt at the
+    // loop header (it waits for every load older than the header's own) is paid once per UNR steps
+    constexpr int UNR = NS * DFX_RW_UNROLL;
+    const int groups = (y1 - y0 + 2 * DT + UNR - 1) / UNR;
+    int y = y0 - 2 * DT;
+    for (int grp = 0; grp < groups; ++grp) {
+#pragma unroll
+      for (int jj = 0; jj < UNR; ++jj) {
+        const int j = jj % NS;
+        L[(j + 2 * DT) % NS] = load_row(y + 2 * DT);
+        geom(L[(j + DT) % NS], S[(j + DT) % NS], (y + DT >= y0 && y + DT < y1) ? ~0u : 0u);
+        eat(S[j]);
+        ++y;
+      }
     }
   }
   return inliers;
@@ -270,7 +308,7 @@ __device__ __forceinline__ void se3_step_body(const SimplePairDev& p, const floa
 #pragma unroll
   for (int q = 0; q < 28; ++q) acc[q] = 0.f;
   const float fx = p.fx, fy = p.fy;
-  const unsigned inl = row_walk<true>(p, R, t, e1, e2, W, H, [&](const RowPix<true>& S) {
+  const unsigned inl = row_walk<true, DFX_TAP_DIST_SE3>(p, R, t, e1, e2, W, H, [&](const RowPix<true>& S) {
     const float gx = lerpf(lerpf(S.ga.x, S.ga.z, S.ax), lerpf(S.gb.x, S.gb.z, S.ax), S.ay);
     const float gy = lerpf(lerpf(S.ga.y, S.ga.w, S.ax), lerpf(S.gb.y, S.gb.w, S.ax), S.ay);
     float r = S.i0 - pix_img(S);
@@ -567,7 +605,7 @@ hipError_t launch_sparse_geometric(int cs, const void* desc_host, const float* c
 __device__ __forceinline__ void sfm_error_body(const SimplePairDev& p, const int W, const int H, const float huber_delta, float* __restrict__ out_row) {
   __shared__ float red[kT / 64][kSimpleRow];
   float acc = 0.f;
-  const unsigned inl = row_walk<false>(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, [&](const RowPix<false>& S) {
+  const unsigned inl = row_walk<false, DFX_TAP_DIST_ERR>(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, [&](const RowPix<false>& S) {
     float r = S.i0 - pix_img(S);
     r *= huber_weight(r, huber_delta);
     acc = __builtin_fmaf(r, r, acc);

@@ -71,17 +71,17 @@ def row_walk_model(qt, cam, img0, img1, dpt0, grad1, huber_delta, want_grad):
     rx = ((np.arange(W, dtype=f32) - u0) / fx)[None, :].repeat(H, 0)
     ry = ((np.arange(H, dtype=f32) - v0) / fy)[:, None].repeat(W, 1)
     d = dpt0.astype(f32)
+    # (K) R ray: the column part is loop-invariant per lane, the row part one fma per component (row_walk: cx, cy, cz)
+    M = R if want_grad else g["KR"]
+    rr = [fma(M[3 * i + 1], ry, fma(M[3 * i], rx, M[3 * i + 2])) for i in range(3)]
     if want_grad:
-        rr = [fma(R[3 * i], rx, fma(R[3 * i + 1], ry, R[3 * i + 2])) for i in range(3)]
         vx, vy, vz = rr[0] * d, rr[1] * d, rr[2] * d
         Z = vz + t[2]
         X = fma(fx, vx + t[0], g["cu"] * Z)
         Y = fma(fy, vy + t[1], g["cv"] * Z)
     else:
-        KR, Kt = g["KR"], g["Kt"]
-        X = fma(fma(KR[0], rx, fma(KR[1], ry, KR[2])), d, Kt[0])
-        Y = fma(fma(KR[3], rx, fma(KR[4], ry, KR[5])), d, Kt[1])
-        Z = fma(fma(KR[6], rx, fma(KR[7], ry, KR[8])), d, Kt[2])
+        Kt = g["Kt"]
+        X, Y, Z = fma(rr[0], d, Kt[0]), fma(rr[1], d, Kt[1]), fma(rr[2], d, Kt[2])
     with np.errstate(all="ignore"):
         iz = (f32(1.0) / Z).astype(f32)
         mu, mv = fma(-g["hw"], Z, np.abs(X)), fma(-g["hh"], Z, np.abs(Y))

@@ -39,6 +39,7 @@ def main():
                                    grad1=p["grad1"]) for p in prs])
     us = ev_us(lambda: al.EvaluateErrorBatch(earr, eitems), reps, warm)
     print(f"{tag} sfm_error_batch {P} pairs: {us:.1f} us frac {12 * W * H * P / us / 1e3 / 8000:.3f}", flush=True)
+    if os.environ.get("BATCH_ONLY"): return
     # tracker, 3 levels, 20 iterations (tools/profile_tracker.py)
     p = prs[0]
     cams = synth.camera_pyramid(p["cam"], 3)
