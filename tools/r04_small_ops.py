@@ -24,7 +24,9 @@ def main():
     ctx = dfx.Context(0)
     W, H, CS, P = 640, 480, 16, int(os.environ.get("PAIRS", "128"))
     reps, warm = int(os.environ.get("REPS", "60")), int(os.environ.get("WARM", "300"))
-    prs = [synth.make_pair(W, H, CS, seed=0x2200 + k, device=dev, with_decoder=False) for k in range(P)]
+    nd = int(os.environ.get("DISTINCT", str(P)))   # distinct image sets (1: everything cache-resident)
+    base = [synth.make_pair(W, H, CS, seed=0x2200 + k, device=dev, with_decoder=False) for k in range(nd)]
+    prs = [base[k % nd] for k in range(P)]
     al, se3 = dfx.SfmAligner(code_size=CS, ctx=ctx), dfx.SE3Aligner(ctx=ctx)
     sitems = torch.zeros(P * dfx.item_size(6), dtype=torch.uint8, device=dev)
     eitems = torch.zeros(P * 16, dtype=torch.uint8, device=dev)
