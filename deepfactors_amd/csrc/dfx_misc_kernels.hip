@@ -69,13 +69,6 @@ constexpr int kBand = 64;
 #ifndef DFX_TAP_DIST_ERR
 #define DFX_TAP_DIST_ERR 1
 #endif
-// taps out of the wave's LDS window (row_walk WIN) or by global gathers only
-#ifndef DFX_WIN_SE3
-#define DFX_WIN_SE3 1
-#endif
-#ifndef DFX_WIN_ERR
-#define DFX_WIN_ERR 1
-#endif
 
 __device__ __forceinline__ float rfl(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -110,30 +103,11 @@ __device__ __forceinline__ void fast_band(const float (&R)[9], const float (&t)[
   e2 = rfl(c.gscale * tau * 1.00001f);
 }
 
-// ---- taps out of an LDS window ---------------------------------------------------------------------------------------------------------
-// What bounds the row walk with per-pixel global taps is the vector L1's tag pipeline (profiles/r04_rowwalk_pmc.txt: TCP_TOTAL_CACHE_ACCESSES =
-// 128 per 64-pixel step of the SE3 operator, ~1 per cycle and CU -> 146 us of the kernel's 192; tools/ubench/vmem_issue_cost.cpp: a
-// per-lane-addressed load is processed a quad of lanes per cycle, a quad that straddles a 64-byte boundary twice).  The warp is coherent,
-// so the taps of a band walking down its rows sweep a slowly moving window of img1 / grad1: each wave keeps the last kWinRows rows of a
-// kWinCols-column window in its own slice of the LDS -- ONE coalesced 8-byte (img1) and ONE 16-byte (grad1) load per step instead of
-// four gathers -- and reads the taps with ds_read2_b32 / ds_read2_b64 (4 / 7 cycles per wave-instruction against 16 / 32).  Nothing is
-// assumed about the warp: every lane tests its taps against the resident rows / columns, and a step with a lane outside (depth edges,
-// strong zoom or rotation, a window that has not caught up) takes the global gathers for the whole wave.
-constexpr int kWinRows = 8, kWinCols = 128;
-constexpr int kWinImgFloats = kWinRows * kWinCols, kWinGradFloats = 2 * kWinRows * kWinCols;
-template <bool GRAD> struct WinRow { f32x2 iw; f32x4 gw; };   // one window row in flight: lane l holds columns wx0 + 2 l, + 1
-
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off, 64); v = o < v ? o : v; }
-  return v;
-}
-
 // Walks the calling wave's share of the image; `consume(const RowPix<GRAD>&)` is called once per row with exec = the row's inliers.
-// Returns the wave's inlier count (wave-uniform).  WIN: taps out of the wave's LDS window (imgw / gradw: this wave's slices).
-template <bool GRAD, int DT, bool WIN, typename F>
+// Returns the wave's inlier count (wave-uniform).
+template <bool GRAD, int DT, typename F>
 __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float (&R)[9], const float (&t)[3], const float e1, const float e2,
-                                             const int W, const int H, float* __restrict__ imgw, float* __restrict__ gradw, F&& consume) {
+                                             const int W, const int H, F&& consume) {
   const FastGeo& fg = p.fg;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -151,13 +125,6 @@ __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float
   g.t[0] = t[0]; g.t[1] = t[1]; g.t[2] = t[2];
   g.fx = p.fx; g.fy = p.fy; g.u0 = p.u0; g.v0 = p.v0; g.w = p.w; g.h = p.h;
 
-  // pipeline geometry: streaming loads DL rows ahead, taps DT rows ahead, window rows written two steps after their issue
-  constexpr int DL = WIN ? DT + 2 : 2 * DT;
-  constexpr int NS = DT + 1, NL = DL - DT + 1, NW = 3;
-  constexpr int kRot = WIN ? (NS == 2 ? 6 : 3 * NS) : NS;          // steps after which every rotating buffer is back in place (NL = NW = 3 | NS)
-  static_assert(!WIN || (kRot % NS == 0 && kRot % NL == 0 && kRot % NW == 0), "rotation period");
-  constexpr int UNR = kRot * DFX_RW_UNROLL;
-
   // items = (band, row segment): all bands of a segment are adjacent items, so the waves of a workgroup read adjacent 256-byte runs
   const unsigned nb = ((unsigned)W + kBand - 1) / kBand;
   const unsigned waves = gridDim.x * (kT / 64);
@@ -165,7 +132,8 @@ __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float
   nseg = nseg > HB ? HB : nseg;
   nseg = nseg < 1 ? 1 : nseg;
   unsigned rps = (HB + nseg - 1) / nseg;                // rows per segment ...
-  rps = (rps + DL + UNR - 1) / UNR * UNR - DL;          // ... such that the warm-up + the rows are whole groups of the unrolled loop
+  constexpr unsigned kUnr = (unsigned)((DT + 1) * DFX_RW_UNROLL);
+  rps = (rps + 2 * DT + kUnr - 1) / kUnr * kUnr - 2 * DT;   // ... such that the warm-up + the rows are whole groups of the unrolled loop
   const unsigned nitems = nb * ((HB + rps - 1) / rps);
   unsigned inliers = 0;
   for (unsigned item = blockIdx.x * (kT / 64) + (unsigned)wave; item < nitems; item += waves) {
@@ -190,74 +158,22 @@ __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float
       L.ry = bload1(rRay, 0, ((unsigned)W + yc) * 4u);
       return L;
     };
-    // fast geometry of one row: homogeneous image coordinates centred on (w/2, h/2)
-    auto project = [&](const float d, const float ry, float& X, float& Y, float& Z, float& vx, float& vy, float& vz) {
+    // geometry of one row + issue of its taps.  `rowmask` (scalar): all ones if the row belongs to the segment
+    auto geom = [&](const RowIn& L, RowPix<GRAD>& S, const unsigned rowmask) {
+      const float d = L.d, ry = L.ry;
+      S.i0 = L.i0;
+      float X, Y, Z;
       const float rrx = __builtin_fmaf(M[1], ry, cx), rry = __builtin_fmaf(M[4], ry, cy), rrz = __builtin_fmaf(M[7], ry, cz);
       if constexpr (GRAD) {
-        vx = rrx * d; vy = rry * d; vz = rrz * d;
-        Z = vz + t[2];
-        X = __builtin_fmaf(p.fx, vx + t[0], fg.cu * Z);
-        Y = __builtin_fmaf(p.fy, vy + t[1], fg.cv * Z);
+        S.vx = rrx * d; S.vy = rry * d; S.vz = rrz * d;
+        Z = S.vz + t[2];
+        X = __builtin_fmaf(p.fx, S.vx + t[0], fg.cu * Z);
+        Y = __builtin_fmaf(p.fy, S.vy + t[1], fg.cv * Z);
       } else {
         X = __builtin_fmaf(rrx, d, fg.Kt[0]);
         Y = __builtin_fmaf(rry, d, fg.Kt[1]);
         Z = __builtin_fmaf(rrz, d, fg.Kt[2]);
       }
-    };
-
-    // ---- the LDS window of this item: columns [wx0, wx0 + kWinCols), rows [wlo, wtop] resident, wiss = last row whose load was issued ----
-    int wx0 = 0, wlo = 0, wtop = -1, wiss = -1, wfirst = 0;
-    // lane l loads columns wx0 + 2 l, + 1; images narrower than the window repeat their last column pair (never a valid tap's column)
-    const int wcol = 2 * lane <= W - 2 ? 2 * lane : (W >= 2 ? W - 2 : 0);
-    const unsigned lvo_i = (unsigned)wcol * 4u, lvo_g = (unsigned)wcol * 8u;
-    auto win_load = [&](int r) {
-      WinRow<GRAD> w;
-      const unsigned rc = (unsigned)(r < 0 ? 0 : (r >= H ? H - 1 : r));
-      w.iw = bload2(rI1, lvo_i, rc * p.pitch_img1 + (unsigned)wx0 * 4u);
-      if constexpr (GRAD) w.gw = bload4(rG1, lvo_g, rc * p.pitch_grad1 + (unsigned)wx0 * 8u);
-      return w;
-    };
-    auto win_write = [&](const WinRow<GRAD>& w, int r) {
-      const int slot = r & (kWinRows - 1);
-      *reinterpret_cast<f32x2_u*>(imgw + slot * kWinCols + wcol) = w.iw;     // at the column it was loaded from (wcol: odd for the last pair of an odd width)
-      if constexpr (GRAD) *reinterpret_cast<f32x4_u8*>(gradw + slot * 2 * kWinCols + 2 * wcol) = w.gw;
-      wtop = r > wtop ? r : wtop;
-      const int l2 = wtop - (kWinRows - 1);
-      wlo = l2 > wfirst ? l2 : wfirst;
-    };
-    if constexpr (WIN) {
-      // place the window from the fast geometry of the segment's first row (no exactness needed: a misplaced window only costs gathers)
-      const RowIn L0 = load_row(y0);
-      float X, Y, Z, vx, vy, vz;
-      project(L0.d, L0.ry, X, Y, Z, vx, vy, vz);
-      const float iz = __builtin_amdgcn_rcpf(Z);
-      const float tu = __builtin_fmaf(X, iz, fg.fcx), tv = __builtin_fmaf(Y, iz, fg.fcy);
-      const bool ok = lane_ok && fabsf(tu) < fg.hw && fabsf(tv) < fg.hh && Z > 0.f;
-      const int big = 0x3fffffff;
-      int ixm = wave_min_i32(ok ? (int)floorf(tu) + fg.icx : big), iym = wave_min_i32(ok ? (int)floorf(tv) + fg.icy : big);
-      ixm = __builtin_amdgcn_readfirstlane(ixm); iym = __builtin_amdgcn_readfirstlane(iym);
-      if (ixm == big) { ixm = (int)band * kBand; iym = y0; }     // no pixel of the first row in view: the band's own place
-      int wmax = (W - kWinCols) & ~1;
-      wmax = wmax < 0 ? 0 : wmax;
-      wx0 = (ixm - 24) & ~1;
-      wx0 = wx0 < 0 ? 0 : (wx0 > wmax ? wmax : wx0);
-      wfirst = iym - 1 < 0 ? 0 : iym - 1;
-      wlo = wfirst; wtop = wfirst - 1;
-      // initial burst: four rows
-      WinRow<GRAD> b0 = win_load(wfirst), b1 = win_load(wfirst + 1), b2 = win_load(wfirst + 2), b3 = win_load(wfirst + 3);
-      win_write(b0, wfirst); win_write(b1, wfirst + 1); win_write(b2, wfirst + 2); win_write(b3, wfirst + 3);
-      wiss = wfirst + 3;
-    }
-    const int dxw = fg.icx - wx0;   // window column of a tap = ix (relative to icx) + dxw
-
-    bool near = true;               // some lane's taps come within three rows of the last issued window row: keep loading
-    // geometry of one row + issue of its taps.  `rowmask` (scalar): all ones if the row belongs to the segment
-    auto geom = [&](const RowIn& L, RowPix<GRAD>& S, const unsigned rowmask) {
-      const float d = L.d, ry = L.ry;
-      S.i0 = L.i0;
-      float X, Y, Z, vx = 0.f, vy = 0.f, vz = 0.f;
-      project(d, ry, X, Y, Z, vx, vy, vz);
-      if constexpr (GRAD) { S.vx = vx; S.vy = vy; S.vz = vz; }
       float iz = __builtin_amdgcn_rcpf(Z);
       // |u_c| < hw and |v_c| < hh and q.z > 0  <=>  max(|X| - hw Z, |Y| - hh Z) < 0
       const float mu = __builtin_fmaf(-fg.hw, Z, fabsf(X)), mv = __builtin_fmaf(-fg.hh, Z, fabsf(Y));
@@ -281,42 +197,14 @@ __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float
       const float fu = floorf(tu), fv = floorf(tv);
       S.ax = tu - fu; S.ay = tv - fv;
       const int ix = (int)fu, iy = (int)fv;
-      bool use_gather = true;
-      if constexpr (WIN) {
-        // every lane with a correspondence must find its 2 x 2 taps inside the resident rows / columns of the window
-        const int cxw = ix + dxw, ryw = iy + (fg.icy - wlo);
-        const bool inwin = (unsigned)cxw <= (unsigned)(kWinCols - 2) && (unsigned)ryw < (unsigned)(wtop - wlo);
-        near = __builtin_amdgcn_ballot_w64(vm != 0u && iy > wiss - 3 - fg.icy) != 0;
-        use_gather = __builtin_amdgcn_ballot_w64(vm != 0u && !inwin) != 0;
-        if (!use_gather) {
-          const int ya = iy + fg.icy;
-          const unsigned ia0 = (unsigned)(((ya & (kWinRows - 1)) * kWinCols) + cxw) & vm;          // lanes without correspondence: element 0
-          const unsigned ib0 = (unsigned)((((ya + 1) & (kWinRows - 1)) * kWinCols) + cxw) & vm;
-          S.ia = *reinterpret_cast<const f32x2_u*>(imgw + ia0);
-          S.ib = *reinterpret_cast<const f32x2_u*>(imgw + ib0);
-          if constexpr (GRAD) {
-            S.ga = *reinterpret_cast<const f32x4_u8*>(gradw + 2 * ia0);
-            S.gb = *reinterpret_cast<const f32x4_u8*>(gradw + 2 * ib0);
-          }
-        }
-      }
-      if (use_gather) {
-        // a lane without correspondence reads offset 0: in range, never used (and no wave-load is ever entirely out of range)
-        const unsigned o1 = (unsigned)(__mul24(iy, (int)p.pitch_img1) + ((ix << 2) + (int)c1)) & vm;
-        S.ia = bload2(rI1, o1, 0);
-        S.ib = bload2(rI1, o1, p.pitch_img1);
-        if constexpr (GRAD) {
-          const unsigned og = (unsigned)(__mul24(iy, (int)p.pitch_grad1) + ((ix << 3) + (int)cg)) & vm;
-          S.ga = bload4(rG1, og, 0);
-          S.gb = bload4(rG1, og, p.pitch_grad1);
-        }
-        if constexpr (WIN) {
-          // the rare path of the window build: wait for the gathers HERE.  Left pending across the join, they make the compiler count
-          // them into every later vmcnt -- of the common path too, where none was issued -- and the streaming / window loads would be
-          // waited for a step early (measured: 250 us against 195 without the window).  The empty asm reads the registers, no more.
-          asm volatile("" : "+v"(S.ia), "+v"(S.ib));
-          if constexpr (GRAD) asm volatile("" : "+v"(S.ga), "+v"(S.gb));
-        }
+      // a lane without correspondence reads offset 0: in range, never used (and no wave-load is ever entirely out of range)
+      const unsigned o1 = (unsigned)(__mul24(iy, (int)p.pitch_img1) + ((ix << 2) + (int)c1)) & vm;
+      S.ia = bload2(rI1, o1, 0);
+      S.ib = bload2(rI1, o1, p.pitch_img1);
+      if constexpr (GRAD) {
+        const unsigned og = (unsigned)(__mul24(iy, (int)p.pitch_grad1) + ((ix << 3) + (int)cg)) & vm;
+        S.ga = bload4(rG1, og, 0);
+        S.gb = bload4(rG1, og, p.pitch_grad1);
       }
     };
     auto eat = [&](const RowPix<GRAD>& S) {
@@ -324,47 +212,35 @@ __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float
       inliers += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(v));
       if (v) consume(S);
     };
-    // Software pipeline: at step y the streaming loads of row y + DL are issued, the geometry of row y + DT is evaluated and its taps are
-    // issued, row y is consumed.  The row states rotate through the unrolled steps, so nothing is copied.  The warm-up runs INSIDE the
-    // loop and without branches: steps y0 - DL .. y0 - 1 run every stage on zero-initialised / repeated rows whose lanes are masked
-    // (`rowmask`), so the loop header sees the same queue of outstanding loads from the preheader and from the back edge (the
-    // compiler's vmcnt counts stay exact; a separate prologue made the header wait for all but 4 loads) and a step holds no scalar
-    // control flow but the loop itself, the rare border branch and the window's hit / miss branch.
-    RowIn L[NL];
+    // Software pipeline, DT rows deep: at step y the loads of row y + 2 DT are issued, the geometry of row y + DT is evaluated and its
+    // taps are issued, row y is consumed.  The DT + 1 row states rotate through the unrolled steps, so nothing is copied.  The warm-up
+    // runs INSIDE the loop and without branches: steps y0 - 2 DT .. y0 - 1 run every stage on zero-initialised / repeated rows whose
+    // lanes are masked (`rowmask`), so the loop header sees the same queue of outstanding loads from the preheader and from the back
+    // edge (the compiler's vmcnt counts stay exact; a separate prologue made the header wait for all but 4 loads) and a step holds no
+    // scalar control flow but the loop itself and the rare border branch.
+    constexpr int NS = DT + 1;
+    RowIn L[NS];
     RowPix<GRAD> S[NS];
-    WinRow<GRAD> Wq[NW];
-    int wrow[NW];
-#pragma unroll
-    for (int j = 0; j < NL; ++j) { L[j].d = 0.f; L[j].i0 = 0.f; L[j].ry = 0.f; }
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
+      L[j].d = 0.f; L[j].i0 = 0.f; L[j].ry = 0.f;
       S[j].i0 = S[j].ax = S[j].ay = 0.f; S[j].vmask = 0u;
       S[j].ia = S[j].ib = f32x2{ 0.f, 0.f };
       if constexpr (GRAD) { S[j].iz = S[j].U = S[j].V = S[j].vx = S[j].vy = S[j].vz = 0.f; S[j].ga = S[j].gb = f32x4{ 0.f, 0.f, 0.f, 0.f }; }
     }
-    if constexpr (WIN) {
-      // two window rows are in flight when the loop starts (its first two steps write them)
-#pragma unroll
-      for (int k = 1; k < NW; ++k) { ++wiss; Wq[k] = win_load(wiss); wrow[k] = wiss; }
-      Wq[0] = Wq[1]; wrow[0] = wrow[1];
-    }
     // UNR steps per loop iteration and no exit inside: the steps past the segment's last row are masked like the warm-up's (the
-    // segments are sized so that only a wave's last group of a short last segment has any)
-    const int groups = (y1 - y0 + DL + UNR - 1) / UNR;
-    int y = y0 - DL;
+    // segments are sized so that only a wave's last group of a short last segment has any), and the compiler's conservative vmcnt at the
+    // loop header (it waits for every load older than the header's own) is paid once per UNR steps
+    constexpr int UNR = NS * DFX_RW_UNROLL;
+    const int groups = (y1 - y0 + 2 * DT + UNR - 1) / UNR;
+    int y = y0 - 2 * DT;
     for (int grp = 0; grp < groups; ++grp) {
 #pragma unroll
       for (int jj = 0; jj < UNR; ++jj) {
-        if constexpr (WIN) win_write(Wq[(jj + 1) % NW], wrow[(jj + 1) % NW]);       // issued two steps ago
-        L[(jj + DL) % NL] = load_row(y + DL);
-        geom(L[(jj + DT) % NL], S[(jj + DT) % NS], (y + DT >= y0 && y + DT < y1) ? ~0u : 0u);
-        if constexpr (WIN) {
-          // one window row per step: the next one while some lane's taps are within three rows of the last issued row (or before the
-          // first geometry), the same one again otherwise (so the ring never runs ahead of the rows still in use)
-          if (near || y + DT < y0) ++wiss;
-          Wq[jj % NW] = win_load(wiss); wrow[jj % NW] = wiss;
-        }
-        eat(S[jj % NS]);
+        const int j = jj % NS;
+        L[(j + 2 * DT) % NS] = load_row(y + 2 * DT);
+        geom(L[(j + DT) % NS], S[(j + DT) % NS], (y + DT >= y0 && y + DT < y1) ? ~0u : 0u);
+        eat(S[j]);
         ++y;
       }
     }
@@ -428,14 +304,11 @@ __device__ __forceinline__ void fold_waves_store(float (&red)[kT / 64][kSimpleRo
 __device__ __forceinline__ void se3_step_body(const SimplePairDev& p, const float (&R)[9], const float (&t)[3], const float e1, const float e2,
                                               const int W, const int H, const float huber_delta, float* __restrict__ out_row) {
   __shared__ float red[kT / 64][kSimpleRow];
-  __shared__ __attribute__((aligned(16))) float win_img[DFX_WIN_SE3 ? kT / 64 : 1][DFX_WIN_SE3 ? kWinImgFloats : 4];
-  __shared__ __attribute__((aligned(16))) float win_grad[DFX_WIN_SE3 ? kT / 64 : 1][DFX_WIN_SE3 ? kWinGradFloats : 4];
-  const int wv = DFX_WIN_SE3 ? (int)(threadIdx.x >> 6) : 0;
   float acc[28];
 #pragma unroll
   for (int q = 0; q < 28; ++q) acc[q] = 0.f;
   const float fx = p.fx, fy = p.fy;
-  const unsigned inl = row_walk<true, DFX_TAP_DIST_SE3, DFX_WIN_SE3 != 0>(p, R, t, e1, e2, W, H, win_img[wv], win_grad[wv], [&](const RowPix<true>& S) {
+  const unsigned inl = row_walk<true, DFX_TAP_DIST_SE3>(p, R, t, e1, e2, W, H, [&](const RowPix<true>& S) {
     const float gx = lerpf(lerpf(S.ga.x, S.ga.z, S.ax), lerpf(S.gb.x, S.gb.z, S.ax), S.ay);
     const float gy = lerpf(lerpf(S.ga.y, S.ga.w, S.ax), lerpf(S.gb.y, S.gb.w, S.ax), S.ay);
     float r = S.i0 - pix_img(S);
@@ -731,10 +604,8 @@ hipError_t launch_sparse_geometric(int cs, const void* desc_host, const float* c
 // ---- SfM error: sum (w r)^2, inliers (dense_sfm.h:79-119: default border 1, min_dpt 0) -------------------------------------------------
 __device__ __forceinline__ void sfm_error_body(const SimplePairDev& p, const int W, const int H, const float huber_delta, float* __restrict__ out_row) {
   __shared__ float red[kT / 64][kSimpleRow];
-  __shared__ __attribute__((aligned(16))) float win_img[DFX_WIN_ERR ? kT / 64 : 1][DFX_WIN_ERR ? kWinImgFloats : 4];
-  const int wv = DFX_WIN_ERR ? (int)(threadIdx.x >> 6) : 0;
   float acc = 0.f;
-  const unsigned inl = row_walk<false, DFX_TAP_DIST_ERR, DFX_WIN_ERR != 0>(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, win_img[wv], nullptr, [&](const RowPix<false>& S) {
+  const unsigned inl = row_walk<false, DFX_TAP_DIST_ERR>(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, [&](const RowPix<false>& S) {
     float r = S.i0 - pix_img(S);
     r *= huber_weight(r, huber_delta);
     acc = __builtin_fmaf(r, r, acc);

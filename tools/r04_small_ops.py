@@ -27,6 +27,13 @@ def main():
     nd = int(os.environ.get("DISTINCT", str(P)))   # distinct image sets (1: everything cache-resident)
     base = [synth.make_pair(W, H, CS, seed=0x2200 + k, device=dev, with_decoder=False) for k in range(nd)]
     prs = [base[k % nd] for k in range(P)]
+    if os.environ.get("STAGGER"):   # every image at its own offset inside its allocation (decorrelates the channel / bank pattern of the 640 buffers)
+        unit = int(os.environ["STAGGER"])
+        def stag(t, k, j):
+            n = t.numel(); off = ((k * 5 + j) * 37 % 61) * unit
+            big = torch.empty(n + 64 * unit, dtype=t.dtype, device=t.device)
+            v = big[off:off + n].view(t.shape); v.copy_(t); return v
+        prs = [dict(p, img0=stag(p["img0"], k, 0), img1=stag(p["img1"], k, 1), dpt0=stag(p["dpt0"], k, 2), grad1=stag(p["grad1"], k, 3)) for k, p in enumerate(prs)]
     al, se3 = dfx.SfmAligner(code_size=CS, ctx=ctx), dfx.SE3Aligner(ctx=ctx)
     sitems = torch.zeros(P * dfx.item_size(6), dtype=torch.uint8, device=dev)
     eitems = torch.zeros(P * 16, dtype=torch.uint8, device=dev)
