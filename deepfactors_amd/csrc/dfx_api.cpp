@@ -466,17 +466,28 @@ size_t shadow_words(uint32_t w, uint32_t h) { return ((size_t)w * h + 63) / 64; 
 
 // A writer the library launches (or a fill / upload) is about to change a library-owned image: its shadow, if it has one, forgets
 // everything (value != 1) or learns that every pixel is 1.0 (a fill with 1.0).  Ordered on the context's stream like the write itself.
+// With a tail stream set, the finalize / tail kernel of an earlier step may still be reading the image (a valid0 map) and REBUILDING its
+// shadow on that stream: the writer -- and the shadow's memset -- are ordered behind every tail first (round-3 advisor finding: a refill
+// right after an async step could race the rebuild and leave "known 1.0" bits over other data).
 int img_note_write(dfx_ctx* c, const dfx_img* im, bool uniform, float value) {
   if (!im || !im->ptr) return DFX_OK;
   std::lock_guard<std::mutex> lk(g_img_mu);
   auto it = g_imgs.find(im->ptr);
   if (it == g_imgs.end()) return DFX_OK;
   ImgRec& r = it->second;
+  // the record ALWAYS learns about the write (a shadow created later starts from it: an early return here once left `uniform, 1.0` behind
+  // an upload, and the first step then took every pixel for "known to hold 1.0"); only the memset needs an existing shadow
   r.uniform = uniform; r.value = value;
-  if (r.shadow) DFX_HIP(hipMemsetAsync(r.shadow, (uniform && value == 1.0f) ? 0xFF : 0x00, 8 + 8 * shadow_words(r.w, r.h), c->stream));
+  if (r.shadow) {
+    if (c->tail_stream && (c->tail_busy[0] || c->tail_busy[1])) {
+      DFX_HIP(hipEventRecord(c->ev_join, c->tail_stream));
+      DFX_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    }
+    DFX_HIP(hipMemsetAsync(r.shadow, (uniform && value == 1.0f) ? 0xFF : 0x00, 8 + 8 * shadow_words(r.w, r.h), c->stream));
+  }
   return DFX_OK;
 }
-int img_note_write(dfx_ctx* c, const dfx_img* im) { return g_shadow_count.load(std::memory_order_relaxed) > 0 ? img_note_write(c, im, false, 0.f) : DFX_OK; }
+int img_note_write(dfx_ctx* c, const dfx_img* im) { return img_note_write(c, im, false, 0.f); }
 
 // The shadow of a valid0 map, created on first use; null for memory the library does not own (or a view that is not the whole image).
 int valid0_shadow(dfx_ctx* c, const dfx_img* v, uint32_t W, uint32_t H, unsigned long long** out) {
@@ -741,6 +752,7 @@ DFX_API int dfx_img_free(dfx_ctx* c, dfx_img* img) {
   if ((rc = ensure_device(c))) return rc;
   if (img->ptr) {
     DFX_HIP(hipStreamSynchronize(c->stream));
+    if (c->tail_stream) DFX_HIP(hipStreamSynchronize(c->tail_stream));   // a deferred tail may still read the map and rewrite its shadow
     unsigned long long* shadow = nullptr;
     {
       std::lock_guard<std::mutex> lk(g_img_mu);
@@ -884,7 +896,12 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
       order[p] = p;
     }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return (size_t)pairs[a].img0.w * pairs[a].img0.h > (size_t)pairs[b].img0.w * pairs[b].img0.h; });
-    for (int p : order) { blk0[p] = (uint32_t)total_blocks; total_blocks += (int)nblk[p]; }
+    // the workgroup map packs (pair << 16 | block): 65535 pairs x 65535 workgroups each, and the grid must stay a positive int
+    if (n > 65535) return fail(DFX_E_INVALID, "a batch of several image sizes holds at most 65535 pairs (got %d)", n);
+    long long tb = 0;
+    for (int p : order) { blk0[p] = (uint32_t)tb; tb += (long long)nblk[p]; }
+    if (tb > 0x7fffffffLL) return fail(DFX_E_INVALID, "launch shape of %lld workgroups exceeds the grid limit", tb);
+    total_blocks = (int)tb;
   }
 
   if ((rc = ray_table_gc(c))) return rc;
@@ -910,7 +927,9 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
   for (int p = 0; p < n; ++p) {
     const dfx_sfm_pair& q = pairs[p];
     if ((rc = fill_sfm_pair(c, cs, &q.pose0, &q.pose1, &q.cam, &q.img0, &q.img1, &q.dpt0, &q.valid0, &q.prx0_jac, &q.grad1, q.img0.w, q.img0.h, &hd[p]))) {
-      g_last_error = "pair " + std::to_string(p) + ": " + g_last_error;
+      const std::string why = "pair " + std::to_string(p) + ": " + g_last_error;
+      if (slot >= 0) (void)stage_release(c, slot);   // the slot was handed out: give it its event like every other path
+      g_last_error = why;
       return rc;
     }
     hd[p].w_px = q.img0.w; hd[p].h_px = q.img0.h;

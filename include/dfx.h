@@ -137,24 +137,20 @@ DFX_API int dfx_sync(dfx_ctx* ctx);
  * CU count and the batch).  A non-zero dfx_sfm_params.step_blocks overrides it per call. */
 DFX_API int dfx_sfm_set_step_blocks(dfx_ctx* ctx, int blocks_per_pair);
 DFX_API int dfx_device_cu_count(dfx_ctx* ctx);
-/* How the JtJ/Jtr outer products of the SfM / DepthAligner step are evaluated on the matrix cores (fp32 in, fp32 out):
- *  DFX_MFMA_F32_CHAIN  (default) v_mfma_f32_16x16x4_f32 -- bitwise an fp32 fmaf chain over the pixels of a wave.
- *  DFX_MFMA_BF16X3     opt-in: every fp32 entry is split EXACTLY into three bf16 pieces (x = h + m + l, round-to-nearest-even
- *                      through v_cvt_pk_bf16_f32) and the products are summed as hh + hm + mh + hl + lh + mm on
- *                      v_mfma_f32_16x16x32_bf16 with fp32 accumulation; the dropped terms are below 2^-26 of a product, i.e.
- *                      below the rounding of an fp32 multiply -- measured error against the fp64 oracle equals the chain's
- *                      (tests/test_gpu_bf16x3.py).  Same inlier sets, same valid0 writes, bit-reproducible for a launch shape
- *                      like the chain, but its bits differ from the chain's.  MI355X, same box: code size 64 at 1280x960
- *                      1200 -> 997 us per 16 pairs (the fp32 chain is matrix-bound there), code size 32 at 640x480 1055 -> 1041 us
- *                      per 128 pairs.  The round-1 implementation of this idea was slower than the chain
- *                      and had been removed; this one costs 11 vector-ALU instructions per pair of values. */
+/* How the JtJ/Jtr outer products of the SfM / DepthAligner step are evaluated on the matrix cores (fp32 in, fp32 out).  A context
+ * starts in DFX_MFMA_AUTO.
+ *  DFX_MFMA_AUTO       (default) the library's choice per code size, by measurement on MI355X: the exact bf16 split
+ *                      from DFX_AUTO_BF16X3_MIN_CS on, i.e. at every supported code size.  Headline sweep (640x480, CS = 32, 128 pairs):
+ *                      0.75 of the 8 TB/s roofline; the same sweep pinned to DFX_MFMA_F32_CHAIN: 0.69.
+ *  DFX_MFMA_BF16X3     every fp32 entry is split EXACTLY into three bf16 pieces (x = h + m + l, round-to-nearest-even through
+ *                      v_cvt_pk_bf16_f32) and the products are summed as hh + hm + mh + hl + lh + mm on v_mfma_f32_16x16x32_bf16
+ *                      with fp32 accumulation; the dropped terms are below 2^-24 of a product, i.e. the rounding of an fp32
+ *                      multiply -- measured error against the fp64 oracle equals the chain's (tests/test_gpu_bf16x3.py).  Same inlier
+ *                      sets, same valid0 writes, bit-reproducible for a launch shape like the chain; its bits differ from the chain's.
+ *  DFX_MFMA_F32_CHAIN  pinned by a caller that wants the fmaf-chain bits: v_mfma_f32_16x16x4_f32 -- bitwise an fp32 fmaf chain over
+ *                      the pixels of a wave.  Matrix-bound at CS = 64 (0.57 - 0.59 of the roofline against 0.72 - 0.77 for the split). */
 #define DFX_MFMA_F32_CHAIN 0
 #define DFX_MFMA_BF16X3 1
-/*  DFX_MFMA_AUTO       (default) the library's choice per code size, by measurement on MI355X: the exact bf16 split
- *                      from DFX_AUTO_BF16X3_MIN_CS on -- since round 3 every code size: 640x480, CS = 32, 128 pairs 1064 -> 1004 us or better,
- *                      1280x960, CS = 64, 16 pairs 1183 -> 1000 us.  Both modes are fp32-accurate against the fp64 oracle (stated tolerance
- *                      1e-4, measured < 5e-6 of the block scale) and bit-reproducible for a launch shape; they differ from each other in
- *                      the last bits.  A caller that wants the fmaf-chain bits pins DFX_MFMA_F32_CHAIN. */
 #define DFX_MFMA_AUTO 2
 #define DFX_AUTO_BF16X3_MIN_CS 16
 DFX_API int dfx_set_mfma_mode(dfx_ctx* ctx, int mode);

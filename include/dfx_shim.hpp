@@ -115,8 +115,8 @@ class Context {
   dfx_ctx* get() const { return ctx_; }
   int device() const { return dfx_ctx_device(ctx_); }
   void SetStream(void* stream) { check(dfx_ctx_set_stream(ctx_, stream)); }
-  // no reference counterpart: how the step kernels evaluate their sums (DFX_MFMA_F32_CHAIN default / DFX_MFMA_BF16X3) and which launch
-  // schedule batched steps use (DFX_SCHEDULE_*), see include/dfx.h
+  // no reference counterpart: how the step kernels evaluate their sums (DFX_MFMA_AUTO = the exact bf16 split is the default;
+  // DFX_MFMA_F32_CHAIN pins the fmaf-chain bits) and which launch schedule batched steps use (DFX_SCHEDULE_*), see include/dfx.h
   void SetMfmaMode(int mode) { check(dfx_set_mfma_mode(ctx_, mode)); }
   void SetSchedule(int mode) { check(dfx_set_schedule(ctx_, mode)); }
   // The thread's default context: created on first use on the thread's CURRENT device (one process per GPU: this rank's GPU),

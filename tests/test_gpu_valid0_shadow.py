@@ -123,3 +123,25 @@ def test_batch_with_shared_and_mixed_maps(dfx, oracle):
     assert np.array_equal(other.download(), fa.cpu().numpy()) and np.array_equal(fc.cpu().numpy(), fb.cpu().numpy())
     sh = other.valid0_shadow()          # reading variant: the bits were not rebuilt, and whatever they say is a subset of the ones
     assert sh is None or not (sh & (other.download() != 1.0)).any()
+
+
+def test_write_before_the_first_step_is_not_forgotten(dfx):
+    """Advisor finding (round 3): fill(1.0) then upload(zeros) while NO shadow exists in the process, then the first use as valid0.  The record
+    of the image must have learned about the upload: the shadow is created all-clear and the step writes its 1.0s (it once started as
+    `every pixel known to hold 1.0` and the map stayed zero)."""
+    w, h, cs = 160, 120, 32
+    n, g = _pair(w, h, cs, seed=77)
+    ctx = dfx.Context(0)
+    al = dfx.SfmAligner(code_size=cs, ctx=ctx)
+    vld = ctx.alloc_image(w, h)
+    vld.fill(1.0)
+    vld.upload(np.zeros((h, w), np.float32))
+    assert vld.valid0_shadow() is None
+    pose1 = n["pose1"].copy(); pose1[4] += 0.01
+    foreign = torch.zeros_like(g["img0"])
+    a = _step(al, n, g, pose1, foreign)
+    b = _step(al, n, g, pose1, vld)
+    assert np.array_equal(a.raw, b.raw)
+    v = vld.download()
+    assert np.array_equal(v, foreign.cpu().numpy()) and v.sum() > 0
+    assert np.array_equal(vld.valid0_shadow(), v == 1.0)
