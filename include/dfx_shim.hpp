@@ -387,6 +387,16 @@ void UpdateDepth(const CodeT& code, const PrxBuf& prx_orig, const JacBuf& prx_ja
   const dfx_img po = dfx::detail::to_img(prx_orig), jc = dfx::detail::to_img(prx_jac), out = dfx::detail::to_img(dpt_out);
   dfx::check(dfx_update_depth(ctx->get(), CS, cd, &po, &jc, (float)avg_dpt, &out));
 }
+#ifdef DFX_SHIM_HAS_EIGEN
+// The reference's own callers name no template argument: `df::UpdateDepth(cde0, prx_orig, prx_jac, 2.0f, dpt)` (photometric_factor.cpp:337,
+// mapper.cpp:883-886, 986-990) deduces T and CS from `const Eigen::Matrix<T,CS,1>& code` (cu_image_proc.h:40-45) -- found by compiling
+// photometric_factor.cpp unmodified against this header (tests/cpp/ref_callers_test.cpp).
+template <typename T, int CS, typename PrxBuf, typename JacBuf, typename ImageBuf>
+void UpdateDepth(const Eigen::Matrix<T, CS, 1>& code, const PrxBuf& prx_orig, const JacBuf& prx_jac, T avg_dpt, ImageBuf& dpt_out,
+                 const std::shared_ptr<dfx::Context>& ctx = dfx::Context::Default()) {
+  UpdateDepth<T, CS, ImageBuf, Eigen::Matrix<T, CS, 1>, PrxBuf, JacBuf>(code, prx_orig, prx_jac, avg_dpt, dpt_out, ctx);
+}
+#endif
 template <typename ImgBuf, typename GradBuf>
 void SobelGradients(const ImgBuf& img, GradBuf& grad, const std::shared_ptr<dfx::Context>& ctx = dfx::Context::Default()) {
   const dfx_img i = dfx::detail::to_img(img), g = dfx::detail::to_img(grad);

@@ -139,6 +139,20 @@ class SE3 {
     return SE3(invR, invR * (t_ * T(-1)));
   }
   SE3 operator*(const SE3& o) const { return SE3(so3_ * o.so3_, t_ + so3_ * o.t_); }
+  // log: (V^-1 t, omega) with V^-1 = I - 1/2 Omega + (1 - theta cos(theta/2) / (2 sin(theta/2))) / theta^2 Omega^2   (sophus/se3.hpp)
+  Tangent log() const {
+    using std::sqrt; using std::sin; using std::cos; using std::abs;
+    const typename SO3Type::Tangent w = so3_.log();
+    const T theta = sqrt(w.squaredNorm());
+    const typename SO3Type::Transformation Om = SO3Type::hat(w);
+    typename SO3Type::Transformation Vinv = SO3Type::Transformation::Identity() - Om * T(0.5);
+    if (abs(theta) < T(1e-10)) Vinv = Vinv + (Om * Om) * T(1.0 / 12.0);
+    else { const T half = T(0.5) * theta; Vinv = Vinv + (Om * Om) * ((T(1) - theta * cos(half) / (T(2) * sin(half))) / (theta * theta)); }
+    const Point u = Vinv * t_;
+    Tangent r;
+    r(0) = u(0); r(1) = u(1); r(2) = u(2); r(3) = w(0); r(4) = w(1); r(5) = w(2);
+    return r;
+  }
   template <typename D> Point operator*(const Eigen::MatrixBase<D>& p) const { return so3_ * p + t_; }
 
  private:

@@ -25,3 +25,15 @@ def test_cpp_host_layer():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300, stdin=subprocess.DEVNULL)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "host_test OK" in out.stdout
+
+
+@pytest.mark.gpu
+def test_reference_callers_compiled_unmodified_against_the_shim():
+    """tests/cpp/ref_callers_test.cpp #includes the reference's core/gtsam/photometric_factor.cpp and core/system/camera_tracker.cpp whole and
+    unmodified (built by tests/cpp/Makefile in the container that holds /root/reference; the build FAILS if a reference call site stops
+    compiling against include/dfx_shim.hpp) and checks linearize() / error() / TrackFrame() against the C ABI bit for bit."""
+    exe = os.path.join(ROOT, "tests", "cpp", "ref_callers_test")
+    assert os.path.exists(exe), "tests/cpp/ref_callers_test not built: run __graft_entry__.build() where /root/reference exists"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300, stdin=subprocess.DEVNULL)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ref_callers_test OK" in out.stdout
