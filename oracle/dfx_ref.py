@@ -177,3 +177,42 @@ def depth_aligner_step(code, tgt_dpt, prx_orig, prx_jac):
     lib().ref_depth_aligner_step_cs32(_p(_f32(code)), _p(tgt_dpt), _p(prx_orig), _p(prx_jac), C.c_int(w), C.c_int(h), _p(jtj), _p(jtr), C.byref(r), C.byref(n))
     res.JtJ, res.Jtr, res.residual, res.inliers = jtj.astype(np.float64), jtr.astype(np.float64), float(r.value), int(n.value)
     return res
+
+
+# ---- part 3 (oracle/ref_harness_f1.cpp): the reference's image-proc kernel bodies and SE3Aligner::Warp's, cut out at build time ----
+def sobel_gradients(img):
+    """kernel_sobel_gradients (cuda/cu_image_proc.cpp:57-92) over every pixel: [H][W][2] = (gx, gy)."""
+    a = _f32(img).copy()
+    h, w = a.shape
+    out = np.zeros((h, w, 2), np.float32)
+    lib().ref_sobel_gradients(_p(a), C.c_int(w), C.c_int(h), _p(out))
+    return out
+
+
+def gaussian_blur_down(img):
+    """kernel_gaussian_blur_down (cu_image_proc.cpp:134-164): [H/2][W/2]."""
+    a = _f32(img).copy()
+    h, w = a.shape
+    out = np.zeros((h // 2, w // 2), np.float32)
+    lib().ref_gaussian_blur_down(_p(a), C.c_int(w), C.c_int(h), _p(out), C.c_int(w // 2), C.c_int(h // 2))
+    return out
+
+
+def squared_error(a, b):
+    """kernel_squared_error (cu_image_proc.cpp:190-206), its float sum in pixel order."""
+    a, b = _f32(a).copy(), _f32(b).copy()
+    h, w = a.shape
+    f = lib().ref_squared_error
+    f.restype = C.c_float
+    return float(f(_p(a), _p(b), C.c_int(w), C.c_int(h)))
+
+
+def se3_warp(pose_qt, cam, img0, img1, dpt0):
+    """kernel_warp_calculate (cuda/cu_se3aligner.cpp:61-113): (img2, signed residual sum, inliers)."""
+    i0, i1, d0 = _f32(img0).copy(), _f32(img1).copy(), _f32(dpt0).copy()
+    h, w = i0.shape
+    img2 = np.zeros((h, w), np.float32)
+    r = C.c_float(0)
+    n = C.c_uint64(0)
+    lib().ref_se3_warp(_p(_f32(pose_qt)), _p(_f32(cam)), _p(i0), _p(i1), _p(d0), C.c_int(w), C.c_int(h), _p(img2), C.byref(r), C.byref(n))
+    return img2, float(r.value), int(n.value)

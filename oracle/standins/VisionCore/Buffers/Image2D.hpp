@@ -27,6 +27,12 @@ class Image2DView {
   std::size_t area() const { return w_ * h_; }
   T* rowPtr(std::size_t y) const { return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(ptr_)) + y * pitch_); }
   T& operator()(std::size_t x, std::size_t y) const { return rowPtr(y)[x]; }
+  // Buffer2DView::inBounds / getWithClampedRange (used by the image-proc kernels, cu_image_proc.cpp:71,84): inside the image / the nearest pixel inside
+  template <typename I> bool inBounds(I x, I y) const { return x >= I(0) && y >= I(0) && (std::size_t)x < w_ && (std::size_t)y < h_; }
+  const T& getWithClampedRange(int x, int y) const {
+    const int cx = x < 0 ? 0 : (x >= (int)w_ ? (int)w_ - 1 : x), cy = y < 0 ? 0 : (y >= (int)h_ ? (int)h_ - 1 : y);
+    return rowPtr((std::size_t)cy)[cx];
+  }
 
   template <typename TR, typename S>
   TR getBilinear(S u, S v) const {

@@ -63,6 +63,7 @@ def main():
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
     make_f3(synth, ref)
+    make_f1(synth, ref)
 
 
 OUT_F3 = os.path.join(HERE, "ref_vectors_f3.npz")
@@ -95,8 +96,34 @@ def make_f3(synth, ref):
     print("wrote", OUT_F3, os.path.getsize(OUT_F3), "bytes")
 
 
+OUT_F1 = os.path.join(HERE, "ref_vectors_f1.npz")
+
+
+def make_f1(synth, ref):
+    """tests/golden/ref_vectors_f1.npz: the reference's kernel bodies kernel_sobel_gradients / kernel_gaussian_blur_down / kernel_squared_error
+    (cuda/cu_image_proc.cpp:57-206) and kernel_warp_calculate (cuda/cu_se3aligner.cpp:61-113), cut out at build time (oracle/ref_harness_f1.cpp),
+    on stored inputs: an even and an odd image size."""
+    out = {"sources": np.frombuffer(b"cuda/cu_image_proc.cpp:34-206 (SetSobelCoefficients, kernel_sobel_gradients, SetGaussCoefficients, kernel_gaussian_blur_down, "
+                                    b"kernel_squared_error) + cuda/cu_se3aligner.cpp:61-113 (kernel_warp_calculate): kernel bodies cut out at build time", dtype=np.uint8)}
+    for name, w, h, seed in (("a", 64, 40, 0x6F10), ("b", 53, 37, 0x6F11)):
+        n = synth.to_numpy(synth.make_pair(w, h, 16, seed=seed, device="cpu", with_decoder=False))
+        img2, r, k = ref.se3_warp(n["pose10_true"], n["cam"], n["img0"], n["img1"], n["dpt0"])
+        assert k > 0.5 * w * h
+        out.update({f"{name}_cam": n["cam"], f"{name}_pose10": n["pose10_true"], f"{name}_img0": n["img0"], f"{name}_img1": n["img1"], f"{name}_dpt0": n["dpt0"],
+                    f"{name}_sobel": ref.sobel_gradients(n["img0"]), f"{name}_blur": ref.gaussian_blur_down(n["img0"]),
+                    f"{name}_sqerr": np.float32(ref.squared_error(n["img0"], n["img1"])),
+                    f"{name}_warp_img2": img2, f"{name}_warp_residual": np.float32(r), f"{name}_warp_inliers": np.int64(k)})
+    np.savez_compressed(OUT_F1, **out)
+    print("wrote", OUT_F1, os.path.getsize(OUT_F1), "bytes")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--f3-only":   # the first file is left as committed
+    if len(sys.argv) > 1 and sys.argv[1] == "--f1-only":   # the other files are left as committed
+        from deepfactors_amd import synth as _synth
+        from oracle import dfx_ref as _ref
+        _ref.build()
+        make_f1(_synth, _ref)
+    elif len(sys.argv) > 1 and sys.argv[1] == "--f3-only":   # the first file is left as committed
         from deepfactors_amd import synth as _synth
         from oracle import dfx_ref as _ref
         _ref.build()

@@ -127,3 +127,48 @@ def test_hip_path_reproduces_the_reference_f3_vectors(dfx, gold_f3):
     assert np.abs(got.JtJ.astype(np.float64) - g["da_JtJ"]).max() <= 2e-4 * sj        # the reference item itself is a float sum over w*h pixels
     assert np.abs(got.Jtr.astype(np.float64) - g["da_Jtr"]).max() <= 2e-4 * max(float(np.abs(g["da_Jtr"]).max()), float(np.sqrt(sj * float(g["da_residual"]))))
     assert abs(got.residual - float(g["da_residual"])) <= 2e-4 * float(g["da_residual"])
+
+
+# ---- f1 (pyramid construction) and a4 (SE3Aligner::Warp): outputs of the reference's kernel bodies, cut out at build time ---------------------
+GOLD_F1 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_vectors_f1.npz")
+
+
+@pytest.fixture(scope="module")
+def gold_f1():
+    z = np.load(GOLD_F1)
+    return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_oracle_reproduces_the_reference_f1_vectors(oracle, gold_f1, name):
+    g = {k[2:]: v for k, v in gold_f1.items() if k.startswith(name + "_")}
+    assert b"kernel_sobel_gradients" in bytes(gold_f1["sources"])
+    h, w = g["img0"].shape
+    assert np.array_equal(oracle.sobel(g["img0"]), g["sobel"]) and np.array_equal(oracle.blur_down(g["img0"]), g["blur"])
+    assert oracle.squared_error(g["img0"], g["img1"], accum_f64=False) == float(g["sqerr"])
+    img2, r, k = oracle.se3_warp(g["pose10"], g["cam"], g["img0"], g["img1"], g["dpt0"], accum_f64=False)
+    assert abs(k - int(g["warp_inliers"])) <= 1 and int((np.abs(img2 - g["warp_img2"]) > 1e-5).sum()) <= 2
+    assert abs(r - float(g["warp_residual"])) <= 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_hip_path_reproduces_the_reference_f1_vectors(dfx, gold_f1, name):
+    import torch
+    g = {k[2:]: v for k, v in gold_f1.items() if k.startswith(name + "_")}
+    h, w = g["img0"].shape
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()   # noqa: E731
+    i0, i1, d0 = t(g["img0"]), t(g["img1"]), t(g["dpt0"])
+    grad = torch.empty((h, w, 2), dtype=torch.float32, device="cuda")
+    dfx.SobelGradients(i0, grad)
+    assert np.array_equal(grad.cpu().numpy(), g["sobel"])                                   # exact: taps x1, x2, /8
+    half = torch.empty((h // 2, w // 2), dtype=torch.float32, device="cuda")
+    dfx.GaussianBlurDown(i0, half)
+    assert np.abs(half.cpu().numpy() - g["blur"]).max() <= 2e-7                                # 25 taps, one rounding each
+    se = dfx.SquaredError(i0, i1)
+    assert abs(se - float(g["sqerr"])) <= 2e-5 * float(g["sqerr"])                             # the reference's own float sum in pixel order
+    img2 = torch.empty_like(i0)
+    got = dfx.SE3Aligner().Warp(g["pose10"], g["cam"], i0, i1, d0, img2)
+    assert abs(int(got.inliers) - int(g["warp_inliers"])) <= 1
+    assert int((np.abs(img2.cpu().numpy() - g["warp_img2"]) > 1e-5).sum()) <= 2
+    assert abs(got.residual - float(g["warp_residual"])) <= 1e-3

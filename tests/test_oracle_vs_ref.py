@@ -218,3 +218,32 @@ def test_depth_aligner_oracle_equals_reference_code(oracle, refl, w, h, seed):
     assert np.abs(got.JtJ - want.JtJ).max() <= 2e-4 * sj
     assert np.abs(got.Jtr - want.Jtr).max() <= 2e-4 * max(float(np.abs(want.Jtr).max()), float(np.sqrt(sj * want.residual)))
     assert abs(got.residual - want.residual) <= 2e-4 * want.residual
+
+
+@pytest.mark.parametrize("w,h,seed", [(160, 120, 51), (101, 67, 52), (64, 48, 53)])
+def test_image_proc_oracle_equals_reference_kernel_bodies(oracle, refl, w, h, seed):
+    """cuda/cu_image_proc.cpp:57-92 (Sobel), :134-164 (5 x 5 blur + decimate), :190-206 (squared error): the kernel bodies, cut out at build
+    time and run over every pixel (oracle/ref_harness_f1.cpp).  Sobel and the blur are exact: same taps, same order, same division."""
+    n = _pair(w, h, 16, seed, with_decoder=False)
+    assert np.array_equal(oracle.sobel(n["img0"]), refl.sobel_gradients(n["img0"]))
+    assert np.array_equal(oracle.blur_down(n["img0"]), refl.gaussian_blur_down(n["img0"]))
+    want = refl.squared_error(n["img0"], n["img1"])
+    got32 = oracle.squared_error(n["img0"], n["img1"], accum_f64=False)
+    got64 = oracle.squared_error(n["img0"], n["img1"], accum_f64=True)
+    assert got32 == want                                  # the float sum in pixel order is the reference's
+    assert abs(got64 - want) <= 2e-5 * want               # and the fp64 oracle is within the float sum's own rounding
+
+
+@pytest.mark.parametrize("w,h,seed", [(160, 120, 61), (101, 67, 62)])
+def test_se3_warp_oracle_equals_reference_kernel_body(oracle, refl, w, h, seed):
+    """cuda/cu_se3aligner.cpp:61-113: rendered image, SIGNED residual sum, inlier count -- identity and a real relative pose."""
+    from deepfactors_amd import synth
+    n = _pair(w, h, 16, seed, with_decoder=False)
+    for qt in (synth.IDENTITY, n["pose10_true"]):
+        img2_w, r_w, n_w = refl.se3_warp(qt, n["cam"], n["img0"], n["img1"], n["dpt0"])
+        img2_g, r_g, n_g = oracle.se3_warp(qt, n["cam"], n["img0"], n["img1"], n["dpt0"], accum_f64=False)
+        # Sophus rotates through the quaternion in float, the oracle through R rounded once: coordinates differ by ~1 ulp
+        assert abs(n_g - n_w) <= max(1, int(1e-5 * w * h))
+        diff = np.abs(img2_g - img2_w)
+        assert int((diff > 1e-5).sum()) <= max(1, int(1e-5 * w * h)) + abs(n_g - n_w)
+        assert abs(r_g - r_w) <= 2e-5 * max(1.0, float(np.abs(n["img0"]).sum()) * 1e-2)
