@@ -142,6 +142,7 @@ _PROTOS = {
     "dfx_graph_reduce_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "dfx_comm_reduce_f32_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "dfx_items_all_gather_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dfx_comm_broadcast_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "dfx_update_depth": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(Img), C.POINTER(Img), C.c_float,
                                    C.POINTER(Img)]),
     "dfx_update_depth_batch_async": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(Img), C.POINTER(Img), C.c_float, C.POINTER(Img)]),

@@ -515,6 +515,13 @@ extern "C" int dfx_internal_fail(int code, const char* msg) { g_last_error = msg
 // the stream the results of the batched step become complete on: where an exchange of them has to be enqueued
 extern "C" void* dfx_internal_exchange_stream(dfx_ctx* c) { return c->tail_stream ? (void*)c->tail_stream : (void*)c->stream; }
 extern "C" int dfx_internal_ctx_device(dfx_ctx* c) { (void)hipSetDevice(c->device); return c->device; }
+// the stream the INPUTS of the library's launches are ordered on (a broadcast that rewrites keyframe buffers goes there)
+extern "C" void* dfx_internal_main_stream(dfx_ctx* c) { return (void*)c->stream; }
+// a collective is about to overwrite device memory: if it is a library-owned image, its record / valid0 shadow learn about the write
+extern "C" int dfx_internal_note_write(dfx_ctx* c, void* ptr) {
+  const dfx_img im{ ptr, 0, 0, 0 };
+  return img_note_write(c, &im);
+}
 
 // -------------------------------------------------------------------------------------------------------------
 extern "C" {

@@ -24,10 +24,12 @@
 extern "C" int dfx_internal_fail(int code, const char* msg);
 extern "C" void* dfx_internal_exchange_stream(dfx_ctx* ctx);
 extern "C" int dfx_internal_ctx_device(dfx_ctx* ctx);
+extern "C" void* dfx_internal_main_stream(dfx_ctx* ctx);
+extern "C" int dfx_internal_note_write(dfx_ctx* ctx, void* ptr);
 
 namespace {
 
-// the subset of rccl.h (ROCm 7.x: /opt/rocm/include/rccl/rccl.h:40-43,187,220,448-466,550,611,678) this file needs
+// the subset of rccl.h (ROCm 7.x: /opt/rocm/include/rccl/rccl.h:40-43,187,220,448-466,550,590,611,678) this file needs
 struct NcclUniqueId { char internal[128]; };
 typedef void* NcclComm;
 enum { kNcclSuccess = 0, kNcclSum = 0, kNcclUint8 = 1, kNcclFloat = 7 };
@@ -39,6 +41,7 @@ struct Rccl {
   int (*Reduce)(const void*, void*, size_t, int, int, int, NcclComm, void*) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, void*) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, NcclComm, void*) = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, NcclComm, void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   std::string path;
 };
@@ -78,6 +81,7 @@ int load_rccl() {
   r.Reduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, int, NcclComm, void*)>(sym("ncclReduce"));
   r.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, NcclComm, void*)>(sym("ncclAllReduce"));
   r.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, NcclComm, void*)>(sym("ncclAllGather"));
+  r.Broadcast = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, NcclComm, void*)>(sym("ncclBroadcast"));
   r.GetErrorString = reinterpret_cast<const char* (*)(int)>(sym("ncclGetErrorString"));
   if (!ok) return fail(DFX_E_HIP, r.path + " lacks an RCCL entry point this library needs");
   g_rccl = r;
@@ -164,6 +168,21 @@ DFX_API int dfx_items_all_gather_async(dfx_ctx* ctx, dfx_comm* c, const void* it
   void* stream = ctx ? dfx_internal_exchange_stream(ctx) : nullptr;
   const int e = g_rccl.AllGather(items_local_dev, items_all_dev, bytes_per_rank, kNcclUint8, c->comm, stream);
   if (e != kNcclSuccess) return nccl_fail("ncclAllGather", e);
+  return DFX_OK;
+}
+
+// Replication of a new keyframe's buffers ("replicate all keyframe pyramids on every GPU ... one-time broadcast per new keyframe";
+// the buffers are those of core/mapping/keyframe.h:46-56).  Unlike the exchange of a step's RESULTS, this one is ordered on the context's
+// MAIN stream: it rewrites inputs of the next launches there, behind whatever still reads the old content.
+DFX_API int dfx_comm_broadcast_async(dfx_ctx* ctx, dfx_comm* c, void* buf_dev, size_t bytes, int root) {
+  if (!c || !buf_dev || bytes == 0) return fail(DFX_E_INVALID, "dfx_comm_broadcast_async: null argument");
+  if (root < 0 || root >= c->world) return fail(DFX_E_INVALID, "root " + std::to_string(root) + " outside the world of " + std::to_string(c->world));
+  void* stream = ctx ? dfx_internal_main_stream(ctx) : nullptr;
+  int rc;
+  if ((rc = load_rccl())) return rc;
+  if (ctx && c->rank != root && (rc = dfx_internal_note_write(ctx, buf_dev))) return rc;   // a valid0 map with a shadow: the bits forget
+  const int e = g_rccl.Broadcast(buf_dev, buf_dev, bytes, kNcclUint8, root, c->comm, stream);
+  if (e != kNcclSuccess) return nccl_fail("ncclBroadcast", e);
   return DFX_OK;
 }
 

@@ -362,6 +362,12 @@ DFX_API int dfx_graph_reduce_async(dfx_ctx* ctx, dfx_comm* comm, const dfx_graph
 /* The collective underneath: n floats summed in place over the ranks (what dfx_graph_reduce_async does with dfx_graph_system_floats(graph)). */
 DFX_API int dfx_comm_reduce_f32_async(dfx_ctx* ctx, dfx_comm* comm, float* buf_dev, size_t n, int root);
 DFX_API int dfx_items_all_gather_async(dfx_ctx* ctx, dfx_comm* comm, const void* items_local_dev, size_t bytes_per_rank, void* items_all_dev);
+/* Replication of keyframe buffers (the pyramids of core/mapping/keyframe.h:46-56: img, dpt, vld, stdev, prx_orig, jac [H][W*CS], plus code and
+ * pose): `bytes` bytes at buf_dev of rank `root` overwrite the same bytes on every other rank (ncclBroadcast, in place).  Every rank calls it with
+ * a buffer of the same size -- pitched images as pitch_bytes * h.  Ordered on the context's MAIN stream (it rewrites inputs of later launches),
+ * not on the tail stream.  include/dfx_host.hpp `dfx::KeyframeBroadcast` walks a keyframe's buffers; one call per buffer, ~60 MB per keyframe
+ * at 640x480x32. */
+DFX_API int dfx_comm_broadcast_async(dfx_ctx* ctx, dfx_comm* comm, void* buf_dev, size_t bytes, int root);
 
 /* ---- image-proc free functions (cuda/cu_image_proc.h:27-46) ---------------------------------- */
 /* UpdateDepth (cu_image_proc.cpp:248-277): dpt = a/(prx_orig + prx_jac . code) - a; code is a HOST array of cs floats. */

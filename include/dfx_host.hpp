@@ -20,6 +20,8 @@
 #pragma once
 #include <array>
 #include <cmath>
+#include <cstdint>
+#include <cstring>
 #include <limits>
 #include <map>
 #include <memory>
@@ -148,6 +150,40 @@ struct Keyframe : Frame {
   DeviceImage<Grad2f> dpt_grad;
   std::array<float, CS> code;
 };
+
+// ---- replication of a keyframe over the ranks (the multi-GPU C ABI of include/dfx.h) ----------------------------------------------
+// Every rank constructs the keyframe with the same sizes; rank `root` holds the content (FillPyramids, SetDecoderOutputs, code, pose).  One
+// ncclBroadcast per buffer on the context's stream, the small host-side fields (code, pose, id, timestamp) through one device scratch image.
+template <int CS>
+void KeyframeBroadcast(Keyframe<CS>& kf, dfx_comm* comm, int root) {
+  dfx_ctx* c = kf.ctx->get();
+  auto bc = [&](const dfx_img& im) { check(dfx_comm_broadcast_async(c, comm, im.ptr, im.pitch_bytes * (std::size_t)im.h, root)); };
+  for (std::size_t i = 0; i < kf.pyr_img.Levels(); ++i) {
+    bc(kf.pyr_img[i].c_img()); bc(kf.pyr_grad[i].c_img()); bc(kf.pyr_dpt[i].c_img()); bc(kf.pyr_vld[i].c_img()); bc(kf.pyr_stdev[i].c_img());
+    bc(kf.pyr_prx_orig[i].c_img()); bc(kf.pyr_jac[i].c_img());
+  }
+  bc(kf.dpt_grad.c_img());
+  // code (CS), pose (7), id, timestamp as one row of floats / raw words
+  constexpr std::size_t kWords = CS + 7 + 4;
+  DeviceImage<float> small(kWords, 1, kf.ctx);
+  std::vector<float> h(kWords, 0.f);
+  for (int k = 0; k < CS; ++k) h[(std::size_t)k] = kf.code[(std::size_t)k];
+  for (int k = 0; k < 4; ++k) h[CS + (std::size_t)k] = kf.pose_wk.q[k];
+  for (int k = 0; k < 3; ++k) h[CS + 4 + (std::size_t)k] = kf.pose_wk.t[k];
+  const std::uint64_t id64 = kf.id;
+  std::memcpy(&h[CS + 7], &id64, 8);
+  std::memcpy(&h[CS + 9], &kf.timestamp, 8);
+  small.Upload(h);
+  bc(small.c_img());
+  h = small.Download();   // blocking: also the point where the broadcasts above are known to be complete on this rank
+  for (int k = 0; k < CS; ++k) kf.code[(std::size_t)k] = h[(std::size_t)k];
+  for (int k = 0; k < 4; ++k) kf.pose_wk.q[k] = h[CS + (std::size_t)k];
+  for (int k = 0; k < 3; ++k) kf.pose_wk.t[k] = h[CS + 4 + (std::size_t)k];
+  std::uint64_t idr;
+  std::memcpy(&idr, &h[CS + 7], 8);
+  kf.id = (std::size_t)idr;
+  std::memcpy(&kf.timestamp, &h[CS + 9], 8);
+}   // (the valid0 shadows of the rewritten maps are reset by dfx_comm_broadcast_async itself: it is a writer the library sees)
 
 // ---- gtsam::traits<Sophus::SE3f>::Local (core/gtsam/gtsam_traits.h:66-72): (t2 - t1, log(R2 R1^T)) -------------------------------------
 namespace detail {

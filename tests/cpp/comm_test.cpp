@@ -44,6 +44,13 @@ static void rank_main(int rank, const unsigned char* id, std::vector<std::vector
   (*reduced)[rank] = sys;
   (*reduced)[kWorld + rank] = sys2;
   REQUIRE(dfx_comm_reduce_f32_async(nullptr, comm, sys.data(), sys.size(), kWorld) == DFX_E_INVALID);   // root outside the world
+  // ---- keyframe replication: rank 1's buffer lands on every rank, bytes and all
+  std::vector<unsigned char> kfbuf(1000 + 37);
+  for (size_t i = 0; i < kfbuf.size(); ++i) kfbuf[i] = (unsigned char)((rank * 131 + i * 7) & 0xff);
+  REQUIRE(dfx_comm_broadcast_async(nullptr, comm, kfbuf.data(), kfbuf.size(), 1) == DFX_OK);
+  for (size_t i = 0; i < kfbuf.size(); ++i) REQUIRE(kfbuf[i] == (unsigned char)((1 * 131 + i * 7) & 0xff));
+  REQUIRE(dfx_comm_broadcast_async(nullptr, comm, kfbuf.data(), kfbuf.size(), kWorld) == DFX_E_INVALID);
+  REQUIRE(dfx_comm_broadcast_async(nullptr, comm, kfbuf.data(), 0, 0) == DFX_E_INVALID);
   dfx_comm_destroy(comm);
 }
 
@@ -89,6 +96,6 @@ int main() {
       REQUIRE(std::memcmp(&gathered[r][((size_t)owner * per + (p - first)) * kItemFloats], it, sizeof(it)) == 0);
     }
   }
-  std::printf("comm_test OK (%d pairs over %d ranks: gather, reduce, all-reduce)\n", kPairs, kWorld);
+  std::printf("comm_test OK (%d pairs over %d ranks: gather, reduce, all-reduce, broadcast)\n", kPairs, kWorld);
   return 0;
 }

@@ -143,6 +143,17 @@ int main() {
       }
       REQUIRE(sum == total);
     }
+    {   // keyframe replication over the multi-GPU C ABI (real RCCL, a world of one): the root's content stays, the call orders on the stream
+      unsigned char id[DFX_COMM_ID_BYTES];
+      dfx::check(dfx_comm_get_unique_id(id));
+      dfx_comm* comm = nullptr;
+      dfx::check(dfx_comm_create(ctx->get(), id, 0, 1, &comm));
+      const std::vector<float> before = kfs[1]->pyr_jac[0].Download();
+      const std::array<float, CS> code_before = kfs[1]->code;
+      dfx::KeyframeBroadcast<CS>(*kfs[1], comm, 0);
+      REQUIRE(kfs[1]->pyr_jac[0].Download() == before && kfs[1]->code == code_before && kfs[1]->id == 1);
+      dfx_comm_destroy(comm);
+    }
     std::printf("host_test OK (%d factors, %d relinearised after moving one node)\n", n, expect);
   } catch (const std::exception& e) {
     std::printf("exception: %s\n", e.what());

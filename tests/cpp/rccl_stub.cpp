@@ -1,4 +1,4 @@
-// rccl_stub.cpp -- TEST INFRASTRUCTURE: a host-memory stand-in for the seven RCCL entry points libdfx resolves at run time
+// rccl_stub.cpp -- TEST INFRASTRUCTURE: a host-memory stand-in for the eight RCCL entry points libdfx resolves at run time
 // (deepfactors_amd/csrc/dfx_comm.cpp), so that the exchange step behind the C ABI can run as two "ranks" (threads of one process) on a
 // box without a GPU: tests/cpp/comm_test.cpp, loaded through DFX_RCCL_LIB.  Buffers are host pointers, streams are ignored, every
 // collective is blocking (rendezvous of all ranks of the communicator).  Sums are formed in rank order, like a ring reduce would not:
@@ -70,6 +70,16 @@ static int reduce_impl(const void* send, void* recv, size_t count, int dt, int r
 }
 int ncclReduce(const void* send, void* recv, size_t count, int dt, int op, int root, void* comm, void*) { return op == 0 ? reduce_impl(send, recv, count, dt, root, comm) : 4; }
 int ncclAllReduce(const void* send, void* recv, size_t count, int dt, int op, void* comm, void*) { return op == 0 ? reduce_impl(send, recv, count, dt, -1, comm) : 4; }
+int ncclBroadcast(const void* send, void* recv, size_t count, int dt, int root, void* comm, void*) {
+  Comm* c = static_cast<Comm*>(comm);
+  Group* g = c->g;
+  if (root < 0 || root >= g->n) return 4;
+  g->slot[c->rank] = send;
+  g->barrier();
+  if (c->rank != root) std::memcpy(recv, g->slot[root], count * elem(dt));
+  g->barrier();
+  return 0;
+}
 int ncclAllGather(const void* send, void* recv, size_t sendcount, int dt, void* comm, void*) {
   Comm* c = static_cast<Comm*>(comm);
   Group* g = c->g;

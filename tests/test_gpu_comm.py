@@ -55,4 +55,12 @@ def test_comm_world_of_one_reduce_and_gather_follow_the_step(dfx):
         assert all(it.inliers > 0.5 * w * h for it in its)
     with pytest.raises(dfx.DfxError):
         _lib.check(L.dfx_comm_reduce_f32_async(ctx.handle, comm, C.c_void_p(neq.buf.data_ptr()), neq.buf.numel(), 3))
+    # keyframe replication (ncclBroadcast on real RCCL, world of one: the root's bytes stay; a root outside the world is refused), ordered on
+    # the context's stream: a step enqueued behind it reads the broadcast buffer
+    kfimg = keep[0]["img0"].clone()
+    _lib.check(L.dfx_comm_broadcast_async(ctx.handle, comm, C.c_void_p(kfimg.data_ptr()), kfimg.numel() * 4, 0))
+    ctx.sync()
+    assert torch.equal(kfimg, keep[0]["img0"])
+    with pytest.raises(dfx.DfxError):
+        _lib.check(L.dfx_comm_broadcast_async(ctx.handle, comm, C.c_void_p(kfimg.data_ptr()), kfimg.numel() * 4, 1))
     L.dfx_comm_destroy(comm)
