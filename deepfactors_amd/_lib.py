@@ -92,6 +92,7 @@ _PROTOS = {
     "dfx_version": (C.c_char_p, []),
     "dfx_sync": (C.c_int, [C.c_void_p]),
     "dfx_sfm_set_step_blocks": (C.c_int, [C.c_void_p, C.c_int]),
+    "dfx_sfm_auto_step_blocks": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "dfx_device_cu_count": (C.c_int, [C.c_void_p]),
     "dfx_set_mfma_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "dfx_last_mfma_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),

@@ -315,6 +315,14 @@ class SfmAligner:
             raise DfxError(_lib.DFX_E_INVALID, "blocks out of range [0, 65535]")
         self.params_.step_threads, self.params_.step_blocks = threads, int(blocks)
 
+    def AutoStepBlocks(self, w, h, n_pairs, distinct_jacobians=False):
+        """The launch shape the library would pick for `n_pairs` pairs of w x h (dfx_sfm_auto_step_blocks).  A rank of a sharded job pins the
+        shape of the WHOLE pair list (`SetStepThreadsBlocks(256, AutoStepBlocks(w, h, n_total))`): its pairs' items are then the bytes the
+        single-process run of the whole list produces."""
+        out = C.c_int(0)
+        check(_lib.lib().dfx_sfm_auto_step_blocks(self.ctx.handle, self.CS, int(w), int(h), int(n_pairs), int(bool(distinct_jacobians)), C.byref(out)))
+        return int(out.value)
+
     def SetEvalThreadsBlocks(self, threads, blocks):
         if threads % 64:
             raise DfxError(_lib.DFX_E_INVALID, "threads must be a multiple of 64 (the CDNA wavefront)")

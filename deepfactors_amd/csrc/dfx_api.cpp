@@ -661,6 +661,18 @@ DFX_API int dfx_tail_join(dfx_ctx* c) {
   return DFX_OK;
 }
 
+// The launch shape the library would pick for a batch of `npairs` pairs of one size -- what a rank of a sharded job pins (dfx_sfm_params.step_blocks)
+// so that its pairs see the shape of the WHOLE job: per-pair results are then bit-identical however the pair list is split.
+DFX_API int dfx_sfm_auto_step_blocks(dfx_ctx* c, int cs, uint32_t w, uint32_t h, int npairs, int distinct_jacobians, int* blocks_out) {
+  if (!c || !blocks_out) return fail(DFX_E_INVALID, "dfx_sfm_auto_step_blocks: null argument");
+  if (!cs_supported(cs) || w == 0 || h == 0 || npairs < 1) return fail(DFX_E_INVALID, "dfx_sfm_auto_step_blocks: bad argument");
+  const int pinned = c->step_blocks, last = c->last_mfma;
+  c->step_blocks = 0;            // the context's own pinned value must not answer the question
+  *blocks_out = auto_step_blocks(c, w, h, npairs, cs, 0, resolve_mfma(c, cs) == DFX_MFMA_BF16X3, distinct_jacobians != 0);
+  c->step_blocks = pinned; c->last_mfma = last;
+  return DFX_OK;
+}
+
 DFX_API int dfx_sfm_set_step_blocks(dfx_ctx* c, int blocks_per_pair) {
   if (!c) return fail(DFX_E_INVALID, "null context");
   if (blocks_per_pair < 0 || blocks_per_pair > 65535) return fail(DFX_E_INVALID, "blocks_per_pair out of range");

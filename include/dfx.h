@@ -136,6 +136,12 @@ DFX_API int dfx_sync(dfx_ctx* ctx);
 /* Context-wide default of dfx_sfm_params.step_blocks (workgroups per pair of the step kernel); 0 = automatic (sized from the
  * CU count and the batch).  A non-zero dfx_sfm_params.step_blocks overrides it per call. */
 DFX_API int dfx_sfm_set_step_blocks(dfx_ctx* ctx, int blocks_per_pair);
+/* The automatic choice for a batch of `npairs` pairs of w x h (distinct_jacobians: every pair streams its own prx_jac), without launching
+ * anything.  A pair's sums are bit-reproducible for a launch SHAPE (workgroups per pair); the automatic shape depends on the batch size, so the
+ * same pair inside a 1024-pair launch and inside a 128-pair shard differs in the last bits.  A sharded job ("1/2/4/8-GPU results
+ * bit-identical per pair") asks for the shape of the WHOLE pair list here and pins it on every rank through dfx_sfm_params.step_blocks:
+ * tests/test_gpu_shard_invariance.py. */
+DFX_API int dfx_sfm_auto_step_blocks(dfx_ctx* ctx, int cs, uint32_t w, uint32_t h, int npairs, int distinct_jacobians, int* blocks_out);
 DFX_API int dfx_device_cu_count(dfx_ctx* ctx);
 /* How the JtJ/Jtr outer products of the SfM / DepthAligner step are evaluated on the matrix cores (fp32 in, fp32 out).  A context
  * starts in DFX_MFMA_AUTO.
