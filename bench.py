@@ -262,6 +262,13 @@ def small_operator_rooflines(dfx, synth, ctx, dev):
     byts = 20 * W * H * P
     out["se3_step_batch_128pairs"] = dict(us=us, algorithmic_bytes=byts, algorithmic_gbs=byts / us / 1e3, frac=byts / us / 1e3 / HBM_PEAK_GBS,
                                           note="k_se3_step_batch + finalize: 128 distinct 640x480 pairs in one launch (786 MB: beyond the 256 MB Infinity Cache)")
+    # the same launch at the pairs' true relative poses: what a tracker evaluates from its second iteration on.  At the exact identity (the entry above,
+    # kept for continuity with rounds 1-3) the outermost pixel columns / rows project ONTO the view border, where the fast geometry defers to the
+    # reference-order evaluation: two of the ten 64-pixel bands take that path on every row
+    sarr2 = se3.make_pairs([dict(se3=p["pose10_true"], cam=p["cam"], img0=p["img0"], img1=p["img1"], dpt0=p["dpt0"], grad1=p["grad1"]) for p in prs])
+    us = event_time_us(torch, lambda: se3.RunStepBatch(sarr2, sitems), reps=60, warm=150)
+    out["se3_step_batch_128pairs_true_pose"] = dict(us=us, algorithmic_bytes=byts, algorithmic_gbs=byts / us / 1e3, frac=byts / us / 1e3 / HBM_PEAK_GBS,
+                                                    note="as se3_step_batch_128pairs, evaluated at each pair's generating pose instead of the identity")
     earr = al.make_pairs([dict(pose0=p["pose0"], pose1=p["pose1"], cam=p["cam"], img0=p["img0"], img1=p["img1"], dpt0=p["dpt0"], prx0_jac=p["prx_jac"],
                                grad1=p["grad1"]) for p in prs])
     eitems = torch.zeros(P * 16, dtype=torch.uint8, device=dev)
@@ -377,6 +384,268 @@ def secondary_configs(dfx, synth, ctx, dev):
     return out
 
 
+
+def _R_of(q):
+    x, y, z, w = [float(v) for v in q]
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def gauss_newton_round(dfx, synth, ctx, al, kfs, graph, poses, reps=8, serial=True):
+    """ONE Gauss-Newton iteration of a keyframe window, end to end, the way a mapper would wait for it (Mapper::MappingStep, core/mapping/mapper.cpp:450-552,
+    minus iSAM2): UpdateDepth of every keyframe (batched) -> ONE batched RunStep + block-sparse assembly -> D2H of the system -> host Cholesky of the
+    (gauge-fixed, damped) normal equations -> pose / code update.  Every stage is timed on its own (wall clock, synchronised); `serial` adds the
+    reference's call pattern for the same linearisation: PhotometricFactor::linearize factor by factor -- cold (every call a blocking UpdateDepth +
+    RunStep, photometric_factor.cpp:86-181) and warmed by ONE batched round that seeds every factor's cache (deepfactors_amd.factors.linearize_all)."""
+    import torch
+    import scipy.linalg
+    from types import SimpleNamespace
+    from deepfactors_amd.dist import NormalEquations
+    from deepfactors_amd import factors as F
+    cs, K, D = al.CS, len(kfs), 6 + al.CS
+    n_pairs = graph.n_pairs
+    neq = NormalEquations(graph, cs, kfs[0]["img0"].device)
+    items = torch.zeros(n_pairs * dfx.item_size(12 + cs), dtype=torch.uint8, device=kfs[0]["img0"].device)
+    codes = np.stack([np.asarray(k["code"], np.float32) for k in kfs])
+    poses = [np.asarray(p, np.float32).copy() for p in poses]
+    prx, jac, dpt = [k["prx_orig"] for k in kfs], [k["prx_jac"] for k in kfs], [k["dpt0"] for k in kfs]
+
+    def pairs_of(ps):
+        return al.make_pairs([dict(pose0=ps[int(i)], pose1=ps[int(j)], cam=kfs[int(i)]["cam"], img0=kfs[int(i)]["img0"], img1=kfs[int(j)]["img0"], dpt0=kfs[int(i)]["dpt0"],
+                                   valid0=kfs[int(i)]["valid0"], prx0_jac=kfs[int(i)]["prx_jac"], grad1=kfs[int(j)]["grad1"]) for (i, j) in graph.pairs])
+    keep = np.ones(K * D, bool)
+    keep[0:6] = False                                    # gauge: pose of keyframe 0
+    stages = dict(marshal_ms=[], gpu_ms=[], d2h_ms=[], host_system_ms=[], host_solve_ms=[], update_ms=[], total_ms=[])
+    for rep in range(reps + 2):
+        t = [time.perf_counter()]
+        arr = pairs_of(poses)
+        t.append(time.perf_counter())
+        dfx.UpdateDepthBatch(codes, prx, jac, 2.0, dpt, ctx=ctx)
+        al.RunStepBatchAssembleAsync(arr, items, neq, 0)
+        ctx.sync()
+        t.append(time.perf_counter())
+        buf = neq.buf.cpu()
+        t.append(time.perf_counter())
+        H, g = neq.dense_from(buf.numpy())
+        if rep == 0:
+            keep &= np.diag(H) > 0                       # unknowns no factor touches (the code of a keyframe that is never a pair's keyframe)
+        A = H[np.ix_(keep, keep)]
+        A[np.diag_indices_from(A)] *= 1.0 + 1e-4
+        t.append(time.perf_counter())
+        d = np.zeros(K * D)
+        d[keep] = -scipy.linalg.cho_solve(scipy.linalg.cho_factor(A, lower=True, overwrite_a=True, check_finite=False), g[keep], check_finite=False)
+        t.append(time.perf_counter())
+        # (the timed rounds re-evaluate the same point: the update is computed and retracted into copies)
+        new_poses = [synth.pose_qt(synth.so3_exp(d[k * D + 3:k * D + 6]) @ _R_of(poses[k][:4]), poses[k][4:].astype(np.float64) + d[k * D:k * D + 3]) for k in range(K)]
+        new_codes = (codes + d.reshape(K, D)[:, 6:]).astype(np.float32)
+        del new_poses, new_codes
+        t.append(time.perf_counter())
+        if rep >= 2:
+            for name, a, b in (("marshal_ms", 0, 1), ("gpu_ms", 1, 2), ("d2h_ms", 2, 3), ("host_system_ms", 3, 4), ("host_solve_ms", 4, 5), ("update_ms", 5, 6), ("total_ms", 0, 6)):
+                stages[name].append((t[b] - t[a]) * 1e3)
+    out = {k: float(np.median(v)) for k, v in stages.items()}
+    out.update(keyframes=K, pairs=n_pairs, unknowns=int(keep.sum()), system_bytes=int(neq.buf.numel() * 4),
+               note="one Gauss-Newton iteration end to end (median of %d): pair descriptors (host) | batched UpdateDepth + batched RunStep + assembly (GPU, to sync) | D2H of the "
+                    "block-sparse system | dense host system | scipy Cholesky (LAPACK, all host cores) | retract" % reps)
+    if serial:
+        # the reference's per-factor pattern over the same factor set
+        mk = lambda k: SimpleNamespace(pyr_img=[k["img0"]], pyr_grad=[k["grad1"]], pyr_dpt=[k["dpt0"]], pyr_vld=[k["valid0"]], pyr_stdev=[k["std0"]],   # noqa: E731
+                                       pyr_prx_orig=[k["prx_orig"]], pyr_jac=[k["prx_jac"]])
+        objs = [mk(k) for k in kfs]
+        facs = [F.PhotometricFactor(kfs[int(i)]["cam"], objs[int(i)], objs[int(j)], ("p", int(i)), ("p", int(j)), ("c", int(i)), 0, al) for (i, j) in graph.pairs]
+        vals = [(poses[int(i)], poses[int(j)], codes[int(i)]) for (i, j) in graph.pairs]
+        for f, v in zip(facs, vals):
+            f.linearize(*v)
+        ctx.sync()
+        cold, warm = [], []
+        for rep in range(3):
+            for f in facs:
+                f.first_ = True                          # forget the cache: every linearize() is a blocking UpdateDepth + RunStep
+            t0 = time.perf_counter()
+            for f, v in zip(facs, vals):
+                f.linearize(*v)
+            cold.append((time.perf_counter() - t0) * 1e3)
+            for f in facs:
+                f.first_ = True
+            t0 = time.perf_counter()
+            F.linearize_all(facs, vals)                  # ONE batched round seeds every cache ...
+            for f, v in zip(facs, vals):
+                f.linearize(*v)                          # ... and the serial calls iSAM2 makes launch nothing
+            warm.append((time.perf_counter() - t0) * 1e3)
+        out.update(serial_linearize_cold_ms=float(np.median(cold)), serial_linearize_warmed_ms=float(np.median(warm)),
+                   serial_note="PhotometricFactor::linearize called factor by factor over the same factors (Python mirror deepfactors_amd.factors, incl. the "
+                               "G11..G33 slicing per factor): cold = every call a blocking UpdateDepth + RunStep (the reference's pattern); warmed = one "
+                               "linearize_all round first, then the same serial calls hit their caches")
+    return out
+
+
+def tracker_and_geometric_configs(dfx, synth, ctx, dev):
+    """BASELINE configs[0] (3-level SE3 tracker; the synthetic 640x480 pair of SURVEY 8d cfg 1 AND the reference's 320x240 fixture 1047 -> 1052 of
+    tests/ut_se3aligner.cpp:173-211) and the geometric half of configs[2] (SparseGeometricFactor::linearize with geo_npoints = 500,
+    data/flags/common.flags:29-34, for the 120 pairs of the 16-keyframe window)."""
+    import torch
+    from scipy import ndimage
+    out = {}
+    # ---- configs[0], synthetic 640x480, levels 0..2, iterations 10,5,5 (flags tracking_iters = 5,5,10 are coarse-to-fine)
+    p = synth.make_pair(640, 480, 16, seed=0xDF01, device=dev, with_decoder=False)
+    cams = synth.camera_pyramid(p["cam"], 3)
+    lv = [dict(img0=p["img0"], img1=p["img1"], dpt0=p["dpt0"], grad1=p["grad1"])]
+    for _ in range(2):
+        q = lv[-1]
+        h, w = q["img0"].shape
+        n = {}
+        for k in ("img0", "img1"):
+            n[k] = torch.empty((h // 2, w // 2), dtype=torch.float32, device=dev)
+            dfx.GaussianBlurDown(q[k], n[k], ctx)
+        n["dpt0"] = q["dpt0"][::2, ::2].contiguous()
+        n["grad1"] = torch.empty((h // 2, w // 2, 2), dtype=torch.float32, device=dev)
+        dfx.SobelGradients(n["img1"], n["grad1"], ctx)
+        lv.append(n)
+    iters = (10, 5, 5)
+    trk = dfx.CameraTracker(cams, dfx.TrackerConfig(3, iters, 0.1), ctx)
+    trk.SetKeyframe([l["img0"] for l in lv], [l["dpt0"] for l in lv])
+
+    def frame():
+        trk.Reset()
+        return trk.TrackFrame([l["img1"] for l in lv], [l["grad1"] for l in lv])
+    for _ in range(20):
+        pose = frame()
+    t0 = time.perf_counter()
+    reps = 100
+    for _ in range(reps):
+        pose = frame()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    gt = np.asarray(p["pose10_true"], np.float64)
+    out["configs0_se3_tracker_3level"] = dict(ms_per_frame=ms, frames_per_s=1e3 / ms, iterations=list(iters), levels=3, width=640, height=480,
+                                              pose_error_t=float(np.linalg.norm(pose[4:] - gt[4:])), pose_error_q=float(np.linalg.norm(pose[:4] - gt[:4])),
+                                              residual_per_inlier=float(trk.GetError()), inliers_frac=float(trk.GetInliers()),
+                                              note="CameraTracker::TrackFrame (core/system/camera_tracker.cpp:42-71) as ONE enqueue (dfx_track_frame: SE3 step + 6x6 LDL^T + retract "
+                                                   "on the device, 20 iterations over 3 levels), from identity, incl. the blocking read-back of the pose")
+    # ---- configs[0], the reference's fixture (ut_se3aligner.cpp:45-97,173-211): 320x240, 25x25 box blur, depth mm -> m, 40 iterations, criterion residual / inliers <= 1e-3
+    fx = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "se3_fixture_1047_1052.npz")
+    if os.path.exists(fx):
+        d = np.load(fx)
+        img0 = ndimage.uniform_filter(d["img0"].astype(np.float32) / np.float32(255), 25, mode="mirror")
+        img1 = ndimage.uniform_filter(d["img1"].astype(np.float32) / np.float32(255), 25, mode="mirror")
+        dpt0 = d["dpt0_mm"].astype(np.float32) / np.float32(1000)
+        cam = np.array([np.float32(160 / 0.5773502691896257), np.float32(120 / 0.41421356237309503), 160, 120, 320, 240], np.float32)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+        g1 = torch.empty((240, 320, 2), dtype=torch.float32, device=dev)
+        i0, i1, d0 = t(img0), t(img1), t(dpt0)
+        dfx.SobelGradients(i1, g1, ctx)
+        tr = dfx.CameraTracker([cam], dfx.TrackerConfig(1, (40,), 0.1), ctx)
+        tr.SetKeyframe([i0], [d0])
+        for _ in range(10):
+            tr.Reset(); tr.TrackFrame([i1], [g1])
+        t0 = time.perf_counter()
+        for _ in range(50):
+            tr.Reset(); tr.TrackFrame([i1], [g1])
+        ms = (time.perf_counter() - t0) / 50 * 1e3
+        out["configs0_se3_fixture_1047_1052"] = dict(ms_per_alignment=ms, iterations=40, width=320, height=240, residual_per_inlier=float(tr.GetError()),
+                                                     inliers_frac=float(tr.GetInliers()), passes_reference_criterion=bool(tr.GetError() <= 1e-3),
+                                                     note="ut_se3aligner.cpp ImageAlignmentTest on the reference's own images (data/testimg/1047.jpg, 1052.jpg, 1047.png): 40 "
+                                                          "Gauss-Newton iterations from identity in one enqueue; criterion residual / inliers <= 1e-3")
+    # ---- configs[2], geometric half: 120 pairs x 500 points
+    W, H, CS, K, NPTS = 640, 480, 32, 16, 500
+    from deepfactors_amd.dist import PairGraph
+    graph = PairGraph.all_pairs(K, both_directions=False)
+    kfs = [synth.make_pair(W, H, CS, seed=0x1600 + k, device=dev) for k in range(K)]
+    dgrad = []
+    for k in kfs:
+        g = torch.empty((H, W, 2), dtype=torch.float32, device=dev)
+        dfx.SobelGradients(k["dpt0"], g, ctx)            # mapper.cpp:998-1000: the keyframe's depth gradient
+        dgrad.append(g)
+    rng = np.random.default_rng(0xDF02)
+    facs = []
+    for (i, j) in graph.pairs:
+        pts = np.stack([rng.integers(0, W, NPTS), rng.integers(0, H, NPTS)], 1).astype(np.int32)
+        a, b = kfs[int(i)], kfs[int(j)]
+        facs.append((dfx.SparseGeometricFactor(a["cam"], pts, dict(prx_orig=a["prx_orig"], prx_jac=a["prx_jac"]),
+                                               dict(prx_orig=b["prx_orig"], prx_jac=b["prx_jac"], dpt_grad=dgrad[int(j)]), 0.1, code_size=CS, ctx=ctx), a, b))
+    def geo_round():
+        rows = None
+        for f, a, b in facs:
+            rows = f.linearize(a["pose0"], b["pose1"], a["code"], b["code"])
+        return rows
+    for _ in range(3):
+        rows = geo_round()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        rows = geo_round()
+    dt = (time.perf_counter() - t0) / 5
+    out["configs2_sparse_geometric_500pts"] = dict(round_ms=dt * 1e3, factors=len(facs), points_per_factor=NPTS, us_per_factor=dt / len(facs) * 1e6,
+                                                   nonzero_rows_last=int((np.abs(rows).sum(1) > 0).sum()),
+                                                   note="SparseGeometricFactor::linearize (core/gtsam/sparse_geometric_factor.cpp:147-275) for the 120 pairs of the 16-keyframe window, "
+                                                        "500 points each: one blocking dfx_sparse_geometric_linearize per factor (the reference's per-factor pattern; it is a CPU loop "
+                                                        "there that first syncs the 39 MB code Jacobian to the host), rows read back to the host")
+    # ---- configs[2]: one Gauss-Newton iteration of the 16-keyframe / 120-pair window end to end
+    al = dfx.SfmAligner(code_size=CS, ctx=ctx)
+    poses = []
+    for k in range(K):
+        R = synth.so3_exp(rng.normal(0, 0.004, 3))
+        poses.append(synth.pose_qt(R, rng.normal(0, 0.008, 3)))
+    out["configs2_gauss_newton_round_16kf_120pairs"] = gauss_newton_round(dfx, synth, ctx, al, kfs, graph, poses)
+    del kfs, facs, dgrad
+    torch.cuda.empty_cache()
+    # the same relinearisation round from C++ (include/dfx_host.hpp; the Python mirror above pays ~0.1 ms of interpreter time per factor): the reference's serial
+    # linearize() pattern, the batched seam, and the serial pattern warmed by the batched seam -- tools/cpp/gn_round_bench.cpp, built by tests/cpp/Makefile
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "cpp", "gn_round_bench")
+    if os.path.exists(exe):
+        try:
+            r = subprocess.run([exe, "16", "7"], capture_output=True, text=True, timeout=120, stdin=subprocess.DEVNULL)
+            vals = {}
+            for line in r.stdout.splitlines():
+                tok = line.split()
+                if len(tok) == 4 and tok[0].endswith("_ms"):
+                    vals[tok[0]] = float(tok[1]); vals[tok[0][:-3] + "_per_factor_us"] = float(tok[3])
+            if r.returncode == 0 and vals:
+                vals["note"] = ("C++ host layer, 16 keyframes / 120 factors of 640x480x32 per round, median of 7: serial_cold = PhotometricFactor::linearize factor by factor "
+                                "(blocking UpdateDepth + RunStep each: what a header-swap build under iSAM2 delivers); batched = dfx::LinearizeAll (one decode + one step launch); "
+                                "serial_warmed = LinearizeAll, then the serial calls hit their caches; every variant incl. the G11..G33 slicing")
+                out["configs2_relinearisation_round_cpp"] = vals
+            else:
+                out["configs2_relinearisation_round_cpp"] = {"error": (r.stdout + r.stderr)[-300:]}
+        except Exception as e:   # noqa: BLE001 -- an extra figure, never the line
+            out["configs2_relinearisation_round_cpp"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def cpu_baseline_se3(levels_iters=(10, 5, 5)):
+    """cpu_baseline leg of configs[0]: the oracle's SE3 step + the reference's solve-and-update (lucas_kanade_se3.h:85-95) in the coarse-to-fine
+    schedule of CameraTracker::TrackFrame on the synthetic 640x480 pair, fp32 accumulate, OpenMP over rows on all host cores and on one thread."""
+    from deepfactors_amd import synth
+    from oracle import dfx_oracle as orc   # cpu_baseline leg only
+    orc.build_native()
+    n = synth.to_numpy(synth.make_pair(640, 480, 16, seed=0xDF01, device="cpu", with_decoder=False))
+    cams = synth.camera_pyramid(n["cam"], 3)
+    lv = [dict(img0=n["img0"], img1=n["img1"], dpt0=n["dpt0"], grad1=orc.sobel(n["img1"]))]
+    for _ in range(2):
+        q = lv[-1]
+        i0, i1 = orc.blur_down(q["img0"]), orc.blur_down(q["img1"])
+        lv.append(dict(img0=i0, img1=i1, dpt0=np.ascontiguousarray(q["dpt0"][::2, ::2][: i0.shape[0], : i0.shape[1]]), grad1=orc.sobel(i1)))
+
+    def track(threads):
+        qt = synth.IDENTITY.copy()
+        for level in (2, 1, 0):
+            for _ in range(levels_iters[level]):
+                r = orc.se3_step(qt, cams[level], lv[level]["img0"], lv[level]["img1"], lv[level]["dpt0"], lv[level]["grad1"], 0.1, accum_f64=False, threads=threads)
+                qt = orc.se3_solve_update(r.JtJ, r.Jtr, qt)
+        return qt
+    cores = orc.max_threads()
+    res = {}
+    for name, th, reps in (("all_cores", cores, 5), ("single_thread", 1, 2)):
+        track(th)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            track(th)
+            ts.append(time.perf_counter() - t0)
+        res[name] = float(np.median(ts)) * 1e3
+    return dict(ms_per_frame=res["all_cores"], cores=cores, single_thread_ms_per_frame=res["single_thread"], kind="port",
+                sample="the oracle's SE3 step (a port of LucasKanadeSE3, lucas_kanade_se3.h:41-77) + SE3SolveAndUpdate in the 10/5/5 schedule over 3 levels of the synthetic "
+                       "640x480 pair, g++ -O3 -march=native, OpenMP over rows")
+
 def window_config(dfx, synth, ctx, dev, dist, rank, world):
     """BASELINE configs[3]: 64 keyframes (replicated on every rank), each linked to its 16 nearest -> 1024 directed pairs, sharded
     contiguously (by source keyframe) over the ranks; per step: one batched launch per rank + graph assembly + RCCL reduce."""
@@ -423,10 +692,16 @@ def window_config(dfx, synth, ctx, dev, dist, rank, world):
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     el = float(el.item())
-    return dict(keyframes=K, pairs=graph.n_pairs, pairs_per_rank=hi - lo, ms_per_step=el / steps * 1e3, evals_per_s=graph.n_pairs * steps / el,
-                system_bytes=int(neq.buf.numel() * 4),
-                note="keyframe pyramids replicated; 16 pairs share each keyframe's 39 MB Jacobian, so this configuration re-reads from L2 / Infinity Cache "
-                     "(not an HBM-roofline figure)")
+    res = dict(keyframes=K, pairs=graph.n_pairs, pairs_per_rank=hi - lo, ms_per_step=el / steps * 1e3, evals_per_s=graph.n_pairs * steps / el,
+               system_bytes=int(neq.buf.numel() * 4),
+               note="keyframe pyramids replicated; 16 pairs share each keyframe's 39 MB Jacobian, so this configuration re-reads from L2 / Infinity Cache "
+                    "(not an HBM-roofline figure)")
+    if dist is None or world == 1:
+        # what a mapper waits for per Gauss-Newton iteration of this window: decode + step + assembly + D2H + host solve + update, and the
+        # reference's serial linearize() pattern over the same 1024 factors (cold / warmed by one batched round)
+        del items, neq, arr
+        res["gauss_newton_round"] = gauss_newton_round(dfx, synth, ctx, al, kfs, graph, poses, reps=4)
+    return res
 
 
 def run_protocol(a, dist, dev, ctx, step, barrier, P):
@@ -630,6 +905,8 @@ def main():
         torch.cuda.empty_cache()
         configs.update(small_operator_rooflines(dfx, synth, ctx, dev))
         torch.cuda.empty_cache()
+        configs.update(tracker_and_geometric_configs(dfx, synth, ctx, dev))
+        torch.cuda.empty_cache()
     if a.window or (world == 1 and not a.no_configs):
         configs["configs3_window64"] = window_config(dfx, synth, ctx, dev, dist, rank, world)
     if dist is not None:
@@ -650,6 +927,8 @@ def main():
                 out["roofline"].update({f"traffic_{k}": v for k, v in detail.items()})
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(W, H, CS)
+                if "configs0_se3_tracker_3level" in configs:
+                    configs["configs0_se3_tracker_3level"]["cpu_baseline"] = cpu_baseline_se3()
         else:
             out["roofline"]["traffic_source"] = "not collected for N > 1 (per-rank kernels are identical to the N = 1 run)"
         print(json.dumps(out), flush=True)

@@ -176,6 +176,22 @@ class NormalEquations:
         return torch.cat(chunks)
 
     # ---- for tests / small systems ----------------------------------------------------------------------------------------
+    def dense_from(self, buf_host):
+        """dense() and the gradient from a HOST copy of the flat buffer (`buf.cpu()`): (H [K D, K D] float64, g [K D] float64), numpy."""
+        D, K, P = self.D, self.graph.n_nodes, self.graph.n_pairs
+        b = np.asarray(buf_host, np.float32)
+        nd, no = K * D * D, P * D * 6
+        Hd = b[:nd].reshape(K, D, D).astype(np.float64)
+        Ho = b[nd:nd + no].reshape(P, D, 6).astype(np.float64)
+        M = np.zeros((K * D, K * D), np.float64)
+        for k in range(K):
+            M[k * D:(k + 1) * D, k * D:(k + 1) * D] = Hd[k]
+        for p, (a, c) in enumerate(self.graph.pairs):
+            a, c = int(a), int(c)
+            M[a * D:(a + 1) * D, c * D:c * D + 6] += Ho[p]
+            M[c * D:c * D + 6, a * D:(a + 1) * D] += Ho[p].T
+        return M, b[nd + no:].astype(np.float64)
+
     def dense(self):
         """Full symmetric (n_nodes * D)^2 matrix and the gradient vector."""
         D, K = self.D, self.graph.n_nodes

@@ -162,6 +162,12 @@ def _run_main(argv, out_path):
     spec = importlib.util.spec_from_file_location("dfx_bench", os.path.join(ROOT, "bench.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
+    # the single-process measurements that drive the tracker, the geometric factor and the host solver are device code end to end (covered on the
+    # GPU by tests/test_gpu_tracker.py, test_gpu_sparse_geometric.py, test_gpu_window.py): here only their place in main()'s control flow
+    b.tracker_and_geometric_configs = lambda *a, **k: {"configs0_se3_tracker_3level": {"ms_per_frame": 1.0}, "configs2_sparse_geometric_500pts": {"round_ms": 1.0},
+                                                       "configs2_gauss_newton_round_16kf_120pairs": {"total_ms": 1.0}}
+    b.gauss_newton_round = lambda *a, **k: {"total_ms": 1.0}
+    b.cpu_baseline_se3 = lambda *a, **k: {"ms_per_frame": 1.0, "cores": 1}
     n_threads = torch.get_num_threads()
     torch.set_num_threads(1)   # the stand-in device runs hundreds of tiny torch ops per second: intra-op threads only add wake-up latency (58 ms vs 0.3 ms per assembly)
     real_device, real_init = torch.device, tdist.init_process_group
@@ -248,7 +254,9 @@ def test_main_with_the_secondary_configurations(tmp_path, monkeypatch):
     d = _check_line(out.read_text(), 1)
     c = d["configs"]
     assert set(c) >= {"headline_workload_other_mode", "configs1_single_pair_blocking", "configs1_pyramid3_128pairs", "configs4_1280x960_cs64", "configs2_linearize_16kf_120pairs",
-                      "update_depth_batch_64kf", "se3_step_batch_128pairs", "sfm_error_batch_128pairs", "configs3_window64"}
+                      "update_depth_batch_64kf", "se3_step_batch_128pairs", "sfm_error_batch_128pairs", "configs3_window64",
+                      "configs0_se3_tracker_3level", "configs2_sparse_geometric_500pts", "configs2_gauss_newton_round_16kf_120pairs"}
+    assert "gauss_newton_round" in c["configs3_window64"]
     assert c["headline_workload_other_mode"]["kernel_us"] > 0 and "error" not in c["headline_workload_other_mode"] and "fp32 fmaf chain" in c["headline_workload_other_mode"]["mfma"]
     assert c["configs4_1280x960_cs64"]["f32_chain"]["kernel_us"] > 0 and "error" not in c["configs4_1280x960_cs64"]["f32_chain"]
     assert c["configs4_1280x960_cs64"]["frac"] > 0 and len(c["configs1_pyramid3_128pairs"]["level_by_level_kernel_us"]) == 3 and c["configs1_pyramid3_128pairs"]["one_launch_kernel_us"] > 0
