@@ -71,8 +71,10 @@ constexpr int kBand = 64;
 #endif
 
 __device__ __forceinline__ float rfl(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+// AUX = cache policy bits of the instruction (0 default, 2 = nt)
+template <int AUX = 0>
 __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, AUX));
 }
 __device__ __forceinline__ f32x2 bload2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
@@ -153,8 +155,11 @@ __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float
     auto load_row = [&](int y) {
       const unsigned yc = (unsigned)(y < y1 ? y : y1 - 1);        // rows past the segment repeat its last row (masked)
       RowIn L;
-      L.d = bload1(rD0, voff, yc * p.pitch_dpt0);
-      L.i0 = bload1(rI0, voff, yc * p.pitch_img0);
+      // depth and intensity are read ONCE: non-temporal, so that they do not push the img1 / grad1 rows the taps re-read (the next row of this
+      // band, the neighbouring band) out of the L2 / Infinity Cache.  The operators are bound by the memory system (profiles/
+      // r04_rowwalk_memory_bound.txt): EvaluateError 120 -> 110 us per 128 pairs, SE3 step -1 %; `nt` on the taps themselves costs 5 - 30 %.
+      L.d = bload1<2>(rD0, voff, yc * p.pitch_dpt0);
+      L.i0 = bload1<2>(rI0, voff, yc * p.pitch_img0);
       L.ry = bload1(rRay, 0, ((unsigned)W + yc) * 4u);
       return L;
     };
