@@ -3,8 +3,8 @@
 //   SfmAligner::EvaluateError    (cu_sfmaligner.cpp:72-147, dense_sfm.h:79-119)
 //   UpdateDepth, SobelGradients, GaussianBlurDown, SquaredError (cu_image_proc.cpp:57-277)
 //   DepthAligner::RunStep        (cu_depthaligner.cpp:32-110)
-// All reductions: lane = pixel, grid-stride over 64-pixel chunks, wave shuffle (64 wide) -> LDS across the
-// 4 waves in fixed order -> one 32-float partial per workgroup -> k_finalize_rows sums the partials in double
+// Warp / SquaredError: lane = pixel, grid-stride over 64-pixel chunks; SE3 step / EvaluateError: the row walk below.  All reductions: wave
+// fold -> LDS across the 4 waves in fixed order -> one 32-float partial per workgroup -> k_finalize_rows sums the partials in double
 // in fixed order.  Inlier counts travel as exact floats (< 2^24 per workgroup) and are summed in double.
 #include "dfx_device.hpp"
 #include "dfx_kernels.hpp"
@@ -118,6 +118,11 @@ __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float
   const __amdgpu_buffer_rsrc_t rI1 = make_rsrc(p.img1, p.pitch_img1 * HB);
   const __amdgpu_buffer_rsrc_t rG1 = make_rsrc(GRAD ? p.grad1 : p.img1, (GRAD ? p.pitch_grad1 : p.pitch_img1) * HB);
   const __amdgpu_buffer_rsrc_t rRay = make_rsrc(p.ray_tab, (unsigned)(W + H) * 4u);
+  // the row part of the ray table is wave-uniform: read through the scalar cache (s_load_dword), not the vector memory pipeline -- the
+  // reductions are bound by the number of vector-memory instructions per row (tools/ubench/band_walk.cpp: a broadcast dword load per row
+  // costs the EvaluateError skeleton 6 us of 82 per 128 pairs; the kernels: EvaluateError 114.3 -> 110.3 us, SE3 step 189.5 -> 185.7)
+  typedef const float __attribute__((address_space(4)))* ConstF;
+  const ConstF ray_rows = (ConstF)(unsigned long long)(p.ray_tab + W);
   // tap offsets are relative to pixel (icx, icy): fold it into a scalar
   const unsigned c1 = (unsigned)fg.icy * p.pitch_img1 + (unsigned)fg.icx * 4u;
   const unsigned cg = GRAD ? (unsigned)fg.icy * p.pitch_grad1 + (unsigned)fg.icx * 8u : 0u;
@@ -160,7 +165,7 @@ __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float
       // r04_rowwalk_memory_bound.txt): EvaluateError 120 -> 110 us per 128 pairs, SE3 step -1 %; `nt` on the taps themselves costs 5 - 30 %.
       L.d = bload1<2>(rD0, voff, yc * p.pitch_dpt0);
       L.i0 = bload1<2>(rI0, voff, yc * p.pitch_img0);
-      L.ry = bload1(rRay, 0, ((unsigned)W + yc) * 4u);
+      L.ry = ray_rows[yc];
       return L;
     };
     // geometry of one row + issue of its taps.  `rowmask` (scalar): all ones if the row belongs to the segment

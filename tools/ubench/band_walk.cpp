@@ -1,0 +1,326 @@
+// band_walk.cpp -- what does HBM deliver for the ACCESS PATTERN of the row-walk reductions (SE3 step, EvaluateError), with everything else removed?
+// The kernels walk [480][640] fp32 images of 128 pairs: a wave owns a 64-pixel column band and walks down a segment of rows, one 256-byte
+// wave load per image and row; a workgroup = 4 adjacent bands.  They reach 4.5 TB/s (algorithmic) from HBM and 6.7 TB/s when the batch fits the
+// Infinity Cache, whatever the instruction count (profiles/r04_rowwalk_*.txt), while a contiguous stream reaches 7.05 TB/s
+// (profiles/r04_stream_ring.txt).  This program walks the same images with nothing but the coalesced loads and varies
+//   VEC   pixels per lane: 1 (256-byte wave loads, the kernels'), 2 (512 B), 4 (1 KiB)  -> band = 64 VEC pixels wide
+//   SEG   rows per item (a wave walks SEG rows of its band)
+//   D     rows in flight per wave and image
+//   ARR   images walked side by side (EvaluateError touches 3 arrays, the SE3 step 4 with the 8-byte gradient)
+//   nt / default cache policy;   order: a workgroup's 4 waves = 4 adjacent bands of one segment ("seg") or 4 consecutive segments of one band ("band")
+// build: hipcc -O3 --offload-arch=gfx950 -o band_walk band_walk.cpp
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+constexpr int W = 640, H = 480;
+constexpr size_t kImg = (size_t)W * H * 4;
+
+template <int VEC> struct Vt;
+template <> struct Vt<1> { typedef unsigned T; };
+template <> struct Vt<2> { typedef u2 T; };
+template <> struct Vt<4> { typedef u4 T; };
+template <int VEC, int AUX> __device__ __forceinline__ typename Vt<VEC>::T ld(const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) {
+  if constexpr (VEC == 1) return __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, AUX);
+  else if constexpr (VEC == 2) return __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, AUX));
+  else return __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, AUX));
+}
+__device__ __forceinline__ unsigned fold(unsigned v) { return v; }
+__device__ __forceinline__ unsigned fold(u2 v) { return v.x ^ v.y; }
+__device__ __forceinline__ unsigned fold(u4 v) { return v.x ^ v.y ^ v.z ^ v.w; }
+
+// grid.x = items of a pair / 4 (4 waves per workgroup), grid.y = pair
+template <int VEC, int ARR, int D, int AUX, bool BANDMAJOR>
+__global__ __launch_bounds__(256) void k_walk(const char* __restrict__ base, int seg, unsigned* sink) {
+  constexpr int BW = 64 * VEC, NB = (W + BW - 1) / BW;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nseg = H / seg;
+  const int item = blockIdx.x * 4 + wave;
+  int band, sg;
+  if (BANDMAJOR) { band = item / nseg; sg = item % nseg; } else { sg = item / NB; band = item % NB; }
+  if (band >= NB || sg >= nseg) return;
+  const int x = band * BW + lane * VEC;
+  if (x >= W) return;
+  const char* pair = base + (size_t)blockIdx.y * ARR * kImg;
+  __amdgpu_buffer_rsrc_t rs[ARR];
+#pragma unroll
+  for (int a = 0; a < ARR; ++a) rs[a] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pair + a * kImg), 0, (int)kImg, 0x00020000);
+  const unsigned voff = x * 4u;
+  typedef typename Vt<VEC>::T V;
+  V ring[D][ARR];
+  unsigned acc = 0;
+  const int y0 = sg * seg;
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+#pragma unroll
+    for (int a = 0; a < ARR; ++a) ring[d][a] = ld<VEC, AUX>(rs[a], voff, (unsigned)(y0 + d) * (W * 4u));
+  for (int y = y0 + D; y < y0 + seg; y += D) {    // seg is a multiple of D
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+#pragma unroll
+      for (int a = 0; a < ARR; ++a) { acc ^= fold(ring[d][a]); ring[d][a] = ld<VEC, AUX>(rs[a], voff, (unsigned)(y + d) * (W * 4u)); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+#pragma unroll
+    for (int a = 0; a < ARR; ++a) acc ^= fold(ring[d][a]);
+  if (acc == 0x12345u) *sink = acc;
+}
+
+// ---- the reductions' own pipeline, rebuilt piece by piece ---------------------------------------------------------------------------
+// Step y of a wave: issue the coalesced loads of row y + 2 (image 0 = depth, image 1 = intensity, both nt), "geometry" of row y + 1 = wait for
+// its depth, derive the tap address, issue the bilinear taps of image 2 (two 8-byte loads at a 4-byte lane stride, rows y+1 and y+2 of the
+// image: the identity warp) [GRAD: and two 16-byte loads at an 8-byte lane stride from the 8-byte-per-pixel image 3], consume row y.
+//   DEP    the tap address depends on the loaded depth (images are zero: address += depth bits)  -> two dependent round trips per row, as in the kernels
+//   FG/FC  dependent fmas per row in the geometry / consume stage (the kernels: ~45 / ~15 EvaluateError, ~45 / ~90 SE3 step)
+//   RAY    the wave-uniform ray-table load of the row (a broadcast dword load)
+template <bool GRAD, bool DEP, int FG, int FC, bool RAY>
+__global__ __launch_bounds__(256) void k_rw(const char* __restrict__ base, const char* __restrict__ gbase, int seg, unsigned* sink) {
+  constexpr int NB = W / 64;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nseg = H / seg;
+  const int item = blockIdx.x * 4 + wave;
+  const int sg = item / NB, band = item % NB;
+  if (sg >= nseg) return;
+  const char* pair = base + (size_t)blockIdx.y * 3 * kImg;
+  const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pair), 0, (int)kImg, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pair + kImg), 0, (int)kImg, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pair + 2 * kImg), 0, (int)kImg, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(gbase + (size_t)blockIdx.y * 2 * kImg), 0, (int)(2 * kImg), 0x00020000);
+  const unsigned voff = (band * 64 + lane) * 4u;
+  const int y0 = sg * seg, y1 = y0 + seg;
+  struct In { unsigned d, i0, ry; };
+  struct St { u2 ia, ib; u4 ga, gb; unsigned i0; float g; };
+  In L[2] = {};
+  St S[2] = {};
+  float accf = 0.f; unsigned acc = 0;
+  auto load_row = [&](int y) {
+    const unsigned yc = (unsigned)(y < y1 ? y : y1 - 1);
+    In r;
+    r.d = __builtin_amdgcn_raw_buffer_load_b32(rD, (int)voff, (int)(yc * (W * 4u)), 2);
+    r.i0 = __builtin_amdgcn_raw_buffer_load_b32(rI, (int)voff, (int)(yc * (W * 4u)), 2);
+    r.ry = RAY ? __builtin_amdgcn_raw_buffer_load_b32(rD, 0, (int)(yc * 4u), 0) : 0u;
+    return r;
+  };
+  auto geom = [&](const In& in, St& st, int y) {
+    float g = __uint_as_float(in.d) + 1.0f;
+#pragma unroll
+    for (int k = 0; k < FG; ++k) g = __builtin_fmaf(g, 0.999f, 0.001f);
+    st.g = g; st.i0 = in.i0 ^ in.ry;
+    const unsigned yc = (unsigned)(y < y1 - 1 ? (y < y0 ? y0 : y) : y1 - 2);
+    unsigned o = voff < (W - 2) * 4u ? voff : (W - 2) * 4u;
+    if (DEP) o += in.d;     // zero in memory: the address now waits for the depth
+    st.ia = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(r1, (int)o, (int)(yc * (W * 4u)), 0));
+    st.ib = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(r1, (int)o, (int)((yc + 1) * (W * 4u)), 0));
+    if constexpr (GRAD) {
+      const unsigned og = 2 * o;
+      st.ga = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rG, (int)og, (int)(yc * (W * 8u)), 0));
+      st.gb = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rG, (int)og, (int)((yc + 1) * (W * 8u)), 0));
+    }
+  };
+  auto eat = [&](const St& st) {
+    unsigned v = st.ia.x ^ st.ia.y ^ st.ib.x ^ st.ib.y ^ st.i0;
+    if constexpr (GRAD) v ^= fold(st.ga) ^ fold(st.gb);
+    float f = st.g + __uint_as_float(v & 0x3fu);
+#pragma unroll
+    for (int k = 0; k < FC; ++k) f = __builtin_fmaf(f, 0.999f, 0.001f);
+    accf += f; acc ^= v;
+  };
+  int y = y0 - 2;
+  const int groups = (seg + 2 + 1) / 2;
+  for (int grp = 0; grp < groups; ++grp) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      L[j] = load_row(y + 2);
+      geom(L[(j + 1) % 2], S[(j + 1) % 2], y + 1);
+      eat(S[j]);
+      ++y;
+    }
+  }
+  if (acc == 0x12345u || accf == 1.2345f) *sink = acc;
+}
+
+// ---- the same pipeline with the tap images staged through LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`) ------------------------------
+// Each wave keeps a private window of image 2 (and of the gradient image): 128 columns around its band, a ring of 8 (GR) rows.  One DMA
+// instruction moves 1 KiB = two image rows (lanes 0-31 row r, lanes 32-63 row r + 1: the source address is per lane, the LDS destination
+// linear) or one gradient row; the taps are ds_read2_b32 / ds_read2_b64.  Per row: 2 coalesced loads + 0.5 (+ 1) DMA instead of 2 (+ 2) tap
+// gathers.  All waits by hand (the VGPR loads and the LDS reads are inline assembly; the compiler only sees the DMA builtins).
+template <bool GRAD, int GR, int FG, int FC>
+__global__ __launch_bounds__(256) void k_rwl(const char* __restrict__ base, const char* __restrict__ gbase, int seg, unsigned* sink) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int NB = W / 64, kWin = 128;
+  constexpr int kImgRing = 8 * kWin * 4, kGradRing = GRAD ? GR * kWin * 8 : 0;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nseg = H / seg;
+  const int item = blockIdx.x * 4 + wave;
+  const int sg = item / NB, band = item % NB;
+  if (sg >= nseg) return;
+  char* imgw = lds + wave * (kImgRing + kGradRing);
+  char* gradw = imgw + kImgRing;
+  const char* pair = base + (size_t)blockIdx.y * 3 * kImg;
+  auto words = [&](const char* p, unsigned bytes) { const unsigned long long a = (unsigned long long)p; u4 r; r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu); r.z = bytes; r.w = 0x00020000u; return r; };
+  const u4 rD = words(pair, (unsigned)kImg), rI = words(pair + kImg, (unsigned)kImg);
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pair + 2 * kImg), 0, (int)kImg, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(gbase + (size_t)blockIdx.y * 2 * kImg), 0, (int)(2 * kImg), 0x00020000);
+  const int x = band * 64 + lane;
+  const unsigned voff = x * 4u;
+  int wx0 = band * 64 - 32; wx0 = wx0 < 0 ? 0 : (wx0 > W - kWin ? W - kWin : wx0);
+  const unsigned vo_i = (unsigned)(lane >> 5) * (W * 4u) + (unsigned)(wx0 + (lane & 31) * 4) * 4u;
+  const unsigned vo_g = (unsigned)(wx0 + lane * 2) * 8u;
+  const int y0 = sg * seg, y1 = y0 + seg;
+  auto dma_img = [&](int r) {     // rows r, r + 1 (r even)
+    const unsigned rc = (unsigned)(r > H - 2 ? H - 2 : r);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (__attribute__((address_space(3))) void*)(imgw + (r & 7) * (kWin * 4)), 16, (int)vo_i, (int)(rc * (W * 4u)), 0, 0);
+  };
+  auto dma_grad = [&](int r) {
+    const unsigned rc = (unsigned)(r > H - 1 ? H - 1 : r);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rG, (__attribute__((address_space(3))) void*)(gradw + (r & (GR - 1)) * (kWin * 8)), 16, (int)vo_g, (int)(rc * (W * 8u)), 0, 0);
+  };
+  struct In { unsigned d, i0; };
+  struct St { u2 ia, ib; u4 ga, gb; unsigned i0; float g; };
+  In L[2] = {};
+  St S[2] = {};
+  float accf = 0.f; unsigned acc = 0;
+  auto load_row = [&](int y, In& r) {
+    const unsigned yc = (unsigned)(y < y1 ? y : y1 - 1);
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen nt" : "=v"(r.d) : "v"(voff), "s"(rD), "s"(yc * (W * 4u)) : "memory");
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen nt" : "=v"(r.i0) : "v"(voff), "s"(rI), "s"(yc * (W * 4u)) : "memory");
+  };
+  const unsigned imgw_a = (unsigned)(size_t)imgw, gradw_a = (unsigned)(size_t)gradw;
+  const unsigned cx = (unsigned)(x - wx0);
+  auto geom = [&](const In& in, St& st, int y) {   // taps of row y out of the window
+    float g = __uint_as_float(in.d) + 1.0f;
+#pragma unroll
+    for (int k = 0; k < FG; ++k) g = __builtin_fmaf(g, 0.999f, 0.001f);
+    st.g = g; st.i0 = in.i0;
+    const unsigned c = (cx < kWin - 2 ? cx : kWin - 2) + in.d;     // zero in memory: the address waits for the depth
+    const unsigned a0 = imgw_a + (unsigned)(y & 7) * (kWin * 4) + c * 4u, a1 = imgw_a + (unsigned)((y + 1) & 7) * (kWin * 4) + c * 4u;
+    asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(st.ia) : "v"(a0) : "memory");
+    asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(st.ib) : "v"(a1) : "memory");
+    if constexpr (GRAD) {
+      const unsigned g0 = gradw_a + (unsigned)(y & (GR - 1)) * (kWin * 8) + c * 8u, g1 = gradw_a + (unsigned)((y + 1) & (GR - 1)) * (kWin * 8) + c * 8u;
+      asm volatile("ds_read2_b64 %0, %1 offset1:1" : "=v"(st.ga) : "v"(g0) : "memory");
+      asm volatile("ds_read2_b64 %0, %1 offset1:1" : "=v"(st.gb) : "v"(g1) : "memory");
+    }
+  };
+  auto eat = [&](St& st) {
+    if constexpr (GRAD) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(st.ia), "+v"(st.ib), "+v"(st.ga), "+v"(st.gb) :: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(st.ia), "+v"(st.ib) :: "memory");
+    unsigned v = st.ia.x ^ st.ia.y ^ st.ib.x ^ st.ib.y ^ st.i0;
+    if constexpr (GRAD) v ^= fold(st.ga) ^ fold(st.gb);
+    float f = st.g + __uint_as_float(v & 0x3fu);
+#pragma unroll
+    for (int k = 0; k < FC; ++k) f = __builtin_fmaf(f, 0.999f, 0.001f);
+    accf += f; acc ^= v;
+  };
+  // prologue: window rows y0, y0 + 1 (the loop's step y issues row y + 4; its first step is y0 - 2)
+  dma_img(y0);
+  if constexpr (GRAD) { dma_grad(y0); dma_grad(y0 + 1); }
+  int y = y0 - 2;
+  const int groups = (seg + 2 + 1) / 2;
+  for (int grp = 0; grp < groups; ++grp) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      load_row(y + 2, L[j]);
+      if constexpr (GRAD) dma_grad(y + 4);
+      if (j == 0) dma_img(y + 4);
+      // depth AND intensity of row y + 1 have landed when at most the ops issued after them are outstanding: this step's 2 loads + its DMAs + last step's DMAs
+      if constexpr (GRAD) asm volatile("s_waitcnt vmcnt(5)" : "+v"(L[(j + 1) % 2].d), "+v"(L[(j + 1) % 2].i0) :: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" : "+v"(L[(j + 1) % 2].d), "+v"(L[(j + 1) % 2].i0) :: "memory");
+      eat(S[j]);
+      geom(L[(j + 1) % 2], S[(j + 1) % 2], y + 1 < y0 ? y0 : y + 1);
+      ++y;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (acc == 0x12345u || accf == 1.2345f) *sink = acc;
+}
+
+template <typename F> double time_us(F launch) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int i = 0; i < 4; ++i) launch();
+  CK(hipDeviceSynchronize());
+  double sum = 0; const int reps = 10;
+  for (int i = 0; i < reps; ++i) {
+    CK(hipEventRecord(a)); launch(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b)); sum += ms;
+  }
+  CK(hipGetLastError());
+  return sum / reps * 1e3;
+}
+
+template <int VEC, int ARR, int D, int AUX, bool BM>
+void run(const char* src, unsigned* sink, int pairs, int seg) {
+  constexpr int BW = 64 * VEC, NB = (W + BW - 1) / BW;
+  const int items = NB * (H / seg);
+  const dim3 grid((items + 3) / 4, pairs);
+  const double us = time_us([&] { hipLaunchKernelGGL((k_walk<VEC, ARR, D, AUX, BM>), grid, dim3(256), 0, 0, src, seg, sink); });
+  const double bytes = (double)pairs * ARR * kImg;
+  printf("   %4d B/wave-load  %d images  seg %3d rows  %d rows in flight  %-7s %-5s  %5d workgroups  %7.1f us  %6.3f TB/s\n", 256 * VEC, ARR, seg, D,
+         AUX == 2 ? "nt" : "default", BM ? "band" : "seg", (int)(grid.x * grid.y), us, bytes / us / 1e6);
+}
+
+template <bool GRAD, bool DEP, int FG, int FC, bool RAY>
+void run_rw(const char* src, const char* gsrc, unsigned* sink, int pairs, int seg, const char* what) {
+  const int items = (W / 64) * (H / seg);
+  const dim3 grid((items + 3) / 4, pairs);
+  const double us = time_us([&] { hipLaunchKernelGGL((k_rw<GRAD, DEP, FG, FC, RAY>), grid, dim3(256), 0, 0, src, gsrc, seg, sink); });
+  const double bytes = (double)pairs * (GRAD ? 5 : 3) * kImg;
+  printf("   %-88s seg %3d  %7.1f us  %6.3f TB/s\n", what, seg, us, bytes / us / 1e6);
+}
+
+template <bool GRAD, int GR, int FG, int FC>
+void run_rwl(const char* src, const char* gsrc, unsigned* sink, int pairs, int seg, const char* what) {
+  const int items = (W / 64) * (H / seg);
+  const dim3 grid((items + 3) / 4, pairs);
+  const int ldsb = 4 * (8 * 128 * 4 + (GRAD ? GR * 128 * 8 : 0));
+  const double us = time_us([&] { hipLaunchKernelGGL((k_rwl<GRAD, GR, FG, FC>), grid, dim3(256), ldsb, 0, src, gsrc, seg, sink); });
+  const double bytes = (double)pairs * (GRAD ? 5 : 3) * kImg;
+  printf("   %-88s seg %3d  %7.1f us  %6.3f TB/s\n", what, seg, us, bytes / us / 1e6);
+}
+
+int main(int argc, char** argv) {
+  const int pairs = argc > 1 ? atoi(argv[1]) : 128;
+  char* src; unsigned* sink;
+  const size_t total = (size_t)pairs * 4 * kImg;
+  CK(hipMalloc(&src, total)); CK(hipMalloc(&sink, 4)); CK(hipMemset(src, 0, total));
+  printf("%d pairs x up to 4 images of 640 x 480 fp32 (%.0f MB with 4, %.0f MB with 3)\n", pairs, total / 1e6, total * 0.75 / 1e6);
+  printf("-- wave-load size (the kernels': 256 B), 3 images, 40-row segments, 2 rows in flight, nt\n");
+  run<1, 3, 2, 2, false>(src, sink, pairs, 40); run<2, 3, 2, 2, false>(src, sink, pairs, 40); run<4, 3, 2, 2, false>(src, sink, pairs, 40);
+  printf("-- the same with 4 images\n");
+  run<1, 4, 2, 2, false>(src, sink, pairs, 40); run<2, 4, 2, 2, false>(src, sink, pairs, 40); run<4, 4, 2, 2, false>(src, sink, pairs, 40);
+  printf("-- rows in flight (256-byte loads, 3 images)\n");
+  run<1, 3, 4, 2, false>(src, sink, pairs, 40); run<1, 3, 8, 2, false>(src, sink, pairs, 40); run<2, 3, 4, 2, false>(src, sink, pairs, 40); run<2, 3, 8, 2, false>(src, sink, pairs, 40);
+  printf("-- segment length (256-byte and 512-byte loads, 3 images, 4 rows in flight)\n");
+  for (int seg : {8, 16, 48, 120, 240, 480}) { run<1, 3, 4, 2, false>(src, sink, pairs, seg); run<2, 3, 4, 2, false>(src, sink, pairs, seg); }
+  printf("-- cache policy and item order (3 images, 40-row segments, 4 rows in flight)\n");
+  run<1, 3, 4, 0, false>(src, sink, pairs, 40); run<2, 3, 4, 0, false>(src, sink, pairs, 40);
+  run<1, 3, 4, 2, true>(src, sink, pairs, 40); run<2, 3, 4, 2, true>(src, sink, pairs, 40);
+  printf("-- one image at a time (1 image per pass; bytes = 1 image per pair)\n");
+  run<1, 1, 4, 2, false>(src, sink, pairs * 4, 40); run<2, 1, 4, 2, false>(src, sink, pairs * 4, 40); run<4, 1, 4, 2, false>(src, sink, pairs * 4, 40);
+  char* gsrc; CK(hipMalloc(&gsrc, (size_t)pairs * 2 * kImg)); CK(hipMemset(gsrc, 0, (size_t)pairs * 2 * kImg));
+  printf("-- the reductions' pipeline rebuilt: EvaluateError shape (12 B/px: depth + intensity coalesced, image-1 taps), then the SE3 step's (20 B/px: + gradient taps)\n");
+  for (int seg : {24, 48}) {
+    run_rw<false, false, 0, 0, false>(src, gsrc, sink, pairs, seg, "E0 taps at a known address, no arithmetic");
+    run_rw<false, true, 0, 0, false>(src, gsrc, sink, pairs, seg, "E1 tap address depends on the loaded depth");
+    run_rw<false, true, 0, 0, true>(src, gsrc, sink, pairs, seg, "E2 + the row's ray-table load (broadcast dword)");
+    run_rw<false, true, 45, 15, true>(src, gsrc, sink, pairs, seg, "E3 + 45 dependent fmas in the geometry stage, 15 in the consume stage");
+    run_rw<false, true, 90, 30, true>(src, gsrc, sink, pairs, seg, "E4 twice that arithmetic");
+    run_rw<true, false, 0, 0, false>(src, gsrc, sink, pairs, seg, "S0 with gradient taps, known address, no arithmetic");
+    run_rw<true, true, 0, 0, true>(src, gsrc, sink, pairs, seg, "S2 dependent address + ray load");
+    run_rw<true, true, 45, 90, true>(src, gsrc, sink, pairs, seg, "S3 + 45 / 90 dependent fmas");
+    run_rw<true, true, 90, 180, true>(src, gsrc, sink, pairs, seg, "S4 twice that arithmetic");
+    run_rwl<false, 8, 0, 0>(src, gsrc, sink, pairs, seg, "EL0 image-1 window by LDS-DMA (16 KB LDS / workgroup), ds_read2 taps, no arithmetic");
+    run_rwl<false, 8, 45, 15>(src, gsrc, sink, pairs, seg, "EL3 + 45 / 15 dependent fmas");
+    run_rwl<true, 8, 0, 0>(src, gsrc, sink, pairs, seg, "SL0 + gradient window, 8-row ring (48 KB LDS / workgroup: 3 workgroups per CU)");
+    run_rwl<true, 4, 0, 0>(src, gsrc, sink, pairs, seg, "SL0 + gradient window, 4-row ring (32 KB LDS / workgroup: 5 workgroups per CU)");
+    run_rwl<true, 4, 45, 90>(src, gsrc, sink, pairs, seg, "SL3 4-row ring + 45 / 90 dependent fmas");
+  }
+  return 0;
+}
