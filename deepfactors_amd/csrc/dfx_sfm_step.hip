@@ -89,6 +89,10 @@ namespace dfx {
                                  // 128 pairs 1039.5 -> 1004.0 us; CS = 64, 1280x960, 16 pairs 950.9 -> 929.9 us (232 -> 247 VGPRs, still two waves).  0 disables
                                  // it.  Two round-2 ideas measured in round 3 and removed: the P block split in phase A and handed over as packed bf16
                                  // through LDS (+2.4 %), 128 registers for a fourth wave (spills: +37 %).
+#ifndef DFX_STEP_TAPS_DWORD
+#define DFX_STEP_TAPS_DWORD 0   // A/B: the img1 taps of phase A as four dword loads instead of two 8-byte loads (the row-walk reductions gain 5-7 % from it;
+                                // this kernel nothing: 957.4 / 962.9 against 975.7 / 960.3 us in interleaved bench runs, profiles/r04_tap_loads.txt)
+#endif
 #ifndef DFX_RING_AUX
 #define DFX_RING_AUX 2       // cache policy of the code-Jacobian stream loads: 2 = nt (read once: do not displace the img1 / grad1 rows
 #endif                       // the bilinear taps of the next chunk row re-use from the L2); -1.6 % kernel time, -3 % read requests with the collapse below
@@ -471,6 +475,10 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
   // (their weight is 0 through v_mul_legacy): an out-of-range offset would be cheaper per lane, but a chunk whose 64 pixels
   // ALL lack a correspondence (image regions that leave the view) would then issue wave-loads that touch no memory, and
   // those may retire ahead of the older ring loads the counted waits of phase B rely on.
+#if DFX_STEP_TAPS_DWORD
+  unsigned tap_four = 4u;
+  asm volatile("" : "+s"(tap_four));   // opaque: the compiler would fuse the dword pairs back into 8-byte loads
+#endif
   auto issue_gathers = [&](unsigned pbase, Pix& q) {
     if (MODE == 0) {
       const Corr c = find_correspondence_ray<B3>(g, q.rx, q.ry, q.d, prm.border, prm.min_dpt);
@@ -485,8 +493,15 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
       q.ia = f32x2{ c.u, c.v }; q.ib = f32x2{ c.qx, c.qy }; q.ga = f32x4{ c.vx, c.vy, c.vz, c.iz }; q.gb = q.ga;
       (void)oi; (void)oi2; (void)og; (void)og2;
 #else
+#if DFX_STEP_TAPS_DWORD
+      q.ia.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(i1_rs, (int)oi, 0, 0));
+      q.ia.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(i1_rs, (int)oi, (int)tap_four, 0));
+      q.ib.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(i1_rs, (int)oi2, 0, 0));
+      q.ib.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(i1_rs, (int)oi2, (int)tap_four, 0));
+#else
       q.ia = bload(i1_rs, oi, (f32x2*)nullptr);
       q.ib = bload(i1_rs, oi2, (f32x2*)nullptr);
+#endif
       q.ga = bload(g1_rs, og, (f32x4*)nullptr);
       q.gb = bload(g1_rs, og2, (f32x4*)nullptr);
 #endif

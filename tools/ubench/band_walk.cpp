@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_walk(const char* __restrict__ base, int
 //   DEP    the tap address depends on the loaded depth (images are zero: address += depth bits)  -> two dependent round trips per row, as in the kernels
 //   FG/FC  dependent fmas per row in the geometry / consume stage (the kernels: ~45 / ~15 EvaluateError, ~45 / ~90 SE3 step)
 //   RAY    the wave-uniform ray-table load of the row (a broadcast dword load)
-template <bool GRAD, bool DEP, int FG, int FC, bool RAY>
+template <bool GRAD, bool DEP, int FG, int FC, bool RAY, int TAPMODE = 0>   // TAPMODE: 0 two 8-byte tap loads, 1 four 4-byte ones, 2 two 4-byte ones (half the taps)
 __global__ __launch_bounds__(256) void k_rw(const char* __restrict__ base, const char* __restrict__ gbase, int seg, unsigned* sink) {
   constexpr int NB = W / 64;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -115,12 +115,29 @@ __global__ __launch_bounds__(256) void k_rw(const char* __restrict__ base, const
     const unsigned yc = (unsigned)(y < y1 - 1 ? (y < y0 ? y0 : y) : y1 - 2);
     unsigned o = voff < (W - 2) * 4u ? voff : (W - 2) * 4u;
     if (DEP) o += in.d;     // zero in memory: the address now waits for the depth
-    st.ia = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(r1, (int)o, (int)(yc * (W * 4u)), 0));
-    st.ib = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(r1, (int)o, (int)((yc + 1) * (W * 4u)), 0));
+    if constexpr (TAPMODE == 0) {
+      st.ia = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(r1, (int)o, (int)(yc * (W * 4u)), 0));
+      st.ib = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(r1, (int)o, (int)((yc + 1) * (W * 4u)), 0));
+    } else {
+      st.ia.x = __builtin_amdgcn_raw_buffer_load_b32(r1, (int)o, (int)(yc * (W * 4u)), 0);
+      st.ib.x = __builtin_amdgcn_raw_buffer_load_b32(r1, (int)o, (int)((yc + 1) * (W * 4u)), 0);
+      if constexpr (TAPMODE == 1 || TAPMODE == 3) {
+        st.ia.y = __builtin_amdgcn_raw_buffer_load_b32(r1, (int)o, (int)(yc * (W * 4u) + 4u), 0);
+        st.ib.y = __builtin_amdgcn_raw_buffer_load_b32(r1, (int)o, (int)((yc + 1) * (W * 4u) + 4u), 0);
+      } else { st.ia.y = 0; st.ib.y = 0; }
+    }
     if constexpr (GRAD) {
       const unsigned og = 2 * o;
-      st.ga = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rG, (int)og, (int)(yc * (W * 8u)), 0));
-      st.gb = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rG, (int)og, (int)((yc + 1) * (W * 8u)), 0));
+      if constexpr (TAPMODE == 1) {   // four aligned 8-byte loads: (gx, gy) of column ix and of column ix + 1, two rows
+        const u2 a0 = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(rG, (int)og, (int)(yc * (W * 8u)), 0));
+        const u2 a1 = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(rG, (int)og, (int)(yc * (W * 8u) + 8u), 0));
+        const u2 b0 = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(rG, (int)og, (int)((yc + 1) * (W * 8u)), 0));
+        const u2 b1 = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(rG, (int)og, (int)((yc + 1) * (W * 8u) + 8u), 0));
+        st.ga = u4{ a0.x, a0.y, a1.x, a1.y }; st.gb = u4{ b0.x, b0.y, b1.x, b1.y };
+      } else {
+        st.ga = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rG, (int)og, (int)(yc * (W * 8u)), 0));
+        st.gb = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rG, (int)og, (int)((yc + 1) * (W * 8u)), 0));
+      }
     }
   };
   auto eat = [&](const St& st) {
@@ -266,11 +283,11 @@ void run(const char* src, unsigned* sink, int pairs, int seg) {
          AUX == 2 ? "nt" : "default", BM ? "band" : "seg", (int)(grid.x * grid.y), us, bytes / us / 1e6);
 }
 
-template <bool GRAD, bool DEP, int FG, int FC, bool RAY>
+template <bool GRAD, bool DEP, int FG, int FC, bool RAY, int TAPMODE = 0>
 void run_rw(const char* src, const char* gsrc, unsigned* sink, int pairs, int seg, const char* what) {
   const int items = (W / 64) * (H / seg);
   const dim3 grid((items + 3) / 4, pairs);
-  const double us = time_us([&] { hipLaunchKernelGGL((k_rw<GRAD, DEP, FG, FC, RAY>), grid, dim3(256), 0, 0, src, gsrc, seg, sink); });
+  const double us = time_us([&] { hipLaunchKernelGGL((k_rw<GRAD, DEP, FG, FC, RAY, TAPMODE>), grid, dim3(256), 0, 0, src, gsrc, seg, sink); });
   const double bytes = (double)pairs * (GRAD ? 5 : 3) * kImg;
   printf("   %-88s seg %3d  %7.1f us  %6.3f TB/s\n", what, seg, us, bytes / us / 1e6);
 }
@@ -309,10 +326,15 @@ int main(int argc, char** argv) {
   for (int seg : {24, 48}) {
     run_rw<false, false, 0, 0, false>(src, gsrc, sink, pairs, seg, "E0 taps at a known address, no arithmetic");
     run_rw<false, true, 0, 0, false>(src, gsrc, sink, pairs, seg, "E1 tap address depends on the loaded depth");
+    run_rw<false, true, 0, 0, false, 1>(src, gsrc, sink, pairs, seg, "E1 with the taps as four 4-byte loads");
+    run_rw<false, true, 0, 0, false, 2>(src, gsrc, sink, pairs, seg, "E1 with two 4-byte loads (half the taps: instruction count of E1, half its returned bytes)");
     run_rw<false, true, 0, 0, true>(src, gsrc, sink, pairs, seg, "E2 + the row's ray-table load (broadcast dword)");
     run_rw<false, true, 45, 15, true>(src, gsrc, sink, pairs, seg, "E3 + 45 dependent fmas in the geometry stage, 15 in the consume stage");
     run_rw<false, true, 90, 30, true>(src, gsrc, sink, pairs, seg, "E4 twice that arithmetic");
     run_rw<true, false, 0, 0, false>(src, gsrc, sink, pairs, seg, "S0 with gradient taps, known address, no arithmetic");
+    run_rw<true, true, 0, 0, false>(src, gsrc, sink, pairs, seg, "S1 dependent address");
+    run_rw<true, true, 0, 0, false, 3>(src, gsrc, sink, pairs, seg, "S1 image taps as four 4-byte loads, gradient taps as before (two 16-byte)");
+    run_rw<true, true, 0, 0, false, 1>(src, gsrc, sink, pairs, seg, "S1 image taps as four 4-byte loads, gradient taps as four aligned 8-byte loads");
     run_rw<true, true, 0, 0, true>(src, gsrc, sink, pairs, seg, "S2 dependent address + ray load");
     run_rw<true, true, 45, 90, true>(src, gsrc, sink, pairs, seg, "S3 + 45 / 90 dependent fmas");
     run_rw<true, true, 90, 180, true>(src, gsrc, sink, pairs, seg, "S4 twice that arithmetic");
