@@ -234,6 +234,18 @@ def event_time_us(torch, enqueue, reps, warm):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
+def kernel_only_us(ctx, enqueue, reps=30):
+    """Average duration of the bracketed main kernel of `enqueue` (dfx_set_profiling: HIP events on the context's stream around the reduction
+    kernel alone -- what rocprofv3's kernel trace shows for it, without the finalize kernel and the two launch boundaries of a call)."""
+    ctx.set_profiling(True)
+    ctx.profile_read()
+    for _ in range(reps):
+        enqueue()
+    n, ms = ctx.profile_read()
+    ctx.set_profiling(False)
+    return ms * 1e3 / max(n, 1)
+
+
 def small_operator_rooflines(dfx, synth, ctx, dev):
     """HBM-resident sweeps of the operators beside the SfM step (SURVEY 8d byte counts): the code-Jacobian decoder UpdateDepth (136 B/px at
     CS = 32) over 64 distinct keyframes (2.7 GB), SE3Aligner::RunStep (20 B/px) and SfmAligner::EvaluateError (12 B/px) over 128 distinct
@@ -259,22 +271,30 @@ def small_operator_rooflines(dfx, synth, ctx, dev):
     sarr = se3.make_pairs([dict(se3=synth.IDENTITY, cam=p["cam"], img0=p["img0"], img1=p["img1"], dpt0=p["dpt0"], grad1=p["grad1"]) for p in prs])
     sitems = torch.zeros(P * dfx.item_size(6), dtype=torch.uint8, device=dev)
     us = event_time_us(torch, lambda: se3.RunStepBatch(sarr, sitems), reps=60, warm=300)
+    kus = kernel_only_us(ctx, lambda: se3.RunStepBatch(sarr, sitems))
     byts = 20 * W * H * P
     out["se3_step_batch_128pairs"] = dict(us=us, algorithmic_bytes=byts, algorithmic_gbs=byts / us / 1e3, frac=byts / us / 1e3 / HBM_PEAK_GBS,
-                                          note="k_se3_step_batch + finalize: 128 distinct 640x480 pairs in one launch (786 MB: beyond the 256 MB Infinity Cache)")
+                                          kernel_us=kus, kernel_frac=byts / kus / 1e3 / HBM_PEAK_GBS,
+                                          note="k_se3_step_batch + finalize: 128 distinct 640x480 pairs in one launch (786 MB: beyond the 256 MB Infinity Cache); "
+                                               "us / frac = the whole call in back-to-back enqueues (reduction kernel + finalize kernel + two launch boundaries), "
+                                               "kernel_us / kernel_frac = the reduction kernel alone (HIP events around it)")
     # the same launch at the pairs' true relative poses: what a tracker evaluates from its second iteration on.  At the exact identity (the entry above,
     # kept for continuity with rounds 1-3) the outermost pixel columns / rows project ONTO the view border, where the fast geometry defers to the
     # reference-order evaluation: two of the ten 64-pixel bands take that path on every row
     sarr2 = se3.make_pairs([dict(se3=p["pose10_true"], cam=p["cam"], img0=p["img0"], img1=p["img1"], dpt0=p["dpt0"], grad1=p["grad1"]) for p in prs])
     us = event_time_us(torch, lambda: se3.RunStepBatch(sarr2, sitems), reps=60, warm=150)
+    kus = kernel_only_us(ctx, lambda: se3.RunStepBatch(sarr2, sitems))
     out["se3_step_batch_128pairs_true_pose"] = dict(us=us, algorithmic_bytes=byts, algorithmic_gbs=byts / us / 1e3, frac=byts / us / 1e3 / HBM_PEAK_GBS,
+                                                    kernel_us=kus, kernel_frac=byts / kus / 1e3 / HBM_PEAK_GBS,
                                                     note="as se3_step_batch_128pairs, evaluated at each pair's generating pose instead of the identity")
     earr = al.make_pairs([dict(pose0=p["pose0"], pose1=p["pose1"], cam=p["cam"], img0=p["img0"], img1=p["img1"], dpt0=p["dpt0"], prx0_jac=p["prx_jac"],
                                grad1=p["grad1"]) for p in prs])
     eitems = torch.zeros(P * 16, dtype=torch.uint8, device=dev)
     us = event_time_us(torch, lambda: al.EvaluateErrorBatch(earr, eitems), reps=60, warm=300)
+    kus = kernel_only_us(ctx, lambda: al.EvaluateErrorBatch(earr, eitems))
     byts = 12 * W * H * P
     out["sfm_error_batch_128pairs"] = dict(us=us, algorithmic_bytes=byts, algorithmic_gbs=byts / us / 1e3, frac=byts / us / 1e3 / HBM_PEAK_GBS,
+                                           kernel_us=kus, kernel_frac=byts / kus / 1e3 / HBM_PEAK_GBS,
                                            note="k_sfm_error_batch + finalize: 128 distinct 640x480 pairs in one launch (472 MB)")
     return out
 

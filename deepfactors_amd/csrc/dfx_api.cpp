@@ -162,6 +162,22 @@ int grow_dev(void** p, size_t* cap, size_t need, hipStream_t stream) {
   return DFX_OK;
 }
 
+// Measurement hook (dfx_set_profiling): the next pair of events bracketing a launch's main kernel, or nulls when profiling is off
+int prof_events(dfx_ctx* c, hipEvent_t* eb, hipEvent_t* ee) {
+  *eb = *ee = nullptr;
+  if (!c->profiling) return DFX_OK;
+  if (c->prof_used == c->prof_pool.size()) {
+    hipEvent_t a, b;
+    DFX_HIP(hipEventCreate(&a));
+    DFX_HIP(hipEventCreate(&b));
+    c->prof_pool.emplace_back(a, b);
+  }
+  *eb = c->prof_pool[c->prof_used].first;
+  *ee = c->prof_pool[c->prof_used].second;
+  c->prof_used++;
+  return DFX_OK;
+}
+
 // Workgroup-partials scratch.  Growing drains the stream first (the old
 // buffer may be in use); the clear is ordered on the context's stream in front of the kernels that use the buffer.
 // `for_step` = false (every user but the batched SfM step): the caller is about to write half 0 from the context's stream, so that stream
@@ -1043,17 +1059,7 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
 
   dfx::SfmParamsDev prm{ params->huber_delta, params->avg_dpt, params->min_dpt, (float)params->valid_border, next_launch_id() };
   hipEvent_t eb = nullptr, ee = nullptr;
-  if (c->profiling) {
-    if (c->prof_used == c->prof_pool.size()) {
-      hipEvent_t a, b;
-      DFX_HIP(hipEventCreate(&a));
-      DFX_HIP(hipEventCreate(&b));
-      c->prof_pool.emplace_back(a, b);
-    }
-    eb = c->prof_pool[c->prof_used].first;
-    ee = c->prof_pool[c->prof_used].second;
-    c->prof_used++;
-  }
+  if ((rc = prof_events(c, &eb, &ee))) return rc;
   if (dyn.qhead) {
     if (c->qhead_dirty) {   // a failed launch left heads behind: nothing may be in flight on them when they are cleared
       if (c->tail_stream) DFX_HIP(hipStreamSynchronize(c->tail_stream));
@@ -1247,7 +1253,10 @@ DFX_API int dfx_sfm_error(dfx_ctx* c, const dfx_se3* pose0, const dfx_se3* pose1
 
 // ---- batched EvaluateError / SE3 step -------------------------------------------------------------------------------
 namespace {
-// uploads n SimplePairDev through the staging ring and returns their device copy; `slot` must be released after the launches
+// uploads n SimplePairDev through the staging ring and returns their device copy; simple_launched(slot) must follow the launches.
+// As in the batched step (dfx_sfm_step_batch_async): the copy runs on the context's copy stream, beside the kernels of the previous launch,
+// and the launch stream waits for it.  On the launch stream itself the 40 KB copy sat between the finalize kernel of one call and the
+// reduction kernel of the next: 18-19 us of idle GPU per call in a kernel trace of back-to-back calls (profiles/r04_launch_gaps.txt).
 int upload_simple(dfx_ctx* c, const std::vector<dfx::SimplePairDev>& descs, const dfx::SimplePairDev** dev_out, int* slot_out) {
   int rc, slot;
   char* host;
@@ -1256,6 +1265,7 @@ int upload_simple(dfx_ctx* c, const std::vector<dfx::SimplePairDev>& descs, cons
   std::memcpy(host, descs.data(), bytes);
   if (c->sdesc_cap < bytes) {
     DFX_HIP(hipStreamSynchronize(c->stream));
+    DFX_HIP(hipStreamSynchronize(c->copy_stream));
     if (c->sdesc_dev) DFX_HIP(hipFree(c->sdesc_dev));
     c->sdesc_dev = nullptr;
     const size_t cap = (bytes * 2 + 255) & ~(size_t)255;
@@ -1263,9 +1273,20 @@ int upload_simple(dfx_ctx* c, const std::vector<dfx::SimplePairDev>& descs, cons
     c->sdesc_cap = cap;
   }
   char* dd = c->sdesc_dev + (size_t)slot * c->sdesc_cap;
-  DFX_HIP(hipMemcpyAsync(dd, host, bytes, hipMemcpyHostToDevice, c->stream));
+  if (c->slot_busy[slot]) DFX_HIP(hipStreamWaitEvent(c->copy_stream, c->slot_done[slot], 0));   // the last kernels that read this slot's device copy
+  DFX_HIP(hipMemcpyAsync(dd, host, bytes, hipMemcpyHostToDevice, c->copy_stream));
+  DFX_HIP(hipEventRecord(c->stage_ev[slot], c->copy_stream));   // the host slot is free again once the copy has run
+  c->stage_used[slot] = true;
+  DFX_HIP(hipStreamWaitEvent(c->stream, c->stage_ev[slot], 0));
   *dev_out = reinterpret_cast<const dfx::SimplePairDev*>(dd);
   *slot_out = slot;
+  return DFX_OK;
+}
+
+// behind the kernels that read the slot's device copy
+int simple_launched(dfx_ctx* c, int slot) {
+  DFX_HIP(hipEventRecord(c->slot_done[slot], c->stream));
+  c->slot_busy[slot] = true;
   return DFX_OK;
 }
 
@@ -1306,8 +1327,10 @@ DFX_API int dfx_sfm_error_batch_async(dfx_ctx* c, const dfx_sfm_params* params, 
   if ((rc = upload_simple(c, descs, &dd, &slot))) return rc;
   bool all_identity = true;
   for (const auto& d : descs) all_identity = all_identity && d.exact_identity != 0;
-  DFX_HIP(dfx::launch_sfm_error_batch(dd, n, (int)W, (int)H, params->huber_delta, blocks, c->partials, out_items_dev, all_identity, c->stream));
-  return stage_release(c, slot);
+  hipEvent_t eb, ee;
+  if ((rc = prof_events(c, &eb, &ee))) return rc;
+  DFX_HIP(dfx::launch_sfm_error_batch(dd, n, (int)W, (int)H, params->huber_delta, blocks, c->partials, out_items_dev, all_identity, c->stream, eb, ee));
+  return simple_launched(c, slot);
 }
 
 DFX_API int dfx_sfm_error_batch(dfx_ctx* c, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n, dfx_corr_item* out_items_host) {
@@ -1352,8 +1375,10 @@ DFX_API int dfx_se3_step_batch_async(dfx_ctx* c, const dfx_se3_pair* pairs, int 
   if ((rc = upload_simple(c, descs, &dd, &slot))) return rc;
   bool all_identity = true;
   for (const auto& d : descs) all_identity = all_identity && d.exact_identity != 0;
-  DFX_HIP(dfx::launch_se3_step_batch(dd, n, (int)W, (int)H, huber_delta, blocks, c->partials, out_items_dev, all_identity, c->stream));
-  return stage_release(c, slot);
+  hipEvent_t eb, ee;
+  if ((rc = prof_events(c, &eb, &ee))) return rc;
+  DFX_HIP(dfx::launch_se3_step_batch(dd, n, (int)W, (int)H, huber_delta, blocks, c->partials, out_items_dev, all_identity, c->stream, eb, ee));
+  return simple_launched(c, slot);
 }
 
 DFX_API int dfx_se3_step_batch(dfx_ctx* c, const dfx_se3_pair* pairs, int n, float huber_delta, void* out_items_host) {

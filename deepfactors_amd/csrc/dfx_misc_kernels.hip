@@ -707,6 +707,9 @@ __global__ __launch_bounds__(kT) void k_squared_error(const float* __restrict__ 
 // ---- finalize: out[e] = sum_b partials[b][e] in double, fixed order; layout-specific scatter -------------------
 enum FinalKind { kFinalItem6 = 0, kFinalCorr = 1, kFinalScalar = 2 };
 
+// MAXQ: rows per row group the launch can hold (nblocks <= 32 MAXQ).  Rows past nblocks add +0.0, so every MAXQ gives the same bits; the
+// batched reductions run 24 - 60 workgroups per pair and take MAXQ = 2 (2 loads per thread instead of 32: 4.7 -> ~3 us per 128 pairs).
+template <int MAXQ>
 __global__ __launch_bounds__(1024) void k_finalize_rows(const float* __restrict__ partials_all, const int nblocks, const int kind,
                                                         char* __restrict__ out_all, const size_t out_stride) {
   // blockIdx.x = pair of a batched launch (0 for the single-pair operators)
@@ -715,7 +718,7 @@ __global__ __launch_bounds__(1024) void k_finalize_rows(const float* __restrict_
   __shared__ double red[32][kSimpleRow];
   const int e = threadIdx.x & 31, rg = threadIdx.x >> 5;   // 32 row groups
   static_assert(kMaxSimpleBlocks <= 32 * 32, "one load per row group and thread");
-  double s = strided_sum_f64_wide<32, 32>(partials + e, rg, nblocks, kSimpleRow);
+  double s = strided_sum_f64_wide<32, MAXQ>(partials + e, rg, nblocks, kSimpleRow);
   red[rg][e] = s;
   __syncthreads();
   if (rg != 0) return;
@@ -859,13 +862,19 @@ __global__ __launch_bounds__(kT) void k_blur_down(const float* __restrict__ in, 
 // ---------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------
+static void launch_finalize_rows(int n, int blocks, int kind, const float* partials_dev, void* out_dev, size_t stride, hipStream_t stream) {
+  if (blocks <= 64) hipLaunchKernelGGL(k_finalize_rows<2>, dim3(n), dim3(1024), 0, stream, partials_dev, blocks, kind, (char*)out_dev, stride);
+  else if (blocks <= 256) hipLaunchKernelGGL(k_finalize_rows<8>, dim3(n), dim3(1024), 0, stream, partials_dev, blocks, kind, (char*)out_dev, stride);
+  else hipLaunchKernelGGL(k_finalize_rows<32>, dim3(n), dim3(1024), 0, stream, partials_dev, blocks, kind, (char*)out_dev, stride);
+}
+
 hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
                            void* item_dev, hipStream_t stream) {
   if (p.exact_identity) hipLaunchKernelGGL(k_se3_step<true>, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
   else hipLaunchKernelGGL(k_se3_step<false>, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalItem6, (char*)item_dev, (size_t)0);
+  launch_finalize_rows(1, blocks, (int)kFinalItem6, (const float*)partials_dev, item_dev, (size_t)0, stream);
   return hipGetLastError();
 }
 
@@ -875,27 +884,31 @@ hipError_t launch_sfm_error(const SimplePairDev& p, int W, int H, float huber_de
   else hipLaunchKernelGGL(k_sfm_error<false>, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalCorr, (char*)corr_item_dev, (size_t)0);
+  launch_finalize_rows(1, blocks, (int)kFinalCorr, (const float*)partials_dev, corr_item_dev, (size_t)0, stream);
   return hipGetLastError();
 }
 
 hipError_t launch_sfm_error_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
-                                  void* corr_items_dev, bool all_identity, hipStream_t stream) {
+                                  void* corr_items_dev, bool all_identity, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end) {
+  if (ev_begin) (void)hipEventRecord(ev_begin, stream);
   if (all_identity) hipLaunchKernelGGL(k_sfm_error_batch<true>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
   else hipLaunchKernelGGL(k_sfm_error_batch<false>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_finalize_rows, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalCorr, (char*)corr_items_dev, (size_t)16);
+  if (ev_end) (void)hipEventRecord(ev_end, stream);
+  launch_finalize_rows(n, blocks, (int)kFinalCorr, (const float*)partials_dev, corr_items_dev, (size_t)16, stream);
   return hipGetLastError();
 }
 
 hipError_t launch_se3_step_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
-                                 void* items_dev, bool all_identity, hipStream_t stream) {
+                                 void* items_dev, bool all_identity, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end) {
+  if (ev_begin) (void)hipEventRecord(ev_begin, stream);
   if (all_identity) hipLaunchKernelGGL(k_se3_step_batch<true>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
   else hipLaunchKernelGGL(k_se3_step_batch<false>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_finalize_rows, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalItem6, (char*)items_dev, (size_t)120);
+  if (ev_end) (void)hipEventRecord(ev_end, stream);
+  launch_finalize_rows(n, blocks, (int)kFinalItem6, (const float*)partials_dev, items_dev, (size_t)120, stream);
   return hipGetLastError();
 }
 
@@ -904,7 +917,7 @@ hipError_t launch_se3_warp(const SimplePairDev& p, int W, int H, int blocks, flo
   hipLaunchKernelGGL(k_se3_warp, dim3(blocks), dim3(kT), 0, stream, p, W, H, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalCorr, (char*)corr_item_dev, (size_t)0);
+  launch_finalize_rows(1, blocks, (int)kFinalCorr, (const float*)partials_dev, corr_item_dev, (size_t)0, stream);
   return hipGetLastError();
 }
 
@@ -913,7 +926,7 @@ hipError_t launch_squared_error(const float* a, uint32_t pitch_a, const float* b
   hipLaunchKernelGGL(k_squared_error, dim3(blocks), dim3(kT), 0, stream, a, pitch_a, b, pitch_b, W, H, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_finalize_rows, dim3(1), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (int)kFinalScalar, (char*)out_dev, (size_t)0);
+  launch_finalize_rows(1, blocks, (int)kFinalScalar, (const float*)partials_dev, out_dev, (size_t)0, stream);
   return hipGetLastError();
 }
 

@@ -182,8 +182,9 @@ DFX_API int dfx_last_mfma_mode(dfx_ctx* ctx, int* mode);
 DFX_API int dfx_set_schedule(dfx_ctx* ctx, int mode);
 DFX_API int dfx_last_schedule(dfx_ctx* ctx, int* dynamic);
 /* Measurement hook (no reference counterpart; the reference times with std::clock around blocking calls,
- * tools/kernel_benchmark.cpp:145-180): when enabled, every SfM step launch is bracketed by HIP events on the
- * context's stream -- around the step kernel only, excluding the finalize kernel and copies.
+ * tools/kernel_benchmark.cpp:145-180): when enabled, every SfM step launch -- and every batched SE3-step / EvaluateError launch
+ * (dfx_se3_step_batch*, dfx_sfm_error_batch*) -- is bracketed by HIP events on the context's stream: around the step (reduction)
+ * kernel only, excluding the finalize kernel and copies.
  * dfx_profile_read waits for the stream, returns the number of bracketed launches and their summed
  * duration in milliseconds since the last read, and resets the counters. */
 DFX_API int dfx_set_profiling(dfx_ctx* ctx, int enable);

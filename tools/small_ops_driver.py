@@ -17,7 +17,7 @@ def main():
     W, H, CS, P = 640, 480, 32, 128
     prs = [synth.make_pair(W, H, CS, seed=0x2200 + k, device=dev) for k in range(P)]
     al, se3 = dfx.SfmAligner(code_size=CS, ctx=ctx), dfx.SE3Aligner(ctx=ctx)
-    sarr = se3.make_pairs([dict(se3=synth.IDENTITY, cam=p["cam"], img0=p["img0"], img1=p["img1"], dpt0=p["dpt0"], grad1=p["grad1"]) for p in prs])
+    sarr = se3.make_pairs([dict(se3=(p["pose10_true"] if os.environ.get("POSE") == "true" else synth.IDENTITY), cam=p["cam"], img0=p["img0"], img1=p["img1"], dpt0=p["dpt0"], grad1=p["grad1"]) for p in prs])
     sitems = torch.zeros(P * dfx.item_size(6), dtype=torch.uint8, device=dev)
     earr = al.make_pairs([dict(pose0=p["pose0"], pose1=p["pose1"], cam=p["cam"], img0=p["img0"], img1=p["img1"], dpt0=p["dpt0"], prx0_jac=p["prx_jac"],
                                grad1=p["grad1"]) for p in prs])

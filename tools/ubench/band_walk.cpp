@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_rw(const char* __restrict__ base, const
     } else {
       st.ia.x = __builtin_amdgcn_raw_buffer_load_b32(r1, (int)o, (int)(yc * (W * 4u)), 0);
       st.ib.x = __builtin_amdgcn_raw_buffer_load_b32(r1, (int)o, (int)((yc + 1) * (W * 4u)), 0);
-      if constexpr (TAPMODE == 1 || TAPMODE == 3) {
+      if constexpr (TAPMODE == 1 || TAPMODE == 3 || TAPMODE == 4) {
         st.ia.y = __builtin_amdgcn_raw_buffer_load_b32(r1, (int)o, (int)(yc * (W * 4u) + 4u), 0);
         st.ib.y = __builtin_amdgcn_raw_buffer_load_b32(r1, (int)o, (int)((yc + 1) * (W * 4u) + 4u), 0);
       } else { st.ia.y = 0; st.ib.y = 0; }
@@ -134,6 +134,15 @@ __global__ __launch_bounds__(256) void k_rw(const char* __restrict__ base, const
         const u2 b0 = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(rG, (int)og, (int)((yc + 1) * (W * 8u)), 0));
         const u2 b1 = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(rG, (int)og, (int)((yc + 1) * (W * 8u) + 8u), 0));
         st.ga = u4{ a0.x, a0.y, a1.x, a1.y }; st.gb = u4{ b0.x, b0.y, b1.x, b1.y };
+      } else if constexpr (TAPMODE == 4) {   // eight dword loads at an 8-byte lane stride
+        st.ga.x = __builtin_amdgcn_raw_buffer_load_b32(rG, (int)og, (int)(yc * (W * 8u)), 0);
+        st.ga.y = __builtin_amdgcn_raw_buffer_load_b32(rG, (int)og, (int)(yc * (W * 8u) + 4u), 0);
+        st.ga.z = __builtin_amdgcn_raw_buffer_load_b32(rG, (int)og, (int)(yc * (W * 8u) + 8u), 0);
+        st.ga.w = __builtin_amdgcn_raw_buffer_load_b32(rG, (int)og, (int)(yc * (W * 8u) + 12u), 0);
+        st.gb.x = __builtin_amdgcn_raw_buffer_load_b32(rG, (int)og, (int)((yc + 1) * (W * 8u)), 0);
+        st.gb.y = __builtin_amdgcn_raw_buffer_load_b32(rG, (int)og, (int)((yc + 1) * (W * 8u) + 4u), 0);
+        st.gb.z = __builtin_amdgcn_raw_buffer_load_b32(rG, (int)og, (int)((yc + 1) * (W * 8u) + 8u), 0);
+        st.gb.w = __builtin_amdgcn_raw_buffer_load_b32(rG, (int)og, (int)((yc + 1) * (W * 8u) + 12u), 0);
       } else {
         st.ga = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rG, (int)og, (int)(yc * (W * 8u)), 0));
         st.gb = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rG, (int)og, (int)((yc + 1) * (W * 8u)), 0));
@@ -335,6 +344,7 @@ int main(int argc, char** argv) {
     run_rw<true, true, 0, 0, false>(src, gsrc, sink, pairs, seg, "S1 dependent address");
     run_rw<true, true, 0, 0, false, 3>(src, gsrc, sink, pairs, seg, "S1 image taps as four 4-byte loads, gradient taps as before (two 16-byte)");
     run_rw<true, true, 0, 0, false, 1>(src, gsrc, sink, pairs, seg, "S1 image taps as four 4-byte loads, gradient taps as four aligned 8-byte loads");
+    run_rw<true, true, 0, 0, false, 4>(src, gsrc, sink, pairs, seg, "S1 image taps as four 4-byte loads, gradient taps as eight 4-byte loads");
     run_rw<true, true, 0, 0, true>(src, gsrc, sink, pairs, seg, "S2 dependent address + ray load");
     run_rw<true, true, 45, 90, true>(src, gsrc, sink, pairs, seg, "S3 + 45 / 90 dependent fmas");
     run_rw<true, true, 90, 180, true>(src, gsrc, sink, pairs, seg, "S4 twice that arithmetic");
