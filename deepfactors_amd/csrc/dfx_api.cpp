@@ -201,6 +201,20 @@ int grow_partials(dfx_ctx* c, size_t need, bool for_step = false) {
   return DFX_OK;
 }
 
+// Zero-copy descriptors: the kernels of a batched launch read their descriptor array straight out of the pinned staging slot (host memory,
+// mapped) instead of a device copy -- no copy, no event between the copy stream and the launch stream; the slot is free again behind the
+// kernels.  Measured (profiles/r04_launch_gaps.txt): the batched SE3 step / EvaluateError gain 7 / 3.5 us per call (165.8 -> 158.7,
+// 93.0 -> 89.7 us per 128 pairs) -> default for them (DFX_SIMPLE_DESC_ZEROCOPY=0 restores the device copy); the batched SfM step gains
+// 8 us outside its kernel and loses 4 inside it (3840 long-lived workgroups read 1.5 MB over PCIe) -> opt-in (DFX_STEP_DESC_ZEROCOPY=1).
+bool simple_zerocopy() {
+  static const bool v = [] { const char* ev = std::getenv("DFX_SIMPLE_DESC_ZEROCOPY"); return !ev || std::atoi(ev) != 0; }();
+  return v;
+}
+bool desc_zerocopy() {
+  static const bool v = [] { const char* ev = std::getenv("DFX_STEP_DESC_ZEROCOPY"); return ev && std::atoi(ev) != 0; }();
+  return v;
+}
+
 // Pinned staging ring: returns a host slot whose previous upload has completed.
 int stage_acquire(dfx_ctx* c, size_t bytes, int* slot, char** host) {
   if (bytes > c->stage_slot_bytes) {
@@ -989,13 +1003,20 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
       for (int i = 0; i < kStageSlots; ++i) c->slot_busy[i] = false;
     }
     char* region = reinterpret_cast<char*>(c->pairs_dev) + (size_t)slot * c->pairs_cap;
+    if (desc_zerocopy()) {
+      void* hdev = nullptr;
+      DFX_HIP(hipHostGetDevicePointer(&hdev, hd, 0));
+      region = reinterpret_cast<char*>(hdev);   // the staging slot itself; stage_ev[slot] is recorded behind the kernels below
+    }
     dd = reinterpret_cast<dfx::SfmPairDev*>(region);
     if (!uniform) map_dev = reinterpret_cast<unsigned*>(region + desc_bytes);
-    if (c->slot_busy[slot]) DFX_HIP(hipStreamWaitEvent(c->copy_stream, c->slot_done[slot], 0));
-    DFX_HIP(hipMemcpyAsync(region, hd, desc_bytes + map_bytes, hipMemcpyHostToDevice, c->copy_stream));
-    DFX_HIP(hipEventRecord(c->stage_ev[slot], c->copy_stream));
-    c->stage_used[slot] = true;
-    DFX_HIP(hipStreamWaitEvent(c->stream, c->stage_ev[slot], 0));
+    if (!desc_zerocopy()) {
+      if (c->slot_busy[slot]) DFX_HIP(hipStreamWaitEvent(c->copy_stream, c->slot_done[slot], 0));
+      DFX_HIP(hipMemcpyAsync(region, hd, desc_bytes + map_bytes, hipMemcpyHostToDevice, c->copy_stream));
+      DFX_HIP(hipEventRecord(c->stage_ev[slot], c->copy_stream));
+      c->stage_used[slot] = true;
+      DFX_HIP(hipStreamWaitEvent(c->stream, c->stage_ev[slot], 0));
+    }
   }
 
   // the dense-stream variant needs every pair's Jacobian rows back to back (and, in a mixed batch, whole 64-pixel chunks: the launcher
@@ -1083,8 +1104,13 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
   }
   if (c->tail_stream) c->tail_parity ^= 1;
   if (n > 1) {   // the finalize kernel reads the descriptors too
-    DFX_HIP(hipEventRecord(c->slot_done[slot], fin_stream));
-    c->slot_busy[slot] = true;
+    if (desc_zerocopy()) {   // the kernels read the staging slot itself: it is free again behind them
+      DFX_HIP(hipEventRecord(c->stage_ev[slot], fin_stream));
+      c->stage_used[slot] = true;
+    } else {
+      DFX_HIP(hipEventRecord(c->slot_done[slot], fin_stream));
+      c->slot_busy[slot] = true;
+    }
   }
   return DFX_OK;
 }
@@ -1253,10 +1279,11 @@ DFX_API int dfx_sfm_error(dfx_ctx* c, const dfx_se3* pose0, const dfx_se3* pose1
 
 // ---- batched EvaluateError / SE3 step -------------------------------------------------------------------------------
 namespace {
-// uploads n SimplePairDev through the staging ring and returns their device copy; simple_launched(slot) must follow the launches.
-// As in the batched step (dfx_sfm_step_batch_async): the copy runs on the context's copy stream, beside the kernels of the previous launch,
-// and the launch stream waits for it.  On the launch stream itself the 40 KB copy sat between the finalize kernel of one call and the
-// reduction kernel of the next: 18-19 us of idle GPU per call in a kernel trace of back-to-back calls (profiles/r04_launch_gaps.txt).
+// Hands n SimplePairDev to the kernels through the staging ring; simple_launched(slot) must follow the launches.  Default: the kernels read
+// the pinned slot itself (simple_zerocopy above).  Otherwise, as in the batched step (dfx_sfm_step_batch_async): a device copy made on the
+// context's copy stream, beside the kernels of the previous launch, and the launch stream waits for it.  (Rounds 1-4a copied on the launch
+// stream: the 40 KB copy sat between the finalize kernel of one call and the reduction kernel of the next, 18-19 us of idle GPU per call
+// in a kernel trace of back-to-back calls, 11.6 with the copy stream, profiles/r04_launch_gaps.txt.)
 int upload_simple(dfx_ctx* c, const std::vector<dfx::SimplePairDev>& descs, const dfx::SimplePairDev** dev_out, int* slot_out) {
   int rc, slot;
   char* host;
@@ -1272,6 +1299,13 @@ int upload_simple(dfx_ctx* c, const std::vector<dfx::SimplePairDev>& descs, cons
     DFX_HIP(hipMalloc((void**)&c->sdesc_dev, cap * kStageSlots));
     c->sdesc_cap = cap;
   }
+  if (simple_zerocopy()) {
+    void* hdev = nullptr;
+    DFX_HIP(hipHostGetDevicePointer(&hdev, host, 0));
+    *dev_out = reinterpret_cast<const dfx::SimplePairDev*>(hdev);
+    *slot_out = slot;
+    return DFX_OK;
+  }
   char* dd = c->sdesc_dev + (size_t)slot * c->sdesc_cap;
   if (c->slot_busy[slot]) DFX_HIP(hipStreamWaitEvent(c->copy_stream, c->slot_done[slot], 0));   // the last kernels that read this slot's device copy
   DFX_HIP(hipMemcpyAsync(dd, host, bytes, hipMemcpyHostToDevice, c->copy_stream));
@@ -1285,6 +1319,7 @@ int upload_simple(dfx_ctx* c, const std::vector<dfx::SimplePairDev>& descs, cons
 
 // behind the kernels that read the slot's device copy
 int simple_launched(dfx_ctx* c, int slot) {
+  if (simple_zerocopy()) return stage_release(c, slot);   // the kernels read the staging slot itself: free again behind them
   DFX_HIP(hipEventRecord(c->slot_done[slot], c->stream));
   c->slot_busy[slot] = true;
   return DFX_OK;
@@ -1634,6 +1669,12 @@ int update_depth_jobs(dfx_ctx* c, int cs, const std::vector<dfx::DepthJobDev>& j
   const size_t bytes = sizeof(dfx::DepthJobDev) * (size_t)n;
   if ((rc = stage_acquire(c, bytes, &slot, &host))) return rc;
   std::memcpy(host, jobs.data(), bytes);
+  if (simple_zerocopy()) {   // the kernel reads the job list out of the pinned slot (see simple_zerocopy)
+    void* hdev = nullptr;
+    DFX_HIP(hipHostGetDevicePointer(&hdev, host, 0));
+    DFX_HIP(dfx::launch_update_depth_batch(cs, reinterpret_cast<const dfx::DepthJobDev*>(hdev), n, avg_dpt, (int)W, (int)H, c->stream));
+    return stage_release(c, slot);
+  }
   if (c->jobs_cap < (size_t)n) {
     DFX_HIP(hipStreamSynchronize(c->stream));
     if (c->jobs_dev) DFX_HIP(hipFree(c->jobs_dev));

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timeline of the last N dispatches of a rocprofv3 --kernel-trace CSV: kernel, duration, idle gap since the previous kernel's end [us].
-usage: kt_gaps.py <kernel_trace.csv> [--last 12]"""
+usage: kt_gaps.py <kernel_trace.csv> [--last 12] [--like SUBSTR]   (--like keeps only the kernels whose name contains SUBSTR)"""
 import csv
 import sys
 
@@ -8,9 +8,12 @@ import sys
 def main():
     path = sys.argv[1]
     last = int(sys.argv[sys.argv.index("--last") + 1]) if "--last" in sys.argv else 12
+    like = sys.argv[sys.argv.index("--like") + 1] if "--like" in sys.argv else ""
     rows = []
     with open(path) as fh:
         for r in csv.DictReader(fh):
+            if like and like not in (r.get("Kernel_Name") or ""):
+                continue
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), (r.get("Kernel_Name") or "")[:60]))
     rows.sort()
     prev_end = None
