@@ -505,7 +505,6 @@ def tracker_and_geometric_configs(dfx, synth, ctx, dev):
     tests/ut_se3aligner.cpp:173-211) and the geometric half of configs[2] (SparseGeometricFactor::linearize with geo_npoints = 500,
     data/flags/common.flags:29-34, for the 120 pairs of the 16-keyframe window)."""
     import torch
-    from scipy import ndimage
     out = {}
     # ---- configs[0], synthetic 640x480, levels 0..2, iterations 10,5,5 (flags tracking_iters = 5,5,10 are coarse-to-fine)
     p = synth.make_pair(640, 480, 16, seed=0xDF01, device=dev, with_decoder=False)
@@ -544,6 +543,7 @@ def tracker_and_geometric_configs(dfx, synth, ctx, dev):
                                                    "on the device, 20 iterations over 3 levels), from identity, incl. the blocking read-back of the pose")
     # ---- configs[0], the reference's fixture (ut_se3aligner.cpp:45-97,173-211): 320x240, 25x25 box blur, depth mm -> m, 40 iterations, criterion residual / inliers <= 1e-3
     fx = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "se3_fixture_1047_1052.npz")
+    from scipy import ndimage   # (already imported by main(): see there)
     if os.path.exists(fx):
         d = np.load(fx)
         img0 = ndimage.uniform_filter(d["img0"].astype(np.float32) / np.float32(255), 25, mode="mirror")
@@ -797,6 +797,10 @@ def main():
     from deepfactors_amd import _lib as _dl
     from deepfactors_amd import synth
     from deepfactors_amd.dist import NormalEquations, PairGraph, PipelinedReduce
+    # Imported HERE, far from any timed loop: the first import of scipy.ndimage starts a thread pool whose start-up keeps the host cores busy for
+    # a moment -- imported right in front of the tracker loop of tracker_and_geometric_configs() it made that host-driven loop read 0.97 ms
+    # per frame instead of 0.26 (profiles/r04_bench_scipy_import.txt).
+    import scipy.ndimage  # noqa: F401
 
     W, H, CS, P = a.width, a.height, a.cs, a.pairs
     ctx = dfx.Context(local)
