@@ -436,6 +436,14 @@ def gauss_newton_round(dfx, synth, ctx, al, kfs, graph, poses, reps=8, serial=Tr
                                    valid0=kfs[int(i)]["valid0"], prx0_jac=kfs[int(i)]["prx_jac"], grad1=kfs[int(j)]["grad1"]) for (i, j) in graph.pairs])
     keep = np.ones(K * D, bool)
     keep[0:6] = False                                    # gauge: pose of keyframe 0
+    # LAPACK on 8 threads: with the pool's default (every host core: 128 on the GPU box) a 570- or 2426-unknown Cholesky is SLOWER (1.7 / 31-41 ms)
+    # and the pool's idle workers keep spinning into the next iteration's enqueue (the GPU stage of the 64-keyframe round read 9 - 36 ms)
+    try:
+        from threadpoolctl import threadpool_limits
+        blas_limit = lambda: threadpool_limits(limits=8, user_api="blas")   # noqa: E731
+    except Exception:   # noqa: BLE001
+        import contextlib
+        blas_limit = contextlib.nullcontext
     stages = dict(marshal_ms=[], gpu_ms=[], d2h_ms=[], host_system_ms=[], host_solve_ms=[], update_ms=[], total_ms=[])
     for rep in range(reps + 2):
         t = [time.perf_counter()]
@@ -454,7 +462,8 @@ def gauss_newton_round(dfx, synth, ctx, al, kfs, graph, poses, reps=8, serial=Tr
         A[np.diag_indices_from(A)] *= 1.0 + 1e-4
         t.append(time.perf_counter())
         d = np.zeros(K * D)
-        d[keep] = -scipy.linalg.cho_solve(scipy.linalg.cho_factor(A, lower=True, overwrite_a=True, check_finite=False), g[keep], check_finite=False)
+        with blas_limit():
+            d[keep] = -scipy.linalg.cho_solve(scipy.linalg.cho_factor(A, lower=True, overwrite_a=True, check_finite=False), g[keep], check_finite=False)
         t.append(time.perf_counter())
         # (the timed rounds re-evaluate the same point: the update is computed and retracted into copies)
         new_poses = [synth.pose_qt(synth.so3_exp(d[k * D + 3:k * D + 6]) @ _R_of(poses[k][:4]), poses[k][4:].astype(np.float64) + d[k * D:k * D + 3]) for k in range(K)]
@@ -467,7 +476,7 @@ def gauss_newton_round(dfx, synth, ctx, al, kfs, graph, poses, reps=8, serial=Tr
     out = {k: float(np.median(v)) for k, v in stages.items()}
     out.update(keyframes=K, pairs=n_pairs, unknowns=int(keep.sum()), system_bytes=int(neq.buf.numel() * 4),
                note="one Gauss-Newton iteration end to end (median of %d): pair descriptors (host) | batched UpdateDepth + batched RunStep + assembly (GPU, to sync) | D2H of the "
-                    "block-sparse system | dense host system | scipy Cholesky (LAPACK, all host cores) | retract" % reps)
+                    "block-sparse system | dense host system | scipy Cholesky (LAPACK, 8 threads) | retract" % reps)
     if serial:
         # the reference's per-factor pattern over the same factor set
         mk = lambda k: SimpleNamespace(pyr_img=[k["img0"]], pyr_grad=[k["grad1"]], pyr_dpt=[k["dpt0"]], pyr_vld=[k["valid0"]], pyr_stdev=[k["std0"]],   # noqa: E731
