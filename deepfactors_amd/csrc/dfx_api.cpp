@@ -446,8 +446,6 @@ int fill_simple(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam, const df
   quat_to_R(pose_10->q, R);
   for (int i = 0; i < 9; ++i) d->R[i] = R10 ? R10[i] : (float)R[i];
   d->t[0] = pose_10->t[0]; d->t[1] = pose_10->t[1]; d->t[2] = pose_10->t[2];
-  d->exact_identity = d->R[0] == 1.f && d->R[4] == 1.f && d->R[8] == 1.f && d->R[1] == 0.f && d->R[2] == 0.f && d->R[3] == 0.f && d->R[5] == 0.f &&
-                      d->R[6] == 0.f && d->R[7] == 0.f && d->t[0] == 0.f && d->t[1] == 0.f && d->t[2] == 0.f;
   d->fx = cam->fx; d->fy = cam->fy; d->u0 = cam->u0; d->v0 = cam->v0; d->w = cam->w; d->h = cam->h;
   {
     // constants of the fast geometry of the pixel reductions (dfx_kernels.hpp FastGeo), of the fp32 pose the kernels see
@@ -1360,11 +1358,9 @@ DFX_API int dfx_sfm_error_batch_async(dfx_ctx* c, const dfx_sfm_params* params, 
   const dfx::SimplePairDev* dd;
   int slot;
   if ((rc = upload_simple(c, descs, &dd, &slot))) return rc;
-  bool all_identity = true;
-  for (const auto& d : descs) all_identity = all_identity && d.exact_identity != 0;
   hipEvent_t eb, ee;
   if ((rc = prof_events(c, &eb, &ee))) return rc;
-  DFX_HIP(dfx::launch_sfm_error_batch(dd, n, (int)W, (int)H, params->huber_delta, blocks, c->partials, out_items_dev, all_identity, c->stream, eb, ee));
+  DFX_HIP(dfx::launch_sfm_error_batch(dd, n, (int)W, (int)H, params->huber_delta, blocks, c->partials, out_items_dev, c->stream, eb, ee));
   return simple_launched(c, slot);
 }
 
@@ -1408,11 +1404,9 @@ DFX_API int dfx_se3_step_batch_async(dfx_ctx* c, const dfx_se3_pair* pairs, int 
   const dfx::SimplePairDev* dd;
   int slot;
   if ((rc = upload_simple(c, descs, &dd, &slot))) return rc;
-  bool all_identity = true;
-  for (const auto& d : descs) all_identity = all_identity && d.exact_identity != 0;
   hipEvent_t eb, ee;
   if ((rc = prof_events(c, &eb, &ee))) return rc;
-  DFX_HIP(dfx::launch_se3_step_batch(dd, n, (int)W, (int)H, huber_delta, blocks, c->partials, out_items_dev, all_identity, c->stream, eb, ee));
+  DFX_HIP(dfx::launch_se3_step_batch(dd, n, (int)W, (int)H, huber_delta, blocks, c->partials, out_items_dev, c->stream, eb, ee));
   return simple_launched(c, slot);
 }
 

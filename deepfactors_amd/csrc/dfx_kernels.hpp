@@ -148,7 +148,6 @@ struct SimplePairDev {   // SE3Aligner / EvaluateError / Warp
   float* img2;          // warp output or null
   const float* ray_tab; // per-camera ray table ([W] (x - u0) / fx, then [H ...] (y - v0) / fy) or null: the rays are then computed per pixel
   uint32_t pitch_img0, pitch_img1, pitch_dpt0, pitch_grad1, pitch_img2;
-  uint32_t exact_identity;   // host side only: (R, t) is bit for bit the identity -> the launchers pick the pair-load form of the img1 taps (row_walk TAPQ)
 };
 
 // z-space size of the SfM step partials: one 256-float block for the 29 (P,P) sums + the packed 16x16 MFMA blocks
@@ -180,11 +179,11 @@ hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_del
 hipError_t launch_sfm_error(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
                             void* corr_item_dev, hipStream_t stream);
 // batched forms: descs_dev[n], partials [n][blocks][kSimpleRow], results packed (16 bytes per dfx_corr_item, 120 per JTJJrReductionItem<float,6>)
-// all_identity: every pair's pose is the exact identity (SimplePairDev::exact_identity); ev_begin / ev_end (optional) bracket the reduction kernel only
+// ev_begin / ev_end (optional) bracket the reduction kernel only
 hipError_t launch_sfm_error_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
-                                  void* corr_items_dev, bool all_identity, hipStream_t stream, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
+                                  void* corr_items_dev, hipStream_t stream, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 hipError_t launch_se3_step_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
-                                 void* items_dev, bool all_identity, hipStream_t stream, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
+                                 void* items_dev, hipStream_t stream, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 hipError_t launch_se3_warp(const SimplePairDev& p, int W, int H, int blocks, float* partials_dev, void* corr_item_dev,
                            hipStream_t stream);
 hipError_t launch_update_depth(int cs, const float* code_dev, const float* prx_orig, uint32_t pitch_prx, const float* jac,

@@ -107,8 +107,7 @@ __device__ __forceinline__ void fast_band(const float (&R)[9], const float (&t)[
 
 // Walks the calling wave's share of the image; `consume(const RowPix<GRAD>&)` is called once per row with exec = the row's inliers.
 // Returns the wave's inlier count (wave-uniform).
-// TAPQ: the 2 x 2 taps of img1 as two 8-byte loads per lane instead of four dword loads (launches at the EXACT identity, see geom below)
-template <bool GRAD, int DT, bool TAPQ, typename F>
+template <bool GRAD, int DT, typename F>
 __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float (&R)[9], const float (&t)[3], const float e1, const float e2,
                                              const int W, const int H, F&& consume) {
   const FastGeo& fg = p.fg;
@@ -207,25 +206,28 @@ __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float
       const unsigned vm = (valid ? lanemask : 0u) & rowmask;
       S.vmask = vm;
       if constexpr (GRAD) { S.iz = iz; S.U = U; S.V = V; }
+      {
+        // A tap coordinate within 2^-13 pixel of an integer IS that integer: the fast projection itself is only good to ~3e-5 pixel (E above),
+        // so the snapped position is as right as the computed one -- and at (near-)integer warps, the exact identity first of all, it keeps
+        // floor() from flipping between x and x - 1 with the rounding noise from lane to lane, which would cost the dword taps below their
+        // contiguity (SE3 step at the identity: 224 us per 128 pairs with the flips, 165 with the snap = what real poses take; profiles/r04_tap_loads.txt).
+        const float ru = __builtin_rintf(tu), rv = __builtin_rintf(tv);
+        tu = fabsf(tu - ru) < 0x1p-13f ? ru : tu;
+        tv = fabsf(tv - rv) < 0x1p-13f ? rv : tv;
+      }
       const float fu = floorf(tu), fv = floorf(tv);
       S.ax = tu - fu; S.ay = tv - fv;
       const int ix = (int)fu, iy = (int)fv;
       // a lane without correspondence reads offset 0: in range, never used (and no wave-load is ever entirely out of range)
       const unsigned o1 = (unsigned)(__mul24(iy, (int)p.pitch_img1) + ((ix << 2) + (int)c1)) & vm;
-      if constexpr (!TAPQ) {
-        // four dword loads, not two 8-byte ones: an 8-byte load at a 4-byte lane stride (every lane's pair overlaps its neighbour's) costs the
-        // texture addresser 14 cycles per wave, a dword load whose lanes are (nearly) contiguous 4 (profiles/r04_ubench_vmem_issue_cost.txt);
-        // the reductions' skeleton runs 11 % faster with them (profiles/r04_band_walk.txt), EvaluateError 108 -> 101 us, the SE3 step 181 ->
-        // 172 us per 128 pairs.  Not at the exact identity: there u = x + (rounding noise), floor(u) is x or x - 1 at random from lane to
-        // lane, and the dword loads lose their contiguity (224 against 205 us) -- those launches keep the pair loads (TAPQ, chosen by the host).
-        S.ia.x = bload1(rI1, o1, 0);
-        S.ia.y = bload1(rI1, o1, four);                       // (`four` is opaque: the compiler would fuse the pairs back into 8-byte loads)
-        S.ib.x = bload1(rI1, o1, p.pitch_img1);
-        S.ib.y = bload1(rI1, o1, p.pitch_img1 + four);
-      } else {
-        S.ia = bload2(rI1, o1, 0);
-        S.ib = bload2(rI1, o1, p.pitch_img1);
-      }
+      // four dword loads, not two 8-byte ones: an 8-byte load at a 4-byte lane stride (every lane's pair overlaps its neighbour's) costs the
+      // texture addresser 14 cycles per wave, a dword load whose lanes are (nearly) contiguous 4 (profiles/r04_ubench_vmem_issue_cost.txt);
+      // the reductions' skeleton runs 11 % faster with them (profiles/r04_band_walk.txt), EvaluateError 108 -> 101 us, the SE3 step 181 ->
+      // 172 us per 128 pairs (profiles/r04_tap_loads.txt; the snap above keeps them contiguous at the identity).
+      S.ia.x = bload1(rI1, o1, 0);
+      S.ia.y = bload1(rI1, o1, four);                       // (`four` is opaque: the compiler would fuse the pairs back into 8-byte loads)
+      S.ib.x = bload1(rI1, o1, p.pitch_img1);
+      S.ib.y = bload1(rI1, o1, p.pitch_img1 + four);
       if constexpr (GRAD) {
         const unsigned og = (unsigned)(__mul24(iy, (int)p.pitch_grad1) + ((ix << 3) + (int)cg)) & vm;
         S.ga = bload4(rG1, og, 0);
@@ -326,7 +328,6 @@ __device__ __forceinline__ void fold_waves_store(float (&red)[kT / 64][kSimpleRo
 // ---- SE3 step: 21 JtJ + 6 Jtr + r^2 + inliers = 29 floats per workgroup row ---------------------------------------------------------
 // One SE3 Gauss-Newton step (lucas_kanade_se3.h:41-77) over this workgroup's share of the pair; shared by the blocking operator, the
 // batched form and the device-resident tracker (R, t = the pose the step is evaluated at).
-template <bool TAPQ>
 __device__ __forceinline__ void se3_step_body(const SimplePairDev& p, const float (&R)[9], const float (&t)[3], const float e1, const float e2,
                                               const int W, const int H, const float huber_delta, float* __restrict__ out_row) {
   __shared__ float red[kT / 64][kSimpleRow];
@@ -334,7 +335,7 @@ __device__ __forceinline__ void se3_step_body(const SimplePairDev& p, const floa
 #pragma unroll
   for (int q = 0; q < 28; ++q) acc[q] = 0.f;
   const float fx = p.fx, fy = p.fy;
-  const unsigned inl = row_walk<true, DFX_TAP_DIST_SE3, TAPQ>(p, R, t, e1, e2, W, H, [&](const RowPix<true>& S) {
+  const unsigned inl = row_walk<true, DFX_TAP_DIST_SE3>(p, R, t, e1, e2, W, H, [&](const RowPix<true>& S) {
     const float gx = lerpf(lerpf(S.ga.x, S.ga.z, S.ax), lerpf(S.gb.x, S.gb.z, S.ax), S.ay);
     const float gy = lerpf(lerpf(S.ga.y, S.ga.w, S.ax), lerpf(S.gb.y, S.gb.w, S.ax), S.ay);
     float r = S.i0 - pix_img(S);
@@ -371,10 +372,9 @@ __device__ __forceinline__ void se3_step_body(const SimplePairDev& p, const floa
   fold_waves_store(red, 29, out_row);
 }
 
-template <bool TAPQ>
 __global__ __launch_bounds__(kT) void k_se3_step(const SimplePairDev p, const int W, const int H, const float huber_delta,
                                                  float* __restrict__ partials) {
-  se3_step_body<TAPQ>(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
+  se3_step_body(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
 // ---- device-resident tracker (CameraTracker::TrackFrame, reference core/system/camera_tracker.cpp:42-71) -------------
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev* __rest
   for (int q = 0; q < 9; ++q) R[q] = st->Rf[q];
   t[0] = st->tf[0]; t[1] = st->tf[1]; t[2] = st->tf[2];
   fast_band(R, t, p.fc, e1, e2);   // the descriptor's band belongs to the pose it was filled with, not to the state's
-  se3_step_body<false>(p, R, t, e1, e2, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);   // dword taps: a running tracker's pose is the exact identity at most in its first iteration (0.271 vs 0.274 ms per frame with the pair loads)
+  se3_step_body(p, R, t, e1, e2, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
 __global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__ partials_all, const int nblocks, TrackState* __restrict__ states) {
@@ -629,11 +629,10 @@ hipError_t launch_sparse_geometric(int cs, const void* desc_host, const float* c
 }
 
 // ---- SfM error: sum (w r)^2, inliers (dense_sfm.h:79-119: default border 1, min_dpt 0) -------------------------------------------------
-template <bool TAPQ>
 __device__ __forceinline__ void sfm_error_body(const SimplePairDev& p, const int W, const int H, const float huber_delta, float* __restrict__ out_row) {
   __shared__ float red[kT / 64][kSimpleRow];
   float acc = 0.f;
-  const unsigned inl = row_walk<false, DFX_TAP_DIST_ERR, TAPQ>(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, [&](const RowPix<false>& S) {
+  const unsigned inl = row_walk<false, DFX_TAP_DIST_ERR>(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, [&](const RowPix<false>& S) {
     float r = S.i0 - pix_img(S);
     r *= huber_weight(r, huber_delta);
     acc = __builtin_fmaf(r, r, acc);
@@ -644,26 +643,23 @@ __device__ __forceinline__ void sfm_error_body(const SimplePairDev& p, const int
   fold_waves_store(red, 2, out_row);
 }
 
-template <bool TAPQ>
 __global__ __launch_bounds__(kT) void k_sfm_error(const SimplePairDev p, const int W, const int H, const float huber_delta,
                                                   float* __restrict__ partials) {
-  sfm_error_body<TAPQ>(p, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
+  sfm_error_body(p, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
 // ---- batched forms (blockIdx.y = pair): PhotometricFactor::error over a factor set evaluates one pair per blocking call in the reference
 // (core/gtsam/photometric_factor.cpp:61-81,197-216); a relocalisation / loop-closure check steps one live frame against many keyframes.
 // Same per-pair arithmetic and reduction order as the single-pair kernels launched with the same number of workgroups.
-template <bool TAPQ>
 __global__ __launch_bounds__(kT) void k_sfm_error_batch(const SimplePairDev* __restrict__ descs, const int W, const int H, const float huber_delta,
                                                         float* __restrict__ partials_all) {
-  sfm_error_body<TAPQ>(descs[blockIdx.y], W, H, huber_delta, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
+  sfm_error_body(descs[blockIdx.y], W, H, huber_delta, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
 }
 
-template <bool TAPQ>
 __global__ __launch_bounds__(kT) void k_se3_step_batch(const SimplePairDev* __restrict__ descs, const int W, const int H, const float huber_delta,
                                                        float* __restrict__ partials_all) {
   const SimplePairDev& p = descs[blockIdx.y];
-  se3_step_body<TAPQ>(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, huber_delta, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
+  se3_step_body(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, huber_delta, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
 }
 
 // ---- Warp: render img1 into frame 0, SIGNED residual sum (cu_se3aligner.cpp:106) ----------------------------
@@ -870,8 +866,7 @@ static void launch_finalize_rows(int n, int blocks, int kind, const float* parti
 
 hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
                            void* item_dev, hipStream_t stream) {
-  if (p.exact_identity) hipLaunchKernelGGL(k_se3_step<true>, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
-  else hipLaunchKernelGGL(k_se3_step<false>, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
+  hipLaunchKernelGGL(k_se3_step, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   launch_finalize_rows(1, blocks, (int)kFinalItem6, (const float*)partials_dev, item_dev, (size_t)0, stream);
@@ -880,8 +875,7 @@ hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_del
 
 hipError_t launch_sfm_error(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
                             void* corr_item_dev, hipStream_t stream) {
-  if (p.exact_identity) hipLaunchKernelGGL(k_sfm_error<true>, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
-  else hipLaunchKernelGGL(k_sfm_error<false>, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
+  hipLaunchKernelGGL(k_sfm_error, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   launch_finalize_rows(1, blocks, (int)kFinalCorr, (const float*)partials_dev, corr_item_dev, (size_t)0, stream);
@@ -889,10 +883,9 @@ hipError_t launch_sfm_error(const SimplePairDev& p, int W, int H, float huber_de
 }
 
 hipError_t launch_sfm_error_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
-                                  void* corr_items_dev, bool all_identity, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end) {
+                                  void* corr_items_dev, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end) {
   if (ev_begin) (void)hipEventRecord(ev_begin, stream);
-  if (all_identity) hipLaunchKernelGGL(k_sfm_error_batch<true>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
-  else hipLaunchKernelGGL(k_sfm_error_batch<false>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
+  hipLaunchKernelGGL(k_sfm_error_batch, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_end) (void)hipEventRecord(ev_end, stream);
@@ -901,10 +894,9 @@ hipError_t launch_sfm_error_batch(const SimplePairDev* descs_dev, int n, int W, 
 }
 
 hipError_t launch_se3_step_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
-                                 void* items_dev, bool all_identity, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end) {
+                                 void* items_dev, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end) {
   if (ev_begin) (void)hipEventRecord(ev_begin, stream);
-  if (all_identity) hipLaunchKernelGGL(k_se3_step_batch<true>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
-  else hipLaunchKernelGGL(k_se3_step_batch<false>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
+  hipLaunchKernelGGL(k_se3_step_batch, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_end) (void)hipEventRecord(ev_end, stream);

@@ -385,8 +385,7 @@ def test_batched_error_and_se3_step_match_the_single_pair_operators_and_the_orac
         assert np.frombuffer(e[16 * k:16 * k + 4].tobytes(), np.float32)[0] == np.float32(errs[k].residual)
         assert int(np.frombuffer(e[16 * k + 8:16 * k + 16].tobytes(), np.uint64)[0]) == errs[k].inliers
     assert np.array_equal(sd.cpu().numpy(), np.concatenate([s.raw for s in steps]))
-    # a launch whose poses are ALL the exact identity takes the pair-load form of the img1 taps (row_walk TAPQ), a mixed launch the dword form:
-    # the same bytes arrive either way, so an identity pair gives the same item in both
+    # an identity pair gives the same item whatever the poses of the other pairs of its launch are
     ident = [dict(s, se3=synth.IDENTITY) for s in slist]
     steps_id = se3.RunStepBatch(se3.make_pairs(ident))
     for k in range(0, n, 2):
