@@ -1323,11 +1323,14 @@ int simple_launched(dfx_ctx* c, int slot) {
   return DFX_OK;
 }
 
-// workgroups per pair of a batched simple kernel: ~24 per CU over the whole batch, at least one wave-row of pixels each
+// workgroups per pair of a batched simple kernel: ~20 per CU over the whole batch, at least one wave-row of pixels each.  What matters is how
+// the row walk's items fall out of it (row_walk: waves per pair / bands -> row segments): 20 per CU = 40 workgroups per 640x480 pair of a
+// 128-pair batch = 16 segments of exactly 30 rows and 80 waves per CU = four full rounds of the SE3 step's 20 resident waves; 24 (rounds 3-4a)
+// gave 19 segments of 26 rows with a short last one (profiles/r04_launch_shape.txt: SE3 step 165 -> 160 us, EvaluateError 92 -> 88).
 int batch_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int n) {
   int b = simple_blocks(W, H);
   static const int k_env = [] { const char* ev = std::getenv("DFX_BATCH_WGS_PER_CU"); const int v = ev ? std::atoi(ev) : 0; return v > 0 && v <= 256 ? v : 0; }();   // tuning aid
-  const int cap = ((k_env ? k_env : 24) * c->cu_count + n - 1) / n;
+  const int cap = ((k_env ? k_env : 20) * c->cu_count + n - 1) / n;
   if (b > cap) b = cap;
   return b < 1 ? 1 : b;
 }

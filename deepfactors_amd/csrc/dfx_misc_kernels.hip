@@ -62,12 +62,13 @@ constexpr int kBand = 64;
 #define DFX_RW_UNROLL 1   // rotations of the row states per loop iteration
 #endif
 // rows between the issue of a row's bilinear taps and their use (the depth of the software pipeline, see row_walk), per operator: the
-// SE3 step carries 21 registers of row state per stage (4 waves per SIMD at depth 2), EvaluateError 8
+// SE3 step carries 21 registers of row state per stage (5 waves per SIMD at depth 1; depth 2 costs a wave: 176 vs 165 us per 128 pairs),
+// EvaluateError 8 (depth 2: 92 -> 87 us; depth 3 no better) -- profiles/r04_launch_shape.txt
 #ifndef DFX_TAP_DIST_SE3
 #define DFX_TAP_DIST_SE3 1
 #endif
 #ifndef DFX_TAP_DIST_ERR
-#define DFX_TAP_DIST_ERR 1
+#define DFX_TAP_DIST_ERR 2
 #endif
 
 __device__ __forceinline__ float rfl(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
