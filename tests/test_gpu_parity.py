@@ -343,6 +343,17 @@ def test_tiny_and_narrow_images(dfx, oracle, w, h):
     s_got = se3.RunStep(pose1, cam, g2["img0"], g2["img1"], g2["dpt0"], g2["grad1"])
     s_ref = oracle.se3_step(pose1, cam, n2["img0"], n2["img1"], n2["dpt0"], n2["grad1"], 0.1)
     assert s_got.inliers == s_ref.inliers
+    # EvaluateError walks rows two deep (row_walk DT = 2): images with fewer rows than its warm-up, and the batched forms on them
+    e_got = al.EvaluateError(pose0, pose1, cam, g2["img0"], g2["img1"], g2["dpt0"], None, g2["grad1"])
+    e_res, e_inl = oracle.sfm_error(pose0, pose1, cam, n2["img0"], n2["img1"], n2["dpt0"], 0.1)
+    assert e_got.inliers == e_inl
+    assert abs(e_got.residual - e_res) <= 1e-4 * abs(e_res) + 1e-6
+    pl = [dict(pose0=pose0, pose1=pose1, cam=cam, img0=g2["img0"], img1=g2["img1"], dpt0=g2["dpt0"], prx0_jac=g2["prx_jac"], grad1=g2["grad1"])] * 3
+    for e in al.EvaluateErrorBatch(al.make_pairs(pl)):
+        assert e.inliers == e_got.inliers and e.residual == e_got.residual
+    sl = [dict(se3=pose1, cam=cam, img0=g2["img0"], img1=g2["img1"], dpt0=g2["dpt0"], grad1=g2["grad1"])] * 3
+    for st in se3.RunStepBatch(se3.make_pairs(sl)):
+        assert st.inliers == s_got.inliers
     out = torch.empty_like(g2["img0"])
     dfx.UpdateDepth(n["code"], g2["prx_orig"], g2["prx_jac"], 2.0, out)
     d_ref = oracle.update_depth(n["code"], n2["prx_orig"], n2["prx_jac"], 2.0)
