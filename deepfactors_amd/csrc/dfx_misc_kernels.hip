@@ -47,8 +47,12 @@ __device__ __forceinline__ Geo geo_from(const SimplePairDev& p) {
 //  * a wave owns a 64-pixel-wide column BAND and walks down a segment of its rows: x (and the ray K^-1 x) is loop-invariant per lane, the
 //    row is wave-uniform, so every streaming load is `buffer_load  voffset = x * 4 (constant), soffset = y * pitch (scalar unit)` -- no
 //    vector-ALU address arithmetic at all, 256 contiguous bytes per wave-load, adjacent waves of a workgroup take adjacent bands;
-//  * three rows are in flight per wave: the depth / intensity / ray of row y + 2 are loaded, the geometry of row y + 1 is evaluated and its
-//    bilinear taps are issued, row y is consumed (the compiler counts the `vmcnt` waits: loads return in order);
+//  * a software pipeline DT rows deep (DFX_TAP_DIST_*): the depth / intensity of row y + 2 DT are loaded (read once: non-temporal), the
+//    geometry of row y + DT is evaluated and its bilinear taps are issued, row y is consumed (the compiler counts the `vmcnt` waits: loads
+//    return in order); the row's ray-table entry comes through the scalar cache;
+//  * the taps: what bounds these kernels is the FORM of the tap loads, not bytes or arithmetic (tools/ubench/band_walk.cpp):
+//    img1 as four dword loads (contiguous from lane to lane under a coherent warp), grad1 as two 16-byte loads; a tap coordinate within
+//    2^-13 pixel of an integer is snapped to it so that floor() does not flip from lane to lane at (near-)integer warps;
 //  * FAST geometry (FastGeo, dfx_kernels.hpp): fused multiply-adds, one v_rcp_f32, validity as a margin in homogeneous coordinates.  The
 //    inlier set is still EXACTLY the reference's: a wave with a pixel whose margin is within the error bound E of zero re-evaluates those
 //    pixels in the reference's operation order (find_correspondence_ray<true>) -- a wave-uniform branch taken for a ~1e-3-pixel band
