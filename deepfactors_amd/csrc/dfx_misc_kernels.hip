@@ -211,17 +211,13 @@ __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float
       const unsigned vm = (valid ? lanemask : 0u) & rowmask;
       S.vmask = vm;
       if constexpr (GRAD) { S.iz = iz; S.U = U; S.V = V; }
-      {
-        // A tap coordinate within 2^-13 pixel of an integer IS that integer: the fast projection itself is only good to ~3e-5 pixel (E above),
-        // so the snapped position is as right as the computed one -- and at (near-)integer warps, the exact identity first of all, it keeps
-        // floor() from flipping between x and x - 1 with the rounding noise from lane to lane, which would cost the dword taps below their
-        // contiguity (SE3 step at the identity: 224 us per 128 pairs with the flips, 165 with the snap = what real poses take; profiles/r04_tap_loads.txt).
-        const float ru = __builtin_rintf(tu), rv = __builtin_rintf(tv);
-        tu = fabsf(tu - ru) < 0x1p-13f ? ru : tu;
-        tv = fabsf(tv - rv) < 0x1p-13f ? rv : tv;
-      }
-      const float fu = floorf(tu), fv = floorf(tv);
-      S.ax = tu - fu; S.ay = tv - fv;
+      // A tap coordinate less than 2^-13 pixel BELOW an integer is that integer (floor of the biased coordinate, weight clamped at 0): the fast
+      // projection itself is only good to ~3e-5 pixel (E above), so the snapped position is as right as the computed one -- and at (near-)
+      // integer warps, the exact identity first of all, it keeps floor() from flipping between x and x - 1 with the rounding noise from lane to
+      // lane, which would cost the dword taps below their contiguity (SE3 step at the identity: 224 us per 128 pairs with the flips, 165 with
+      // the snap = what real poses take; profiles/r04_tap_loads.txt).  Coordinates just ABOVE an integer need nothing: their floor is stable.
+      const float fu = floorf(tu + 0x1p-13f), fv = floorf(tv + 0x1p-13f);
+      S.ax = fmaxf(tu - fu, 0.f); S.ay = fmaxf(tv - fv, 0.f);
       const int ix = (int)fu, iy = (int)fv;
       // a lane without correspondence reads offset 0: in range, never used (and no wave-load is ever entirely out of range)
       const unsigned o1 = (unsigned)(__mul24(iy, (int)p.pitch_img1) + ((ix << 2) + (int)c1)) & vm;
