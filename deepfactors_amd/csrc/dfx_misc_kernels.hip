@@ -133,6 +133,7 @@ __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float
   const unsigned cg = GRAD ? (unsigned)fg.icy * p.pitch_grad1 + (unsigned)fg.icx * 8u : 0u;
   unsigned four = 4u;
   asm volatile("" : "+s"(four));
+  const float ixmax = (float)(W - 2 - fg.icx), iymax = (float)(H - 2 - fg.icy);   // last cell of the tap grid, relative to pixel (icx, icy)
   Geo g;   // the reference-order fall-back
 #pragma unroll
   for (int q = 0; q < 9; ++q) g.R[q] = R[q];
@@ -216,7 +217,9 @@ __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float
       // integer warps, the exact identity first of all, it keeps floor() from flipping between x and x - 1 with the rounding noise from lane to
       // lane, which would cost the dword taps below their contiguity (SE3 step at the identity: 224 us per 128 pairs with the flips, 165 with
       // the snap = what real poses take; profiles/r04_tap_loads.txt).  Coordinates just ABOVE an integer need nothing: their floor is stable.
-      const float fu = floorf(tu + 0x1p-13f), fv = floorf(tv + 0x1p-13f);
+      // (never past the last cell: an inlier with u in [W - 1 - 2^-13, W - 1) keeps ix = W - 2 with a weight of almost 1 -- its right-hand tap must stay
+      // inside the row, a zero weight does not neutralise a NaN in whatever lies behind it)
+      const float fu = fminf(floorf(tu + 0x1p-13f), ixmax), fv = fminf(floorf(tv + 0x1p-13f), iymax);
       S.ax = fmaxf(tu - fu, 0.f); S.ay = fmaxf(tv - fv, 0.f);
       const int ix = (int)fu, iy = (int)fv;
       // a lane without correspondence reads offset 0: in range, never used (and no wave-load is ever entirely out of range)

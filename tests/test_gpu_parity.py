@@ -409,3 +409,37 @@ def test_batched_error_and_se3_step_match_the_single_pair_operators_and_the_orac
     nl, ms = ctx.profile_read()
     ctx.set_profiling(False)
     assert nl == 2 and 0.0 < ms < 50.0
+
+
+def test_snapped_taps_never_touch_what_lies_behind_a_row(dfx, oracle):
+    """The row walk snaps a tap coordinate that is less than 2^-13 pixel below an integer onto it.  An inlier whose u lies that
+    close under W - 1 must keep its taps at columns W - 2, W - 1: a right-hand tap at column W would read the row's padding (or the next row) --
+    with a weight of zero, which does not neutralise a NaN.  Constructed case: constant depth 1, a pure x translation of (1 - 6e-5) / fx, so
+    column W - 2 of every row maps to u = W - 1 - 6e-5; img1 / grad1 pitched with NaN behind every row and NaN rows behind the image."""
+    from deepfactors_amd import synth
+    w, h = 192, 144
+    p = synth.make_pair(w, h, 16, seed=77, device="cpu", with_decoder=False)
+    n = synth.to_numpy(p)
+    cam = n["cam"]
+    n["dpt0"] = np.ones((h, w), np.float32)
+    for shift_px, axis in ((1.0 - 6e-5, 0), (1.0 - 6e-5, 1)):
+        pose = synth.IDENTITY.copy()
+        pose[4 + axis] = np.float32(shift_px / float(cam[axis]))        # u = x + fx tx / d   (v = y + fy ty / d)
+
+        def nan_padded(a, pad_cols, pad_rows):
+            t = torch.from_numpy(a).cuda()
+            big = torch.full((a.shape[0] + pad_rows, a.shape[1] + pad_cols) + tuple(a.shape[2:]), float("nan"), dtype=t.dtype, device="cuda")
+            big[: a.shape[0], : a.shape[1]] = t
+            return big[: a.shape[0], : a.shape[1]]
+        i0, d0 = torch.from_numpy(n["img0"]).cuda(), torch.from_numpy(n["dpt0"]).cuda()
+        i1, g1 = nan_padded(n["img1"], 8, 3), nan_padded(n["grad1"], 8, 3)
+        se3, al = dfx.SE3Aligner(), dfx.SfmAligner(code_size=16)
+        s_got = se3.RunStep(pose, cam, i0, i1, d0, g1)
+        s_ref = oracle.se3_step(pose, cam, n["img0"], n["img1"], n["dpt0"], n["grad1"], 0.1)
+        assert np.all(np.isfinite(s_got.JtJ)) and np.isfinite(s_got.residual)
+        assert s_got.inliers == s_ref.inliers
+        assert_item_close(s_got, s_ref, w, h, what=f"snap at the border, axis {axis}")
+        e_got = al.EvaluateError(synth.IDENTITY, pose, cam, i0, i1, d0, None, g1)
+        e_res, e_inl = oracle.sfm_error(synth.IDENTITY, pose, cam, n["img0"], n["img1"], n["dpt0"], 0.1)
+        assert np.isfinite(e_got.residual) and e_got.inliers == e_inl
+        assert abs(e_got.residual - e_res) <= 1e-4 * abs(e_res) + 1e-6

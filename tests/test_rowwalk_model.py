@@ -99,9 +99,13 @@ def row_walk_model(qt, cam, img0, img1, dpt0, grad1, huber_delta, want_grad):
                  exact_inliers=int(valid_e.sum()), set_equal=bool(np.array_equal(valid, valid_e)))
     ys, xs = np.nonzero(valid)
     tu, tv, U, V, iz = tu[ys, xs], tv[ys, xs], U[ys, xs], V[ys, xs], iz[ys, xs]
-    fu, fv = np.floor(tu), np.floor(tv)
-    ax, ay = tu - fu, tv - fv
+    # the snap: a tap coordinate less than 2^-13 pixel below an integer is that integer (biased floor, weight clamped at 0)
+    SNAP = f32(2.0 ** -13)
+    fu, fv = np.minimum(np.floor(tu + SNAP), f32(W - 2 - g["icx"])), np.minimum(np.floor(tv + SNAP), f32(H - 2 - g["icy"]))   # never past the last cell
+    ax, ay = np.maximum(tu - fu, f32(0)), np.maximum(tv - fv, f32(0))
     ix, iy = fu.astype(np.int64) + g["icx"], fv.astype(np.int64) + g["icy"]
+    stats["ix_minus_x"] = (ix - xs)
+    stats["iy_minus_y"] = (iy - ys)
     assert ix.min() >= 0 and ix.max() + 1 <= W - 1 and iy.min() >= 0 and iy.max() + 1 <= H - 1, "tap out of range"
     lerp = lambda a, b, w: fma(w, b - a, a)
     samp = lerp(lerp(img1[iy, ix], img1[iy, ix + 1], ax), lerp(img1[iy + 1, ix], img1[iy + 1, ix + 1], ax), ay)
@@ -171,3 +175,34 @@ def test_degenerate_depths_fall_back_or_drop_out():
 def _inverse(qt):
     R = synth.quat_to_R(np.asarray(qt[:4], np.float64))
     return synth.pose_qt(R.T, -R.T @ np.asarray(qt[4:], np.float64))
+
+
+def test_the_snap_makes_the_identity_warp_lane_contiguous():
+    """At the exact identity u = x + rounding noise: floor(u) would be x or x - 1 at random from pixel to pixel (the dword tap loads of the kernels
+    would lose their contiguity); with the snap every inlier taps (x, y) itself -- and the sums still agree with the oracle, for which u = x."""
+    w, h = 160, 120
+    p = synth.make_pair(w, h, 16, seed=11, device="cpu", with_decoder=False)
+    n = synth.to_numpy(p)
+    ident = np.asarray(synth.IDENTITY, np.float32)
+    got, st = row_walk_model(ident, n["cam"], n["img0"], n["img1"], n["dpt0"], n["grad1"], 0.1, True)
+    assert st["set_equal"]
+    assert np.all(st["ix_minus_x"] == 0) and np.all(st["iy_minus_y"] == 0)
+    # without the snap the same arithmetic flips: some pixels land on x - 1 (this is what the snap is for)
+    cam = n["cam"]
+    Rd = synth.quat_to_R(np.asarray(ident[:4], np.float64))
+    g = derive_fast(Rd.reshape(9), np.zeros(3), cam, w, h)
+    fx, fy, u0, v0 = [f32(c) for c in cam[:4]]
+    rx = ((np.arange(w, dtype=f32) - u0) / fx)[None, :].repeat(h, 0)
+    ry = ((np.arange(h, dtype=f32) - v0) / fy)[:, None].repeat(w, 1)
+    d = n["dpt0"].astype(f32)
+    R = Rd.astype(f32).reshape(9)
+    rr = [fma(R[3 * i + 1], ry, fma(R[3 * i], rx, R[3 * i + 2])) for i in range(3)]
+    Z = rr[2] * d
+    X, Y = fma(fx, rr[0] * d, g["cu"] * Z), fma(fy, rr[1] * d, g["cv"] * Z)
+    iz = (f32(1.0) / Z).astype(f32)
+    tu = fma(X, iz, g["fcx"])
+    flips = np.floor(tu).astype(np.int64) + g["icx"] - np.arange(w)[None, :]
+    assert (flips[2:-2, 2:-2] == -1).any() and (flips[2:-2, 2:-2] == 0).any()
+    ref = orc.se3_step(ident, n["cam"], n["img0"], n["img1"], n["dpt0"], n["grad1"], 0.1)
+    assert got.inliers == ref.inliers
+    assert_item_close(got, ref, w, h, what="identity, snapped taps")
