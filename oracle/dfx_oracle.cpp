@@ -15,8 +15,11 @@
 // camera_pyramid}.h, from where they lie under /root/reference -- against stand-in Eigen / Sophus / VisionCore headers
 // (oracle/standins/), and tests/test_oracle_vs_ref.py checks this restatement against it per pixel item and per reduced system; the
 // outputs of that library on stored inputs are committed as known-answer vectors (tests/golden/ref_vectors.npz,
-// tests/test_golden_ref_vectors.py), so the pin also holds where /root/reference is absent.  Beside it, the reference's own test
-// criteria are kept as known-answer tests:
+// tests/test_golden_ref_vectors.py), so the pin also holds where /root/reference is absent.  The same for the rows beside the step
+// kernel: SparseGeometricFactor::linearize (the reference's .cpp #included whole, ref_harness_f3.cpp) and the kernel bodies of DepthAligner,
+// SobelGradients, GaussianBlurDown, SquaredError and SE3Aligner::Warp, cut out of cuda/cu_depthaligner.cpp, cu_image_proc.cpp and
+// cu_se3aligner.cpp at build time (oracle/Makefile, ref_harness_f1.cpp; vectors tests/golden/ref_vectors_f3.npz, ref_vectors_f1.npz).
+// Beside it, the reference's own test criteria are kept as known-answer tests:
 //   - tests/ut_se3aligner.cpp:173-211  ImageAlignmentTest on data/testimg/1047->1052
 //     (residual/inliers <= 1e-3 after 40 Gauss-Newton iterations)        -> tests/test_oracle_kat.py
 //   - tests/ut_warping.cpp:72-380, tests/ut_pinhole_camera.cpp:50-134   finite-difference checks
