@@ -371,6 +371,40 @@ def secondary_configs(dfx, synth, ctx, dev):
     from deepfactors_amd import _lib as _dl4
     out["configs4_1280x960_cs64"]["f32_chain"] = mode_kernel_us(ctx, lambda: al4.RunStepBatchAsync(arr, items), bpl, warm=150, steps=20, mode=_dl4.DFX_MFMA_F32_CHAIN)
     del pairs, keep, arr, items
+    torch.cuda.empty_cache()
+    # ---- configs[4] AS BASELINE STATES IT: "1280x960 input, 4-level pyramid, 64-dim code" -- levels 1280x960 ... 160x120 (the decoder emits one
+    # Jacobian per level, core/network/decoder_network.cpp:258-259; pyramid_levels = 4 in core/deepfactors_options.h:43,83) of 16 factor sets: 64 pairs
+    # in ONE launch (mixed image sizes: the per-tile finalize kernel in its mixed-size form), and level by level as the reference walks them
+    # (tools/kernel_benchmark.cpp:192-203)
+    lv4 = ((1280, 960), (640, 480), (320, 240), (160, 120))
+    lv_pairs, lv_keep = [], []
+    for (w, h) in lv4:
+        pr, kp = build_pairs(dfx, synth, dev, 11, P, w, h, CS, ctx=ctx)
+        lv_pairs.append(pr); lv_keep.append(kp)
+    items = torch.zeros(len(lv4) * P * dfx.item_size(12 + CS), dtype=torch.uint8, device=dev)
+
+    def kernel_us4(arr, warm, reps):
+        for _ in range(warm):
+            al4.RunStepBatchAsync(arr, items)
+        ctx.sync()
+        ctx.set_profiling(True)
+        for _ in range(reps):
+            al4.RunStepBatchAsync(arr, items)
+        nl, ms = ctx.profile_read()
+        ctx.set_profiling(False)
+        return ms / nl * 1e3
+    one_us = kernel_us4(al4.make_pairs([p for pr in lv_pairs for p in pr]), 200, 20)
+    lv_us = [kernel_us4(al4.make_pairs(pr), 200 if k == 0 else 600, 20) for k, pr in enumerate(lv_pairs)]
+    px4 = sum(w * h for (w, h) in lv4) * P
+    out["configs4_pyramid4"] = dict(pairs_per_launch=len(lv4) * P, factor_sets=P, levels=[list(s) for s in lv4], one_launch_kernel_us=one_us,
+                                    evals_per_s=P / (one_us * 1e-6), algorithmic_bytes=(20 + 4 * CS) * px4, algorithmic_gbs=(20 + 4 * CS) * px4 / (one_us * 1e-6) / 1e9,
+                                    frac=(20 + 4 * CS) * px4 / (one_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                    level_by_level_kernel_us=lv_us, level_by_level_frac=(20 + 4 * CS) * px4 / (sum(lv_us) * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                    mfma=MFMA_NAMES[ctx.last_mfma_mode()] + " -- the library default (DFX_MFMA_AUTO)",
+                                    note="BASELINE configs[4] as stated: SfmAligner::RunStep over the FOUR pyramid levels 1280x960 ... 160x120 of 16 factor sets at CS = 64 "
+                                         "(7.2 GB working set): one 'evaluation' = all four levels; ONE launch over the 64 pairs vs one launch per level; step kernels only")
+    del lv_pairs, lv_keep, items
+    torch.cuda.empty_cache()
     # ---- configs[2] as the reference's relinearisation round (PhotometricFactor::RunAlignmentStep, photometric_factor.cpp:225-293, for every
     # factor of a 16-keyframe window): UpdateDepth once per keyframe whose code moved + one batched RunStep over the 120 pairs
     from deepfactors_amd.dist import PairGraph
@@ -608,6 +642,36 @@ def tracker_and_geometric_configs(dfx, synth, ctx, dev):
                                                    note="SparseGeometricFactor::linearize (core/gtsam/sparse_geometric_factor.cpp:147-275) for the 120 pairs of the 16-keyframe window, "
                                                         "500 points each: one blocking dfx_sparse_geometric_linearize per factor (the reference's per-factor pattern; it is a CPU loop "
                                                         "there that first syncs the 39 MB code Jacobian to the host), rows read back to the host")
+    # the same round as ONE launch (dfx_sparse_geometric_linearize_batch: CS / 4 lanes per point, grid.y = factor): rows left on the device (what a device-side
+    # consumer -- a normal-equation assembly -- would read), and fetched to the host with one copy (what gtsam::JacobianFactor needs: 18.5 MB per round)
+    gfs = [f for f, _, _ in facs]
+    gvals = [(a["pose0"], b["pose1"], a["code"], b["code"]) for _, a, b in facs]
+    ncol = 12 + 2 * CS + 1
+    rows_dev = torch.empty((len(gfs) * NPTS, ncol), dtype=torch.float32, device=dev)
+    batch_rows = dfx.SparseGeometricFactor.linearize_all(gfs, gvals)
+    same = all(np.array_equal(batch_rows[k], gfs[k].linearize(*gvals[k])) for k in (0, 57, 119))
+    for f in gfs:
+        f.upload_points()                                    # the reference samples a factor's points once, in its constructor
+    enq = lambda: dfx.SparseGeometricFactor.linearize_all(gfs, gvals, rows_dev=rows_dev)   # noqa: E731
+    for _ in range(5):
+        enq()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        enq()
+    ctx.sync()
+    dev_round = (time.perf_counter() - t0) / 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    enq(); e0.record(); enq(); e1.record(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        dfx.SparseGeometricFactor.linearize_all(gfs, gvals)
+    host_round = (time.perf_counter() - t0) / 5
+    out["configs2_sparse_geometric_500pts"].update(batched_round_ms_rows_on_device=dev_round * 1e3, batched_gpu_ms=e0.elapsed_time(e1), batched_round_ms_rows_to_host=host_round * 1e3,
+                                                   batched_equals_per_factor_bits=bool(same), rows_bytes=int(rows_dev.numel() * 4),
+                                                   batched_note="the 120 factors in ONE launch: rows_on_device = wall clock per round of back-to-back enqueues incl. the Python marshalling of "
+                                                                "120 descriptors (points resident on the device); batched_gpu_ms = one round on the stream (H2D of the descriptors + kernel, HIP "
+                                                                "events); rows_to_host = the blocking form with ONE device-to-host copy of all rows")
     # ---- configs[2]: one Gauss-Newton iteration of the 16-keyframe / 120-pair window end to end
     al = dfx.SfmAligner(code_size=CS, ctx=ctx)
     poses = []
@@ -620,23 +684,28 @@ def tracker_and_geometric_configs(dfx, synth, ctx, dev):
     # the same relinearisation round from C++ (include/dfx_host.hpp; the Python mirror above pays ~0.1 ms of interpreter time per factor): the reference's serial
     # linearize() pattern, the batched seam, and the serial pattern warmed by the batched seam -- tools/cpp/gn_round_bench.cpp, built by tests/cpp/Makefile
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "cpp", "gn_round_bench")
-    if os.path.exists(exe):
+    for key, argv, what in (("configs2_relinearisation_round_cpp", ["16", "7"], "16 keyframes / 120 factors (all pairs i < j)"),
+                            ("configs3_relinearisation_round_cpp", ["64", "3", "16"], "64 keyframes / 1024 factors (every keyframe linked to its 16 nearest: BASELINE configs[3])")):
+        if not os.path.exists(exe):
+            break
         try:
-            r = subprocess.run([exe, "16", "7"], capture_output=True, text=True, timeout=120, stdin=subprocess.DEVNULL)
+            r = subprocess.run([exe] + argv, capture_output=True, text=True, timeout=240, stdin=subprocess.DEVNULL)
             vals = {}
             for line in r.stdout.splitlines():
                 tok = line.split()
                 if len(tok) == 4 and tok[0].endswith("_ms"):
                     vals[tok[0]] = float(tok[1]); vals[tok[0][:-3] + "_per_factor_us"] = float(tok[3])
             if r.returncode == 0 and vals:
-                vals["note"] = ("C++ host layer, 16 keyframes / 120 factors of 640x480x32 per round, median of 7: serial_cold = PhotometricFactor::linearize factor by factor "
-                                "(blocking UpdateDepth + RunStep each: what a header-swap build under iSAM2 delivers); batched = dfx::LinearizeAll (one decode + one step launch); "
-                                "serial_warmed = LinearizeAll, then the serial calls hit their caches; every variant incl. the G11..G33 slicing")
-                out["configs2_relinearisation_round_cpp"] = vals
+                vals["note"] = (f"C++ host layer (include/dfx_host.hpp, tools/cpp/gn_round_bench.cpp), {what} of 640x480x32 per round, median of {argv[1]}: serial_cold = "
+                                "PhotometricFactor::linearize factor by factor (blocking UpdateDepth + RunStep each: what a header-swap build under iSAM2 delivers); batched = "
+                                "dfx::LinearizeAll (one decode + one step launch); serial_warmed = LinearizeAll, then the serial calls hit their caches; every variant incl. the "
+                                "G11..G33 slicing.  geometric_* = the sparse geometric factors of the same links (500 points each): all factors in ONE launch with the rows left on the "
+                                "device / fetched with one copy (dfx::SparseGeometricLinearizeAll), and one blocking call per factor")
+                out[key] = vals
             else:
-                out["configs2_relinearisation_round_cpp"] = {"error": (r.stdout + r.stderr)[-300:]}
+                out[key] = {"error": (r.stdout + r.stderr)[-300:]}
         except Exception as e:   # noqa: BLE001 -- an extra figure, never the line
-            out["configs2_relinearisation_round_cpp"] = {"error": f"{type(e).__name__}: {e}"}
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 

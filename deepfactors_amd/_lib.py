@@ -67,6 +67,12 @@ class SE3Pair(C.Structure):
     _fields_ = [("pose_10", SE3), ("cam", Cam), ("img0", Img), ("img1", Img), ("dpt0", Img), ("grad1", Img)]
 
 
+class SparseGeoFactor(C.Structure):
+    _fields_ = [("pose0", SE3), ("pose1", SE3), ("cam", Cam), ("code0", C.POINTER(C.c_float)), ("code1", C.POINTER(C.c_float)), ("points_xy", C.c_void_p),
+                ("n_points", C.c_int32), ("points_on_device", C.c_int32), ("prx0_orig", Img), ("prx0_jac", Img), ("prx1_orig", Img), ("prx1_jac", Img),
+                ("dpt1_grad", Img)]
+
+
 def item_jtj_len(np_):
     return np_ * (np_ + 1) // 2
 
@@ -121,6 +127,8 @@ _PROTOS = {
     "dfx_sparse_geometric_linearize": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SE3), C.POINTER(SE3), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                                  C.POINTER(Cam), C.POINTER(C.c_int32), C.c_int, C.POINTER(Img), C.POINTER(Img), C.POINTER(Img),
                                                  C.POINTER(Img), C.POINTER(Img), C.c_float, C.c_float, C.POINTER(C.c_float)]),
+    "dfx_sparse_geometric_linearize_batch_async": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SparseGeoFactor), C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "dfx_sparse_geometric_linearize_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SparseGeoFactor), C.c_int, C.c_float, C.c_float, C.POINTER(C.c_float)]),
     "dfx_sfm_step": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SE3), C.POINTER(SE3), C.POINTER(Cam), C.POINTER(SfmParams),
                                C.POINTER(Img), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img),
                                C.POINTER(Img), C.c_void_p]),

@@ -709,3 +709,53 @@ class SparseGeometricFactor:
     def error(self, pose0, pose1, code0, code1):
         rows = self.linearize(pose0, pose1, code0, code1)
         return 0.5 * float(np.sum(rows[:, -1].astype(np.float64) ** 2))
+
+    def upload_points(self):
+        """Keep the factor's points in device memory (the reference samples them once, in the constructor, sparse_geometric_factor.cpp:50-53):
+        batched linearisations then copy no point list."""
+        self.points_dev_ = torch.from_numpy(self.points_).to(torch.device("cuda", self.ctx.device))
+        return self
+
+    def _fill(self, f, pose0, pose1, code0, code1, keep):
+        c0 = np.ascontiguousarray(np.asarray(code0, np.float32).reshape(self.CS))
+        c1 = np.ascontiguousarray(np.asarray(code1, np.float32).reshape(self.CS))
+        keep.extend((c0, c1))
+        fp = C.POINTER(C.c_float)
+        f.pose0, f.pose1, f.cam = _se3(pose0), _se3(pose1), _cam(self.cam_)
+        f.code0, f.code1 = c0.ctypes.data_as(fp), c1.ctypes.data_as(fp)
+        dev = getattr(self, "points_dev_", None)
+        f.points_xy = C.c_void_p(dev.data_ptr()) if dev is not None else self.points_.ctypes.data_as(C.c_void_p)
+        f.n_points, f.points_on_device = len(self.points_), int(dev is not None)
+        f.prx0_orig, f.prx0_jac = _img(self.kf0_["prx_orig"], "prx0_orig"), _img(self.kf0_["prx_jac"], "prx0_jac")
+        f.prx1_orig, f.prx1_jac = _img(self.kf1_["prx_orig"], "prx1_orig"), _img(self.kf1_["prx_jac"], "prx1_jac")
+        f.dpt1_grad = _img(self.kf1_["dpt_grad"], "dpt1_grad", 2)
+
+    @staticmethod
+    def linearize_all(factors, values, rows_dev=None):
+        """Every factor of a relinearisation round in ONE launch (dfx_sparse_geometric_linearize_batch[_async]); the reference linearises them one
+        after the other inside ISAM2::update.  `values[k]` = (pose0, pose1, code0, code1) of factor k.  With `rows_dev` (float32 CUDA tensor of
+        sum(n_points) x (12 + 2 CS + 1)) the rows stay on the device and the call only enqueues; otherwise it returns one host array per factor
+        (views of one buffer, one device-to-host copy)."""
+        factors = list(factors)
+        n = len(factors)
+        f0 = factors[0]
+        if any(f.CS != f0.CS or f.huber_delta_ != f0.huber_delta_ or f.avg_dpt_ != f0.avg_dpt_ or f.ctx is not f0.ctx for f in factors):
+            raise ValueError("the factors of a batch share code size, huber_delta, avg_dpt and context")
+        arr = (_lib.SparseGeoFactor * n)()
+        keep = []
+        for k, (f, v) in enumerate(zip(factors, values)):
+            f._fill(arr[k], *v, keep)
+        nc = 12 + 2 * f0.CS + 1
+        total = sum(len(f.points_) for f in factors)
+        if rows_dev is not None:
+            if rows_dev.dtype != torch.float32 or rows_dev.numel() < total * nc or not rows_dev.is_contiguous():
+                raise ValueError("rows_dev: contiguous float32 CUDA tensor of sum(n_points) x (12 + 2 CS + 1) required")
+            check(_lib.lib().dfx_sparse_geometric_linearize_batch_async(f0.ctx.handle, f0.CS, arr, n, f0.huber_delta_, f0.avg_dpt_, C.c_void_p(rows_dev.data_ptr())))
+            return None
+        rows = np.zeros((total, nc), np.float32)
+        check(_lib.lib().dfx_sparse_geometric_linearize_batch(f0.ctx.handle, f0.CS, arr, n, f0.huber_delta_, f0.avg_dpt_, rows.ctypes.data_as(C.POINTER(C.c_float))))
+        out, o = [], 0
+        for f in factors:
+            out.append(rows[o:o + len(f.points_)])
+            o += len(f.points_)
+        return out

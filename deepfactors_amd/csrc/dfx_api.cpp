@@ -1568,54 +1568,109 @@ DFX_API int dfx_track_frame_batch(dfx_ctx* c, int n, const dfx_se3* pose_init, c
   return track_frames_impl(c, n, pose_init, levels, n_levels, huber_delta, out);
 }
 
+// ---- SparseGeometricFactor::linearize: all factors of a round in ONE launch ------------------------------------------------------------
+namespace {
+// rows_dev != null: rows stay on the device (enqueue only); rows_host != null: one device-to-host copy of all rows, blocking
+int sparse_geo_batch_impl(dfx_ctx* c, int cs, const dfx_sparse_geo_factor* f, int n, float huber_delta, float avg_dpt, float* rows_dev, float* rows_host) {
+  if (!c || !f || (!rows_dev && !rows_host)) return fail(DFX_E_INVALID, "dfx_sparse_geometric_linearize_batch: null argument");
+  if (!cs_supported(cs)) return fail(DFX_E_INVALID, "unsupported code size %d (16, 32, 64)", cs);
+  if (n <= 0 || n > 65535) return fail(DFX_E_INVALID, "factor count %d out of range [1,65535]", n);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  const size_t nc = 12 + 2 * (size_t)cs + 1;
+  size_t total_pts = 0, host_pts = 0;
+  int max_pts = 0;
+  for (int k = 0; k < n; ++k) {
+    const dfx_sparse_geo_factor& q = f[k];
+    if (!q.code0 || !q.code1 || !q.points_xy) return fail(DFX_E_INVALID, "factor %d: null code / points", k);
+    if (q.n_points <= 0 || q.n_points > (1 << 20)) return fail(DFX_E_INVALID, "factor %d: n_points %d out of range", k, q.n_points);
+    if (!img_ok(&q.prx0_orig)) return fail(DFX_E_INVALID, "factor %d: prx0_orig: null or empty image view", k);
+    const uint32_t W = q.prx0_orig.w, H = q.prx0_orig.h;
+    if ((rc = check_img(&q.prx0_orig, "prx0_orig", W, H, 4)) || (rc = check_img(&q.prx1_orig, "prx1_orig", W, H, 4)) ||
+        (rc = check_img(&q.prx0_jac, "prx0_jac", W * (uint32_t)cs, H, 4)) || (rc = check_img(&q.prx1_jac, "prx1_jac", W * (uint32_t)cs, H, 4)) ||
+        (rc = check_img(&q.dpt1_grad, "dpt1_grad", W, H, 8))) {
+      g_last_error = "factor " + std::to_string(k) + ": " + g_last_error;
+      return rc;
+    }
+    if (((uintptr_t)q.dpt1_grad.ptr | q.dpt1_grad.pitch_bytes) & 7) return fail(DFX_E_INVALID, "factor %d: dpt1_grad: pointer/pitch must be 8-byte aligned", k);
+    if ((((uintptr_t)q.prx0_jac.ptr | q.prx0_jac.pitch_bytes) | ((uintptr_t)q.prx1_jac.ptr | q.prx1_jac.pitch_bytes)) & 15)
+      return fail(DFX_E_INVALID, "factor %d: prx_jac: pointer/pitch must be 16-byte aligned", k);
+    if (!q.points_on_device) {
+      for (int i = 0; i < q.n_points; ++i)
+        if (q.points_xy[2 * i] < 0 || q.points_xy[2 * i] >= (int)W || q.points_xy[2 * i + 1] < 0 || q.points_xy[2 * i + 1] >= (int)H)
+          return fail(DFX_E_INVALID, "factor %d: point %d = (%d, %d) outside the %ux%u image", k, i, q.points_xy[2 * i], q.points_xy[2 * i + 1], W, H);
+      host_pts += (size_t)q.n_points;
+    }
+    total_pts += (size_t)q.n_points;
+    max_pts = std::max(max_pts, (int)q.n_points);
+  }
+  const size_t dsz = dfx::sparse_geo_desc_bytes();
+  const size_t off_pts = ((size_t)n * dsz + 255) & ~(size_t)255;
+  const size_t up = off_pts + host_pts * 8;
+  const size_t off_rows = (up + 255) & ~(size_t)255;
+  const size_t row_bytes = total_pts * nc * sizeof(float);
+  const size_t need = off_rows + (rows_dev ? 0 : row_bytes);
+  if (c->sg_bytes < need) DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = grow_dev((void**)&c->sg_dev, &c->sg_bytes, need, c->stream))) return rc;
+  float* const rows_base = rows_dev ? rows_dev : reinterpret_cast<float*>(c->sg_dev + off_rows);
+  int slot;
+  char* host;
+  if ((rc = stage_acquire(c, up, &slot, &host))) return rc;
+  size_t pt_off = 0, row_off = 0;
+  for (int k = 0; k < n; ++k) {
+    const dfx_sparse_geo_factor& q = f[k];
+    float R10[9], t10[3], M[9], HM[9];
+    relative_pose(q.pose0, q.pose1, R10, t10, M, HM);
+    const float cam6[6] = { q.cam.fx, q.cam.fy, q.cam.u0, q.cam.v0, q.cam.w, q.cam.h };
+    const int* pts_dev = (const int*)q.points_xy;
+    if (!q.points_on_device) {
+      std::memcpy(host + off_pts + pt_off * 8, q.points_xy, (size_t)q.n_points * 8);
+      pts_dev = reinterpret_cast<const int*>(c->sg_dev + off_pts + pt_off * 8);
+      pt_off += (size_t)q.n_points;
+    }
+    dfx::sparse_geo_fill(host + (size_t)k * dsz, R10, t10, M, HM, cam6, q.code0, q.code1, cs, (const float*)q.prx0_orig.ptr, (uint32_t)q.prx0_orig.pitch_bytes,
+                         (const float*)q.prx0_jac.ptr, (uint32_t)q.prx0_jac.pitch_bytes, (const float*)q.prx1_orig.ptr, (uint32_t)q.prx1_orig.pitch_bytes,
+                         (const float*)q.prx1_jac.ptr, (uint32_t)q.prx1_jac.pitch_bytes, (const float*)q.dpt1_grad.ptr, (uint32_t)q.dpt1_grad.pitch_bytes,
+                         pts_dev, q.n_points, (int)q.prx0_orig.w, (int)q.prx0_orig.h, rows_base + row_off * nc, huber_delta, avg_dpt);
+    row_off += (size_t)q.n_points;
+  }
+  DFX_HIP(hipMemcpyAsync(c->sg_dev, host, up, hipMemcpyHostToDevice, c->stream));
+  if ((rc = stage_release(c, slot))) return rc;
+  DFX_HIP(dfx::launch_sparse_geometric_batch(cs, c->sg_dev, n, max_pts, c->stream));
+  if (!rows_host) return DFX_OK;
+  if (row_bytes <= kDirectResultMax) return fetch_result(c, rows_base, rows_host, row_bytes);
+  // a whole round of rows (18 MB for 120 factors x 500 points at CS = 32): straight into the caller's memory, no bounce through the result area
+  DFX_HIP(hipMemcpyAsync(rows_host, rows_base, row_bytes, hipMemcpyDeviceToHost, c->stream));
+  DFX_HIP(hipStreamSynchronize(c->stream));
+  return DFX_OK;
+}
+}  // namespace
+
+DFX_API int dfx_sparse_geometric_linearize_batch_async(dfx_ctx* c, int cs, const dfx_sparse_geo_factor* factors, int n, float huber_delta, float avg_dpt,
+                                                       float* rows_dev) {
+  if (!rows_dev) return fail(DFX_E_INVALID, "dfx_sparse_geometric_linearize_batch_async: null row buffer");
+  return sparse_geo_batch_impl(c, cs, factors, n, huber_delta, avg_dpt, rows_dev, nullptr);
+}
+
+DFX_API int dfx_sparse_geometric_linearize_batch(dfx_ctx* c, int cs, const dfx_sparse_geo_factor* factors, int n, float huber_delta, float avg_dpt,
+                                                 float* rows_host) {
+  if (!rows_host) return fail(DFX_E_INVALID, "dfx_sparse_geometric_linearize_batch: null row buffer");
+  return sparse_geo_batch_impl(c, cs, factors, n, huber_delta, avg_dpt, nullptr, rows_host);
+}
+
+// one factor per blocking call (the reference's pattern): the same kernel with a batch of one
 DFX_API int dfx_sparse_geometric_linearize(dfx_ctx* c, int cs, const dfx_se3* pose0, const dfx_se3* pose1, const float* code0,
                                            const float* code1, const dfx_cam* cam, const int32_t* points_xy, int n_points,
                                            const dfx_img* prx0_orig, const dfx_img* prx0_jac, const dfx_img* prx1_orig,
                                            const dfx_img* prx1_jac, const dfx_img* dpt1_grad, float huber_delta, float avg_dpt,
                                            float* rows_host) {
-  if (!c || !pose0 || !pose1 || !code0 || !code1 || !cam || !points_xy || !rows_host) return fail(DFX_E_INVALID, "dfx_sparse_geometric_linearize: null argument");
-  if (!cs_supported(cs)) return fail(DFX_E_INVALID, "unsupported code size %d (16, 32, 64)", cs);
-  if (n_points <= 0 || n_points > (1 << 20)) return fail(DFX_E_INVALID, "n_points %d out of range", n_points);
-  int rc;
-  if ((rc = ensure_device(c))) return rc;
-  if (!img_ok(prx0_orig)) return fail(DFX_E_INVALID, "prx0_orig: null or empty image view");
-  const uint32_t W = prx0_orig->w, H = prx0_orig->h;
-  if ((rc = check_img(prx0_orig, "prx0_orig", W, H, 4))) return rc;
-  if ((rc = check_img(prx1_orig, "prx1_orig", W, H, 4))) return rc;
-  if ((rc = check_img(prx0_jac, "prx0_jac", W * (uint32_t)cs, H, 4))) return rc;
-  if ((rc = check_img(prx1_jac, "prx1_jac", W * (uint32_t)cs, H, 4))) return rc;
-  if ((rc = check_img(dpt1_grad, "dpt1_grad", W, H, 8))) return rc;
-  if (((uintptr_t)dpt1_grad->ptr | dpt1_grad->pitch_bytes) & 7) return fail(DFX_E_INVALID, "dpt1_grad: pointer/pitch must be 8-byte aligned");
-  for (int i = 0; i < n_points; ++i)
-    if (points_xy[2 * i] < 0 || points_xy[2 * i] >= (int)W || points_xy[2 * i + 1] < 0 || points_xy[2 * i + 1] >= (int)H)
-      return fail(DFX_E_INVALID, "point %d = (%d, %d) outside the %ux%u image", i, points_xy[2 * i], points_xy[2 * i + 1], W, H);
-  const int nc = 12 + 2 * cs + 1;
-  const size_t off_pts = 2 * 64 * sizeof(float), off_rows = off_pts + (((size_t)n_points * 8 + 255) & ~(size_t)255);
-  const size_t need = off_rows + (size_t)n_points * nc * sizeof(float);
-  if (c->sg_bytes < need) DFX_HIP(hipStreamSynchronize(c->stream));
-  if ((rc = grow_dev((void**)&c->sg_dev, &c->sg_bytes, need, c->stream))) return rc;
-  // stage codes + points
-  int slot;
-  char* host;
-  const size_t up = off_pts + (size_t)n_points * 8;
-  if ((rc = stage_acquire(c, up, &slot, &host))) return rc;
-  std::memset(host, 0, off_pts);
-  std::memcpy(host, code0, sizeof(float) * (size_t)cs);
-  std::memcpy(host + 64 * sizeof(float), code1, sizeof(float) * (size_t)cs);
-  std::memcpy(host + off_pts, points_xy, (size_t)n_points * 8);
-  DFX_HIP(hipMemcpyAsync(c->sg_dev, host, up, hipMemcpyHostToDevice, c->stream));
-  if ((rc = stage_release(c, slot))) return rc;
-  float R10[9], t10[3], M[9], HM[9];
-  relative_pose(*pose0, *pose1, R10, t10, M, HM);
-  const float cam6[6] = { cam->fx, cam->fy, cam->u0, cam->v0, cam->w, cam->h };
-  std::vector<char> desc(dfx::sparse_geo_desc_bytes());
-  dfx::sparse_geo_fill(desc.data(), R10, t10, M, HM, cam6, (const float*)prx0_orig->ptr, (uint32_t)prx0_orig->pitch_bytes,
-                       (const float*)prx0_jac->ptr, (uint32_t)prx0_jac->pitch_bytes, (const float*)prx1_orig->ptr, (uint32_t)prx1_orig->pitch_bytes,
-                       (const float*)prx1_jac->ptr, (uint32_t)prx1_jac->pitch_bytes, (const float*)dpt1_grad->ptr, (uint32_t)dpt1_grad->pitch_bytes,
-                       huber_delta, avg_dpt);
-  DFX_HIP(dfx::launch_sparse_geometric(cs, desc.data(), (const float*)c->sg_dev, (const float*)c->sg_dev + 64, (const int*)(c->sg_dev + off_pts),
-                                       n_points, (float*)(c->sg_dev + off_rows), c->stream));
-  return fetch_result(c, c->sg_dev + off_rows, rows_host, (size_t)n_points * nc * sizeof(float));
+  if (!c || !pose0 || !pose1 || !code0 || !code1 || !cam || !points_xy || !rows_host || !prx0_orig || !prx0_jac || !prx1_orig || !prx1_jac || !dpt1_grad)
+    return fail(DFX_E_INVALID, "dfx_sparse_geometric_linearize: null argument");
+  dfx_sparse_geo_factor f;
+  std::memset(&f, 0, sizeof(f));
+  f.pose0 = *pose0; f.pose1 = *pose1; f.cam = *cam; f.code0 = code0; f.code1 = code1; f.points_xy = points_xy; f.n_points = n_points; f.points_on_device = 0;
+  f.prx0_orig = *prx0_orig; f.prx0_jac = *prx0_jac; f.prx1_orig = *prx1_orig; f.prx1_jac = *prx1_jac; f.dpt1_grad = *dpt1_grad;
+  return sparse_geo_batch_impl(c, cs, &f, 1, huber_delta, avg_dpt, nullptr, rows_host);
 }
 
 // ---- image-proc ------------------------------------------------------------------------------------------------

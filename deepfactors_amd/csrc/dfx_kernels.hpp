@@ -206,13 +206,12 @@ void track_state_read(const void* host_state, double* R, double* t, float* resid
 hipError_t launch_track_iteration(const SimplePairDev* descs_dev, int n, void* states_dev, int W, int H, float huber_delta, int blocks,
                                   float* partials_dev, hipStream_t stream);
 
-// SparseGeometricFactor::linearize
+// SparseGeometricFactor::linearize, n factors per launch (descriptors in device-visible memory; codes inside the descriptor, points and rows device pointers)
 size_t sparse_geo_desc_bytes();
-void sparse_geo_fill(void* desc, const float* R, const float* t, const float* M, const float* HM, const float* cam6, const float* prx0,
-                     uint32_t pp0, const float* jac0, uint32_t pj0, const float* prx1, uint32_t pp1, const float* jac1, uint32_t pj1,
-                     const float* dgrad1, uint32_t pg1, float huber_delta, float avg_dpt);
-hipError_t launch_sparse_geometric(int cs, const void* desc_host, const float* code0_dev, const float* code1_dev, const int* pts_dev, int npts,
-                                   float* rows_dev, hipStream_t stream);
+void sparse_geo_fill(void* desc, const float* R, const float* t, const float* M, const float* HM, const float* cam6, const float* code0, const float* code1, int cs,
+                     const float* prx0, uint32_t pp0, const float* jac0, uint32_t pj0, const float* prx1, uint32_t pp1, const float* jac1, uint32_t pj1,
+                     const float* dgrad1, uint32_t pg1, const int* pts_dev, int npts, int W, int H, float* rows_dev, float huber_delta, float avg_dpt);
+hipError_t launch_sparse_geometric_batch(int cs, const void* descs_dev, int n_factors, int max_points, hipStream_t stream);
 
 constexpr int kSimpleRow = 32;       // floats per block partial of the VALU reduction kernels
 constexpr int kMaxSimpleBlocks = 1024;

@@ -13,6 +13,12 @@ namespace dfx {
 
 constexpr int kT = 256;   // threads per workgroup (4 waves)
 
+// A/B aid: DFX_RW_NX=0 runs the pixel reductions with the direct tap loads of round 4 instead of the neighbour exchange (same bits)
+static bool rw_nx() {
+  static const bool v = [] { const char* ev = getenv("DFX_RW_NX"); return !ev || atoi(ev) != 0; }();
+  return v;
+}
+
 template <int N>
 __device__ __forceinline__ void block_reduce_store(float (&v)[N], float* __restrict__ out_row) {
   static_assert(N <= kSimpleRow, "partial row too small");
@@ -62,6 +68,13 @@ __device__ __forceinline__ Geo geo_from(const SimplePairDev& p) {
 //    inlier count rides the scalar unit (s_bcnt1 of the validity mask), and the 28 + 1 sums of a wave are folded with
 //    v_permlane32_swap / v_permlane16_swap + four DPP row shifts (70 vector-ALU instructions instead of 29 64-lane shuffle ladders).
 constexpr int kBand = 64;
+// the SE3 step runs five waves per SIMD (96 registers: four rounds of 20 resident waves per CU at the batched launch shape)
+#ifndef DFX_NX_FUSED
+#define DFX_NX_FUSED 1   // 0: exchange and select as compiler-visible operations (A/B, second opinion for the asm form)
+#endif
+#ifndef DFX_SE3_WAVES
+#define DFX_SE3_WAVES
+#endif
 #ifndef DFX_RW_UNROLL
 #define DFX_RW_UNROLL 1   // rotations of the row states per loop iteration
 #endif
@@ -93,10 +106,27 @@ template <bool GRAD>
 struct RowPix {                       // geometry of one row + its taps (possibly still in flight)
   float i0, ax, ay;
   float iz, U, V, vx, vy, vz;         // GRAD (SE3 step) only: 1 / q.z, u - u0, v - v0, R p
-  unsigned vmask;                     // all ones: the pixel has a correspondence (and belongs to the wave's share)
-  f32x2 ia, ib;                       // img1 rows iy, iy + 1: (x, x + 1)
-  f32x4 ga, gb;                       // grad1 rows iy, iy + 1: (gx, gy)(x), (gx, gy)(x + 1)
+  unsigned vmask;                     // non-zero: the pixel has a correspondence (and belongs to the wave's share).  Neighbour exchange (NX): 2 = and
+                                      // the lane's right-hand taps are the NEXT lane's own taps ("hit"), 1 = it loaded them itself
+  f32x2 ia, ib;                       // img1 rows iy, iy + 1: (x, x + 1)     [NX: .x = the lane's own tap, .y = its fix-up load (0 under a hit)]
+  f32x4 ga, gb;                       // grad1 rows iy, iy + 1: (gx, gy)(x), (gx, gy)(x + 1)     [NX: .xy own, .zw fix-up]
 };
+
+// Neighbour exchange (round 5).  What bounded the SE3 step after round 4 was the L1's tag pipeline: TCP_TOTAL_CACHE_ACCESSES = 2.0 per pixel --
+// ~8 per dword wave-load, ~38 per 16-byte gradient tap load whose lanes overlap their neighbours' -- against a budget of ~125 clocks per
+// 64-pixel row and CU (profiles/r04_rowwalk_pmc.txt, TCP_GATE_EN1 = the kernel's duration).  Under a coherent warp lane l + 1 taps cell
+// (ix + 1, iy) when lane l taps (ix, iy): the right-hand column of a lane's 2x2 taps IS the next lane's left-hand column.  So every lane
+// loads only its own column (img1: two dwords, grad1: two 8-byte pairs -- lanes contiguous, no overlap) and takes the other one from lane
+// l + 1 by DPP (v_mov_b32_dpp wave_shl:1).  Whether that holds is decided per lane by comparing the neighbour's tap OFFSET with its own
+// (+ 4 bytes): the scheme is self-validating -- whatever lane the DPP reads, equal offsets mean its loaded values are the wanted ones.
+// Lanes without such a neighbour (lane 63, a jump of floor(u) or floor(v) between the two lanes, a neighbour without correspondence) load the
+// column themselves in a second pair of instructions in which every OTHER lane is out of range (buffer offset kOobOffset: returns 0, moves no
+// data, costs the L1 nothing); lane 63 is always in range there, so no wave-load is entirely out of range and loads keep returning in order.
+// Same taps, same arithmetic: results are bit-identical to the direct form (DFX_RW_NX=0 keeps it for A/B runs).
+__device__ __forceinline__ unsigned lane_next(unsigned v) {   // lane l <- lane l + 1; lane 63 <- 0
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+}
+__device__ __forceinline__ float lane_next(float v) { return __builtin_bit_cast(float, lane_next(__builtin_bit_cast(unsigned, v))); }
 
 // pose-dependent part of the ambiguity band on the device (the tracker's pose lives in device memory): E = e1 |d| + e2, derive_fast_geo
 __device__ __forceinline__ void fast_band(const float (&R)[9], const float (&t)[3], const FastCam& c, float& e1, float& e2) {
@@ -112,7 +142,7 @@ __device__ __forceinline__ void fast_band(const float (&R)[9], const float (&t)[
 
 // Walks the calling wave's share of the image; `consume(const RowPix<GRAD>&)` is called once per row with exec = the row's inliers.
 // Returns the wave's inlier count (wave-uniform).
-template <bool GRAD, int DT, typename F>
+template <bool GRAD, int DT, bool NX, typename F>
 __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float (&R)[9], const float (&t)[3], const float e1, const float e2,
                                              const int W, const int H, F&& consume) {
   const FastGeo& fg = p.fg;
@@ -131,8 +161,9 @@ __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float
   // tap offsets are relative to pixel (icx, icy): fold it into a scalar
   const unsigned c1 = (unsigned)fg.icy * p.pitch_img1 + (unsigned)fg.icx * 4u;
   const unsigned cg = GRAD ? (unsigned)fg.icy * p.pitch_grad1 + (unsigned)fg.icx * 8u : 0u;
-  unsigned four = 4u;
+  unsigned four = 4u, eight = 8u;
   asm volatile("" : "+s"(four));
+  asm volatile("" : "+s"(eight));
   const float ixmax = (float)(W - 2 - fg.icx), iymax = (float)(H - 2 - fg.icy);   // last cell of the tap grid, relative to pixel (icx, icy)
   Geo g;   // the reference-order fall-back
 #pragma unroll
@@ -228,6 +259,24 @@ __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float
       // texture addresser 14 cycles per wave, a dword load whose lanes are (nearly) contiguous 4 (profiles/r04_ubench_vmem_issue_cost.txt);
       // the reductions' skeleton runs 11 % faster with them (profiles/r04_band_walk.txt), EvaluateError 108 -> 101 us, the SE3 step 181 ->
       // 172 us per 128 pairs (profiles/r04_tap_loads.txt; the snap above keeps them contiguous at the identity).
+      if constexpr (NX) {
+        // own column + the fix-up column of the lanes whose neighbour does not hold it (see "Neighbour exchange" above)
+        const bool hit = lane_next(o1) == o1 + 4u;
+        S.vmask = hit ? (vm & 2u) : (vm & 1u);
+        const unsigned of = hit ? kOobOffset : o1;
+        S.ia.x = bload1(rI1, o1, 0);
+        S.ib.x = bload1(rI1, o1, p.pitch_img1);
+        S.ia.y = bload1(rI1, of, four);
+        S.ib.y = bload1(rI1, of, p.pitch_img1 + four);
+        if constexpr (GRAD) {
+          const unsigned og = (unsigned)(__mul24(iy, (int)p.pitch_grad1) + ((ix << 3) + (int)cg)) & vm;
+          const unsigned ogf = hit ? kOobOffset : og;
+          const f32x2 a0 = bload2(rG1, og, 0), b0 = bload2(rG1, og, p.pitch_grad1);
+          const f32x2 a1 = bload2(rG1, ogf, eight), b1 = bload2(rG1, ogf, p.pitch_grad1 + eight);
+          S.ga = f32x4{ a0.x, a0.y, a1.x, a1.y };
+          S.gb = f32x4{ b0.x, b0.y, b1.x, b1.y };
+        }
+      } else {
       S.ia.x = bload1(rI1, o1, 0);
       S.ia.y = bload1(rI1, o1, four);                       // (`four` is opaque: the compiler would fuse the pairs back into 8-byte loads)
       S.ib.x = bload1(rI1, o1, p.pitch_img1);
@@ -237,8 +286,58 @@ __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float
         S.ga = bload4(rG1, og, 0);
         S.gb = bload4(rG1, og, p.pitch_grad1);
       }
+      }
     };
-    auto eat = [&](const RowPix<GRAD>& S) {
+    auto eat = [&](const RowPix<GRAD>& S0) {
+      RowPix<GRAD> S = S0;
+      if constexpr (NX) {
+        // the right-hand column: the next lane's own taps under a hit, the lane's fix-up loads otherwise.  All 64 lanes are active here (the
+        // DPP reads lane l + 1's registers: it has to run outside the divergent `if (v)` below)
+        // (the exchange is evaluated for every lane and THEN selected: written as `hit ? lane_next(..) : ..` the DPP would run under exec = hit and
+        // read lanes that are switched off)
+#if DFX_NX_FUSED
+        // exchange + select in ONE instruction per value: v_cndmask_b32_dpp dst = vcc ? dst : lane_next(own), vcc = the lanes that loaded the
+        // column themselves.  The compiler does not form it (its DPP combiner only folds into e32 encodings whose condition already sits in
+        // vcc) and, left to itself, hoists the six exchanges in front of the six selects: six more registers, a wave per SIMD less.
+        // Hazards (the compiler does not look inside an asm): a DPP operand written by a vector-ALU instruction needs two wait states -- the
+        // operands are load results, but a register copy in front of the block would be such a write: v_cmp + s_nop 0 are the two states.
+        if constexpr (GRAD) {
+          asm volatile("v_cmp_ne_u32_e32 vcc, 2, %[hit]\n\ts_nop 0\n\t"
+                       "v_cndmask_b32_dpp %[f0], %[o0], %[f0], vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_cndmask_b32_dpp %[f1], %[o1], %[f1], vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_cndmask_b32_dpp %[f2], %[o2], %[f2], vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_cndmask_b32_dpp %[f3], %[o3], %[f3], vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_cndmask_b32_dpp %[f4], %[o4], %[f4], vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_cndmask_b32_dpp %[f5], %[o5], %[f5], vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                       : [f0] "+v"(S.ia.y), [f1] "+v"(S.ib.y), [f2] "+v"(S.ga.z), [f3] "+v"(S.ga.w), [f4] "+v"(S.gb.z), [f5] "+v"(S.gb.w)
+                       : [hit] "v"(S0.vmask), [o0] "v"(S0.ia.x), [o1] "v"(S0.ib.x), [o2] "v"(S0.ga.x), [o3] "v"(S0.ga.y), [o4] "v"(S0.gb.x), [o5] "v"(S0.gb.y)
+                       : "vcc");
+        } else {
+          asm volatile("v_cmp_ne_u32_e32 vcc, 2, %[hit]\n\ts_nop 0\n\t"
+                       "v_cndmask_b32_dpp %[f0], %[o0], %[f0], vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_cndmask_b32_dpp %[f1], %[o1], %[f1], vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                       : [f0] "+v"(S.ia.y), [f1] "+v"(S.ib.y)
+                       : [hit] "v"(S0.vmask), [o0] "v"(S0.ia.x), [o1] "v"(S0.ib.x)
+                       : "vcc");
+        }
+#else
+        const bool miss = S0.vmask != 2u;
+        const float na = lane_next(S0.ia.x);
+        S.ia.y = miss ? S0.ia.y : na;
+        const float nb = lane_next(S0.ib.x);
+        S.ib.y = miss ? S0.ib.y : nb;
+        if constexpr (GRAD) {
+          const float n0 = lane_next(S0.ga.x);
+          S.ga.z = miss ? S0.ga.z : n0;
+          const float n1 = lane_next(S0.ga.y);
+          S.ga.w = miss ? S0.ga.w : n1;
+          const float n2 = lane_next(S0.gb.x);
+          S.gb.z = miss ? S0.gb.z : n2;
+          const float n3 = lane_next(S0.gb.y);
+          S.gb.w = miss ? S0.gb.w : n3;
+        }
+#endif
+      }
       const bool v = S.vmask != 0;
       inliers += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(v));
       if (v) consume(S);
@@ -332,6 +431,7 @@ __device__ __forceinline__ void fold_waves_store(float (&red)[kT / 64][kSimpleRo
 // ---- SE3 step: 21 JtJ + 6 Jtr + r^2 + inliers = 29 floats per workgroup row ---------------------------------------------------------
 // One SE3 Gauss-Newton step (lucas_kanade_se3.h:41-77) over this workgroup's share of the pair; shared by the blocking operator, the
 // batched form and the device-resident tracker (R, t = the pose the step is evaluated at).
+template <bool NX>
 __device__ __forceinline__ void se3_step_body(const SimplePairDev& p, const float (&R)[9], const float (&t)[3], const float e1, const float e2,
                                               const int W, const int H, const float huber_delta, float* __restrict__ out_row) {
   __shared__ float red[kT / 64][kSimpleRow];
@@ -339,7 +439,7 @@ __device__ __forceinline__ void se3_step_body(const SimplePairDev& p, const floa
 #pragma unroll
   for (int q = 0; q < 28; ++q) acc[q] = 0.f;
   const float fx = p.fx, fy = p.fy;
-  const unsigned inl = row_walk<true, DFX_TAP_DIST_SE3>(p, R, t, e1, e2, W, H, [&](const RowPix<true>& S) {
+  const unsigned inl = row_walk<true, DFX_TAP_DIST_SE3, NX>(p, R, t, e1, e2, W, H, [&](const RowPix<true>& S) {
     const float gx = lerpf(lerpf(S.ga.x, S.ga.z, S.ax), lerpf(S.gb.x, S.gb.z, S.ax), S.ay);
     const float gy = lerpf(lerpf(S.ga.y, S.ga.w, S.ax), lerpf(S.gb.y, S.gb.w, S.ax), S.ay);
     float r = S.i0 - pix_img(S);
@@ -376,9 +476,10 @@ __device__ __forceinline__ void se3_step_body(const SimplePairDev& p, const floa
   fold_waves_store(red, 29, out_row);
 }
 
-__global__ __launch_bounds__(kT) void k_se3_step(const SimplePairDev p, const int W, const int H, const float huber_delta,
+template <bool NX>
+__global__ __launch_bounds__(kT) DFX_SE3_WAVES void k_se3_step(const SimplePairDev p, const int W, const int H, const float huber_delta,
                                                  float* __restrict__ partials) {
-  se3_step_body(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
+  se3_step_body<NX>(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
 // ---- device-resident tracker (CameraTracker::TrackFrame, reference core/system/camera_tracker.cpp:42-71) -------------
@@ -393,7 +494,8 @@ struct TrackState {      // device-resident
 
 // blockIdx.y = candidate: Relocalize / the loop-closure geometry checks track ONE live frame against N keyframes
 // (deepfactors.cpp:713-743, loop_detector.cpp:146-167); descriptors, states and partials are arrays over candidates.
-__global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev* __restrict__ descs, const TrackState* __restrict__ states, const int W,
+template <bool NX>
+__global__ __launch_bounds__(kT) DFX_SE3_WAVES void k_se3_step_dev(const SimplePairDev* __restrict__ descs, const TrackState* __restrict__ states, const int W,
                                                      const int H, const float huber_delta, float* __restrict__ partials_all) {
   const SimplePairDev& p = descs[blockIdx.y];
   const TrackState* st = states + blockIdx.y;
@@ -403,7 +505,7 @@ __global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev* __rest
   for (int q = 0; q < 9; ++q) R[q] = st->Rf[q];
   t[0] = st->tf[0]; t[1] = st->tf[1]; t[2] = st->tf[2];
   fast_band(R, t, p.fc, e1, e2);   // the descriptor's band belongs to the pose it was filled with, not to the state's
-  se3_step_body(p, R, t, e1, e2, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
+  se3_step_body<NX>(p, R, t, e1, e2, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
 __global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__ partials_all, const int nblocks, TrackState* __restrict__ states) {
@@ -510,7 +612,8 @@ size_t track_state_bytes() { return sizeof(TrackState); }
 
 hipError_t launch_track_iteration(const SimplePairDev* descs_dev, int n, void* states_dev, int W, int H, float huber_delta, int blocks,
                                   float* partials_dev, hipStream_t stream) {
-  hipLaunchKernelGGL(k_se3_step_dev, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (const TrackState*)states_dev, W, H, huber_delta, partials_dev);
+  if (rw_nx()) hipLaunchKernelGGL(k_se3_step_dev<true>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (const TrackState*)states_dev, W, H, huber_delta, partials_dev);
+  else hipLaunchKernelGGL(k_se3_step_dev<false>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (const TrackState*)states_dev, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_track_update, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (TrackState*)states_dev);
@@ -531,112 +634,137 @@ void track_state_read(const void* host_state, double* R, double* t, float* resid
 }
 
 // ---- SparseGeometricFactor::linearize (reference core/gtsam/sparse_geometric_factor.cpp:147-275) ---------------------------
-// One lane per sampled point (N <= a few thousand): decode depth at the point in kf0, warp, decode kf1's depth at the
-// nearest-neighbour pixel of the projection, residual err = dpt1 - (R p + t).z, Huber weight, one row
-// [err_J_pose0 (6) | err_J_pose1 (6) | err_J_cde0 (CS) | err_J_cde1 (CS) | err] per point (zero row if no correspondence).
-struct SparseGeoDev {
+// Per sampled point: decode depth at the point in kf0, warp, decode kf1's depth at the nearest-neighbour pixel of the projection, residual
+// err = dpt1 - (R p + t).z, Huber weight, one row [err_J_pose0 (6) | err_J_pose1 (6) | err_J_cde0 (CS) | err_J_cde1 (CS) | err] (zero row if
+// no correspondence).  Round 5: ALL factors of a round in one launch (blockIdx.y = factor; the reference linearises every factor of the
+// graph inside one ISAM2::update, built per keyframe pair at core/mapping/mapper.cpp:308-311), CS / 4 lanes per point -- both code dot
+// products and the two code blocks of the row move as float4 per lane, 16 CS contiguous bytes per point (the layout of update_depth_body)
+// -- instead of one lane per point walking 2 CS dwords twice (65 us per blocking factor, 7.8 ms per 120-factor round).  The geometry is
+// evaluated redundantly by the lanes of a point (wave-uniform control flow inside a point's lane group).
+struct alignas(16) SparseGeoDev {   // (float4 loads of the codes: 16-byte slots)
   float R[9], t[3], M[9], HM[9];
   float fx, fy, u0, v0, w, h;
+  float code0[64], code1[64];
   const float* prx0; const float* jac0; const float* prx1; const float* jac1; const float* dgrad1;
+  const int* pts;        // device: (x, y) pairs
+  float* rows;           // device: [npts][12 + 2 CS + 1]
   uint32_t pitch_prx0, pitch_jac0, pitch_prx1, pitch_jac1, pitch_dgrad1;
+  int npts;
+  int W, H;              // image size: points are clamped into it (device-resident point lists cannot be checked by the host)
   float huber_delta, avg_dpt;
 };
+static_assert(sizeof(SparseGeoDev) % 16 == 0 && offsetof(SparseGeoDev, code0) % 16 == 0 && offsetof(SparseGeoDev, code1) % 16 == 0, "float4 loads of the codes");
+typedef float f32x4_u4 __attribute__((ext_vector_type(4), aligned(4)));   // rows are 12 + 2 CS + 1 floats apart: dword-aligned vectors
 
 template <int CS>
-__global__ __launch_bounds__(64) void k_sparse_geometric(const SparseGeoDev P, const float* __restrict__ code0, const float* __restrict__ code1,
-                                                         const int* __restrict__ pts, const int npts, float* __restrict__ rows) {
+__global__ __launch_bounds__(kT) void k_sparse_geometric_batch(const SparseGeoDev* __restrict__ descs) {
   constexpr int NC = 12 + 2 * CS + 1;
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= npts) return;
-  float* row = rows + (size_t)i * NC;
-  const int x = pts[2 * i], y = pts[2 * i + 1];
+  constexpr int LPP = CS / 4;        // lanes per point
+  constexpr int PPW = 64 / LPP;      // points per wave step
+  const SparseGeoDev& P = descs[blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane % LPP, grp = lane / LPP;
+  const int npts = P.npts;
   Geo g;
 #pragma unroll
-  for (int q = 0; q < 9; ++q) g.R[q] = P.R[q];
+  for (int k = 0; k < 9; ++k) g.R[k] = P.R[k];
   g.t[0] = P.t[0]; g.t[1] = P.t[1]; g.t[2] = P.t[2];
   g.fx = P.fx; g.fy = P.fy; g.u0 = P.u0; g.v0 = P.v0; g.w = P.w; g.h = P.h;
-  const char* j0p = (const char*)P.jac0 + (size_t)y * P.pitch_jac0 + (size_t)x * CS * 4;
-  float dot0 = 0.f;
-  {
-#pragma clang fp contract(off)
-    for (int k = 0; k < CS; ++k) dot0 += gload<float>(j0p + 4 * k) * code0[k];   // sequential, like DepthFromCode
-  }
+  const f32x4 c0 = *reinterpret_cast<const f32x4*>(P.code0 + 4 * q), c1 = *reinterpret_cast<const f32x4*>(P.code1 + 4 * q);
   const float a = P.avg_dpt;
-  const float d0 = a / (gload<float>((const char*)P.prx0 + (size_t)y * P.pitch_prx0 + (size_t)x * 4) + dot0) - a;
-  const Corr c = find_correspondence(g, x, y, d0, 1.0f, 0.0f);
-  if (!c.valid) {
-    for (int k = 0; k < NC; ++k) row[k] = 0.f;
-    return;
-  }
-  const int nx = (int)c.u, ny = (int)c.v;   // cast<int>: truncation (sparse_geometric_factor.cpp:207)
-  const char* j1p = (const char*)P.jac1 + (size_t)ny * P.pitch_jac1 + (size_t)nx * CS * 4;
-  float dot1 = 0.f;
-  {
-#pragma clang fp contract(off)
-    for (int k = 0; k < CS; ++k) dot1 += gload<float>(j1p + 4 * k) * code1[k];
-  }
-  const float d1 = a / (gload<float>((const char*)P.prx1 + (size_t)ny * P.pitch_prx1 + (size_t)nx * 4) + dot1) - a;
-  const float qz = 1.0f / c.iz;
-  const float err = d1 - (c.vz + g.t[2]);
-  (void)qz;
-  const f32x2 dg = gload<f32x2>((const char*)P.dgrad1 + (size_t)ny * P.pitch_dgrad1 + (size_t)nx * 8);
-  // gC = -(dgrad . C) with C = D [I | -hat(R p)]; third row of [I | -hat(R p)] is (0, 0, 1, v.y, -v.x, 0)
-  float gC[6], D00, D02, D11, D12;
-  pose_row(g, c, d0, dg.x, dg.y, gC, D00, D02, D11, D12);
-  const float a10[6] = { gC[0], gC[1], 1.0f + gC[2], c.vy + gC[3], -c.vx + gC[4], gC[5] };
-  float e0[6], e1[6];
+  auto dot4 = [](const f32x4& j, const f32x4& c) { return __builtin_fmaf(j.w, c.w, __builtin_fmaf(j.z, c.z, __builtin_fmaf(j.y, c.y, j.x * c.x))); };
+  auto lanes_sum = [](float d) {
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    e0[j] = a10[0] * P.M[j] + a10[1] * P.M[3 + j] + a10[2] * P.M[6 + j];
-    e0[3 + j] = a10[3] * P.M[j] + a10[4] * P.M[3 + j] + a10[5] * P.M[6 + j];
-    e1[j] = -e0[j];
-    e1[3 + j] = -(a10[0] * P.HM[j] + a10[1] * P.HM[3 + j] + a10[2] * P.HM[6 + j]) - e0[3 + j];
-  }
-  const float apd0 = a + d0, apd1 = a + d1;
-  const float dprx0 = -(apd0 * apd0) / a;
-  const float pj0 = D00 * c.rrx + D02 * c.rrz, pj1 = D11 * c.rry + D12 * c.rrz;
-  const float sc0 = (c.rrz - (dg.x * pj0 + dg.y * pj1)) * dprx0;
-  const float sc1 = (apd1 * apd1) / a;   // -DepthJacobianPrx(dpt1)
-  const float wgt = huber_weight(err, P.huber_delta);
+    for (int m = 1; m < LPP; m <<= 1) d += __shfl_xor(d, m, 64);   // butterfly: every lane of the point ends with the same bits
+    return d;
+  };
+  for (int base = (blockIdx.x * (kT / 64) + wave) * PPW; base < npts; base += gridDim.x * (kT / 64) * PPW) {
+    const int i = base + grp;
+    const bool have = i < npts;
+    const int ic = have ? i : npts - 1;
+    const int x = min(max(P.pts[2 * ic], 0), P.W - 1), y = min(max(P.pts[2 * ic + 1], 0), P.H - 1);
+    const f32x4 j0 = gload<f32x4>((const char*)P.jac0 + (size_t)y * P.pitch_jac0 + ((size_t)x * CS + 4 * q) * 4);
+    const float dot0 = lanes_sum(dot4(j0, c0));
+    const float d0 = a / (gload<float>((const char*)P.prx0 + (size_t)y * P.pitch_prx0 + (size_t)x * 4) + dot0) - a;
+    const Corr c = find_correspondence(g, x, y, d0, 1.0f, 0.0f);
+    // lanes of a point agree on c.valid (same inputs, same arithmetic); a point without correspondence taps pixel (0, 0) and writes zeros
+    const int nx = c.valid ? (int)c.u : 0, ny = c.valid ? (int)c.v : 0;   // cast<int>: truncation (sparse_geometric_factor.cpp:207)
+    const f32x4 j1 = gload<f32x4>((const char*)P.jac1 + (size_t)ny * P.pitch_jac1 + ((size_t)nx * CS + 4 * q) * 4);
+    const float dot1 = lanes_sum(dot4(j1, c1));
+    const float d1 = a / (gload<float>((const char*)P.prx1 + (size_t)ny * P.pitch_prx1 + (size_t)nx * 4) + dot1) - a;
+    const float err = d1 - (c.vz + g.t[2]);
+    const f32x2 dg = gload<f32x2>((const char*)P.dgrad1 + (size_t)ny * P.pitch_dgrad1 + (size_t)nx * 8);
+    // gC = -(dgrad . C) with C = D [I | -hat(R p)]; third row of [I | -hat(R p)] is (0, 0, 1, v.y, -v.x, 0)
+    float gC[6], D00, D02, D11, D12;
+    pose_row(g, c, d0, dg.x, dg.y, gC, D00, D02, D11, D12);
+    const float a10[6] = { gC[0], gC[1], 1.0f + gC[2], c.vy + gC[3], -c.vx + gC[4], gC[5] };
+    float e[12];
 #pragma unroll
-  for (int j = 0; j < 6; ++j) { row[j] = e0[j] * wgt; row[6 + j] = e1[j] * wgt; }
-  for (int k = 0; k < CS; ++k) {
-    row[12 + k] = sc0 * gload<float>(j0p + 4 * k) * wgt;
-    row[12 + CS + k] = sc1 * gload<float>(j1p + 4 * k) * wgt;
+    for (int j = 0; j < 3; ++j) {
+      e[j] = a10[0] * P.M[j] + a10[1] * P.M[3 + j] + a10[2] * P.M[6 + j];
+      e[3 + j] = a10[3] * P.M[j] + a10[4] * P.M[3 + j] + a10[5] * P.M[6 + j];
+      e[6 + j] = -e[j];
+      e[9 + j] = -(a10[0] * P.HM[j] + a10[1] * P.HM[3 + j] + a10[2] * P.HM[6 + j]) - e[3 + j];
+    }
+    const float apd0 = a + d0, apd1 = a + d1;
+    const float dprx0 = -(apd0 * apd0) / a;
+    const float pj0 = D00 * c.rrx + D02 * c.rrz, pj1 = D11 * c.rry + D12 * c.rrz;
+    const float sc0 = (c.rrz - (dg.x * pj0 + dg.y * pj1)) * dprx0;
+    const float sc1 = (apd1 * apd1) / a;   // -DepthJacobianPrx(dpt1)
+    const float wgt = c.valid ? huber_weight(err, P.huber_delta) : 0.f;
+    if (!have) continue;
+    float* row = P.rows + (size_t)i * NC;
+    const f32x4 z4 = f32x4{ 0.f, 0.f, 0.f, 0.f };
+    // pose blocks: three float4 by the first three lanes of the point; the residual by its last lane (LPP >= 4)
+    if (q < 3) {
+      f32x4 v = q == 0 ? f32x4{ e[0], e[1], e[2], e[3] } : (q == 1 ? f32x4{ e[4], e[5], e[6], e[7] } : f32x4{ e[8], e[9], e[10], e[11] });
+      v = v * wgt;
+      gstore<f32x4_u4>(row + 4 * q, c.valid ? v : z4);
+    }
+    if (q == LPP - 1) gstore<float>(row + 12 + 2 * CS, c.valid ? err * wgt : 0.f);
+    const f32x4 r0 = (sc0 * j0) * wgt, r1 = (sc1 * j1) * wgt;
+    gstore<f32x4_u4>(row + 12 + 4 * q, c.valid ? r0 : z4);
+    gstore<f32x4_u4>(row + 12 + CS + 4 * q, c.valid ? r1 : z4);
   }
-  row[12 + 2 * CS] = err * wgt;
 }
 
 size_t sparse_geo_desc_bytes() { return sizeof(SparseGeoDev); }
-void sparse_geo_fill(void* desc, const float* R, const float* t, const float* M, const float* HM, const float* cam6, const float* prx0,
-                     uint32_t pp0, const float* jac0, uint32_t pj0, const float* prx1, uint32_t pp1, const float* jac1, uint32_t pj1,
-                     const float* dgrad1, uint32_t pg1, float huber_delta, float avg_dpt) {
+void sparse_geo_fill(void* desc, const float* R, const float* t, const float* M, const float* HM, const float* cam6, const float* code0, const float* code1, int cs,
+                     const float* prx0, uint32_t pp0, const float* jac0, uint32_t pj0, const float* prx1, uint32_t pp1, const float* jac1, uint32_t pj1,
+                     const float* dgrad1, uint32_t pg1, const int* pts_dev, int npts, int W, int H, float* rows_dev, float huber_delta, float avg_dpt) {
   SparseGeoDev* d = (SparseGeoDev*)desc;
   for (int i = 0; i < 9; ++i) { d->R[i] = R[i]; d->M[i] = M[i]; d->HM[i] = HM[i]; }
   for (int i = 0; i < 3; ++i) d->t[i] = t[i];
   d->fx = cam6[0]; d->fy = cam6[1]; d->u0 = cam6[2]; d->v0 = cam6[3]; d->w = cam6[4]; d->h = cam6[5];
+  for (int i = 0; i < 64; ++i) { d->code0[i] = i < cs ? code0[i] : 0.f; d->code1[i] = i < cs ? code1[i] : 0.f; }
   d->prx0 = prx0; d->jac0 = jac0; d->prx1 = prx1; d->jac1 = jac1; d->dgrad1 = dgrad1;
+  d->pts = pts_dev; d->rows = rows_dev; d->npts = npts; d->W = W; d->H = H;
   d->pitch_prx0 = pp0; d->pitch_jac0 = pj0; d->pitch_prx1 = pp1; d->pitch_jac1 = pj1; d->pitch_dgrad1 = pg1;
   d->huber_delta = huber_delta; d->avg_dpt = avg_dpt;
 }
-hipError_t launch_sparse_geometric(int cs, const void* desc_host, const float* code0_dev, const float* code1_dev, const int* pts_dev, int npts,
-                                   float* rows_dev, hipStream_t stream) {
-  const SparseGeoDev& P = *(const SparseGeoDev*)desc_host;
-  const int blocks = (npts + 63) / 64;
+hipError_t launch_sparse_geometric_batch(int cs, const void* descs_dev, int n_factors, int max_points, hipStream_t stream) {
+  const int ppb = (kT / 64) * (64 / (cs / 4));        // points per workgroup step
+  int bx = (max_points + ppb - 1) / ppb;
+  const int cap = (16 * 256 + n_factors - 1) / n_factors;   // ~16 workgroups per CU over the whole round: a factor's workgroups loop beyond that
+  if (bx > cap) bx = cap;
+  if (bx < 1) bx = 1;
+  const dim3 grid(bx, n_factors);
+  const SparseGeoDev* d = (const SparseGeoDev*)descs_dev;
   switch (cs) {
-    case 16: hipLaunchKernelGGL(k_sparse_geometric<16>, dim3(blocks), dim3(64), 0, stream, P, code0_dev, code1_dev, pts_dev, npts, rows_dev); break;
-    case 32: hipLaunchKernelGGL(k_sparse_geometric<32>, dim3(blocks), dim3(64), 0, stream, P, code0_dev, code1_dev, pts_dev, npts, rows_dev); break;
-    case 64: hipLaunchKernelGGL(k_sparse_geometric<64>, dim3(blocks), dim3(64), 0, stream, P, code0_dev, code1_dev, pts_dev, npts, rows_dev); break;
+    case 16: hipLaunchKernelGGL(k_sparse_geometric_batch<16>, grid, dim3(kT), 0, stream, d); break;
+    case 32: hipLaunchKernelGGL(k_sparse_geometric_batch<32>, grid, dim3(kT), 0, stream, d); break;
+    case 64: hipLaunchKernelGGL(k_sparse_geometric_batch<64>, grid, dim3(kT), 0, stream, d); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
 // ---- SfM error: sum (w r)^2, inliers (dense_sfm.h:79-119: default border 1, min_dpt 0) -------------------------------------------------
+template <bool NX>
 __device__ __forceinline__ void sfm_error_body(const SimplePairDev& p, const int W, const int H, const float huber_delta, float* __restrict__ out_row) {
   __shared__ float red[kT / 64][kSimpleRow];
   float acc = 0.f;
-  const unsigned inl = row_walk<false, DFX_TAP_DIST_ERR>(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, [&](const RowPix<false>& S) {
+  const unsigned inl = row_walk<false, DFX_TAP_DIST_ERR, NX>(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, [&](const RowPix<false>& S) {
     float r = S.i0 - pix_img(S);
     r *= huber_weight(r, huber_delta);
     acc = __builtin_fmaf(r, r, acc);
@@ -647,23 +775,26 @@ __device__ __forceinline__ void sfm_error_body(const SimplePairDev& p, const int
   fold_waves_store(red, 2, out_row);
 }
 
+template <bool NX>
 __global__ __launch_bounds__(kT) void k_sfm_error(const SimplePairDev p, const int W, const int H, const float huber_delta,
                                                   float* __restrict__ partials) {
-  sfm_error_body(p, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
+  sfm_error_body<NX>(p, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
 // ---- batched forms (blockIdx.y = pair): PhotometricFactor::error over a factor set evaluates one pair per blocking call in the reference
 // (core/gtsam/photometric_factor.cpp:61-81,197-216); a relocalisation / loop-closure check steps one live frame against many keyframes.
 // Same per-pair arithmetic and reduction order as the single-pair kernels launched with the same number of workgroups.
+template <bool NX>
 __global__ __launch_bounds__(kT) void k_sfm_error_batch(const SimplePairDev* __restrict__ descs, const int W, const int H, const float huber_delta,
                                                         float* __restrict__ partials_all) {
-  sfm_error_body(descs[blockIdx.y], W, H, huber_delta, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
+  sfm_error_body<NX>(descs[blockIdx.y], W, H, huber_delta, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
 }
 
-__global__ __launch_bounds__(kT) void k_se3_step_batch(const SimplePairDev* __restrict__ descs, const int W, const int H, const float huber_delta,
+template <bool NX>
+__global__ __launch_bounds__(kT) DFX_SE3_WAVES void k_se3_step_batch(const SimplePairDev* __restrict__ descs, const int W, const int H, const float huber_delta,
                                                        float* __restrict__ partials_all) {
   const SimplePairDev& p = descs[blockIdx.y];
-  se3_step_body(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, huber_delta, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
+  se3_step_body<NX>(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, huber_delta, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
 }
 
 // ---- Warp: render img1 into frame 0, SIGNED residual sum (cu_se3aligner.cpp:106) ----------------------------
@@ -870,7 +1001,8 @@ static void launch_finalize_rows(int n, int blocks, int kind, const float* parti
 
 hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
                            void* item_dev, hipStream_t stream) {
-  hipLaunchKernelGGL(k_se3_step, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
+  if (rw_nx()) hipLaunchKernelGGL(k_se3_step<true>, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
+  else hipLaunchKernelGGL(k_se3_step<false>, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   launch_finalize_rows(1, blocks, (int)kFinalItem6, (const float*)partials_dev, item_dev, (size_t)0, stream);
@@ -879,7 +1011,8 @@ hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_del
 
 hipError_t launch_sfm_error(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
                             void* corr_item_dev, hipStream_t stream) {
-  hipLaunchKernelGGL(k_sfm_error, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
+  if (rw_nx()) hipLaunchKernelGGL(k_sfm_error<true>, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
+  else hipLaunchKernelGGL(k_sfm_error<false>, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   launch_finalize_rows(1, blocks, (int)kFinalCorr, (const float*)partials_dev, corr_item_dev, (size_t)0, stream);
@@ -889,7 +1022,8 @@ hipError_t launch_sfm_error(const SimplePairDev& p, int W, int H, float huber_de
 hipError_t launch_sfm_error_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
                                   void* corr_items_dev, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end) {
   if (ev_begin) (void)hipEventRecord(ev_begin, stream);
-  hipLaunchKernelGGL(k_sfm_error_batch, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
+  if (rw_nx()) hipLaunchKernelGGL(k_sfm_error_batch<true>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
+  else hipLaunchKernelGGL(k_sfm_error_batch<false>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_end) (void)hipEventRecord(ev_end, stream);
@@ -900,7 +1034,8 @@ hipError_t launch_sfm_error_batch(const SimplePairDev* descs_dev, int n, int W, 
 hipError_t launch_se3_step_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
                                  void* items_dev, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end) {
   if (ev_begin) (void)hipEventRecord(ev_begin, stream);
-  hipLaunchKernelGGL(k_se3_step_batch, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
+  if (rw_nx()) hipLaunchKernelGGL(k_se3_step_batch<true>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
+  else hipLaunchKernelGGL(k_se3_step_batch<false>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_end) (void)hipEventRecord(ev_end, stream);

@@ -1302,7 +1302,7 @@ __device__ __forceinline__ int tail_local_degree(const TailGraphDev& tg, int n) 
   return cnt;
 }
 
-template <int NCB, bool ASM>   // ASM: the launch assembles a graph (tg.sys != null)
+template <int NCB, bool ASM, bool ORD = true>   // ASM: the launch assembles a graph (tg.sys != null); ORD: release / acquire on the arrival counter (below)
 __global__ __launch_bounds__(1024) void k_sfm_tail_b3(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs, const int npairs,
                                                       char* __restrict__ items, const size_t item_stride, unsigned* __restrict__ qhead,
                                                       const int Wk, const int Hk, const unsigned launch_id, const int ragged, const TailGraphDev tg) {
@@ -1407,9 +1407,15 @@ __global__ __launch_bounds__(1024) void k_sfm_tail_b3(const float* __restrict__ 
 #pragma unroll
   for (int j = 0; j < MINE; ++j) { const int blk = rg + 4 * j; if (blk < NT3) b3_scatter<NCB, 12, ASM>(blk, el, S[blk], T, item); }
 
-  // ---- graph assembly by the last pair to arrive at each of its two nodes.  No cache writeback / invalidate (a __threadfence per wave
-  // cost 80 us per launch over the 128 workgroups): the item went out in device-scope stores, every wave waits for its stores to complete,
-  // the barrier collects the waves, and only then one lane counts the arrival; the assembling workgroup reads with device-scope loads.
+  // ---- graph assembly by the last pair to arrive at each of its two nodes.
+  // Hand-over protocol (round 5: ordered by the memory model, not by cache behaviour).  Writer: the item goes out in device-scope stores
+  // (write-through), every wave waits for its stores to complete (s_waitcnt 0), the workgroup barrier collects the waves, and ONE lane counts
+  // the arrival with a RELEASE read-modify-write at device scope -- the barrier makes the other waves' stores happen-before it, the release
+  // makes them visible at device scope (one L2 write-back per workgroup; rounds 3-4 measured a __threadfence per WAVE, 2048 per launch: 80 us,
+  // and therefore ran the counter relaxed).  Reader: the workgroup whose arrival completes a node issues one ACQUIRE fence at device scope
+  // behind its read-modify-write (it read the last link of the release sequence formed by the earlier arrivals), the barrier hands the order
+  // to the rest of the workgroup, and the items are read with device-scope loads.  ORD = false keeps the relaxed counter of rounds 3-4 for A/B
+  // runs (DFX_TAIL_ORDERED=0): same bits.
   if (ASM) {
     __builtin_amdgcn_s_waitcnt(0);   // vmcnt = lgkmcnt = expcnt = 0: this wave's stores have completed
     __syncthreads();
@@ -1421,21 +1427,24 @@ __global__ __launch_bounds__(1024) void k_sfm_tail_b3(const float* __restrict__ 
         const int n = tg.pair_nodes[2 * gp + side];
         const int need = tail_local_degree(tg, n);
         if (lane == 0) {
-          const unsigned got = atomicAdd(&tg.node_cnt[n], 1u) + 1u;
+          const unsigned got = (ORD ? __hip_atomic_fetch_add(&tg.node_cnt[n], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) : atomicAdd(&tg.node_cnt[n], 1u)) + 1u;
           const bool last = got == (unsigned)need;
-          if (last) tg.node_cnt[n] = 0u;   // rewound for the next launch: nobody else counts on this node any more
+          if (last) {
+            if (ORD) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(&tg.node_cnt[n], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // rewound for the next launch: nobody else counts on this node any more
+          }
           todo[side] = last ? n : -1;
         }
       }
     }
     __syncthreads();
-    {   // off-diagonal block of this pair: single writer, from the item this workgroup has just written
+    {   // off-diagonal block of this pair: single writer, from the item this workgroup has just written (device-scope loads of device-scope stores)
       float* const Ho = tg.sys + (size_t)tg.G.n_nodes * D * D;
       auto tri = [](int a, int b) { const int lo = a < b ? a : b, hi = a < b ? b : a; return lo * NP - lo * (lo - 1) / 2 + (hi - lo); };
       for (int e = threadIdx.x; e < D * 6; e += 1024) {
         const int r = e / 6, c = e - r * 6;
         const int ia = r < 6 ? r : r + 6;
-        Ho[(size_t)gp * D * 6 + e] = item[tri(ia, 6 + c)];
+        Ho[(size_t)gp * D * 6 + e] = __hip_atomic_load(&item[tri(ia, 6 + c)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     if (todo[0] >= 0) tail_assemble_node<CS>(tg, items, item_stride, todo[0]);
@@ -1443,6 +1452,12 @@ __global__ __launch_bounds__(1024) void k_sfm_tail_b3(const float* __restrict__ 
   }
   // ---- the pair's valid0 shadow, when a wave of this launch changed the map (never in the steady state)
   rebuild_valid0_shadow(PD, W, H, launch_id, 0, 1, stamp);
+}
+
+// A/B aid: DFX_TAIL_ORDERED=0 runs the assembling tail kernel with the relaxed arrival counter of rounds 3-4 (same bits)
+static bool tail_ordered() {
+  static const bool v = [] { const char* ev = getenv("DFX_TAIL_ORDERED"); return !ev || atoi(ev) != 0; }();
+  return v;
 }
 
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair) {
@@ -1503,7 +1518,9 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
       if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
       if ((e = to_fin_stream()) != hipSuccess) return e;
       if (b3 && use_tail) {
-        if (tg.sys) hipLaunchKernelGGL((k_sfm_tail_b3<NCB, true>), dim3(npairs + node_wgs), dim3(1024), 0, fstream,
+        if (tg.sys && tail_ordered()) hipLaunchKernelGGL((k_sfm_tail_b3<NCB, true, true>), dim3(npairs + node_wgs), dim3(1024), 0, fstream,
+                                       (const float*)partials_dev, dyn->team, pairs_dev, npairs, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0, tg);
+        else if (tg.sys) hipLaunchKernelGGL((k_sfm_tail_b3<NCB, true, false>), dim3(npairs + node_wgs), dim3(1024), 0, fstream,
                                        (const float*)partials_dev, dyn->team, pairs_dev, npairs, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0, tg);
         else hipLaunchKernelGGL((k_sfm_tail_b3<NCB, false>), dim3(npairs), dim3(1024), 0, fstream,
                                 (const float*)partials_dev, dyn->team, pairs_dev, npairs, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0, tg);
@@ -1541,7 +1558,9 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
     if (byval) hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, true>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
                                   (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged);
     else if (MODE == 0 && use_tail) {   // batched launches: one workgroup per pair, the graph assembly folded in
-      if (tg.sys) hipLaunchKernelGGL((k_sfm_tail_b3<NCB, true>), dim3(npairs + node_wgs), dim3(1024), 0, fstream,
+      if (tg.sys && tail_ordered()) hipLaunchKernelGGL((k_sfm_tail_b3<NCB, true, true>), dim3(npairs + node_wgs), dim3(1024), 0, fstream,
+                                     (const float*)partials_dev, bpp, fpairs, npairs, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged, tg);
+      else if (tg.sys) hipLaunchKernelGGL((k_sfm_tail_b3<NCB, true, false>), dim3(npairs + node_wgs), dim3(1024), 0, fstream,
                                      (const float*)partials_dev, bpp, fpairs, npairs, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged, tg);
       else hipLaunchKernelGGL((k_sfm_tail_b3<NCB, false>), dim3(npairs), dim3(1024), 0, fstream,
                               (const float*)partials_dev, bpp, fpairs, npairs, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged, tg);

@@ -393,16 +393,42 @@ DFX_API int dfx_squared_error(dfx_ctx* ctx, const dfx_img* a, const dfx_img* b, 
 
 /* ---- SparseGeometricFactor<float,CS>::linearize (core/gtsam/sparse_geometric_factor.cpp:147-275) ----
  * The reference evaluates the N sampled points on the CPU (forcing a device->host sync of both keyframes' 39 MB Jacobians).
- * Here: one lane per point, everything read from device memory.  `points_xy` is a HOST array of N (x, y) int pairs
+ * Here: CS / 4 lanes per point, everything read from device memory.  `points_xy` is a HOST array of N (x, y) int pairs
  * (uniform_sampler.h:28-32), code0/code1 are HOST arrays of cs floats, kf0 = {prx_orig, prx_jac}, kf1 = {prx_orig, prx_jac,
  * dpt_grad} with dpt_grad the Sobel gradient of kf1's depth (mapper.cpp:998-1000).  rows_host receives the N x (12 + 2 cs + 1)
  * row-major matrix [A0 | A1 | A2 | A3 | b] of the gtsam::JacobianFactor (all-zero rows for points without a correspondence).
- * avg_dpt is 2.0 in the reference (:170). */
+ * avg_dpt is 2.0 in the reference (:170).  One factor per blocking call (the reference's pattern): a batch of one of the entry below. */
 DFX_API int dfx_sparse_geometric_linearize(dfx_ctx* ctx, int cs, const dfx_se3* pose0, const dfx_se3* pose1, const float* code0,
                                            const float* code1, const dfx_cam* cam, const int32_t* points_xy, int n_points,
                                            const dfx_img* prx0_orig, const dfx_img* prx0_jac, const dfx_img* prx1_orig,
                                            const dfx_img* prx1_jac, const dfx_img* dpt1_grad, float huber_delta, float avg_dpt,
                                            float* rows_host);
+/* ALL sparse geometric factors of a relinearisation round in ONE launch (new).  The reference linearises every factor of the graph inside one
+ * ISAM2::update -- a SparseGeometricFactor per keyframe pair (core/mapping/mapper.cpp:308-311), each a CPU loop over its points
+ * (sparse_geometric_factor.cpp:147-275) -- so a 16-keyframe window with geo_npoints = 500 is 120 factors x 500 points per round; one blocking
+ * call per factor costs 65 us each (launch + copies), 7.8 ms per round, against 0.9 ms for the round's whole DENSE photometric part.
+ * Factor k's rows ([n_points][12 + 2 cs + 1], as above) start at row sum_{j<k} factors[j].n_points of the output.  The rows of a factor are
+ * the bytes the single-factor call returns (same kernel).
+ *   _async   rows stay in DEVICE memory at rows_dev (enqueue only: descriptors and host-resident point lists ride one host-to-device copy)
+ *   blocking rows_host (HOST) receives all rows in one device-to-host copy (18 MB for 120 x 500 points at cs = 32: the copy, not the kernel,
+ *            is then the cost of the call).
+ * points_xy of a factor may live in DEVICE memory (points_on_device != 0): the reference samples a factor's points once, in its constructor
+ * (sparse_geometric_factor.cpp:50-53; again per linearize only in its stochastic mode, :153-157), so a caller can upload them once; the host cannot range-check those, the kernel clamps them into
+ * the image. */
+typedef struct dfx_sparse_geo_factor {
+  dfx_se3 pose0, pose1;
+  dfx_cam cam;
+  const float* code0;        /* HOST, cs floats */
+  const float* code1;        /* HOST, cs floats */
+  const int32_t* points_xy;  /* n_points (x, y) pairs: HOST memory, or DEVICE memory when points_on_device != 0 */
+  int32_t n_points;
+  int32_t points_on_device;
+  dfx_img prx0_orig, prx0_jac, prx1_orig, prx1_jac, dpt1_grad;
+} dfx_sparse_geo_factor;
+DFX_API int dfx_sparse_geometric_linearize_batch_async(dfx_ctx* ctx, int cs, const dfx_sparse_geo_factor* factors, int n, float huber_delta,
+                                                       float avg_dpt, float* rows_dev);
+DFX_API int dfx_sparse_geometric_linearize_batch(dfx_ctx* ctx, int cs, const dfx_sparse_geo_factor* factors, int n, float huber_delta,
+                                                 float avg_dpt, float* rows_host);
 
 /* ---- DepthAligner<float,CS>::RunStep (cuda/cu_depthaligner.cpp:32-110); avg_dpt is 2 in the reference. */
 DFX_API int dfx_depth_aligner_step(dfx_ctx* ctx, int cs, const float* code, const dfx_img* target_dpt,

@@ -382,4 +382,76 @@ double ErrorAll(df::SfmAligner<float, CS>& aligner, const std::vector<Photometri
   return total;
 }
 
+// ---- df::SparseGeometricFactor<float,CS> without GTSAM (core/gtsam/sparse_geometric_factor.{h,cpp}) -----------------------------------------------------
+// The sampled points are fixed at construction (sparse_geometric_factor.cpp:50-53) and live in device memory; Linearize() is the reference's
+// per-factor pattern (one blocking call), SparseGeometricLinearizeAll the round: every factor of the graph in ONE launch, rows left on the
+// device (or fetched with one copy).  Rows: [n_points][12 + 2 CS + 1] = [A_pose0 | A_pose1 | A_code0 | A_code1 | b] of the JacobianFactor
+// (sparse_geometric_factor.cpp:262-275).
+template <int CS>
+class SparseGeometricFactor {
+ public:
+  static constexpr int kCols = 12 + 2 * CS + 1;
+  SparseGeometricFactor(const dfx_cam& cam, const std::vector<std::array<int32_t, 2>>& points, std::shared_ptr<Keyframe<CS>> kf0, std::shared_ptr<Keyframe<CS>> kf1,
+                        float huber_delta, float avg_dpt = 2.0f)
+      : cam_(cam), kf0_(std::move(kf0)), kf1_(std::move(kf1)), huber_delta_(huber_delta), avg_dpt_(avg_dpt), n_points_((int)points.size()),
+        points_dev_((points.size() * 2), 1, kf0_->ctx) {
+    static_assert(sizeof(std::array<int32_t, 2>) == 8, "packed (x, y) pairs");
+    for (const auto& p : points)
+      if (p[0] < 0 || p[0] >= (int)kf0_->width || p[1] < 0 || p[1] >= (int)kf0_->height) throw Error(DFX_E_INVALID, "SparseGeometricFactor: point outside the image");
+    points_dev_.Upload(reinterpret_cast<const float*>(points.data()));   // raw words
+  }
+  int n_points() const { return n_points_; }
+  float huber_delta() const { return huber_delta_; }
+  float avg_dpt() const { return avg_dpt_; }
+  dfx_ctx* ctx() const { return kf0_->ctx->get(); }
+  // the descriptor of this factor at (pose0, pose1, code0, code1); the code arrays must outlive the call that consumes it
+  dfx_sparse_geo_factor Describe(const dfx_se3& pose0, const dfx_se3& pose1, const std::array<float, CS>& code0, const std::array<float, CS>& code1) const {
+    dfx_sparse_geo_factor f;
+    std::memset(&f, 0, sizeof(f));
+    f.pose0 = pose0; f.pose1 = pose1; f.cam = cam_; f.code0 = code0.data(); f.code1 = code1.data();
+    f.points_xy = reinterpret_cast<const int32_t*>(points_dev_.ptr()); f.n_points = n_points_; f.points_on_device = 1;
+    f.prx0_orig = kf0_->pyr_prx_orig[0].c_img(); f.prx0_jac = kf0_->pyr_jac[0].c_img();
+    f.prx1_orig = kf1_->pyr_prx_orig[0].c_img(); f.prx1_jac = kf1_->pyr_jac[0].c_img(); f.dpt1_grad = kf1_->dpt_grad.c_img();
+    return f;
+  }
+  std::vector<float> Linearize(const dfx_se3& pose0, const dfx_se3& pose1, const std::array<float, CS>& code0, const std::array<float, CS>& code1) const {
+    std::vector<float> rows((std::size_t)n_points_ * kCols);
+    const dfx_sparse_geo_factor f = Describe(pose0, pose1, code0, code1);
+    check(dfx_sparse_geometric_linearize_batch(ctx(), CS, &f, 1, huber_delta_, avg_dpt_, rows.data()));
+    return rows;
+  }
+
+ private:
+  dfx_cam cam_;
+  std::shared_ptr<Keyframe<CS>> kf0_, kf1_;
+  float huber_delta_, avg_dpt_;
+  int n_points_;
+  DeviceImage<float> points_dev_;
+};
+
+template <int CS>
+struct GeoValues { dfx_se3 pose0, pose1; std::array<float, CS> code0, code1; };
+
+// All factors in ONE launch.  rows_dev != nullptr: enqueue only, factor k's rows start at row sum_{j<k} n_points_j of rows_dev (device memory of
+// sum n_points x kCols floats).  Otherwise the rows come back in one host vector (one device-to-host copy).
+template <int CS>
+std::vector<float> SparseGeometricLinearizeAll(const std::vector<SparseGeometricFactor<CS>*>& factors, const std::vector<GeoValues<CS>>& values, float* rows_dev = nullptr) {
+  if (factors.empty() || factors.size() != values.size()) throw Error(DFX_E_INVALID, "SparseGeometricLinearizeAll: one value tuple per factor");
+  std::vector<dfx_sparse_geo_factor> d;
+  std::size_t total = 0;
+  for (std::size_t k = 0; k < factors.size(); ++k) {
+    if (factors[k]->huber_delta() != factors[0]->huber_delta() || factors[k]->avg_dpt() != factors[0]->avg_dpt() || factors[k]->ctx() != factors[0]->ctx())
+      throw Error(DFX_E_INVALID, "SparseGeometricLinearizeAll: the factors of a round share huber_delta, avg_dpt and the context");
+    d.push_back(factors[k]->Describe(values[k].pose0, values[k].pose1, values[k].code0, values[k].code1));
+    total += (std::size_t)factors[k]->n_points();
+  }
+  if (rows_dev) {
+    check(dfx_sparse_geometric_linearize_batch_async(factors[0]->ctx(), CS, d.data(), (int)d.size(), factors[0]->huber_delta(), factors[0]->avg_dpt(), rows_dev));
+    return {};
+  }
+  std::vector<float> rows(total * SparseGeometricFactor<CS>::kCols);
+  check(dfx_sparse_geometric_linearize_batch(factors[0]->ctx(), CS, d.data(), (int)d.size(), factors[0]->huber_delta(), factors[0]->avg_dpt(), rows.data()));
+  return rows;
+}
+
 }  // namespace dfx

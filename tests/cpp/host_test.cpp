@@ -143,6 +143,33 @@ int main() {
       }
       REQUIRE(sum == total);
     }
+    {   // SparseGeometricFactor (sparse_geometric_factor.cpp:147-275): every factor of the window in ONE launch == factor by factor, bit for bit
+      std::vector<std::unique_ptr<dfx::SparseGeometricFactor<CS>>> gown;
+      std::vector<dfx::SparseGeometricFactor<CS>*> gf;
+      std::vector<dfx::GeoValues<CS>> gv;
+      unsigned rs = 12345u;
+      auto rnd = [&](unsigned m) { rs = rs * 1664525u + 1013904223u; return (int)((rs >> 8) % m); };
+      for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) if (i != j) {
+        std::vector<std::array<int32_t, 2>> pts((std::size_t)(37 + 11 * i + j));   // ragged point counts
+        for (auto& q : pts) q = { rnd((unsigned)W), rnd((unsigned)H) };
+        gown.emplace_back(new dfx::SparseGeometricFactor<CS>(cams[0], pts, kfs[i], kfs[j], 0.1f));
+        gf.push_back(gown.back().get());
+        gv.push_back(dfx::GeoValues<CS>{ pose[i], pose[j], kfs[i]->code, kfs[j]->code });
+      }
+      const std::vector<float> all = dfx::SparseGeometricLinearizeAll<CS>(gf, gv);
+      std::size_t off = 0, nonzero = 0;
+      for (std::size_t k = 0; k < gf.size(); ++k) {
+        const std::vector<float> one = gf[k]->Linearize(gv[k].pose0, gv[k].pose1, gv[k].code0, gv[k].code1);
+        REQUIRE(std::memcmp(one.data(), all.data() + off, one.size() * sizeof(float)) == 0);
+        for (float v : one) nonzero += v != 0.0f;
+        off += one.size();
+      }
+      REQUIRE(off == all.size() && nonzero > all.size() / 2);
+      // rows left on the device (enqueue only) == the fetched ones
+      dfx::DeviceImage<float> rows_dev(all.size(), 1, ctx);
+      (void)dfx::SparseGeometricLinearizeAll<CS>(gf, gv, rows_dev.ptr());
+      REQUIRE(rows_dev.Download() == all);
+    }
     {   // keyframe replication over the multi-GPU C ABI (real RCCL, a world of one): the root's content stays, the call orders on the stream
       unsigned char id[DFX_COMM_ID_BYTES];
       dfx::check(dfx_comm_get_unique_id(id));

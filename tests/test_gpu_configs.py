@@ -269,23 +269,32 @@ def test_dynamic_schedule_matches_the_oracle_and_the_static_schedule(dfx, oracle
     assert np.array_equal(one_d[0].raw, one_s[0].raw)
 
 
-@pytest.mark.parametrize("mode", ["auto", "f32"])
-def test_pyramid_levels_in_one_launch(dfx, oracle, mode):
-    """A batch whose pairs differ in image size: the three pyramid levels (640x480, 320x240, 160x120) of four factor sets in ONE launch
-    (1-D grid, workgroups per pair in proportion to the pixel count, large pairs first).  Every item against the fp64 oracle, against the
-    same pairs launched level by level, bit-reproducible, valid0 maps (library-owned, shadowed) written per level; then the same through
-    dfx_sfm_linearize_batch (one decoder launch per image size)."""
+PYR3 = [(640, 480), (320, 240), (160, 120)]
+PYR4_CFG4 = [(1280, 960), (640, 480), (320, 240), (160, 120)]   # BASELINE configs[4]: "1280x960 input, 4-level pyramid, 64-dim code"
+PYR_SMALL = [(160, 120), (80, 60), (40, 30)]
+
+
+@pytest.mark.parametrize("cs,sizes,sets,mode", [(32, PYR3, 4, "auto"), (32, PYR3, 4, "f32"),
+                                                (64, PYR4_CFG4, 2, "auto"), (64, PYR4_CFG4, 2, "f32"),
+                                                (64, PYR_SMALL, 5, "auto"), (16, PYR_SMALL, 5, "auto")])
+def test_pyramid_levels_in_one_launch(dfx, oracle, cs, sizes, sets, mode):
+    """A batch whose pairs differ in image size: the pyramid levels of several factor sets in ONE launch (1-D grid, workgroups per pair in
+    proportion to the pixel count, large pairs first).  Every item against the fp64 oracle, against the same pairs launched level by level,
+    bit-reproducible, valid0 maps (library-owned, shadowed) written per level; then the same through dfx_sfm_linearize_batch (one decoder
+    launch per image size).  CS = 32: levels 640x480 ... 160x120 of four factor sets (the one-workgroup-per-pair tail kernel).  CS = 64,
+    1280x960 ... 160x120: BASELINE configs[4] AS STATED -- four levels (decoder_network.cpp:258-259; deepfactors_options.h:43,83) -- whose
+    largest pair has 3.2 MB of partials, so the launch takes the per-tile finalize kernel in its mixed-size form (DFX_TAIL_MAX_KB,
+    dfx_sfm_step.hip launch_t); CS = 64 / 16 on small levels: the tail kernel's mixed-size form at the other code sizes."""
     from deepfactors_amd import _lib, synth
-    cs = 32
     ctx = dfx.Context(0)
     ctx.set_mfma_mode(_lib.DFX_MFMA_AUTO if mode == "auto" else _lib.DFX_MFMA_F32_CHAIN)
     al = dfx.SfmAligner(code_size=cs, ctx=ctx)
-    sizes = [(640, 480), (320, 240), (160, 120)]
+    nlv = len(sizes)
     plist, meta = [], []
-    for k in range(4):
+    for k in range(sets):
         for lv, (w, h) in enumerate(sizes):
-            p = synth.make_pair(w, h, cs, seed=0x9A0 + k, device="cpu", motion_scale=0.5 + 0.15 * k)
-            n, g = synth.to_numpy(p), synth.to_device(p, "cuda")
+            g = synth.make_pair(w, h, cs, seed=0x9A0 + k, device="cuda", motion_scale=0.5 + 0.15 * k)
+            n = synth.to_numpy(g)
             vld = ctx.alloc_image(w, h)
             plist.append(dict(pose0=n["pose0"], pose1=n["pose1"], cam=n["cam"], img0=g["img0"], img1=g["img1"], dpt0=g["dpt0"], prx0_jac=g["prx_jac"],
                               grad1=g["grad1"], valid0=vld))
@@ -301,9 +310,10 @@ def test_pyramid_levels_in_one_launch(dfx, oracle, mode):
         v = vld.download()
         assert int((v != vref).sum()) <= max(1, int(1e-5 * w * h))
         assert np.array_equal(vld.valid0_shadow(), v == 1.0)
+    assert ctx.last_mfma_mode() == (_lib.DFX_MFMA_F32_CHAIN if mode == "f32" else _lib.DFX_MFMA_BF16X3)
     # level by level (one image size per launch): same sums up to fp32 re-association (the number of workgroups per pair differs)
-    for lv in range(3):
-        sel = [q for q in range(len(plist)) if q % 3 == lv]
+    for lv in range(nlv):
+        sel = [q for q in range(len(plist)) if q % nlv == lv]
         sub = al.RunStepBatch(al.make_pairs([plist[q] for q in sel]))
         for q, it in zip(sel, sub):
             assert it.inliers == items[q].inliers
@@ -313,5 +323,5 @@ def test_pyramid_levels_in_one_launch(dfx, oracle, mode):
     codes = np.stack([m[2]["code"] for m in meta])
     lin = al.LinearizeBatch(al.make_pairs(plist), prx, codes)
     for q, it in enumerate(lin):
-        assert it.inliers == items[q].inliers
+        assert abs(int(it.inliers) - int(items[q].inliers)) <= (0 if meta[q][0] <= 640 else 2)   # (a depth that differs in the last bit can move a border pixel)
         assert np.abs(it.JtJ.astype(np.float64) - items[q].JtJ).max() <= 2e-5 * np.abs(items[q].JtJ).max()   # dpt0 is decoded in fp32 here, in fp64 by the generator

@@ -41,3 +41,59 @@ def test_sparse_geometric_rejects_bad_points(dfx):
     fac = dfx.SparseGeometricFactor(p["cam"], [[64, 3]], kf, kf, 0.1)
     with pytest.raises(dfx.DfxError):
         fac.linearize(p["pose0"], p["pose1"], p["code"], p["code"])
+
+
+@pytest.mark.parametrize("cs", [32, 16, 64])
+def test_all_factors_of_a_round_in_one_launch(dfx, oracle, cs):
+    """dfx_sparse_geometric_linearize_batch: the factors of a small window (ragged point counts, two image sizes, host- and device-resident
+    point lists) in ONE launch.  Every factor's rows equal the single-factor call BIT FOR BIT (same kernel, a batch of one) and the oracle's
+    restatement of sparse_geometric_factor.cpp:147-275 within the tolerance of the single-factor test; rows left on the device equal the
+    fetched ones."""
+    from deepfactors_amd import synth
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()   # noqa: E731
+    rng = np.random.default_rng(100 + cs)
+    facs, vals, refs = [], [], []
+    for (w, h), K in (((256, 192), 4), ((128, 96), 3)):
+        host = [synth.to_numpy(synth.make_pair(w, h, cs, seed=700 + 10 * K + k)) for k in range(K)]
+        dev = []
+        for p in host:
+            d1 = oracle.update_depth(p["code"], p["prx_orig"], p["prx_jac"], 2.0)
+            p["dgrad"] = oracle.sobel(d1)
+            dev.append(dict(prx_orig=t(p["prx_orig"]), prx_jac=t(p["prx_jac"]), dpt_grad=t(p["dgrad"])))
+        for i in range(K):
+            for j in range(K):
+                if i == j:
+                    continue
+                npts = int(rng.integers(5, 700))
+                pts = np.stack([rng.integers(0, w, npts), rng.integers(0, h, npts)], 1).astype(np.int32)
+                pose0 = synth.IDENTITY.copy()
+                pose1 = host[i]["pose1"].copy(); pose1[4] += 0.01 * (j - i)
+                f = dfx.SparseGeometricFactor(host[i]["cam"], pts, dev[i], dev[j], 0.1, code_size=cs)
+                if (i + j) % 2:
+                    f.upload_points()
+                facs.append(f)
+                vals.append((pose0, pose1, host[i]["code"], host[j]["code"]))
+                refs.append(oracle.sparse_geometric(pose0, pose1, host[i]["code"], host[j]["code"], host[i]["cam"], pts, host[i]["prx_orig"], host[i]["prx_jac"],
+                                                    host[j]["prx_orig"], host[j]["prx_jac"], host[j]["dgrad"], 0.1))
+    rows = dfx.SparseGeometricFactor.linearize_all(facs, vals)
+    assert len(rows) == len(facs) == 18
+    for k, (f, v, ref) in enumerate(zip(facs, vals, refs)):
+        one = f.linearize(*v)
+        assert np.array_equal(one, rows[k]), k
+        assert np.array_equal(np.abs(ref).sum(1) == 0, np.abs(one).sum(1) == 0), k
+        scale = np.abs(ref).max(0) + 1e-6
+        assert (np.abs(one - ref) / scale).max() <= 2e-4, k
+    total = sum(len(r) for r in rows)
+    rows_dev = torch.full((total, 12 + 2 * cs + 1), float("nan"), dtype=torch.float32, device="cuda")
+    assert dfx.SparseGeometricFactor.linearize_all(facs, vals, rows_dev=rows_dev) is None
+    facs[0].ctx.sync()
+    assert np.array_equal(rows_dev.cpu().numpy(), np.concatenate(rows))
+    # device-resident points cannot be range-checked by the host: the kernel clamps them into the image
+    bad = dfx.SparseGeometricFactor(facs[0].cam_, [[5, 5], [100000, -7]], facs[0].kf0_, facs[0].kf1_, 0.1, code_size=cs).upload_points()
+    edge = dfx.SparseGeometricFactor(facs[0].cam_, [[5, 5], [255, 0]], facs[0].kf0_, facs[0].kf1_, 0.1, code_size=cs)
+    rb = dfx.SparseGeometricFactor.linearize_all([bad], [vals[0]])[0]
+    assert np.array_equal(rb, edge.linearize(*vals[0]))
+    # a host-resident point outside the image fails the whole call, like the single-factor entry
+    worse = dfx.SparseGeometricFactor(facs[0].cam_, [[256, 3]], facs[0].kf0_, facs[0].kf1_, 0.1, code_size=cs)
+    with pytest.raises(dfx.DfxError, match="outside"):
+        dfx.SparseGeometricFactor.linearize_all([facs[1], worse], [vals[1], vals[0]])

@@ -191,3 +191,52 @@ def test_step_batch_assemble_rejects_inconsistent_arguments(dfx):
     al.RunStepBatchAssembleAsync(arr, items, neq, 0)
     ctx.sync()
     assert np.array_equal(items.cpu().numpy(), want_items) and np.array_equal(neq.buf.cpu().numpy(), want_sys)
+
+
+def test_arrival_protocol_stress_on_random_graphs(dfx):
+    """1000 launches of the assembling tail kernel on 25 random graphs (high-degree hubs, isolated nodes, both directions, shards of the pair
+    list), many small pairs per launch so that the pairs' workgroups arrive at their nodes in every order the dispatcher produces: the system
+    every launch leaves behind equals, bit for bit, the assembly of the same launch's items by the separate k_graph_assemble kernel (which
+    starts after the launch has completed) -- a hand-over that lost an item store would show as a stale block.  The counters rewind launch
+    after launch.  (The protocol is release / acquire on the arrival counter since round 5; DFX_TAIL_ORDERED=0 is the relaxed form.)"""
+    from deepfactors_amd.dist import NormalEquations, PairGraph
+    cs = 16
+    ctx = dfx.Context(0)
+    al = dfx.SfmAligner(code_size=cs, ctx=ctx)
+    rng = np.random.default_rng(0x7A11)
+    n_max = 160
+    plist, keep = _plist(dfx, al, ctx, [(64, 48)] * n_max, cs, 0x5900)
+    isz = dfx.item_size(12 + cs)
+    launches = 0
+    for g in range(25):
+        n_nodes = int(rng.integers(3, 40))
+        n_pairs = int(rng.integers(8, n_max + 1))
+        hubs = rng.integers(0, n_nodes, 2)
+        pairs = []
+        while len(pairs) < n_pairs:
+            a = int(hubs[rng.integers(0, 2)]) if rng.random() < 0.5 else int(rng.integers(0, n_nodes - 1))   # the last node stays isolated in half of the graphs
+            b = int(rng.integers(0, n_nodes - (g % 2)))
+            if a != b:
+                pairs.append((a, b))
+        graph = PairGraph(n_nodes, pairs)
+        first = int(rng.integers(0, n_pairs // 2)) if g % 3 == 0 else 0
+        cnt = n_pairs - first - (int(rng.integers(0, 4)) if g % 3 == 0 else 0)
+        arr = al.make_pairs(plist[first:first + cnt])
+        items = torch.zeros(cnt * isz, dtype=torch.uint8, device="cuda")
+        neq, want = NormalEquations(graph, cs, "cuda"), NormalEquations(graph, cs, "cuda")
+        ref = None
+        for r in range(40):
+            neq.buf.fill_(float(r + 1))
+            al.RunStepBatchAssembleAsync(arr, items, neq, first)
+            launches += 1
+            if r % 8 == 0:
+                want.buf.fill_(-1.0)
+                want.assemble_native(ctx, items, first, cnt)
+                ctx.sync()
+                assert torch.equal(want.buf, neq.buf), (g, r)
+                if ref is None:
+                    ref = neq.buf.clone()
+            # back-to-back launches in between: compared at the end against the first
+        ctx.sync()
+        assert torch.equal(ref, neq.buf), g
+    assert launches == 1000
