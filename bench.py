@@ -70,6 +70,10 @@ def parse():
                     "dfx_graph_assemble_async: two tail kernels) instead of dfx_sfm_step_batch_assemble_async (the assembly inside the launch's tail kernel)")
     ap.add_argument("--foreign-valid0", action="store_true", help="keep the valid0 maps in torch tensors (memory the library does not own: the step kernel "
                     "then re-reads the map every step, 4 B/px) instead of library-owned images with a 1-bit shadow")
+    ap.add_argument("--exchange", choices=["cabi", "torch"], default="cabi",
+                    help="how the ranks' normal equations are summed when the script runs under torch.distributed.run: cabi (default) = the SHIPPED exchange, "
+                         "dfx_comm_* of the C ABI (deepfactors_amd/csrc/dfx_comm.cpp: ncclReduce enqueued on the context's exchange stream; the communicator is created "
+                         "from a unique id handed round over the process group that launched the ranks); torch = torch.distributed's collectives on the same buffers (A/B)")
     ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -262,6 +266,26 @@ def small_operator_rooflines(dfx, synth, ctx, dev):
     byts = (8 + 4 * CS) * W * H * K
     out["update_depth_batch_64kf"] = dict(us=us, algorithmic_bytes=byts, algorithmic_gbs=byts / us / 1e3, frac=byts / us / 1e3 / HBM_PEAK_GBS,
                                           note="k_update_depth_batch<32>: dpt = a / (prx + jac . code) - a for 64 distinct 640x480 keyframes in one launch (2.7 GB)")
+    # frame ingest: Frame::FillPyramids for 64 frames of 640x480, 4 levels, in ONE enqueue (dfx_build_pyramid_batch_async: a launch per level
+    # over all frames; a level is read once, its Sobel gradient and its blur-down come from the same LDS tile).  Algorithmic bytes per level-i pixel:
+    # 4 read + 8 written (gradient) + 1 written (a quarter pixel of the next level; not for the last level)
+    F, LV = 64, 4
+    fh, fw = kfs[0]["img0"].shape
+    pyr_i = [[torch.empty((fh >> i, fw >> i), dtype=torch.float32, device=dev) for i in range(LV)] for _ in range(F)]
+    pyr_g = [[torch.empty((fh >> i, fw >> i, 2), dtype=torch.float32, device=dev) for i in range(LV)] for _ in range(F)]
+    for k in range(F):
+        pyr_i[k][0].copy_(kfs[k % K]["img0"])
+    us = event_time_us(torch, lambda: dfx.BuildPyramids(pyr_i, pyr_g, ctx=ctx), reps=40, warm=100)
+    byts = sum((fw >> i) * (fh >> i) * (12 + (1 if i + 1 < LV else 0)) for i in range(LV)) * F
+    lv0 = pyr_i[0][0]
+    ref1 = torch.empty_like(pyr_i[0][1]); refg = torch.empty_like(pyr_g[0][0])
+    dfx.GaussianBlurDown(lv0, ref1, ctx); dfx.SobelGradients(lv0, refg, ctx)
+    one = event_time_us(torch, lambda: dfx.BuildPyramids(pyr_i[:1], pyr_g[:1], ctx=ctx), reps=100, warm=100)
+    out["pyramid_build_64frames_4levels"] = dict(us=us, algorithmic_bytes=byts, algorithmic_gbs=byts / us / 1e3, frac=byts / us / 1e3 / HBM_PEAK_GBS, frames_per_s=F / (us * 1e-6),
+                                                 single_frame_us=one, equals_per_level_operators=bool(torch.equal(pyr_i[0][1], ref1) and torch.equal(pyr_g[0][0], refg)),
+                                                 note="k_pyr_level x 4: image + gradient pyramids of 64 distinct 640x480 frames per enqueue (335 MB: beyond the Infinity Cache); us = the whole "
+                                                      "enqueue (four launches) in back-to-back calls; single_frame_us = one frame per enqueue (latency-bound: four dependent launches)")
+    del pyr_i, pyr_g
     P = 128
     al, se3 = dfx.SfmAligner(code_size=CS, ctx=ctx), dfx.SE3Aligner(ctx=ctx)
     prs = [kfs[k % K] for k in range(P)]
@@ -744,7 +768,7 @@ def cpu_baseline_se3(levels_iters=(10, 5, 5)):
                 sample="the oracle's SE3 step (a port of LucasKanadeSE3, lucas_kanade_se3.h:41-77) + SE3SolveAndUpdate in the 10/5/5 schedule over 3 levels of the synthetic "
                        "640x480 pair, g++ -O3 -march=native, OpenMP over rows")
 
-def window_config(dfx, synth, ctx, dev, dist, rank, world):
+def window_config(dfx, synth, ctx, dev, dist, rank, world, comm=None):
     """BASELINE configs[3]: 64 keyframes (replicated on every rank), each linked to its 16 nearest -> 1024 directed pairs, sharded
     contiguously (by source keyframe) over the ranks; per step: one batched launch per rank + graph assembly + RCCL reduce."""
     import torch
@@ -770,7 +794,9 @@ def window_config(dfx, synth, ctx, dev, dist, rank, world):
 
     def step():
         al.RunStepBatchAssembleAsync(arr, items, neq, lo)
-        if dist is not None:
+        if comm is not None:
+            comm.reduce(ctx, neq.buf, root=0)   # the C-ABI exchange (dfx_comm_reduce_f32_async)
+        elif dist is not None:
             neq.reduce(dist, root=0)
 
     def barrier():
@@ -899,34 +925,50 @@ def main():
         ctx.sync()
         return
 
-    # --deferred-tail: consecutive steps are independent batches, so the reduction tail of step k (finalize kernel + graph assembly, ~35 us
-    # of short dependent kernels) can run on a second stream beside the 1 ms step kernel of step k + 1 (dfx_set_tail_stream); for N > 1 the
-    # RCCL reduce of step k is then issued on that stream too.  Every tail and every reduce has completed when the timed region ends.
-    tail = torch.cuda.Stream(device=dev) if a.deferred_tail else None
+    # The exchange.  cabi (default): the library's own collectives -- a dfx_comm created over RCCL from a unique id that rank 0 hands to the others over the
+    # process group, then per step dfx_comm_reduce_f32_async on the context's exchange stream (what dfx_graph_reduce_async issues for the graph's system).
+    comm = None
+    if dist is not None and a.exchange == "cabi":
+        from deepfactors_amd.dist import Comm
+        comm = Comm.create(ctx, dist, rank, world, dev)
+
+    # Deferred tail: consecutive steps are independent batches, so the reduction tail of step k (the tail kernel with the graph assembly, ~25 us, and the
+    # RCCL reduce of its system) can run on a second stream beside the 1 ms step kernel of step k + 1 (dfx_set_tail_stream).  Opt-in for one rank
+    # (--deferred-tail: measured neutral there); with the C-ABI exchange and N > 1 it is how the collective leaves the launch stream: the library enqueues
+    # ncclReduce on the tail stream, behind the assembly.  Every tail and every reduce has completed when the timed region ends.
+    tail = torch.cuda.Stream(device=dev) if (a.deferred_tail or (comm is not None and world > 1)) else None
     if tail is not None:
         ctx.set_tail_stream(tail)
 
     # the pairs of all ranks form one trajectory: pair p links keyframe node p -> frame node p + 1
     graph = PairGraph.chain(world * P)
-    pipe = PipelinedReduce(dist, [NormalEquations(graph, CS, dev) for _ in range(2)], root=0, stream=tail) if world > 1 else None
-    neq = NormalEquations(graph, CS, dev) if pipe is None else None
+    pipe = PipelinedReduce(dist, [NormalEquations(graph, CS, dev) for _ in range(2)], root=0, stream=tail) if (world > 1 and comm is None) else None
+    # C-ABI exchange: two system buffers used round robin; the reduce of step k and the assembly of step k + 2 into the same buffer are ordered by the
+    # stream they are both enqueued on
+    systems = [NormalEquations(graph, CS, dev) for _ in range(2 if (comm is not None and world > 1) else 1)] if pipe is None else None
+    neq = systems[0] if systems is not None else None
+    step_no = [0]
 
     fused = not a.two_call_tail
 
     def step():
-        # hot path: one launch over P pairs (+ its finalize kernel), then this rank's items are summed into the block-sparse
+        # hot path: one launch over P pairs (+ its tail kernel), then this rank's items are summed into the block-sparse
         # normal equations of the graph; for N > 1 the ranks' buffers are reduced onto the rank that solves
         if pipe is not None:
             al.RunStepBatchAssembleAsync(arr, items, pipe.next(), rank * P, fused=fused)
             pipe.submit()                                      # RCCL reduce over xGMI, overlapped with the next step's kernels
             return
-        al.RunStepBatchAssembleAsync(arr, items, neq, rank * P, fused=fused)
-        if dist is not None:
+        sysb = systems[step_no[0] % len(systems)]
+        step_no[0] += 1
+        al.RunStepBatchAssembleAsync(arr, items, sysb, rank * P, fused=fused)
+        if comm is not None:
+            comm.reduce(ctx, sysb.buf, root=0)                 # ncclReduce on the context's exchange stream, behind the assembly
+        elif dist is not None:
             if tail is not None:
                 with torch.cuda.stream(tail):
-                    neq.reduce(dist, root=0)
+                    sysb.reduce(dist, root=0)
             else:
-                neq.reduce(dist, root=0)
+                sysb.reduce(dist, root=0)
 
     def barrier():
         if pipe is not None:
@@ -949,7 +991,7 @@ def main():
     if dist is not None:
         dist.all_reduce(chk)
     if rank == 0:
-        got = float((neq if pipe is None else pipe.last()).g.double().sum())
+        got = float((systems[(step_no[0] - 1) % len(systems)] if pipe is None else pipe.last()).g.double().sum())
         assert abs(got - float(chk[0])) <= 1e-4 * float(chk[1]) + 1e-6, (got, chk.tolist())
 
     out = None
@@ -977,11 +1019,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1] geometry in the batch size of configs[3] (1k pairs / 8 GPUs): {P} independent {W}x{H} pairs per GPU per step, "
                                    f"CS={CS}, SfmAligner::RunStep (SE3+code Jacobians, JtJ/Jtr) in one launch, level 0; "
-                                   "+ block-sparse normal-equation assembly" + (" + RCCL reduce to rank 0" if world > 1 else "")
+                                   "+ block-sparse normal-equation assembly" + ((" + RCCL reduce to rank 0 through " + ("the C ABI (dfx_comm_reduce_f32_async)" if comm is not None else "torch.distributed")) if dist is not None else "")
                                    + ("; the reduction tail of step k (finalize, assembly" + (", reduce" if world > 1 else "") + ") runs on a second stream beside the kernel of step k + 1"
                                       if tail is not None else ""),
                        "pairs_per_gpu": P, "width": W, "height": H, "code_size": CS,
-                       "parallelism": f"pairs sharded over {world} GPU(s)"},
+                       "parallelism": f"pairs sharded over {world} GPU(s)", "exchange": ("cabi" if comm is not None else ("torch" if dist is not None else "none"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": f"k_sfm_step<NCB={CS // 16}, {'bf16x3' if mode_ran == _dl.DFX_MFMA_BF16X3 else 'f32 chain'}, {'dynamic' if dyn_ran else 'static'}>",
                          "kernel_us": kern_s * 1e6, "kernel_us_min": pr["kern_min_ms"] * 1e3, "kernel_us_max": pr["kern_max_ms"] * 1e3, "launches": n_launch,
@@ -1010,7 +1052,10 @@ def main():
         configs.update(tracker_and_geometric_configs(dfx, synth, ctx, dev))
         torch.cuda.empty_cache()
     if a.window or (world == 1 and not a.no_configs):
-        configs["configs3_window64"] = window_config(dfx, synth, ctx, dev, dist, rank, world)
+        configs["configs3_window64"] = window_config(dfx, synth, ctx, dev, dist, rank, world, comm)
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

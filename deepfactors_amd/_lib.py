@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("DFX_LIB") or os.path.join(_HERE, "libdfx.so")   # DFX_LIB: tuning variants (tools/ab_variants.sh)
+LIB_PATH = os.environ.get("DFX_LIB") or os.path.join(_HERE, "libdfx.so")   # DFX_LIB: tuning variants (tools/variants.sh)
 
 DFX_OK = 0
 DFX_SCHEDULE_AUTO, DFX_SCHEDULE_STATIC, DFX_SCHEDULE_DYNAMIC = 0, 1, 2
@@ -18,6 +18,7 @@ DFX_E_NOGPU = -3
 DFX_MFMA_F32_CHAIN = 0
 DFX_MFMA_BF16X3 = 1
 DFX_MFMA_AUTO = 2
+DFX_COMM_ID_BYTES = 128
 
 
 class DfxError(RuntimeError):
@@ -65,6 +66,13 @@ class SfmPair(C.Structure):
 
 class SE3Pair(C.Structure):
     _fields_ = [("pose_10", SE3), ("cam", Cam), ("img0", Img), ("img1", Img), ("dpt0", Img), ("grad1", Img)]
+
+
+DFX_MAX_PYR_LEVELS = 8
+
+
+class Pyramid(C.Structure):
+    _fields_ = [("levels", C.c_int32), ("img", Img * DFX_MAX_PYR_LEVELS), ("grad", Img * DFX_MAX_PYR_LEVELS)]
 
 
 class SparseGeoFactor(C.Structure):
@@ -161,6 +169,8 @@ _PROTOS = {
                                           C.c_void_p]),
     "dfx_sobel_gradients": (C.c_int, [C.c_void_p, C.POINTER(Img), C.POINTER(Img)]),
     "dfx_gaussian_blur_down": (C.c_int, [C.c_void_p, C.POINTER(Img), C.POINTER(Img)]),
+    "dfx_build_pyramid_batch_async": (C.c_int, [C.c_void_p, C.POINTER(Pyramid), C.c_int]),
+    "dfx_build_pyramid": (C.c_int, [C.c_void_p, C.POINTER(Pyramid)]),
     "dfx_squared_error": (C.c_int, [C.c_void_p, C.POINTER(Img), C.POINTER(Img), C.POINTER(C.c_float)]),
     "dfx_depth_aligner_step": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(Img), C.POINTER(Img),
                                          C.POINTER(Img), C.c_float, C.c_void_p]),

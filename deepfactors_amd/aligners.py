@@ -570,6 +570,32 @@ def GaussianBlurDown(inp, out, ctx=None):
     check(_lib.lib().dfx_gaussian_blur_down(ctx.handle, C.byref(i), C.byref(o)))
 
 
+def BuildPyramids(pyr_imgs, pyr_grads, ctx=None, blocking=False):
+    """``Frame::FillPyramids`` (core/mapping/frame.h:80-94) for n frames in ONE enqueue (dfx_build_pyramid_batch_async): `pyr_imgs[k]` = frame k's
+    image pyramid (level 0 = the input, already on the device; levels 1.. are written), `pyr_grads[k]` its gradient pyramid (written; an entry may be
+    None to skip that level's gradient, as UploadLiveFrame does for level 0, deepfactors.cpp:620-625).  One launch per pyramid level over all
+    frames; same bits as GaussianBlurDown / SobelGradients level by level."""
+    n = len(pyr_imgs)
+    flat = [t for p in pyr_imgs for t in p] + [t for p in pyr_grads for t in p if t is not None]
+    ctx = _ctx_for(ctx, *flat)
+    arr = (_lib.Pyramid * n)()
+    for k in range(n):
+        L = len(pyr_imgs[k])
+        if L > _lib.DFX_MAX_PYR_LEVELS or len(pyr_grads[k]) != L:
+            raise ValueError("pyramid depth")
+        arr[k].levels = L
+        for i in range(L):
+            arr[k].img[i] = _img(pyr_imgs[k][i], "img")
+            if pyr_grads[k][i] is not None:
+                arr[k].grad[i] = _img(pyr_grads[k][i], "grad", 2)
+    if blocking and n == 1:
+        check(_lib.lib().dfx_build_pyramid(ctx.handle, arr))
+        return
+    check(_lib.lib().dfx_build_pyramid_batch_async(ctx.handle, arr, n))
+    if blocking:
+        ctx.sync()
+
+
 def SquaredError(buf1, buf2, ctx=None):
     """``df::SquaredError`` (cu_image_proc.cpp:208-240)."""
     ctx = _ctx_for(ctx, buf1, buf2)

@@ -63,6 +63,7 @@ struct ImgRec {
 std::mutex g_img_mu;
 std::unordered_map<const void*, ImgRec> g_imgs;
 std::atomic<int> g_shadow_count{ 0 };
+std::atomic<int> g_img_count{ 0 };   // registered images: img_note_write returns at once while there is none
 std::atomic<unsigned> g_launch_id{ 0 };
 
 unsigned next_launch_id() {
@@ -78,8 +79,10 @@ struct dfx_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipStream_t copy_stream = nullptr;          // descriptor uploads of batched launches run beside the previous launch's kernels
-  hipEvent_t slot_done[kStageSlots] = {};     // recorded on `stream` behind the kernels that read a slot's device copy
+  hipEvent_t slot_done[kStageSlots] = {};     // recorded on `stream` behind the kernels that read a slot's device copy of the SfM pair descriptors (pairs_dev)
   bool slot_busy[kStageSlots] = {};
+  hipEvent_t sdesc_done[kStageSlots] = {};    // the same for the device copies of the batched SE3 / EvaluateError descriptors (sdesc_dev): own events -- sharing
+  bool sdesc_busy[kStageSlots] = {};          // slot_done let a small-operator launch overwrite the event a deferred SfM tail's descriptor region was guarded by
   int cu_count = 0;
   int step_blocks = 0;   // 0 = auto
   int mfma_mode = DFX_MFMA_AUTO;
@@ -442,6 +445,11 @@ int fill_simple(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam, const df
   if ((rc = check_img(img0, "img0", W, H, 4))) return rc;
   if ((rc = check_img(img1, "img1", W, H, 4))) return rc;
   if ((rc = check_img(dpt0, "dpt0", W, H, 4))) return rc;
+  // The row walk decides validity in the CAMERA's coordinates (PixelValid against cam.width / cam.height, pinhole_camera_impl.h:105-108) and addresses its
+  // taps in the IMAGE: a camera larger than the image would let an inlier tap beyond the image (the buffer load then returns 0 silently).  The reference
+  // always pairs a level's camera with that level's image (camera_pyramid.h:41-46); anything else is a caller error, refused here.
+  if (cam->w != (float)W || cam->h != (float)H)
+    return fail(DFX_E_INVALID, "camera is %gx%g, images are %ux%u: the camera of a pyramid level has the size of that level's images", (double)cam->w, (double)cam->h, W, H);
   double R[9];
   quat_to_R(pose_10->q, R);
   for (int i = 0; i < 9; ++i) d->R[i] = R10 ? R10[i] : (float)R[i];
@@ -501,6 +509,7 @@ size_t shadow_words(uint32_t w, uint32_t h) { return ((size_t)w * h + 63) / 64; 
 // right after an async step could race the rebuild and leave "known 1.0" bits over other data).
 int img_note_write(dfx_ctx* c, const dfx_img* im, bool uniform, float value) {
   if (!im || !im->ptr) return DFX_OK;
+  if (g_img_count.load(std::memory_order_relaxed) == 0) return DFX_OK;   // no library-owned image exists: nothing can have a record (callers with their own memory pay no lock)
   std::lock_guard<std::mutex> lk(g_img_mu);
   auto it = g_imgs.find(im->ptr);
   if (it == g_imgs.end()) return DFX_OK;
@@ -518,6 +527,16 @@ int img_note_write(dfx_ctx* c, const dfx_img* im, bool uniform, float value) {
   return DFX_OK;
 }
 int img_note_write(dfx_ctx* c, const dfx_img* im) { return img_note_write(c, im, false, 0.f); }
+// many images written by one call (a pyramid build): one pass under the lock
+int img_note_writes(dfx_ctx* c, const std::vector<const void*>& ptrs) {
+  if (g_img_count.load(std::memory_order_relaxed) == 0) return DFX_OK;
+  for (const void* p : ptrs) {
+    const dfx_img im{ const_cast<void*>(p), 0, 0, 0 };
+    int rc;
+    if ((rc = img_note_write(c, &im))) return rc;
+  }
+  return DFX_OK;
+}
 
 // The shadow of a valid0 map, created on first use; null for memory the library does not own (or a view that is not the whole image).
 int valid0_shadow(dfx_ctx* c, const dfx_img* v, uint32_t W, uint32_t H, unsigned long long** out) {
@@ -596,6 +615,7 @@ DFX_API int dfx_ctx_create(int device, void* stream, dfx_ctx** out) {
   for (int i = 0; i < kStageSlots; ++i) {
     e = hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->slot_done[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->sdesc_done[i], hipEventDisableTiming);
     if (e != hipSuccess) { dfx_ctx_destroy(c); return fail(DFX_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(e)); }   // destroys what exists so far
   }
   e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
@@ -628,6 +648,7 @@ DFX_API void dfx_ctx_destroy(dfx_ctx* c) {
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   for (int i = 0; i < kStageSlots; ++i) if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
   for (int i = 0; i < kStageSlots; ++i) if (c->slot_done[i]) (void)hipEventDestroy(c->slot_done[i]);
+  for (int i = 0; i < kStageSlots; ++i) if (c->sdesc_done[i]) (void)hipEventDestroy(c->sdesc_done[i]);
   for (auto& pr : c->prof_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -643,7 +664,7 @@ DFX_API int dfx_ctx_set_stream(dfx_ctx* c, void* stream) {
   if (c->tail_stream) DFX_HIP(hipStreamSynchronize(c->tail_stream));
   c->tail_busy[0] = c->tail_busy[1] = false;
   c->stream = (hipStream_t)stream;
-  for (int i = 0; i < kStageSlots; ++i) { c->stage_used[i] = false; c->slot_busy[i] = false; }
+  for (int i = 0; i < kStageSlots; ++i) { c->stage_used[i] = false; c->slot_busy[i] = false; c->sdesc_busy[i] = false; }
   return DFX_OK;
 }
 
@@ -673,7 +694,7 @@ DFX_API int dfx_set_tail_stream(dfx_ctx* c, void* tail_stream) {
   c->tail_stream = (hipStream_t)tail_stream;
   c->tail_busy[0] = c->tail_busy[1] = false;
   c->tail_parity = 0;
-  for (int i = 0; i < kStageSlots; ++i) { c->stage_used[i] = false; c->slot_busy[i] = false; }
+  for (int i = 0; i < kStageSlots; ++i) { c->stage_used[i] = false; c->slot_busy[i] = false; c->sdesc_busy[i] = false; }
   // the scratch is re-created with (or without) its second half on next use
   if (c->partials_base) DFX_HIP(hipFree(c->partials_base));
   c->partials_base = nullptr; c->partials = c->partials_alt = nullptr; c->partials_bytes = 0;
@@ -790,6 +811,7 @@ DFX_API int dfx_img_alloc(dfx_ctx* c, uint32_t w, uint32_t h, size_t elem_bytes,
   {
     std::lock_guard<std::mutex> lk(g_img_mu);
     g_imgs[p] = ImgRec{ c->device, pitch, w, h, elem_bytes, nullptr, true, 0.0f };
+    g_img_count.fetch_add(1, std::memory_order_relaxed);
   }
   *out = dfx_img{ p, pitch, w, h };
   return DFX_OK;
@@ -806,7 +828,7 @@ DFX_API int dfx_img_free(dfx_ctx* c, dfx_img* img) {
     {
       std::lock_guard<std::mutex> lk(g_img_mu);
       auto it = g_imgs.find(img->ptr);
-      if (it != g_imgs.end()) { shadow = it->second.shadow; g_imgs.erase(it); }
+      if (it != g_imgs.end()) { shadow = it->second.shadow; g_imgs.erase(it); g_img_count.fetch_sub(1, std::memory_order_relaxed); }
     }
     if (shadow) { (void)hipFree(shadow); g_shadow_count.fetch_sub(1, std::memory_order_relaxed); }
     DFX_HIP(hipFree(img->ptr));
@@ -1296,6 +1318,7 @@ int upload_simple(dfx_ctx* c, const std::vector<dfx::SimplePairDev>& descs, cons
     const size_t cap = (bytes * 2 + 255) & ~(size_t)255;
     DFX_HIP(hipMalloc((void**)&c->sdesc_dev, cap * kStageSlots));
     c->sdesc_cap = cap;
+    for (int i = 0; i < kStageSlots; ++i) c->sdesc_busy[i] = false;
   }
   if (simple_zerocopy()) {
     void* hdev = nullptr;
@@ -1305,7 +1328,7 @@ int upload_simple(dfx_ctx* c, const std::vector<dfx::SimplePairDev>& descs, cons
     return DFX_OK;
   }
   char* dd = c->sdesc_dev + (size_t)slot * c->sdesc_cap;
-  if (c->slot_busy[slot]) DFX_HIP(hipStreamWaitEvent(c->copy_stream, c->slot_done[slot], 0));   // the last kernels that read this slot's device copy
+  if (c->sdesc_busy[slot]) DFX_HIP(hipStreamWaitEvent(c->copy_stream, c->sdesc_done[slot], 0));   // the last kernels that read this slot's device copy
   DFX_HIP(hipMemcpyAsync(dd, host, bytes, hipMemcpyHostToDevice, c->copy_stream));
   DFX_HIP(hipEventRecord(c->stage_ev[slot], c->copy_stream));   // the host slot is free again once the copy has run
   c->stage_used[slot] = true;
@@ -1318,8 +1341,8 @@ int upload_simple(dfx_ctx* c, const std::vector<dfx::SimplePairDev>& descs, cons
 // behind the kernels that read the slot's device copy
 int simple_launched(dfx_ctx* c, int slot) {
   if (simple_zerocopy()) return stage_release(c, slot);   // the kernels read the staging slot itself: free again behind them
-  DFX_HIP(hipEventRecord(c->slot_done[slot], c->stream));
-  c->slot_busy[slot] = true;
+  DFX_HIP(hipEventRecord(c->sdesc_done[slot], c->stream));
+  c->sdesc_busy[slot] = true;
   return DFX_OK;
 }
 
@@ -1360,11 +1383,13 @@ DFX_API int dfx_sfm_error_batch_async(dfx_ctx* c, const dfx_sfm_params* params, 
   if ((rc = grow_partials(c, (size_t)n * blocks * dfx::kSimpleRow * sizeof(float)))) return rc;
   const dfx::SimplePairDev* dd;
   int slot;
-  if ((rc = upload_simple(c, descs, &dd, &slot))) return rc;
   hipEvent_t eb, ee;
-  if ((rc = prof_events(c, &eb, &ee))) return rc;
-  DFX_HIP(dfx::launch_sfm_error_batch(dd, n, (int)W, (int)H, params->huber_delta, blocks, c->partials, out_items_dev, c->stream, eb, ee));
-  return simple_launched(c, slot);
+  if ((rc = prof_events(c, &eb, &ee))) return rc;          // before the slot is handed out: no exit between acquiring a slot and releasing it but the launch
+  if ((rc = upload_simple(c, descs, &dd, &slot))) return rc;
+  const hipError_t le = dfx::launch_sfm_error_batch(dd, n, (int)W, (int)H, params->huber_delta, blocks, c->partials, out_items_dev, c->stream, eb, ee);
+  rc = simple_launched(c, slot);                            // the slot gets its event whether or not the launch went out
+  if (le != hipSuccess) { if (ee) (void)hipEventRecord(ee, c->stream); return fail(DFX_E_HIP, "k_sfm_error_batch launch failed: %s", hipGetErrorString(le)); }
+  return rc;
 }
 
 DFX_API int dfx_sfm_error_batch(dfx_ctx* c, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n, dfx_corr_item* out_items_host) {
@@ -1406,11 +1431,13 @@ DFX_API int dfx_se3_step_batch_async(dfx_ctx* c, const dfx_se3_pair* pairs, int 
   if ((rc = grow_partials(c, (size_t)n * blocks * dfx::kSimpleRow * sizeof(float)))) return rc;
   const dfx::SimplePairDev* dd;
   int slot;
-  if ((rc = upload_simple(c, descs, &dd, &slot))) return rc;
   hipEvent_t eb, ee;
   if ((rc = prof_events(c, &eb, &ee))) return rc;
-  DFX_HIP(dfx::launch_se3_step_batch(dd, n, (int)W, (int)H, huber_delta, blocks, c->partials, out_items_dev, c->stream, eb, ee));
-  return simple_launched(c, slot);
+  if ((rc = upload_simple(c, descs, &dd, &slot))) return rc;
+  const hipError_t le = dfx::launch_se3_step_batch(dd, n, (int)W, (int)H, huber_delta, blocks, c->partials, out_items_dev, c->stream, eb, ee);
+  rc = simple_launched(c, slot);
+  if (le != hipSuccess) { if (ee) (void)hipEventRecord(ee, c->stream); return fail(DFX_E_HIP, "k_se3_step_batch launch failed: %s", hipGetErrorString(le)); }
+  return rc;
 }
 
 DFX_API int dfx_se3_step_batch(dfx_ctx* c, const dfx_se3_pair* pairs, int n, float huber_delta, void* out_items_host) {
@@ -1866,6 +1893,67 @@ DFX_API int dfx_gaussian_blur_down(dfx_ctx* c, const dfx_img* in, const dfx_img*
   DFX_HIP(dfx::launch_blur_down((const float*)in->ptr, (uint32_t)in->pitch_bytes, (int)in->w, (int)in->h, (float*)out->ptr,
                                 (uint32_t)out->pitch_bytes, (int)out->w, (int)out->h, c->stream));
   DFX_HIP(hipStreamSynchronize(c->stream));
+  return DFX_OK;
+}
+
+// ---- Frame::FillPyramids for n frames: one launch per pyramid level (core/mapping/frame.h:80-94, core/deepfactors.cpp:616-630) ----------------
+DFX_API int dfx_build_pyramid_batch_async(dfx_ctx* c, const dfx_pyramid* frames, int n) {
+  if (!c || !frames) return fail(DFX_E_INVALID, "dfx_build_pyramid_batch: null argument");
+  if (n <= 0 || n > 65535) return fail(DFX_E_INVALID, "frame count %d out of range [1,65535]", n);
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  const int L = frames[0].levels;
+  if (L < 1 || L > DFX_MAX_PYR_LEVELS) return fail(DFX_E_INVALID, "pyramid of %d levels (1 .. %d)", L, DFX_MAX_PYR_LEVELS);
+  int slot;
+  char* host;
+  if ((rc = stage_acquire(c, sizeof(dfx::PyrLevelDev) * (size_t)n * L, &slot, &host))) return rc;
+  dfx::PyrLevelDev* hd = reinterpret_cast<dfx::PyrLevelDev*>(host);
+  std::vector<const void*> written;
+  for (int k = 0; k < n && !rc; ++k) {
+    const dfx_pyramid& f = frames[k];
+    if (f.levels != L) rc = fail(DFX_E_INVALID, "frame %d: %d levels, frame 0 has %d (one schedule per batch)", k, f.levels, L);
+    for (int i = 0; i < L && !rc; ++i) {
+      if (!img_ok(&f.img[i])) { rc = fail(DFX_E_INVALID, "frame %d: level %d image null or empty", k, i); break; }
+      const uint32_t W = f.img[i].w, H = f.img[i].h;
+      if (W != frames[0].img[i].w || H != frames[0].img[i].h) { rc = fail(DFX_E_INVALID, "frame %d: level %d is %ux%u, frame 0 has %ux%u", k, i, W, H, frames[0].img[i].w, frames[0].img[i].h); break; }
+      if (i > 0 && (W != f.img[i - 1].w / 2 || H != f.img[i - 1].h / 2)) { rc = fail(DFX_E_INVALID, "frame %d: level %d is %ux%u, half of level %d is %ux%u", k, i, W, H, i - 1, f.img[i - 1].w / 2, f.img[i - 1].h / 2); break; }
+      if ((rc = check_img(&f.img[i], "img", W, H, 4))) break;
+      dfx::PyrLevelDev& d = hd[(size_t)i * n + k];
+      d.in = (const float*)f.img[i].ptr; d.pitch_in = (uint32_t)f.img[i].pitch_bytes; d.W = (int)W; d.H = (int)H;
+      d.grad = nullptr; d.pitch_grad = 0;
+      if (f.grad[i].ptr) {   // (UploadLiveFrame leaves the live frame's level-0 gradient out, deepfactors.cpp:620-625: a null view skips a level's gradient)
+        if ((rc = check_img(&f.grad[i], "grad", W, H, 8))) break;
+        if (((uintptr_t)f.grad[i].ptr | f.grad[i].pitch_bytes) & 7) { rc = fail(DFX_E_INVALID, "grad: pointer/pitch must be 8-byte aligned"); break; }
+        d.grad = (float*)f.grad[i].ptr; d.pitch_grad = (uint32_t)f.grad[i].pitch_bytes;
+        written.push_back(f.grad[i].ptr);
+      }
+      d.out = nullptr; d.pitch_out = 0; d.OW = 0; d.OH = 0;
+      if (i + 1 < L) {
+        if (!img_ok(&f.img[i + 1])) { rc = fail(DFX_E_INVALID, "frame %d: level %d image null or empty", k, i + 1); break; }
+        d.out = (float*)f.img[i + 1].ptr; d.pitch_out = (uint32_t)f.img[i + 1].pitch_bytes; d.OW = (int)f.img[i + 1].w; d.OH = (int)f.img[i + 1].h;
+        written.push_back(f.img[i + 1].ptr);
+      }
+    }
+    if (rc) g_last_error = "frame " + std::to_string(k) + ": " + g_last_error;
+  }
+  if (!rc) rc = img_note_writes(c, written);
+  if (rc) { (void)stage_release(c, slot); return rc; }
+  void* hdev = nullptr;
+  DFX_HIP(hipHostGetDevicePointer(&hdev, host, 0));   // the kernels read the pinned staging slot (zero-copy descriptors, see simple_zerocopy)
+  for (int i = 0; i < L; ++i) {
+    bool any = false;   // (the last level of a batch whose frames all skip its gradient has nothing to do)
+    for (int k = 0; k < n; ++k) any = any || hd[(size_t)i * n + k].grad || hd[(size_t)i * n + k].out;
+    if (!any) continue;
+    hipError_t e = dfx::launch_pyr_level(reinterpret_cast<const dfx::PyrLevelDev*>(hdev) + (size_t)i * n, n, (int)frames[0].img[i].w, (int)frames[0].img[i].h, c->stream);
+    if (e != hipSuccess) { (void)stage_release(c, slot); return fail(DFX_E_HIP, "k_pyr_level launch failed: %s", hipGetErrorString(e)); }
+  }
+  return stage_release(c, slot);
+}
+
+DFX_API int dfx_build_pyramid(dfx_ctx* c, const dfx_pyramid* frame) {
+  int rc;
+  if ((rc = dfx_build_pyramid_batch_async(c, frame, 1))) return rc;
+  DFX_HIP(hipStreamSynchronize(c->stream));   // like the reference's per-level calls (CudaCheckLastError = cudaDeviceSynchronize, cu_image_proc.cpp:111,185)
   return DFX_OK;
 }
 

@@ -70,7 +70,8 @@ struct alignas(16) DepthJobDev {   // one UpdateDepth of a batch (k_update_depth
 static_assert(sizeof(DepthJobDev) % 16 == 0 && alignof(DepthJobDev) == 16, "float4 loads of DepthJobDev::code need 16-byte slots");
 
 // Wave-uniform constants of the FAST geometry of the pixel reductions (SE3 step, EvaluateError; dfx_misc_kernels.hip `row_walk`), derived
-// once per pair from (R, t, camera) -- on the host when a descriptor is filled, by k_track_update when the pose lives on the device.
+// once per pair from (R, t, camera) on the host when a descriptor is filled; when the pose lives on the device (the tracker) every workgroup of
+// k_se3_step_dev rebuilds the pose-dependent part from the state it reads (fast_band in dfx_misc_kernels.hip: a dozen scalar-unit instructions).
 // Image coordinates are centred on (w/2, h/2) so that PixelValid(border = 1) is the symmetric test |u_c| < w/2 - 1, evaluated without a
 // division as  m = |X| - hw * Z < 0  with  X = fx q.x + (u0 - w/2) q.z,  Z = q.z.  The inlier set stays EXACTLY the reference's
 // (pinhole_camera_impl.h:105-108 on the values of warping.h:204-241): a pixel whose margin lies within E = e1 |d| + e2 of zero -- a
@@ -212,6 +213,14 @@ void sparse_geo_fill(void* desc, const float* R, const float* t, const float* M,
                      const float* prx0, uint32_t pp0, const float* jac0, uint32_t pj0, const float* prx1, uint32_t pp1, const float* jac1, uint32_t pj1,
                      const float* dgrad1, uint32_t pg1, const int* pts_dev, int npts, int W, int H, float* rows_dev, float huber_delta, float avg_dpt);
 hipError_t launch_sparse_geometric_batch(int cs, const void* descs_dev, int n_factors, int max_points, hipStream_t stream);
+
+// one pyramid level of one frame (k_pyr_level): Sobel gradient of `in` (grad may be null) + blur-down into `out` (may be null: last level)
+struct PyrLevelDev {
+  const float* in; float* grad; float* out;
+  uint32_t pitch_in, pitch_grad, pitch_out;
+  int W, H, OW, OH;
+};
+hipError_t launch_pyr_level(const PyrLevelDev* descs_dev, int n, int W, int H, hipStream_t stream);
 
 constexpr int kSimpleRow = 32;       // floats per block partial of the VALU reduction kernels
 constexpr int kMaxSimpleBlocks = 1024;

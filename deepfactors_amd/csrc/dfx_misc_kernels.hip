@@ -13,12 +13,6 @@ namespace dfx {
 
 constexpr int kT = 256;   // threads per workgroup (4 waves)
 
-// A/B aid: DFX_RW_NX=0 runs the pixel reductions with the direct tap loads of round 4 instead of the neighbour exchange (same bits)
-static bool rw_nx() {
-  static const bool v = [] { const char* ev = getenv("DFX_RW_NX"); return !ev || atoi(ev) != 0; }();
-  return v;
-}
-
 template <int N>
 __device__ __forceinline__ void block_reduce_store(float (&v)[N], float* __restrict__ out_row) {
   static_assert(N <= kSimpleRow, "partial row too small");
@@ -68,13 +62,6 @@ __device__ __forceinline__ Geo geo_from(const SimplePairDev& p) {
 //    inlier count rides the scalar unit (s_bcnt1 of the validity mask), and the 28 + 1 sums of a wave are folded with
 //    v_permlane32_swap / v_permlane16_swap + four DPP row shifts (70 vector-ALU instructions instead of 29 64-lane shuffle ladders).
 constexpr int kBand = 64;
-// the SE3 step runs five waves per SIMD (96 registers: four rounds of 20 resident waves per CU at the batched launch shape)
-#ifndef DFX_NX_FUSED
-#define DFX_NX_FUSED 1   // 0: exchange and select as compiler-visible operations (A/B, second opinion for the asm form)
-#endif
-#ifndef DFX_SE3_WAVES
-#define DFX_SE3_WAVES
-#endif
 #ifndef DFX_RW_UNROLL
 #define DFX_RW_UNROLL 1   // rotations of the row states per loop iteration
 #endif
@@ -106,27 +93,10 @@ template <bool GRAD>
 struct RowPix {                       // geometry of one row + its taps (possibly still in flight)
   float i0, ax, ay;
   float iz, U, V, vx, vy, vz;         // GRAD (SE3 step) only: 1 / q.z, u - u0, v - v0, R p
-  unsigned vmask;                     // non-zero: the pixel has a correspondence (and belongs to the wave's share).  Neighbour exchange (NX): 2 = and
-                                      // the lane's right-hand taps are the NEXT lane's own taps ("hit"), 1 = it loaded them itself
-  f32x2 ia, ib;                       // img1 rows iy, iy + 1: (x, x + 1)     [NX: .x = the lane's own tap, .y = its fix-up load (0 under a hit)]
-  f32x4 ga, gb;                       // grad1 rows iy, iy + 1: (gx, gy)(x), (gx, gy)(x + 1)     [NX: .xy own, .zw fix-up]
+  unsigned vmask;                     // all ones: the pixel has a correspondence (and belongs to the wave's share)
+  f32x2 ia, ib;                       // img1 rows iy, iy + 1: (x, x + 1)
+  f32x4 ga, gb;                       // grad1 rows iy, iy + 1: (gx, gy)(x), (gx, gy)(x + 1)
 };
-
-// Neighbour exchange (round 5).  What bounded the SE3 step after round 4 was the L1's tag pipeline: TCP_TOTAL_CACHE_ACCESSES = 2.0 per pixel --
-// ~8 per dword wave-load, ~38 per 16-byte gradient tap load whose lanes overlap their neighbours' -- against a budget of ~125 clocks per
-// 64-pixel row and CU (profiles/r04_rowwalk_pmc.txt, TCP_GATE_EN1 = the kernel's duration).  Under a coherent warp lane l + 1 taps cell
-// (ix + 1, iy) when lane l taps (ix, iy): the right-hand column of a lane's 2x2 taps IS the next lane's left-hand column.  So every lane
-// loads only its own column (img1: two dwords, grad1: two 8-byte pairs -- lanes contiguous, no overlap) and takes the other one from lane
-// l + 1 by DPP (v_mov_b32_dpp wave_shl:1).  Whether that holds is decided per lane by comparing the neighbour's tap OFFSET with its own
-// (+ 4 bytes): the scheme is self-validating -- whatever lane the DPP reads, equal offsets mean its loaded values are the wanted ones.
-// Lanes without such a neighbour (lane 63, a jump of floor(u) or floor(v) between the two lanes, a neighbour without correspondence) load the
-// column themselves in a second pair of instructions in which every OTHER lane is out of range (buffer offset kOobOffset: returns 0, moves no
-// data, costs the L1 nothing); lane 63 is always in range there, so no wave-load is entirely out of range and loads keep returning in order.
-// Same taps, same arithmetic: results are bit-identical to the direct form (DFX_RW_NX=0 keeps it for A/B runs).
-__device__ __forceinline__ unsigned lane_next(unsigned v) {   // lane l <- lane l + 1; lane 63 <- 0
-  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
-}
-__device__ __forceinline__ float lane_next(float v) { return __builtin_bit_cast(float, lane_next(__builtin_bit_cast(unsigned, v))); }
 
 // pose-dependent part of the ambiguity band on the device (the tracker's pose lives in device memory): E = e1 |d| + e2, derive_fast_geo
 __device__ __forceinline__ void fast_band(const float (&R)[9], const float (&t)[3], const FastCam& c, float& e1, float& e2) {
@@ -142,7 +112,7 @@ __device__ __forceinline__ void fast_band(const float (&R)[9], const float (&t)[
 
 // Walks the calling wave's share of the image; `consume(const RowPix<GRAD>&)` is called once per row with exec = the row's inliers.
 // Returns the wave's inlier count (wave-uniform).
-template <bool GRAD, int DT, bool NX, typename F>
+template <bool GRAD, int DT, typename F>
 __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float (&R)[9], const float (&t)[3], const float e1, const float e2,
                                              const int W, const int H, F&& consume) {
   const FastGeo& fg = p.fg;
@@ -161,9 +131,8 @@ __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float
   // tap offsets are relative to pixel (icx, icy): fold it into a scalar
   const unsigned c1 = (unsigned)fg.icy * p.pitch_img1 + (unsigned)fg.icx * 4u;
   const unsigned cg = GRAD ? (unsigned)fg.icy * p.pitch_grad1 + (unsigned)fg.icx * 8u : 0u;
-  unsigned four = 4u, eight = 8u;
+  unsigned four = 4u;
   asm volatile("" : "+s"(four));
-  asm volatile("" : "+s"(eight));
   const float ixmax = (float)(W - 2 - fg.icx), iymax = (float)(H - 2 - fg.icy);   // last cell of the tap grid, relative to pixel (icx, icy)
   Geo g;   // the reference-order fall-back
 #pragma unroll
@@ -259,24 +228,6 @@ __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float
       // texture addresser 14 cycles per wave, a dword load whose lanes are (nearly) contiguous 4 (profiles/r04_ubench_vmem_issue_cost.txt);
       // the reductions' skeleton runs 11 % faster with them (profiles/r04_band_walk.txt), EvaluateError 108 -> 101 us, the SE3 step 181 ->
       // 172 us per 128 pairs (profiles/r04_tap_loads.txt; the snap above keeps them contiguous at the identity).
-      if constexpr (NX) {
-        // own column + the fix-up column of the lanes whose neighbour does not hold it (see "Neighbour exchange" above)
-        const bool hit = lane_next(o1) == o1 + 4u;
-        S.vmask = hit ? (vm & 2u) : (vm & 1u);
-        const unsigned of = hit ? kOobOffset : o1;
-        S.ia.x = bload1(rI1, o1, 0);
-        S.ib.x = bload1(rI1, o1, p.pitch_img1);
-        S.ia.y = bload1(rI1, of, four);
-        S.ib.y = bload1(rI1, of, p.pitch_img1 + four);
-        if constexpr (GRAD) {
-          const unsigned og = (unsigned)(__mul24(iy, (int)p.pitch_grad1) + ((ix << 3) + (int)cg)) & vm;
-          const unsigned ogf = hit ? kOobOffset : og;
-          const f32x2 a0 = bload2(rG1, og, 0), b0 = bload2(rG1, og, p.pitch_grad1);
-          const f32x2 a1 = bload2(rG1, ogf, eight), b1 = bload2(rG1, ogf, p.pitch_grad1 + eight);
-          S.ga = f32x4{ a0.x, a0.y, a1.x, a1.y };
-          S.gb = f32x4{ b0.x, b0.y, b1.x, b1.y };
-        }
-      } else {
       S.ia.x = bload1(rI1, o1, 0);
       S.ia.y = bload1(rI1, o1, four);                       // (`four` is opaque: the compiler would fuse the pairs back into 8-byte loads)
       S.ib.x = bload1(rI1, o1, p.pitch_img1);
@@ -286,58 +237,8 @@ __device__ __forceinline__ unsigned row_walk(const SimplePairDev& p, const float
         S.ga = bload4(rG1, og, 0);
         S.gb = bload4(rG1, og, p.pitch_grad1);
       }
-      }
     };
-    auto eat = [&](const RowPix<GRAD>& S0) {
-      RowPix<GRAD> S = S0;
-      if constexpr (NX) {
-        // the right-hand column: the next lane's own taps under a hit, the lane's fix-up loads otherwise.  All 64 lanes are active here (the
-        // DPP reads lane l + 1's registers: it has to run outside the divergent `if (v)` below)
-        // (the exchange is evaluated for every lane and THEN selected: written as `hit ? lane_next(..) : ..` the DPP would run under exec = hit and
-        // read lanes that are switched off)
-#if DFX_NX_FUSED
-        // exchange + select in ONE instruction per value: v_cndmask_b32_dpp dst = vcc ? dst : lane_next(own), vcc = the lanes that loaded the
-        // column themselves.  The compiler does not form it (its DPP combiner only folds into e32 encodings whose condition already sits in
-        // vcc) and, left to itself, hoists the six exchanges in front of the six selects: six more registers, a wave per SIMD less.
-        // Hazards (the compiler does not look inside an asm): a DPP operand written by a vector-ALU instruction needs two wait states -- the
-        // operands are load results, but a register copy in front of the block would be such a write: v_cmp + s_nop 0 are the two states.
-        if constexpr (GRAD) {
-          asm volatile("v_cmp_ne_u32_e32 vcc, 2, %[hit]\n\ts_nop 0\n\t"
-                       "v_cndmask_b32_dpp %[f0], %[o0], %[f0], vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                       "v_cndmask_b32_dpp %[f1], %[o1], %[f1], vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                       "v_cndmask_b32_dpp %[f2], %[o2], %[f2], vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                       "v_cndmask_b32_dpp %[f3], %[o3], %[f3], vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                       "v_cndmask_b32_dpp %[f4], %[o4], %[f4], vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                       "v_cndmask_b32_dpp %[f5], %[o5], %[f5], vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-                       : [f0] "+v"(S.ia.y), [f1] "+v"(S.ib.y), [f2] "+v"(S.ga.z), [f3] "+v"(S.ga.w), [f4] "+v"(S.gb.z), [f5] "+v"(S.gb.w)
-                       : [hit] "v"(S0.vmask), [o0] "v"(S0.ia.x), [o1] "v"(S0.ib.x), [o2] "v"(S0.ga.x), [o3] "v"(S0.ga.y), [o4] "v"(S0.gb.x), [o5] "v"(S0.gb.y)
-                       : "vcc");
-        } else {
-          asm volatile("v_cmp_ne_u32_e32 vcc, 2, %[hit]\n\ts_nop 0\n\t"
-                       "v_cndmask_b32_dpp %[f0], %[o0], %[f0], vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                       "v_cndmask_b32_dpp %[f1], %[o1], %[f1], vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-                       : [f0] "+v"(S.ia.y), [f1] "+v"(S.ib.y)
-                       : [hit] "v"(S0.vmask), [o0] "v"(S0.ia.x), [o1] "v"(S0.ib.x)
-                       : "vcc");
-        }
-#else
-        const bool miss = S0.vmask != 2u;
-        const float na = lane_next(S0.ia.x);
-        S.ia.y = miss ? S0.ia.y : na;
-        const float nb = lane_next(S0.ib.x);
-        S.ib.y = miss ? S0.ib.y : nb;
-        if constexpr (GRAD) {
-          const float n0 = lane_next(S0.ga.x);
-          S.ga.z = miss ? S0.ga.z : n0;
-          const float n1 = lane_next(S0.ga.y);
-          S.ga.w = miss ? S0.ga.w : n1;
-          const float n2 = lane_next(S0.gb.x);
-          S.gb.z = miss ? S0.gb.z : n2;
-          const float n3 = lane_next(S0.gb.y);
-          S.gb.w = miss ? S0.gb.w : n3;
-        }
-#endif
-      }
+    auto eat = [&](const RowPix<GRAD>& S) {
       const bool v = S.vmask != 0;
       inliers += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(v));
       if (v) consume(S);
@@ -431,7 +332,6 @@ __device__ __forceinline__ void fold_waves_store(float (&red)[kT / 64][kSimpleRo
 // ---- SE3 step: 21 JtJ + 6 Jtr + r^2 + inliers = 29 floats per workgroup row ---------------------------------------------------------
 // One SE3 Gauss-Newton step (lucas_kanade_se3.h:41-77) over this workgroup's share of the pair; shared by the blocking operator, the
 // batched form and the device-resident tracker (R, t = the pose the step is evaluated at).
-template <bool NX>
 __device__ __forceinline__ void se3_step_body(const SimplePairDev& p, const float (&R)[9], const float (&t)[3], const float e1, const float e2,
                                               const int W, const int H, const float huber_delta, float* __restrict__ out_row) {
   __shared__ float red[kT / 64][kSimpleRow];
@@ -439,7 +339,7 @@ __device__ __forceinline__ void se3_step_body(const SimplePairDev& p, const floa
 #pragma unroll
   for (int q = 0; q < 28; ++q) acc[q] = 0.f;
   const float fx = p.fx, fy = p.fy;
-  const unsigned inl = row_walk<true, DFX_TAP_DIST_SE3, NX>(p, R, t, e1, e2, W, H, [&](const RowPix<true>& S) {
+  const unsigned inl = row_walk<true, DFX_TAP_DIST_SE3>(p, R, t, e1, e2, W, H, [&](const RowPix<true>& S) {
     const float gx = lerpf(lerpf(S.ga.x, S.ga.z, S.ax), lerpf(S.gb.x, S.gb.z, S.ax), S.ay);
     const float gy = lerpf(lerpf(S.ga.y, S.ga.w, S.ax), lerpf(S.gb.y, S.gb.w, S.ax), S.ay);
     float r = S.i0 - pix_img(S);
@@ -476,10 +376,9 @@ __device__ __forceinline__ void se3_step_body(const SimplePairDev& p, const floa
   fold_waves_store(red, 29, out_row);
 }
 
-template <bool NX>
-__global__ __launch_bounds__(kT) DFX_SE3_WAVES void k_se3_step(const SimplePairDev p, const int W, const int H, const float huber_delta,
+__global__ __launch_bounds__(kT) void k_se3_step(const SimplePairDev p, const int W, const int H, const float huber_delta,
                                                  float* __restrict__ partials) {
-  se3_step_body<NX>(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
+  se3_step_body(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
 // ---- device-resident tracker (CameraTracker::TrackFrame, reference core/system/camera_tracker.cpp:42-71) -------------
@@ -494,8 +393,7 @@ struct TrackState {      // device-resident
 
 // blockIdx.y = candidate: Relocalize / the loop-closure geometry checks track ONE live frame against N keyframes
 // (deepfactors.cpp:713-743, loop_detector.cpp:146-167); descriptors, states and partials are arrays over candidates.
-template <bool NX>
-__global__ __launch_bounds__(kT) DFX_SE3_WAVES void k_se3_step_dev(const SimplePairDev* __restrict__ descs, const TrackState* __restrict__ states, const int W,
+__global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev* __restrict__ descs, const TrackState* __restrict__ states, const int W,
                                                      const int H, const float huber_delta, float* __restrict__ partials_all) {
   const SimplePairDev& p = descs[blockIdx.y];
   const TrackState* st = states + blockIdx.y;
@@ -505,7 +403,7 @@ __global__ __launch_bounds__(kT) DFX_SE3_WAVES void k_se3_step_dev(const SimpleP
   for (int q = 0; q < 9; ++q) R[q] = st->Rf[q];
   t[0] = st->tf[0]; t[1] = st->tf[1]; t[2] = st->tf[2];
   fast_band(R, t, p.fc, e1, e2);   // the descriptor's band belongs to the pose it was filled with, not to the state's
-  se3_step_body<NX>(p, R, t, e1, e2, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
+  se3_step_body(p, R, t, e1, e2, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
 __global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__ partials_all, const int nblocks, TrackState* __restrict__ states) {
@@ -612,8 +510,7 @@ size_t track_state_bytes() { return sizeof(TrackState); }
 
 hipError_t launch_track_iteration(const SimplePairDev* descs_dev, int n, void* states_dev, int W, int H, float huber_delta, int blocks,
                                   float* partials_dev, hipStream_t stream) {
-  if (rw_nx()) hipLaunchKernelGGL(k_se3_step_dev<true>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (const TrackState*)states_dev, W, H, huber_delta, partials_dev);
-  else hipLaunchKernelGGL(k_se3_step_dev<false>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (const TrackState*)states_dev, W, H, huber_delta, partials_dev);
+  hipLaunchKernelGGL(k_se3_step_dev, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (const TrackState*)states_dev, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_track_update, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (TrackState*)states_dev);
@@ -760,11 +657,10 @@ hipError_t launch_sparse_geometric_batch(int cs, const void* descs_dev, int n_fa
 }
 
 // ---- SfM error: sum (w r)^2, inliers (dense_sfm.h:79-119: default border 1, min_dpt 0) -------------------------------------------------
-template <bool NX>
 __device__ __forceinline__ void sfm_error_body(const SimplePairDev& p, const int W, const int H, const float huber_delta, float* __restrict__ out_row) {
   __shared__ float red[kT / 64][kSimpleRow];
   float acc = 0.f;
-  const unsigned inl = row_walk<false, DFX_TAP_DIST_ERR, NX>(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, [&](const RowPix<false>& S) {
+  const unsigned inl = row_walk<false, DFX_TAP_DIST_ERR>(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, [&](const RowPix<false>& S) {
     float r = S.i0 - pix_img(S);
     r *= huber_weight(r, huber_delta);
     acc = __builtin_fmaf(r, r, acc);
@@ -775,26 +671,23 @@ __device__ __forceinline__ void sfm_error_body(const SimplePairDev& p, const int
   fold_waves_store(red, 2, out_row);
 }
 
-template <bool NX>
 __global__ __launch_bounds__(kT) void k_sfm_error(const SimplePairDev p, const int W, const int H, const float huber_delta,
                                                   float* __restrict__ partials) {
-  sfm_error_body<NX>(p, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
+  sfm_error_body(p, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
 // ---- batched forms (blockIdx.y = pair): PhotometricFactor::error over a factor set evaluates one pair per blocking call in the reference
 // (core/gtsam/photometric_factor.cpp:61-81,197-216); a relocalisation / loop-closure check steps one live frame against many keyframes.
 // Same per-pair arithmetic and reduction order as the single-pair kernels launched with the same number of workgroups.
-template <bool NX>
 __global__ __launch_bounds__(kT) void k_sfm_error_batch(const SimplePairDev* __restrict__ descs, const int W, const int H, const float huber_delta,
                                                         float* __restrict__ partials_all) {
-  sfm_error_body<NX>(descs[blockIdx.y], W, H, huber_delta, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
+  sfm_error_body(descs[blockIdx.y], W, H, huber_delta, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
 }
 
-template <bool NX>
-__global__ __launch_bounds__(kT) DFX_SE3_WAVES void k_se3_step_batch(const SimplePairDev* __restrict__ descs, const int W, const int H, const float huber_delta,
+__global__ __launch_bounds__(kT) void k_se3_step_batch(const SimplePairDev* __restrict__ descs, const int W, const int H, const float huber_delta,
                                                        float* __restrict__ partials_all) {
   const SimplePairDev& p = descs[blockIdx.y];
-  se3_step_body<NX>(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, huber_delta, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
+  se3_step_body(p, p.R, p.t, p.fg.e1, p.fg.e2, W, H, huber_delta, partials_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSimpleRow);
 }
 
 // ---- Warp: render img1 into frame 0, SIGNED residual sum (cu_se3aligner.cpp:106) ----------------------------
@@ -990,6 +883,94 @@ __global__ __launch_bounds__(kT) void k_blur_down(const float* __restrict__ in, 
   reinterpret_cast<float*>((char*)out + (size_t)y * opitch)[x] = sum / wall;
 }
 
+// ---- one pyramid level of n frames in ONE launch: Sobel gradient of level i AND the blur-down to level i + 1 from the same LDS tile ----------
+// Frame::FillPyramids (core/mapping/frame.h:80-94) / UploadLiveFrame (core/deepfactors.cpp:616-630) build L images + L gradients per frame
+// at camera rate with 2 L - 1 blocking single-image launches (cu_image_proc.cpp:94-112,166-186).  Here a level of ALL frames of a batch is one
+// launch (grid.z = frame) that reads the level ONCE: a workgroup stages a (kPyrTW + 8) x (kPyrTH + 4) window of the image in LDS (float4 row
+// loads on the interior; clamped dword loads only in tiles that touch the image border), every thread writes the Sobel / 8 gradient of four
+// pixels (two 16-byte stores) and the 5 x 5 binomial blur-down of one pixel of the next level.  Level 0 of 640x480: 4 B read + 8 + 1 B
+// written per pixel.  Same tap order and arithmetic as k_sobel / k_blur_down below (the per-level operators): the same bits.
+constexpr int kPyrTW = 64, kPyrTH = 16;                 // input pixels per workgroup tile
+constexpr int kPyrLW = kPyrTW + 8, kPyrLH = kPyrTH + 4; // staged window: columns x0 - 4 .. x0 + 67 (16-byte aligned), rows y0 - 2 .. y0 + 17
+__global__ __launch_bounds__(kT) void k_pyr_level(const PyrLevelDev* __restrict__ descs) {
+  const PyrLevelDev& P = descs[blockIdx.z];
+  const int W = P.W, H = P.H, OW = P.OW, OH = P.OH;
+  const int x0 = blockIdx.x * kPyrTW, y0 = blockIdx.y * kPyrTH;
+  __shared__ float tile[kPyrLH][kPyrLW];
+  const bool interior = x0 >= 4 && x0 + kPyrTW + 4 <= W && y0 >= 2 && y0 + kPyrTH + 2 <= H && ((P.pitch_in | (uint32_t)(uintptr_t)P.in) & 15) == 0;
+  if (interior) {
+    for (int e = threadIdx.x; e < kPyrLH * (kPyrLW / 4); e += kT) {
+      const int r = e / (kPyrLW / 4), c4 = e - r * (kPyrLW / 4);
+      const f32x4 v = gload<f32x4>((const char*)P.in + (size_t)(y0 - 2 + r) * P.pitch_in + (size_t)(x0 - 4 + 4 * c4) * 4);
+      *reinterpret_cast<f32x4*>(&tile[r][4 * c4]) = v;
+    }
+  } else {
+    for (int e = threadIdx.x; e < kPyrLH * kPyrLW; e += kT) {
+      const int r = e / kPyrLW, c = e - r * kPyrLW;
+      const int y = min(max(y0 - 2 + r, 0), H - 1), x = min(max(x0 - 4 + c, 0), W - 1);   // getWithClampedRange (cu_image_proc.cpp:66-70,141-146)
+      tile[r][c] = gload<float>((const char*)P.in + (size_t)y * P.pitch_in + (size_t)x * 4);
+    }
+  }
+  __syncthreads();
+  // ---- Sobel / 8 (cu_image_proc.cpp:57-92): thread = 4 adjacent pixels of one row
+  if (P.grad) {
+    const int ty = threadIdx.x >> 4, tx = (threadIdx.x & 15) * 4;   // 16 rows x 16 quads
+    const int y = y0 + ty;
+    if (y < H && x0 + tx < W) {
+      float g[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int lx = tx + k + 4, ly = ty + 2;
+        const float a = tile[ly - 1][lx - 1], b = tile[ly - 1][lx], c = tile[ly - 1][lx + 1], d = tile[ly][lx - 1], f = tile[ly][lx + 1], gg = tile[ly + 1][lx - 1],
+                    h = tile[ly + 1][lx], i = tile[ly + 1][lx + 1];
+        float sx = 0.f, sy = 0.f;   // the tap order of k_sobel (the reference loop, zero taps skipped)
+        sx += a * -1.f; sy += a * -1.f;
+        sy += b * -2.f;
+        sx += c * 1.f;  sy += c * -1.f;
+        sx += d * -2.f;
+        sx += f * 2.f;
+        sx += gg * -1.f; sy += gg * 1.f;
+        sy += h * 2.f;
+        sx += i * 1.f;  sy += i * 1.f;
+        g[2 * k] = sx / 8.f; g[2 * k + 1] = sy / 8.f;
+      }
+      char* row = (char*)P.grad + (size_t)y * P.pitch_grad + (size_t)(x0 + tx) * 8;
+      if (x0 + tx + 4 <= W && ((P.pitch_grad | (uint32_t)(uintptr_t)P.grad) & 15) == 0) {
+        gstore<f32x4>(row, f32x4{ g[0], g[1], g[2], g[3] });
+        gstore<f32x4>(row + 16, f32x4{ g[4], g[5], g[6], g[7] });
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (x0 + tx + k < W) gstore<f32x2>(row + 8 * k, f32x2{ g[2 * k], g[2 * k + 1] });
+      }
+    }
+  }
+  // ---- 5 x 5 binomial blur + decimate (cu_image_proc.cpp:134-164): thread = one pixel of the next level (tile origin is even)
+  if (P.out) {
+    const int oy = threadIdx.x >> 5, ox = threadIdx.x & 31;          // 8 rows x 32 columns
+    const int X = (x0 >> 1) + ox, Y = (y0 >> 1) + oy;
+    if (X < OW && Y < OH) {
+      const float B[5] = { 1.f, 4.f, 6.f, 4.f, 1.f };
+      float sum = 0.f, wall = 0.f;
+#pragma unroll
+      for (int py = 0; py < 5; ++py) {
+#pragma unroll
+        for (int px = 0; px < 5; ++px) {
+          // input (2 X + px - 2, 2 Y + py - 2) with clamped range: the window entry of an (unclamped) coordinate holds the clamped pixel
+          const float k = B[px] * B[py];
+          sum += tile[2 * Y + py - y0][2 * X + px + 2 - x0] * k;
+          wall += k;
+        }
+      }
+      gstore<float>((char*)P.out + (size_t)Y * P.pitch_out + (size_t)X * 4, sum / wall);
+    }
+  }
+}
+
+hipError_t launch_pyr_level(const PyrLevelDev* descs_dev, int n, int W, int H, hipStream_t stream) {
+  hipLaunchKernelGGL(k_pyr_level, dim3((W + kPyrTW - 1) / kPyrTW, (H + kPyrTH - 1) / kPyrTH, n), dim3(kT), 0, stream, descs_dev);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------
@@ -1001,8 +982,7 @@ static void launch_finalize_rows(int n, int blocks, int kind, const float* parti
 
 hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
                            void* item_dev, hipStream_t stream) {
-  if (rw_nx()) hipLaunchKernelGGL(k_se3_step<true>, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
-  else hipLaunchKernelGGL(k_se3_step<false>, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
+  hipLaunchKernelGGL(k_se3_step, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   launch_finalize_rows(1, blocks, (int)kFinalItem6, (const float*)partials_dev, item_dev, (size_t)0, stream);
@@ -1011,8 +991,7 @@ hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_del
 
 hipError_t launch_sfm_error(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
                             void* corr_item_dev, hipStream_t stream) {
-  if (rw_nx()) hipLaunchKernelGGL(k_sfm_error<true>, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
-  else hipLaunchKernelGGL(k_sfm_error<false>, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
+  hipLaunchKernelGGL(k_sfm_error, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   launch_finalize_rows(1, blocks, (int)kFinalCorr, (const float*)partials_dev, corr_item_dev, (size_t)0, stream);
@@ -1022,8 +1001,7 @@ hipError_t launch_sfm_error(const SimplePairDev& p, int W, int H, float huber_de
 hipError_t launch_sfm_error_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
                                   void* corr_items_dev, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end) {
   if (ev_begin) (void)hipEventRecord(ev_begin, stream);
-  if (rw_nx()) hipLaunchKernelGGL(k_sfm_error_batch<true>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
-  else hipLaunchKernelGGL(k_sfm_error_batch<false>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
+  hipLaunchKernelGGL(k_sfm_error_batch, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_end) (void)hipEventRecord(ev_end, stream);
@@ -1034,8 +1012,7 @@ hipError_t launch_sfm_error_batch(const SimplePairDev* descs_dev, int n, int W, 
 hipError_t launch_se3_step_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
                                  void* items_dev, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end) {
   if (ev_begin) (void)hipEventRecord(ev_begin, stream);
-  if (rw_nx()) hipLaunchKernelGGL(k_se3_step_batch<true>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
-  else hipLaunchKernelGGL(k_se3_step_batch<false>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
+  hipLaunchKernelGGL(k_se3_step_batch, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_end) (void)hipEventRecord(ev_end, stream);

@@ -50,7 +50,7 @@
 //   The DEFAULT evaluation mode since round 3 (DFX_MFMA_BF16X3, template flag B3; the chain above is DFX_MFMA_F32_CHAIN): the fp32 MFMA runs at the
 //     vector ALU's rate, the bf16 MFMA at 16x that.  Every fp32 entry of z is split EXACTLY into three bf16 pieces (x = h + m + l, round-to-nearest-
 //     even through v_cvt_pk_bf16_f32, remainders through v_dot2c_f32_bf16: 7 VALU instructions per pair of values) and z z^T is summed as
-//     hh + hm + mh + hl + lh + mm on v_mfma_f32_16x16x32_bf16 (fp32 accumulate; the dropped terms are < 2^-26 of a product).  16x16 tiles (P,P),
+//     hh + hm + mh + hl + lh + mm on v_mfma_f32_16x16x32_bf16 (fp32 accumulate; the dropped terms ml + lm + ll are <= 2^-23 of a product in the worst case -- |m| <= 2^-8 |x|, |l| <= 2^-16 |x| -- the order of an fp32 multiply's own rounding, 2^-24).  16x16 tiles (P,P),
 //     (P,C_b), (C_b,C_b'), b <= b', with the P block stacked as [P_h ; P_m] and four-product diagonal tiles: 48 MFMAs per chunk at CS = 32.  The
 //     operand ring, phase A, the pipeline, both schedules and the epilogue are shared.  Reduction tail: k_sfm_tail_b3 (a workgroup per pair, the
 //     keyframe graph's assembly folded in) for batches, k_sfm_finalize_b3 (a workgroup per tile) for single pairs and pairs with > 512 KB of partials.
@@ -123,7 +123,7 @@ constexpr int kThreads = kWaves * 64;
 #define DFX_USTRIDE 68       // floats between the P rows of a wave in LDS: bank = (4 * row + pixel) % 32 keeps the 16x16 operand reads (8 rows x 4
 #endif                       // pixels) and the 4x4 tile reads (8 rows x 3 pixels per half wave) apart.  66 had twice the bank conflicts (32 M vs
                              // 16 M per 128-pair launch), 65 five times -- and all of 65 .. 80 measure the same kernel time within 0.5 %
-                             // (tools/lds_ab.sh): the LDS is 22 % busy and never the limiter.
+                             // (an A/B of round 2, script in git history): the LDS is 22 % busy and never the limiter.
 constexpr int kUStride = DFX_USTRIDE;
 constexpr int kUFloats = 16 * kUStride;   // per wave
 
@@ -662,8 +662,9 @@ __global__ __launch_bounds__(kThreads, NCB == 4 ? DFX_MIN_WAVES_CS64 : DFX_MIN_W
     if constexpr (B3) {
       // ---- phase B, exact bf16 split (DFX_MFMA_BF16X3): every fp32 entry of z is split into three bf16 pieces, x = h + m + l EXACTLY
       // (h = RNE_bf16(x), m = RNE_bf16(x - h), l = x - h - m: 8 + 8 + 8 significant bits and a sign each), and z z^T is summed as
-      // hh + hm + mh + hl + lh + mm on v_mfma_f32_16x16x32_bf16 (fp32 accumulate; the dropped ml + lm + ll terms are below 2^-26 of
-      // the product, i.e. below the rounding of an fp32 multiply).  A bf16 MFMA covers 32 pixels: half a chunk; lane (li, lk), slot j
+      // hh + hm + mh + hl + lh + mm on v_mfma_f32_16x16x32_bf16 (fp32 accumulate; of the dropped terms ml and lm are each <= 2^-24 of the
+      // product (|m| <= 2^-8 |x|, |l| <= 2^-16 |x|) and ll <= 2^-32: together <= 2^-23 in the worst case, ~2^-26 on average -- the order of
+      // the rounding of an fp32 multiply, 2^-24; include/dfx.h says the same).  A bf16 MFMA covers 32 pixels: half a chunk; lane (li, lk), slot j
       // of a half h holds pixel 4 (8 h + j) + lk -- the ring registers jv[8 h + j] as they are.  A and B use the same
       // pixel -> (lane group, slot) assignment, which is all the sum over k needs.  z blocks: 0 = P (rows 0..7; 8..15 zero), 1 + b = C_b.
       // P stacking: the P block has 8 rows, a tile 16.  Both halves of a 16-lane row read P row (li & 7) and split it; lanes 0..7 keep the
@@ -1410,11 +1411,11 @@ __global__ __launch_bounds__(1024) void k_sfm_tail_b3(const float* __restrict__ 
   // ---- graph assembly by the last pair to arrive at each of its two nodes.
   // Hand-over protocol (round 5: ordered by the memory model, not by cache behaviour).  Writer: the item goes out in device-scope stores
   // (write-through), every wave waits for its stores to complete (s_waitcnt 0), the workgroup barrier collects the waves, and ONE lane counts
-  // the arrival with a RELEASE read-modify-write at device scope -- the barrier makes the other waves' stores happen-before it, the release
-  // makes them visible at device scope (one L2 write-back per workgroup; rounds 3-4 measured a __threadfence per WAVE, 2048 per launch: 80 us,
-  // and therefore ran the counter relaxed).  Reader: the workgroup whose arrival completes a node issues one ACQUIRE fence at device scope
-  // behind its read-modify-write (it read the last link of the release sequence formed by the earlier arrivals), the barrier hands the order
-  // to the rest of the workgroup, and the items are read with device-scope loads.  ORD = false keeps the relaxed counter of rounds 3-4 for A/B
+  // the arrivals behind ONE RELEASE fence at device scope -- the barrier makes the other waves' stores happen-before it, the fence makes them
+  // visible at device scope (one L2 write-back per workgroup; rounds 3-4 measured a __threadfence per WAVE, 2048 per launch: 80 us, and
+  // therefore ran the counter relaxed).  Reader: the workgroup whose arrival completes a node issues one ACQUIRE fence at device scope behind
+  // its read-modify-write (it read the last link of the chain of arrivals, each behind its writer's release fence), the barrier hands the
+  // order to the rest of the workgroup, and the items are read with device-scope loads.  ORD = false keeps the relaxed counter of rounds 3-4 for A/B
   // runs (DFX_TAIL_ORDERED=0): same bits.
   if (ASM) {
     __builtin_amdgcn_s_waitcnt(0);   // vmcnt = lgkmcnt = expcnt = 0: this wave's stores have completed
@@ -1422,19 +1423,28 @@ __global__ __launch_bounds__(1024) void k_sfm_tail_b3(const float* __restrict__ 
     const int gp = tg.first_pair + pair;
     if (threadIdx.x < 64) {
       const int lane = threadIdx.x;
+      int need[2], node[2];
 #pragma unroll
       for (int side = 0; side < 2; ++side) {
-        const int n = tg.pair_nodes[2 * gp + side];
-        const int need = tail_local_degree(tg, n);
-        if (lane == 0) {
-          const unsigned got = (ORD ? __hip_atomic_fetch_add(&tg.node_cnt[n], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) : atomicAdd(&tg.node_cnt[n], 1u)) + 1u;
-          const bool last = got == (unsigned)need;
-          if (last) {
-            if (ORD) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(&tg.node_cnt[n], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // rewound for the next launch: nobody else counts on this node any more
-          }
-          todo[side] = last ? n : -1;
+        node[side] = tg.pair_nodes[2 * gp + side];
+        need[side] = tail_local_degree(tg, node[side]);
+      }
+      if (lane == 0) {
+        // ONE release fence in front of the two arrivals (fence-atomic synchronisation: the relaxed read-modify-writes behind it publish what the
+        // barrier collected), ONE acquire fence behind them if either completed its node
+        if (ORD) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        bool any = false;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+          const unsigned got = __hip_atomic_fetch_add(&tg.node_cnt[node[side]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+          const bool last = got == (unsigned)need[side];
+          any = any || last;
+          todo[side] = last ? node[side] : -1;
         }
+        if (ORD && any) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+        for (int side = 0; side < 2; ++side)   // rewound for the next launch: nobody else counts on a completed node any more
+          if (todo[side] >= 0) __hip_atomic_store(&tg.node_cnt[todo[side]], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     __syncthreads();

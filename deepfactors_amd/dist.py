@@ -208,6 +208,61 @@ class NormalEquations:
 
 
 
+class Comm:
+    """The multi-GPU exchange behind the C ABI (include/dfx.h, dfx_comm_*; deepfactors_amd/csrc/dfx_comm.cpp: RCCL over xGMI, resolved at run time) --
+    what a C++ mapper calls.  A communicator is created collectively: rank 0 draws the 128-byte unique id, the host program hands it to the other
+    ranks by its own means (here: one broadcast over the torch.distributed process group that launched the ranks), every rank calls dfx_comm_create
+    with the context of its GPU.  The collectives only ENQUEUE, on the stream the context's results are complete on (its tail stream in deferred-tail
+    mode, else its stream): behind the assembly that fills the buffer, and -- with a tail stream -- beside the next launch's step kernel."""
+
+    def __init__(self, handle, rank, world):
+        self._h, self.rank, self.world = handle, int(rank), int(world)
+
+    @staticmethod
+    def create(ctx, dist, rank, world, device):
+        """Collective over the ranks of `dist` (None: a world of one)."""
+        from . import _lib
+        L = _lib.lib()
+        uid = torch.zeros(_lib.DFX_COMM_ID_BYTES, dtype=torch.uint8, device=device)
+        if rank == 0:
+            raw = (C.c_ubyte * _lib.DFX_COMM_ID_BYTES)()
+            _lib.check(L.dfx_comm_get_unique_id(raw))
+            uid.copy_(torch.tensor(list(raw), dtype=torch.uint8))
+        if dist is not None and world > 1:
+            dist.broadcast(uid, 0)
+        raw = (C.c_ubyte * _lib.DFX_COMM_ID_BYTES)(*[int(v) for v in uid.cpu().tolist()])
+        h = C.c_void_p()
+        _lib.check(L.dfx_comm_create(getattr(ctx, "handle", None), raw, int(rank), int(world), C.byref(h)))
+        return Comm(h, rank, world)
+
+    def reduce(self, ctx, buf, root=0):
+        """Sum `buf` (float32 tensor: a NormalEquations buffer) over the ranks in place onto `root` (< 0: onto every rank): dfx_comm_reduce_f32_async,
+        i.e. what dfx_graph_reduce_async does with the graph's system.  Enqueue only."""
+        from . import _lib
+        _lib.check(_lib.lib().dfx_comm_reduce_f32_async(getattr(ctx, "handle", None), self._h, C.c_void_p(buf.data_ptr()), buf.numel(), int(root)))
+
+    def all_gather_items(self, ctx, items_local_u8, bytes_per_rank, items_all_u8):
+        from . import _lib
+        _lib.check(_lib.lib().dfx_items_all_gather_async(getattr(ctx, "handle", None), self._h, C.c_void_p(items_local_u8.data_ptr()), int(bytes_per_rank),
+                                                         C.c_void_p(items_all_u8.data_ptr())))
+
+    def broadcast(self, ctx, t, root=0):
+        from . import _lib
+        _lib.check(_lib.lib().dfx_comm_broadcast_async(getattr(ctx, "handle", None), self._h, C.c_void_p(t.data_ptr()), t.numel() * t.element_size(), int(root)))
+
+    def close(self):
+        if self._h:
+            from . import _lib
+            _lib.lib().dfx_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class PipelinedReduce:
     """Reduce-mode exchange of a STREAM of independent batches (bench.py, N > 1): the collective of batch k runs on RCCL's stream beside
     the kernels of batch k + 1.  `systems` are NormalEquations of the same graph used round robin; a system is handed out again only

@@ -52,10 +52,19 @@ class Frame:
         if tuple(img.shape) != (self.height, self.width):
             raise _al.DfxError(-1, f"image is {tuple(img.shape)}, frame is {(self.height, self.width)}")
         self.pyr_img[0].copy_(img)   # H2D (or D2D) upload on the current stream
-        for i in range(n):
-            if i > 0:
-                _al.GaussianBlurDown(self.pyr_img[i - 1], self.pyr_img[i], self.ctx)
-            _al.SobelGradients(self.pyr_img[i], self.pyr_grad[i], self.ctx)
+        # one enqueue: a launch per level, each reading its level once (Sobel + blur-down from one LDS tile); same bits as the per-level operators
+        _al.BuildPyramids([self.pyr_img[:n]], [self.pyr_grad[:n]], self.ctx)
+
+    @staticmethod
+    def FillPyramidsBatch(frames, imgs=None, pyrlevels=None):
+        """FillPyramids of several frames in ONE enqueue (one launch per pyramid level over all frames).  `imgs[k]` (optional) is uploaded into
+        frame k's level 0 first."""
+        frames = list(frames)
+        n = frames[0].levels if pyrlevels is None else int(pyrlevels)
+        if imgs is not None:
+            for f, im in zip(frames, imgs):
+                f.pyr_img[0].copy_(torch.as_tensor(im, dtype=torch.float32))
+        _al.BuildPyramids([f.pyr_img[:n] for f in frames], [f.pyr_grad[:n] for f in frames], frames[0].ctx)
 
     def tensors(self):
         return list(self.pyr_img) + list(self.pyr_grad)

@@ -141,6 +141,9 @@ DFX_API int dfx_sfm_set_step_blocks(dfx_ctx* ctx, int blocks_per_pair);
  * same pair inside a 1024-pair launch and inside a 128-pair shard differs in the last bits.  A sharded job ("1/2/4/8-GPU results
  * bit-identical per pair") asks for the shape of the WHOLE pair list here and pins it on every rank through dfx_sfm_params.step_blocks:
  * tests/test_gpu_shard_invariance.py. */
+/* Preconditions of that claim: the static schedule (a run under DFX_SCHEDULE_DYNAMIC sums whatever its queues hand a wave), ONE image size (a batch of several
+ * sizes takes its shape from the whole batch's pixel count), and ONE value for all ranks -- the figure depends on the local CU count, so ranks on unlike GPUs
+ * must take it from one of them (rank 0 computes, the others receive it with the pair list).  A pinned step_blocks forces the static schedule on that call. */
 DFX_API int dfx_sfm_auto_step_blocks(dfx_ctx* ctx, int cs, uint32_t w, uint32_t h, int npairs, int distinct_jacobians, int* blocks_out);
 DFX_API int dfx_device_cu_count(dfx_ctx* ctx);
 /* How the JtJ/Jtr outer products of the SfM / DepthAligner step are evaluated on the matrix cores (fp32 in, fp32 out).  A context
@@ -150,8 +153,9 @@ DFX_API int dfx_device_cu_count(dfx_ctx* ctx);
  *                      0.75 of the 8 TB/s roofline; the same sweep pinned to DFX_MFMA_F32_CHAIN: 0.69.
  *  DFX_MFMA_BF16X3     every fp32 entry is split EXACTLY into three bf16 pieces (x = h + m + l, round-to-nearest-even through
  *                      v_cvt_pk_bf16_f32) and the products are summed as hh + hm + mh + hl + lh + mm on v_mfma_f32_16x16x32_bf16
- *                      with fp32 accumulation; the dropped terms are below 2^-24 of a product, i.e. the rounding of an fp32
- *                      multiply -- measured error against the fp64 oracle equals the chain's (tests/test_gpu_bf16x3.py).  Same inlier
+ *                      with fp32 accumulation; of the dropped terms ml and lm are each at most 2^-24 of a product (|m| <= 2^-8 |x|,
+ *                      |l| <= 2^-16 |x|) and ll 2^-32: together at most 2^-23 in the worst case, ~2^-26 on average, i.e. the order of the
+ *                      rounding of an fp32 multiply (2^-24) -- measured error against the fp64 oracle equals the chain's (tests/test_gpu_bf16x3.py).  Same inlier
  *                      sets, same valid0 writes, bit-reproducible for a launch shape like the chain; its bits differ from the chain's.
  *  DFX_MFMA_F32_CHAIN  pinned by a caller that wants the fmaf-chain bits: v_mfma_f32_16x16x4_f32 -- bitwise an fp32 fmaf chain over
  *                      the pixels of a wave.  Matrix-bound at CS = 64 (0.57 - 0.59 of the roofline against 0.72 - 0.77 for the split). */
@@ -214,7 +218,15 @@ DFX_API int dfx_img_fill_f32(dfx_ctx* ctx, const dfx_img* dst, float value);
  * bit = pixel known to hold 1.0).  *n_words = 0 when the image has no shadow (foreign memory, or never used as valid0). */
 DFX_API int dfx_debug_read_valid0_shadow(dfx_ctx* ctx, const dfx_img* img, uint64_t* host_words, size_t cap_words, size_t* n_words);
 
-/* ---- SE3Aligner<float> (cuda/cu_se3aligner.h:52-72) ----------------------------------------- */
+/* ---- SE3Aligner<float> (cuda/cu_se3aligner.h:52-72) -----------------------------------------
+ * Accuracy statement shared by RunStep, EvaluateError and the tracker (the "row walk" kernels): the inlier set is exactly the reference's (pixels whose
+ * validity margin is within a rigorous error bound of zero are re-evaluated in the reference's operation order); the sampled position differs from the
+ * reference's in two documented ways, both far below the stated tolerance: the projection is evaluated with fused multiply-adds and one reciprocal
+ * (~3e-5 pixel), and a tap coordinate less than 2^-13 pixel BELOW an integer is taken as that integer (at the exact identity u = x + rounding noise; the
+ * fp64 oracle has u = x there).  The camera of a call must have the size of the images it is used with (w, h of dfx_cam = image width, height: the camera
+ * of that pyramid level, camera_pyramid.h:41-46); other combinations are refused.
+ * Run-ahead of the *_batch_async entries: each call holds one of 8 pinned descriptor slots until its kernels have run, so the 9th call in flight blocks
+ * the host until the first has finished (bounded run-ahead; the blocking forms are unaffected). */
 /* RunStep (cu_se3aligner.cpp:153-176): out_item = JTJJrReductionItem<float,6> on the HOST (120 bytes). */
 DFX_API int dfx_se3_step(dfx_ctx* ctx, const dfx_se3* pose_10, const dfx_cam* cam, const dfx_img* img0,
                          const dfx_img* img1, const dfx_img* dpt0, const dfx_img* grad1, float huber_delta,
@@ -388,6 +400,22 @@ DFX_API int dfx_update_depth_batch_async(dfx_ctx* ctx, int cs, int n, const floa
 DFX_API int dfx_sobel_gradients(dfx_ctx* ctx, const dfx_img* img, const dfx_img* grad_out);
 /* GaussianBlurDown (cu_image_proc.cpp:134-186): 5x5 binomial + decimate by 2; out is (w/2, h/2). */
 DFX_API int dfx_gaussian_blur_down(dfx_ctx* ctx, const dfx_img* in, const dfx_img* out);
+/* Frame::FillPyramids (core/mapping/frame.h:80-94: level i = GaussianBlurDown(level i-1), SobelGradients on every level) and
+ * DeepFactors::UploadLiveFrame (core/deepfactors.cpp:616-630) for n frames in ONE enqueue (new): the reference builds L images + L gradients
+ * per frame with 2L - 1 blocking single-image calls at camera rate.  Here ONE launch per pyramid level over all frames of the batch; a level is
+ * read once -- its Sobel gradient and its blur-down to the next level come from the same LDS tile.  img[0] is the input (device memory, read),
+ * img[1 .. levels-1] and grad[0 .. levels-1] are written; level i + 1 must be (w/2, h/2) of level i; a grad view with a null ptr skips that
+ * level's gradient (UploadLiveFrame leaves level 0 out, deepfactors.cpp:620-625).  All frames of a batch share the sizes of frame 0.
+ * Same bits as the per-level calls dfx_gaussian_blur_down / dfx_sobel_gradients.  _async only enqueues; dfx_build_pyramid blocks like the
+ * reference's calls. */
+#define DFX_MAX_PYR_LEVELS 8
+typedef struct dfx_pyramid {
+  int32_t levels;
+  dfx_img img[DFX_MAX_PYR_LEVELS];
+  dfx_img grad[DFX_MAX_PYR_LEVELS];
+} dfx_pyramid;
+DFX_API int dfx_build_pyramid_batch_async(dfx_ctx* ctx, const dfx_pyramid* frames, int n);
+DFX_API int dfx_build_pyramid(dfx_ctx* ctx, const dfx_pyramid* frame);
 /* SquaredError (cu_image_proc.cpp:190-240): sum (a-b)^2. */
 DFX_API int dfx_squared_error(dfx_ctx* ctx, const dfx_img* a, const dfx_img* b, float* out);
 

@@ -102,12 +102,23 @@ struct Frame {
   virtual bool IsKeyframe() const { return false; }
 
   // frame.h:80-94: level 0 = img (HOST, w x h floats), level i = GaussianBlurDown(level i-1), Sobel / 8 gradient on every level
+  // One enqueue (dfx_build_pyramid_batch_async: a launch per level, each level read once) instead of the reference's 2 L - 1 blocking single-image
+  // calls; same bits as df::GaussianBlurDown / df::SobelGradients level by level.
   void FillPyramids(const float* img_host, std::size_t pyrlevels) {
     pyr_img[0].Upload(img_host);
+    const dfx_pyramid p = Describe(pyrlevels);
+    check(dfx_build_pyramid_batch_async(ctx->get(), &p, 1));
+  }
+  dfx_pyramid Describe(std::size_t pyrlevels, bool level0_gradient = true) const {
+    if (pyrlevels < 1 || pyrlevels > pyr_img.Levels() || pyrlevels > DFX_MAX_PYR_LEVELS) throw Error(DFX_E_INVALID, "Frame: pyramid depth");
+    dfx_pyramid p;
+    std::memset(&p, 0, sizeof(p));
+    p.levels = (int32_t)pyrlevels;
     for (std::size_t i = 0; i < pyrlevels; ++i) {
-      if (i > 0) df::GaussianBlurDown(pyr_img[i - 1], pyr_img[i], ctx);
-      df::SobelGradients(pyr_img[i], pyr_grad[i], ctx);
+      p.img[i] = pyr_img[i].c_img();
+      if (i > 0 || level0_gradient) p.grad[i] = pyr_grad[i].c_img();
     }
+    return p;
   }
 
   std::shared_ptr<Context> ctx;
@@ -119,6 +130,14 @@ struct Frame {
   double timestamp = 0;
   bool marginalized = false;
 };
+
+// FillPyramids of many frames whose level 0 is already on the device (e.g. uploaded by the camera driver's stream): one launch per level over all frames
+inline void FillPyramidsBatch(const std::vector<Frame*>& frames, std::size_t pyrlevels) {
+  if (frames.empty()) return;
+  std::vector<dfx_pyramid> d;
+  for (const Frame* f : frames) d.push_back(f->Describe(pyrlevels));
+  check(dfx_build_pyramid_batch_async(frames[0]->ctx->get(), d.data(), (int)d.size()));
+}
 
 // ---- df::Keyframe (core/mapping/keyframe.h:34-100) ---------------------------------------------------------------------------------
 template <int CS>
@@ -163,8 +182,8 @@ void KeyframeBroadcast(Keyframe<CS>& kf, dfx_comm* comm, int root) {
     bc(kf.pyr_prx_orig[i].c_img()); bc(kf.pyr_jac[i].c_img());
   }
   bc(kf.dpt_grad.c_img());
-  // code (CS), pose (7), id, timestamp as one row of floats / raw words
-  constexpr std::size_t kWords = CS + 7 + 4;
+  // code (CS), pose (7), id, timestamp, marginalized as one row of floats / raw words
+  constexpr std::size_t kWords = CS + 7 + 4 + 1;   // ... + Frame::marginalized
   DeviceImage<float> small(kWords, 1, kf.ctx);
   std::vector<float> h(kWords, 0.f);
   for (int k = 0; k < CS; ++k) h[(std::size_t)k] = kf.code[(std::size_t)k];
@@ -173,6 +192,7 @@ void KeyframeBroadcast(Keyframe<CS>& kf, dfx_comm* comm, int root) {
   const std::uint64_t id64 = kf.id;
   std::memcpy(&h[CS + 7], &id64, 8);
   std::memcpy(&h[CS + 9], &kf.timestamp, 8);
+  h[CS + 11] = kf.marginalized ? 1.0f : 0.0f;
   small.Upload(h);
   bc(small.c_img());
   h = small.Download();   // blocking: also the point where the broadcasts above are known to be complete on this rank
@@ -183,6 +203,7 @@ void KeyframeBroadcast(Keyframe<CS>& kf, dfx_comm* comm, int root) {
   std::memcpy(&idr, &h[CS + 7], 8);
   kf.id = (std::size_t)idr;
   std::memcpy(&kf.timestamp, &h[CS + 9], 8);
+  kf.marginalized = h[CS + 11] != 0.0f;
 }   // (the valid0 shadows of the rewritten maps are reset by dfx_comm_broadcast_async itself: it is a writer the library sees)
 
 // ---- gtsam::traits<Sophus::SE3f>::Local (core/gtsam/gtsam_traits.h:66-72): (t2 - t1, log(R2 R1^T)) -------------------------------------

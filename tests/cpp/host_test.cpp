@@ -60,6 +60,24 @@ int main() {
       const std::vector<dfx::Grad2f> dg = kfs[1]->dpt_grad.Download();
       REQUIRE(std::isfinite(dg[W * 10 + 10].gx));
     }
+    {   // FillPyramids is ONE enqueue (dfx_build_pyramid_batch_async): the same bytes as the per-level operators, for one frame and for a batch
+      std::vector<dfx::Frame*> fr;
+      std::vector<std::unique_ptr<dfx::Frame>> own_fr;
+      for (int k = 0; k < K; ++k) { own_fr.emplace_back(new dfx::Frame(L, W, H, ctx)); own_fr.back()->pyr_img[0].Upload(img_host[k].data()); fr.push_back(own_fr.back().get()); }
+      dfx::FillPyramidsBatch(fr, L);
+      for (int k = 0; k < K; ++k) {
+        dfx::Frame ref(L, W, H, ctx);
+        ref.pyr_img[0].Upload(img_host[k].data());
+        for (std::size_t l = 0; l < L; ++l) {
+          if (l > 0) df::GaussianBlurDown(ref.pyr_img[l - 1], ref.pyr_img[l], ctx);
+          df::SobelGradients(ref.pyr_img[l], ref.pyr_grad[l], ctx);
+          const std::vector<float> a = fr[k]->pyr_img[l].Download(), b = ref.pyr_img[l].Download(), c = kfs[k]->pyr_img[l].Download();
+          REQUIRE(a == b && c == b);
+          const std::vector<dfx::Grad2f> ga = fr[k]->pyr_grad[l].Download(), gb = ref.pyr_grad[l].Download(), gc = kfs[k]->pyr_grad[l].Download();
+          REQUIRE(std::memcmp(ga.data(), gb.data(), ga.size() * sizeof(dfx::Grad2f)) == 0 && std::memcmp(gc.data(), gb.data(), gc.size() * sizeof(dfx::Grad2f)) == 0);
+        }
+      }
+    }
     // cameras per level (camera_pyramid.h:41-46)
     std::vector<dfx_cam> cams;
     for (std::size_t l = 0; l < L; ++l) { const float s = 1.0f / (1 << l); cams.push_back(dfx_cam{ 277.128f * s, 289.706f * s, 160.f * s, 120.f * s, (float)(W >> l), (float)(H >> l) }); }

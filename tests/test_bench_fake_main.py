@@ -12,6 +12,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -20,6 +21,8 @@ ARGS = ["--pairs", "48", "--width", "64", "--height", "48", "--cs", "16", "--ste
 
 
 class FakeCtx:
+    handle = None   # the C-ABI exchange (deepfactors_amd.dist.Comm) passes it through: a null context = no stream, which the host-memory RCCL stand-in ignores anyway
+
     def __init__(self, device=None, stream="torch"):
         self.profiling, self.pending, self.dynamic, self.mfma = False, [], False, 0
 
@@ -183,6 +186,8 @@ def _run_main(argv, out_path):
                (torch.cuda, "Stream", FakeStream), (torch.cuda, "stream", lambda s: contextlib.nullcontext()), (torch.cuda, "empty_cache", lambda: None),
                (torch.cuda, "set_stream", lambda s: None),
                (torch.cuda, "Event", FakeEvent), (deepfactors_amd, "SE3Aligner", FakeSE3), (deepfactors_amd, "UpdateDepthBatch", lambda *a, **k: None),
+               (deepfactors_amd, "BuildPyramids", lambda *a, **k: None), (deepfactors_amd, "GaussianBlurDown", lambda *a, **k: None),
+               (deepfactors_amd, "SobelGradients", lambda *a, **k: None),
                (synth, "make_pair", small_make_pair)]
     saved = [(o, n, getattr(o, n)) for o, n, _ in patches]
     old_argv = sys.argv
@@ -216,7 +221,9 @@ def _check_line(txt, world):
     assert r["launches"] == 3 and r["traffic"] is None and "traffic_source" in r and "mfma" in r and "schedule" in r
     assert "schedule_probe" not in d and len(d["ramp_kernel_us"]) >= 6
     assert 0 < r["kernel_us_min"] <= r["kernel_us"] <= r["kernel_us_max"] and "library default" in r["mfma"] + r["schedule"]
-    assert "second stream" not in d["config"]["workload"]   # the tail runs in order unless --deferred-tail
+    # the tail runs in order unless --deferred-tail -- or the C-ABI exchange moves it (and the collective) to the tail stream for N > 1
+    assert ("second stream" in d["config"]["workload"]) == (world > 1 and d["config"]["exchange"] == "cabi")
+    assert d["config"]["exchange"] == ("none" if world == 1 else d["config"]["exchange"])
     return d
 
 
@@ -228,16 +235,34 @@ def test_main_single_process(tmp_path, monkeypatch):
     _check_line(out.read_text(), 1)
 
 
-def _rank(rank, world, port, outdir):
-    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    _run_main(["--gpus", str(world), "--window"] + ARGS, os.path.join(outdir, f"rank{rank}.txt"))
+STUB = os.path.join(ROOT, "tests", "cpp", "librccl_stub_shm.so")
 
 
-def test_main_two_ranks_over_gloo(tmp_path):
+def _stub():
+    """The host-memory, multi-process stand-in for RCCL (tests/cpp/rccl_stub_shm.cpp), built on demand."""
+    if not os.path.exists(STUB):
+        import subprocess
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", os.path.join(ROOT, "tests", "cpp", "rccl_stub_shm.cpp"), "-o", STUB, "-lrt", "-lpthread"])
+    return STUB
+
+
+def _rank(rank, world, port, outdir, exchange):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DFX_RCCL_LIB=STUB)
+    _run_main(["--gpus", str(world), "--window", "--exchange", exchange] + ARGS, os.path.join(outdir, f"rank{rank}.txt"))
+
+
+@pytest.mark.parametrize("exchange", ["cabi", "torch"])
+def test_main_two_ranks_over_gloo(tmp_path, exchange):
+    """N = 2.  exchange = cabi (bench.py's default): the SHIPPED collectives -- dfx_comm_get_unique_id on rank 0, the 128 bytes handed round over the
+    process group, dfx_comm_create, dfx_comm_reduce_f32_async per step (deepfactors_amd/csrc/dfx_comm.cpp) -- run for real, over a host-memory stand-in
+    for librccl loaded through DFX_RCCL_LIB; main()'s checksum of the exchanged system on rank 0 asserts that the sum arrived.  exchange = torch: the
+    torch.distributed collectives (gloo here) on the same buffers, pipelined over two systems."""
+    _stub()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_rank, args=(2, port, str(tmp_path), exchange), nprocs=2, join=True)
     assert (tmp_path / "rank1.txt").read_text().strip() == ""          # rank 0 alone prints the line
     d = _check_line((tmp_path / "rank0.txt").read_text(), 2)
+    assert d["config"]["exchange"] == exchange and (("C ABI" in d["config"]["workload"]) == (exchange == "cabi"))
     assert "not collected for N > 1" in d["roofline"]["traffic_source"] and "cpu_baseline" not in d
     w = d["configs"]["configs3_window64"]                               # --window: BASELINE configs[3] sharded over the two ranks
     assert w["keyframes"] == 64 and w["pairs"] == 1024 and w["pairs_per_rank"] == 512 and w["evals_per_s"] > 0

@@ -2,17 +2,34 @@
 lucas_kanade_se3.h ... compiled unmodified, oracle/ref_harness.cpp) -- on the same inputs: the comparison the reference makes
 itself in tests/ut_sfmaligner.cpp:235-327 (GPU RunStep vs a host loop over DenseSfm: inliers equal, |dJtJ| <= 1e-1), at the
 tighter tolerance of tests/helpers.py.  The library travels prebuilt to the GPU box (it is built where /root/reference exists)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from helpers import assert_item_close
+from oracle import dfx_ref as ref
 from test_oracle_kat import load_fixture, scenenet_cam
 
-ref = pytest.importorskip("oracle.dfx_ref")
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref.available(), reason="oracle/_ref/libdfx_ref.so not built")]
+# oracle/_ref/libdfx_ref.so is git-ignored and travels to the GPU box as a prebuilt (it is compiled where /root/reference exists, oracle/Makefile).  A
+# snapshot WITHOUT it must not drop the strongest GPU parity test without a red mark: by default its absence FAILS the GPU suite
+# (test_reference_library_travelled_with_the_snapshot); DFX_REQUIRE_REF=0 turns that into a skip for checkouts that cannot have it (no reference
+# tree to build from) -- tests/test_golden_ref_vectors.py (committed outputs of the same reference code) then remain as the backstop.
+REQUIRE_REF = os.environ.get("DFX_REQUIRE_REF", "1") != "0"
+pytestmark = [pytest.mark.gpu]
+needs_ref = pytest.mark.skipif(not ref.available(), reason="oracle/_ref/libdfx_ref.so not built (DFX_REQUIRE_REF=0)")
 
 
+def test_reference_library_travelled_with_the_snapshot():
+    if not ref.available() and not REQUIRE_REF:
+        pytest.skip("oracle/_ref/libdfx_ref.so not built and DFX_REQUIRE_REF=0")
+    assert ref.available(), ("oracle/_ref/libdfx_ref.so is missing: the reference-code parity tests of this file cannot run.  Build it where the reference tree "
+                             "exists (python -c 'import __graft_entry__ as g; g.build()' or make -C oracle ref) so that it travels with the snapshot, or set "
+                             "DFX_REQUIRE_REF=0 to accept the committed golden vectors (tests/test_golden_ref_vectors.py) as the only pin")
+
+
+@needs_ref
 @pytest.mark.parametrize("w,h,cs", [(320, 240, 32), (640, 480, 32), (160, 120, 16), (256, 192, 64)])
 def test_sfm_step_matches_the_reference_code(dfx, w, h, cs):
     from deepfactors_amd import synth
@@ -36,6 +53,7 @@ def test_sfm_step_matches_the_reference_code(dfx, w, h, cs):
     assert np.abs(out.cpu().numpy() - d_ref).max() <= 2e-6 * float(((2.0 + d_ref) ** 2 / 2.0).max())
 
 
+@needs_ref
 def test_se3_tracking_on_the_reference_fixture_matches_the_reference_code(dfx, oracle):
     """ut_se3aligner.cpp:173-211 on data/testimg 1047 -> 1052: every one of the 40 Gauss-Newton steps of the HIP SE3Aligner agrees with
     the reference's LucasKanadeSE3 at the same pose; the loop reaches the reference's criterion."""
@@ -54,6 +72,7 @@ def test_se3_tracking_on_the_reference_fixture_matches_the_reference_code(dfx, o
     assert got.residual / got.inliers <= 1e-3
 
 
+@needs_ref
 def test_sparse_geometric_and_depth_aligner_match_the_reference_code(dfx, oracle):
     """SURVEY 8f-3 against oracle/_ref: the reference's SparseGeometricFactor<float,32>::linearize (sparse_geometric_factor.cpp:147-275, compiled
     unmodified) and its DepthAligner kernel (cu_depthaligner.cpp:32-72) on the inputs the HIP kernels get."""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Average rocprofv3 --pmc counter_collection CSVs per counter for one kernel.  Usage: pmc_summary.py <dir> [regex]"""
+"""Average rocprofv3 --pmc counter_collection CSVs per kernel and counter.  Usage: pmc_summary.py <dir> [regex]   (kernels whose name matches; default k_sfm_step)"""
 import csv, glob, os, re, sys
 from collections import defaultdict
 
@@ -9,10 +9,13 @@ for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recu
     acc, cnt = defaultdict(float), defaultdict(int)
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if not rx.search(row.get("Kernel_Name", "")):
+            name = row.get("Kernel_Name", "")
+            m = rx.search(name)
+            if not m:
                 continue
-            acc[row["Counter_Name"]] += float(row["Counter_Value"])
-            cnt[row["Counter_Name"]] += 1
+            short = re.sub(r"^.*?(k_\w+).*$", r"\1", name)
+            acc[(short, row["Counter_Name"])] += float(row["Counter_Value"])
+            cnt[(short, row["Counter_Name"])] += 1
     print(f"# {os.path.relpath(f, d)}")
     for k in sorted(acc):
-        print(f"{k},{acc[k] / cnt[k]:.1f},dispatches={cnt[k]}")
+        print(f"{k[0]},{k[1]},{acc[k] / cnt[k]:.1f},dispatches={cnt[k]}")
