@@ -62,10 +62,11 @@ def parse():
     ap.add_argument("--mfma", choices=["auto", "f32", "bf16x3"], default="auto",
                     help="evaluation mode of the step kernel: auto = the library's default (DFX_MFMA_AUTO); f32 = fp32 fmaf chain; bf16x3 = exact three-way bf16 split")
     ap.add_argument("--deferred-tail", action="store_true",
-                    help="run the reduction tail of every step (finalize kernel, graph assembly) on a second stream beside the next step's kernel (dfx_set_tail_stream) instead "
-                         "of in order on the launch stream.  Measured on MI355X (profiles/r03_bench_tail_modes.txt): the gap between step time and kernel time falls "
-                         "from 38 to 27 us, but the 768 finalize workgroups take CU slots from the next step kernel (+15 us): 1.0233 vs 1.0200 ms per step -- so "
-                         "the default stays in order (a higher stream priority for the launch stream does not change that: 1.044 vs 1.038 ms, r03_bench_tail_modes.txt)")
+                    help="run the reduction tail of every step (tail kernel with the graph assembly) on a second stream beside the next step's kernel (dfx_set_tail_stream) "
+                         "instead of in order on the launch stream.  Measured on MI355X in interleaved windows of one process (tools/ab_tail_modes.py, profiles/r05_step_gap.txt): "
+                         "step time - kernel time falls from 39 to 15-21 us, but the step kernel beside which the tail runs takes 13-19 us longer (the tail's 47 MB of "
+                         "partials and its issue slots are paid there): 985-990 vs 991 us per step, -0.5 %, at a roofline fraction 1.9 % lower.  So the single-GPU line keeps "
+                         "the tail in order; with the C-ABI exchange and N > 1 the mode is on (it is how the collective leaves the launch stream)")
     ap.add_argument("--two-call-tail", action="store_true", help="issue the step and the graph assembly as two library calls (dfx_sfm_step_batch_async + "
                     "dfx_graph_assemble_async: two tail kernels) instead of dfx_sfm_step_batch_assemble_async (the assembly inside the launch's tail kernel)")
     ap.add_argument("--foreign-valid0", action="store_true", help="keep the valid0 maps in torch tensors (memory the library does not own: the step kernel "
@@ -275,17 +276,19 @@ def small_operator_rooflines(dfx, synth, ctx, dev):
     pyr_g = [[torch.empty((fh >> i, fw >> i, 2), dtype=torch.float32, device=dev) for i in range(LV)] for _ in range(F)]
     for k in range(F):
         pyr_i[k][0].copy_(kfs[k % K]["img0"])
-    us = event_time_us(torch, lambda: dfx.BuildPyramids(pyr_i, pyr_g, ctx=ctx), reps=40, warm=100)
+    parr = dfx.make_pyramids(pyr_i, pyr_g)                   # (the buffers of a frame ring are marshalled once, not per frame)
+    us = event_time_us(torch, lambda: dfx.BuildPyramids(parr, ctx=ctx), reps=40, warm=100)
     byts = sum((fw >> i) * (fh >> i) * (12 + (1 if i + 1 < LV else 0)) for i in range(LV)) * F
     lv0 = pyr_i[0][0]
     ref1 = torch.empty_like(pyr_i[0][1]); refg = torch.empty_like(pyr_g[0][0])
     dfx.GaussianBlurDown(lv0, ref1, ctx); dfx.SobelGradients(lv0, refg, ctx)
-    one = event_time_us(torch, lambda: dfx.BuildPyramids(pyr_i[:1], pyr_g[:1], ctx=ctx), reps=100, warm=100)
+    parr1 = dfx.make_pyramids(pyr_i[:1], pyr_g[:1])
+    one = event_time_us(torch, lambda: dfx.BuildPyramids(parr1, ctx=ctx), reps=100, warm=100)
     out["pyramid_build_64frames_4levels"] = dict(us=us, algorithmic_bytes=byts, algorithmic_gbs=byts / us / 1e3, frac=byts / us / 1e3 / HBM_PEAK_GBS, frames_per_s=F / (us * 1e-6),
                                                  single_frame_us=one, equals_per_level_operators=bool(torch.equal(pyr_i[0][1], ref1) and torch.equal(pyr_g[0][0], refg)),
                                                  note="k_pyr_level x 4: image + gradient pyramids of 64 distinct 640x480 frames per enqueue (335 MB: beyond the Infinity Cache); us = the whole "
                                                       "enqueue (four launches) in back-to-back calls; single_frame_us = one frame per enqueue (latency-bound: four dependent launches)")
-    del pyr_i, pyr_g
+    del pyr_i, pyr_g, parr, parr1
     P = 128
     al, se3 = dfx.SfmAligner(code_size=CS, ctx=ctx), dfx.SE3Aligner(ctx=ctx)
     prs = [kfs[k % K] for k in range(P)]
@@ -676,7 +679,8 @@ def tracker_and_geometric_configs(dfx, synth, ctx, dev):
     same = all(np.array_equal(batch_rows[k], gfs[k].linearize(*gvals[k])) for k in (0, 57, 119))
     for f in gfs:
         f.upload_points()                                    # the reference samples a factor's points once, in its constructor
-    enq = lambda: dfx.SparseGeometricFactor.linearize_all(gfs, gvals, rows_dev=rows_dev)   # noqa: E731
+    gbatch = dfx.SparseGeometricFactor.prepare(gfs)          # cameras, decoder images and points marshalled once; poses and codes per round
+    enq = lambda: dfx.SparseGeometricFactor.linearize_all(gbatch, gvals, rows_dev=rows_dev)   # noqa: E731
     for _ in range(5):
         enq()
     ctx.sync()
@@ -689,7 +693,7 @@ def tracker_and_geometric_configs(dfx, synth, ctx, dev):
     enq(); e0.record(); enq(); e1.record(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(5):
-        dfx.SparseGeometricFactor.linearize_all(gfs, gvals)
+        dfx.SparseGeometricFactor.linearize_all(gbatch, gvals)
     host_round = (time.perf_counter() - t0) / 5
     out["configs2_sparse_geometric_500pts"].update(batched_round_ms_rows_on_device=dev_round * 1e3, batched_gpu_ms=e0.elapsed_time(e1), batched_round_ms_rows_to_host=host_round * 1e3,
                                                    batched_equals_per_factor_bits=bool(same), rows_bytes=int(rows_dev.numel() * 4),
@@ -932,10 +936,10 @@ def main():
         from deepfactors_amd.dist import Comm
         comm = Comm.create(ctx, dist, rank, world, dev)
 
-    # Deferred tail: consecutive steps are independent batches, so the reduction tail of step k (the tail kernel with the graph assembly, ~25 us, and the
-    # RCCL reduce of its system) can run on a second stream beside the 1 ms step kernel of step k + 1 (dfx_set_tail_stream).  Opt-in for one rank
-    # (--deferred-tail: measured neutral there); with the C-ABI exchange and N > 1 it is how the collective leaves the launch stream: the library enqueues
-    # ncclReduce on the tail stream, behind the assembly.  Every tail and every reduce has completed when the timed region ends.
+    # Deferred tail: consecutive steps are independent batches, so the reduction tail of step k (the tail kernel with the graph assembly, and the RCCL reduce of
+    # its system) can run on a second stream beside the 1 ms step kernel of step k + 1 (dfx_set_tail_stream).  Opt-in for one rank (--deferred-tail: -0.5 % step time
+    # at a 1.9 % lower roofline fraction, profiles/r05_step_gap.txt); with the C-ABI exchange and N > 1 it is how the collective leaves the launch stream: the library
+    # enqueues ncclReduce on the tail stream, behind the assembly.  Every tail and every reduce has completed when the timed region ends.
     tail = torch.cuda.Stream(device=dev) if (a.deferred_tail or (comm is not None and world > 1)) else None
     if tail is not None:
         ctx.set_tail_stream(tail)

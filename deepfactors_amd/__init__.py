@@ -5,7 +5,7 @@ host-side mirror of the reference interface plus the device-memory/stream plumbi
 from ._lib import DfxError, EXPORTED_SYMBOLS, LIB_PATH, item_size  # noqa: F401
 from .aligners import (BuildPyramids, CameraTracker, Context, CorrespondenceReductionItem, DenseSfmParams, DepthAligner, DeviceImage, GaussianBlurDown,  # noqa: F401
                        JTJJrReductionItem, SE3Aligner, SfmAligner, SfmAlignerParams, SobelGradients, SparseGeometricFactor, SquaredError,
-                       TrackerConfig, UpdateDepth, UpdateDepthBatch, default_context)
+                       TrackerConfig, UpdateDepth, UpdateDepthBatch, default_context, make_pyramids)
 from .keyframe import (Frame, Keyframe, KeyframeMap, LoadJsonNetworkConfig, NetworkConfig, save_keyframes, save_results,  # noqa: F401
                        save_trajectory_tum, write_png)
 from .factors import HessianBlocks, PhotometricFactor, linearize_all, pose_equals, pose_local  # noqa: F401

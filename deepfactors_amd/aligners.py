@@ -570,14 +570,10 @@ def GaussianBlurDown(inp, out, ctx=None):
     check(_lib.lib().dfx_gaussian_blur_down(ctx.handle, C.byref(i), C.byref(o)))
 
 
-def BuildPyramids(pyr_imgs, pyr_grads, ctx=None, blocking=False):
-    """``Frame::FillPyramids`` (core/mapping/frame.h:80-94) for n frames in ONE enqueue (dfx_build_pyramid_batch_async): `pyr_imgs[k]` = frame k's
-    image pyramid (level 0 = the input, already on the device; levels 1.. are written), `pyr_grads[k]` its gradient pyramid (written; an entry may be
-    None to skip that level's gradient, as UploadLiveFrame does for level 0, deepfactors.cpp:620-625).  One launch per pyramid level over all
-    frames; same bits as GaussianBlurDown / SobelGradients level by level."""
+def make_pyramids(pyr_imgs, pyr_grads):
+    """The dfx_pyramid array of n frames (see BuildPyramids) -- built once for buffers that are reused frame after frame (a camera's ring of frames): the
+    marshalling of 2 L image views per frame is then not paid per call."""
     n = len(pyr_imgs)
-    flat = [t for p in pyr_imgs for t in p] + [t for p in pyr_grads for t in p if t is not None]
-    ctx = _ctx_for(ctx, *flat)
     arr = (_lib.Pyramid * n)()
     for k in range(n):
         L = len(pyr_imgs[k])
@@ -588,6 +584,24 @@ def BuildPyramids(pyr_imgs, pyr_grads, ctx=None, blocking=False):
             arr[k].img[i] = _img(pyr_imgs[k][i], "img")
             if pyr_grads[k][i] is not None:
                 arr[k].grad[i] = _img(pyr_grads[k][i], "grad", 2)
+    arr._keep = (pyr_imgs, pyr_grads)   # the views hold raw pointers: keep the tensors alive with the array
+    return arr
+
+
+def BuildPyramids(pyr_imgs, pyr_grads=None, ctx=None, blocking=False):
+    """``Frame::FillPyramids`` (core/mapping/frame.h:80-94) for n frames in ONE enqueue (dfx_build_pyramid_batch_async): `pyr_imgs[k]` = frame k's
+    image pyramid (level 0 = the input, already on the device; levels 1.. are written), `pyr_grads[k]` its gradient pyramid (written; an entry may be
+    None to skip that level's gradient, as UploadLiveFrame does for level 0, deepfactors.cpp:620-625).  One launch per pyramid level over all
+    frames; same bits as GaussianBlurDown / SobelGradients level by level.  `pyr_imgs` may also be an array from make_pyramids (then `ctx` is required
+    unless the default context is meant)."""
+    if pyr_grads is None:
+        arr = pyr_imgs
+        ctx = ctx or default_context()
+    else:
+        flat = [t for p in pyr_imgs for t in p] + [t for p in pyr_grads for t in p if t is not None]
+        ctx = _ctx_for(ctx, *flat)
+        arr = make_pyramids(pyr_imgs, pyr_grads)
+    n = len(arr)
     if blocking and n == 1:
         check(_lib.lib().dfx_build_pyramid(ctx.handle, arr))
         return
@@ -757,20 +771,49 @@ class SparseGeometricFactor:
         f.dpt1_grad = _img(self.kf1_["dpt_grad"], "dpt1_grad", 2)
 
     @staticmethod
-    def linearize_all(factors, values, rows_dev=None):
-        """Every factor of a relinearisation round in ONE launch (dfx_sparse_geometric_linearize_batch[_async]); the reference linearises them one
-        after the other inside ISAM2::update.  `values[k]` = (pose0, pose1, code0, code1) of factor k.  With `rows_dev` (float32 CUDA tensor of
-        sum(n_points) x (12 + 2 CS + 1)) the rows stay on the device and the call only enqueues; otherwise it returns one host array per factor
-        (views of one buffer, one device-to-host copy)."""
+    def prepare(factors):
+        """The dfx_sparse_geo_factor array of a factor set with everything that does not change from round to round filled in (camera, decoder images, points):
+        `linearize_all(batch, values, ...)` then only writes poses and codes per round."""
         factors = list(factors)
-        n = len(factors)
         f0 = factors[0]
         if any(f.CS != f0.CS or f.huber_delta_ != f0.huber_delta_ or f.avg_dpt_ != f0.avg_dpt_ or f.ctx is not f0.ctx for f in factors):
             raise ValueError("the factors of a batch share code size, huber_delta, avg_dpt and context")
-        arr = (_lib.SparseGeoFactor * n)()
+        arr = (_lib.SparseGeoFactor * len(factors))()
+        zero = np.zeros(f0.CS, np.float32)
         keep = []
-        for k, (f, v) in enumerate(zip(factors, values)):
-            f._fill(arr[k], *v, keep)
+        for k, f in enumerate(factors):
+            f._fill(arr[k], np.array([0, 0, 0, 1, 0, 0, 0], np.float32), np.array([0, 0, 0, 1, 0, 0, 0], np.float32), zero, zero, keep)
+        arr._factors = factors
+        arr._codes = np.zeros((len(factors), 2, f0.CS), np.float32)
+        fp = C.POINTER(C.c_float)
+        for k in range(len(factors)):
+            arr[k].code0 = arr._codes[k, 0].ctypes.data_as(fp)
+            arr[k].code1 = arr._codes[k, 1].ctypes.data_as(fp)
+        return arr
+
+    @staticmethod
+    def linearize_all(factors, values, rows_dev=None):
+        """Every factor of a relinearisation round in ONE launch (dfx_sparse_geometric_linearize_batch[_async]); the reference linearises them one
+        after the other inside ISAM2::update.  `factors`: the factor objects, or the array prepare() made of them (the per-round marshalling is then
+        poses and codes only).  `values[k]` = (pose0, pose1, code0, code1) of factor k.  With `rows_dev` (float32 CUDA tensor of
+        sum(n_points) x (12 + 2 CS + 1)) the rows stay on the device and the call only enqueues; otherwise it returns one host array per factor
+        (views of one buffer, one device-to-host copy)."""
+        if hasattr(factors, "_factors"):      # an array from prepare(): poses and codes only
+            arr, factors = factors, factors._factors
+            for k, v in enumerate(values):
+                arr[k].pose0, arr[k].pose1 = _se3(v[0]), _se3(v[1])
+                arr._codes[k, 0], arr._codes[k, 1] = v[2], v[3]
+            n, f0 = len(factors), factors[0]
+        else:
+            factors = list(factors)
+            n = len(factors)
+            f0 = factors[0]
+            if any(f.CS != f0.CS or f.huber_delta_ != f0.huber_delta_ or f.avg_dpt_ != f0.avg_dpt_ or f.ctx is not f0.ctx for f in factors):
+                raise ValueError("the factors of a batch share code size, huber_delta, avg_dpt and context")
+            arr = (_lib.SparseGeoFactor * n)()
+            keep = []
+            for k, (f, v) in enumerate(zip(factors, values)):
+                f._fill(arr[k], *v, keep)
         nc = 12 + 2 * f0.CS + 1
         total = sum(len(f.points_) for f in factors)
         if rows_dev is not None:

@@ -186,7 +186,7 @@ def _run_main(argv, out_path):
                (torch.cuda, "Stream", FakeStream), (torch.cuda, "stream", lambda s: contextlib.nullcontext()), (torch.cuda, "empty_cache", lambda: None),
                (torch.cuda, "set_stream", lambda s: None),
                (torch.cuda, "Event", FakeEvent), (deepfactors_amd, "SE3Aligner", FakeSE3), (deepfactors_amd, "UpdateDepthBatch", lambda *a, **k: None),
-               (deepfactors_amd, "BuildPyramids", lambda *a, **k: None), (deepfactors_amd, "GaussianBlurDown", lambda *a, **k: None),
+               (deepfactors_amd, "BuildPyramids", lambda *a, **k: None), (deepfactors_amd, "make_pyramids", lambda *a, **k: [None]), (deepfactors_amd, "GaussianBlurDown", lambda *a, **k: None),
                (deepfactors_amd, "SobelGradients", lambda *a, **k: None),
                (synth, "make_pair", small_make_pair)]
     saved = [(o, n, getattr(o, n)) for o, n, _ in patches]

@@ -33,6 +33,17 @@ def test_pyramid_build_equals_the_per_level_operators_and_the_oracle(dfx, oracle
         pyr_i.append(pi); pyr_g.append(pg)
     dfx.BuildPyramids(pyr_i, pyr_g)
     torch.cuda.synchronize()
+    # the pre-marshalled form (a frame ring's buffers described once): same bytes
+    snap = [[t.clone() for t in p] for p in pyr_i], [[t.clone() for t in p] for p in pyr_g]
+    arr = dfx.make_pyramids(pyr_i, pyr_g)
+    for p in pyr_i:
+        for t in p[1:]:
+            t.fill_(-1.0)
+    dfx.BuildPyramids(arr)
+    torch.cuda.synchronize()
+    for k in range(n):
+        for i in range(levels):
+            assert torch.equal(pyr_i[k][i], snap[0][k][i]) and torch.equal(pyr_g[k][i], snap[1][k][i])
     for k in range(n):
         ref_img = imgs[k]
         ri, rg = _alloc(levels, w, h), _alloc(levels, w, h, ch=2)

@@ -83,6 +83,11 @@ def test_all_factors_of_a_round_in_one_launch(dfx, oracle, cs):
         assert np.array_equal(np.abs(ref).sum(1) == 0, np.abs(one).sum(1) == 0), k
         scale = np.abs(ref).max(0) + 1e-6
         assert (np.abs(one - ref) / scale).max() <= 2e-4, k
+    # the prepared form (static parts of the descriptors marshalled once): same rows
+    batch = dfx.SparseGeometricFactor.prepare(facs)
+    for _ in range(2):
+        again = dfx.SparseGeometricFactor.linearize_all(batch, vals)
+        assert all(np.array_equal(a, b) for a, b in zip(again, rows))
     total = sum(len(r) for r in rows)
     rows_dev = torch.full((total, 12 + 2 * cs + 1), float("nan"), dtype=torch.float32, device="cuda")
     assert dfx.SparseGeometricFactor.linearize_all(facs, vals, rows_dev=rows_dev) is None
