@@ -887,81 +887,104 @@ __global__ __launch_bounds__(kT) void k_blur_down(const float* __restrict__ in, 
 // Frame::FillPyramids (core/mapping/frame.h:80-94) / UploadLiveFrame (core/deepfactors.cpp:616-630) build L images + L gradients per frame
 // at camera rate with 2 L - 1 blocking single-image launches (cu_image_proc.cpp:94-112,166-186).  Here a level of ALL frames of a batch is one
 // launch (grid.z = frame) that reads the level ONCE: a workgroup stages a (kPyrTW + 8) x (kPyrTH + 4) window of the image in LDS (float4 row
-// loads on the interior; clamped dword loads only in tiles that touch the image border), every thread writes the Sobel / 8 gradient of four
-// pixels (two 16-byte stores) and the 5 x 5 binomial blur-down of one pixel of the next level.  Level 0 of 640x480: 4 B read + 8 + 1 B
+// loads on the interior; clamped dword loads only in tiles that touch the image border), its waves write the Sobel / 8 gradient row by row
+// (lane = column) and every thread the 5 x 5 binomial blur-down of two pixels of the next level.  Level 0 of 640x480: 4 B read + 8 + 1 B
 // written per pixel.  Same tap order and arithmetic as k_sobel / k_blur_down below (the per-level operators): the same bits.
-constexpr int kPyrTW = 64, kPyrTH = 16;                 // input pixels per workgroup tile
-constexpr int kPyrLW = kPyrTW + 8, kPyrLH = kPyrTH + 4; // staged window: columns x0 - 4 .. x0 + 67 (16-byte aligned), rows y0 - 2 .. y0 + 17
+constexpr int kPyrTW = 64, kPyrTH = 32;                 // input pixels per workgroup tile
+constexpr int kPyrLW = kPyrTW + 8, kPyrLH = kPyrTH + 4; // staged window: columns x0 - 4 .. x0 + 67 (16-byte aligned), rows y0 - 2 .. y0 + 33
+#ifndef DFX_PYR_NT
+#define DFX_PYR_NT 0    // 1: non-temporal stores of the outputs (A/B)
+#endif
+
+template <typename T>
+__device__ __forceinline__ void pyr_store(void* p, const T& v) {
+  if (DFX_PYR_NT) __builtin_nontemporal_store(v, (DFX_GLOBAL T*)p); else gstore<T>(p, v);
+}
 __global__ __launch_bounds__(kT) void k_pyr_level(const PyrLevelDev* __restrict__ descs) {
   const PyrLevelDev& P = descs[blockIdx.z];
   const int W = P.W, H = P.H, OW = P.OW, OH = P.OH;
   const int x0 = blockIdx.x * kPyrTW, y0 = blockIdx.y * kPyrTH;
+  // the window twice: as it is (the Sobel taps: lane = column, unit stride) and split into its even and odd columns (the blur taps of neighbouring
+  // output pixels are TWO columns apart: in the plain window half of the LDS banks would serve them, 2-4 lanes each)
   __shared__ float tile[kPyrLH][kPyrLW];
+  __shared__ float tev[kPyrLH][kPyrLW / 2 + 4], tod[kPyrLH][kPyrLW / 2 + 4];
   const bool interior = x0 >= 4 && x0 + kPyrTW + 4 <= W && y0 >= 2 && y0 + kPyrTH + 2 <= H && ((P.pitch_in | (uint32_t)(uintptr_t)P.in) & 15) == 0;
+  const bool blur = P.out != nullptr;
   if (interior) {
     for (int e = threadIdx.x; e < kPyrLH * (kPyrLW / 4); e += kT) {
       const int r = e / (kPyrLW / 4), c4 = e - r * (kPyrLW / 4);
       const f32x4 v = gload<f32x4>((const char*)P.in + (size_t)(y0 - 2 + r) * P.pitch_in + (size_t)(x0 - 4 + 4 * c4) * 4);
       *reinterpret_cast<f32x4*>(&tile[r][4 * c4]) = v;
+      if (blur) {
+        *reinterpret_cast<f32x2*>(&tev[r][2 * c4]) = f32x2{ v.x, v.z };
+        *reinterpret_cast<f32x2*>(&tod[r][2 * c4]) = f32x2{ v.y, v.w };
+      }
     }
   } else {
     for (int e = threadIdx.x; e < kPyrLH * kPyrLW; e += kT) {
       const int r = e / kPyrLW, c = e - r * kPyrLW;
       const int y = min(max(y0 - 2 + r, 0), H - 1), x = min(max(x0 - 4 + c, 0), W - 1);   // getWithClampedRange (cu_image_proc.cpp:66-70,141-146)
-      tile[r][c] = gload<float>((const char*)P.in + (size_t)y * P.pitch_in + (size_t)x * 4);
+      const float v = gload<float>((const char*)P.in + (size_t)y * P.pitch_in + (size_t)x * 4);
+      tile[r][c] = v;
+      if (c & 1) tod[r][c >> 1] = v; else tev[r][c >> 1] = v;
     }
   }
   __syncthreads();
-  // ---- Sobel / 8 (cu_image_proc.cpp:57-92): thread = 4 adjacent pixels of one row
-  if (P.grad) {
-    const int ty = threadIdx.x >> 4, tx = (threadIdx.x & 15) * 4;   // 16 rows x 16 quads
-    const int y = y0 + ty;
-    if (y < H && x0 + tx < W) {
-      float g[8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // ---- Sobel / 8 (cu_image_proc.cpp:57-92): lane = column, a wave walks 8 rows with the 3 x 3 window sliding through registers (three LDS reads per
+  // pixel, conflict-free; one 512-byte store per wave and row)
+  if (P.grad && x0 + lane < W) {
+    const int lx = lane + 4;
+    int ly = wave * (kPyrTH / 4) + 2;                       // window row of the wave's first pixel row
+    float a = tile[ly - 1][lx - 1], b = tile[ly - 1][lx], c = tile[ly - 1][lx + 1];
+    float d = tile[ly][lx - 1], m = tile[ly][lx], f = tile[ly][lx + 1];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int lx = tx + k + 4, ly = ty + 2;
-        const float a = tile[ly - 1][lx - 1], b = tile[ly - 1][lx], c = tile[ly - 1][lx + 1], d = tile[ly][lx - 1], f = tile[ly][lx + 1], gg = tile[ly + 1][lx - 1],
-                    h = tile[ly + 1][lx], i = tile[ly + 1][lx + 1];
-        float sx = 0.f, sy = 0.f;   // the tap order of k_sobel (the reference loop, zero taps skipped)
-        sx += a * -1.f; sy += a * -1.f;
-        sy += b * -2.f;
-        sx += c * 1.f;  sy += c * -1.f;
-        sx += d * -2.f;
-        sx += f * 2.f;
-        sx += gg * -1.f; sy += gg * 1.f;
-        sy += h * 2.f;
-        sx += i * 1.f;  sy += i * 1.f;
-        g[2 * k] = sx / 8.f; g[2 * k + 1] = sy / 8.f;
-      }
-      char* row = (char*)P.grad + (size_t)y * P.pitch_grad + (size_t)(x0 + tx) * 8;
-      if (x0 + tx + 4 <= W && ((P.pitch_grad | (uint32_t)(uintptr_t)P.grad) & 15) == 0) {
-        gstore<f32x4>(row, f32x4{ g[0], g[1], g[2], g[3] });
-        gstore<f32x4>(row + 16, f32x4{ g[4], g[5], g[6], g[7] });
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (x0 + tx + k < W) gstore<f32x2>(row + 8 * k, f32x2{ g[2 * k], g[2 * k + 1] });
-      }
+    for (int k = 0; k < kPyrTH / 4; ++k, ++ly) {
+      const float g = tile[ly + 1][lx - 1], h = tile[ly + 1][lx], i = tile[ly + 1][lx + 1];
+      float sx = 0.f, sy = 0.f;   // the tap order of k_sobel (the reference loop, zero taps skipped)
+      sx += a * -1.f; sy += a * -1.f;
+      sy += b * -2.f;
+      sx += c * 1.f;  sy += c * -1.f;
+      sx += d * -2.f;
+      sx += f * 2.f;
+      sx += g * -1.f; sy += g * 1.f;
+      sy += h * 2.f;
+      sx += i * 1.f;  sy += i * 1.f;
+      const int y = y0 + ly - 2;
+      if (y < H) pyr_store<f32x2>((char*)P.grad + (size_t)y * P.pitch_grad + (size_t)(x0 + lane) * 8, f32x2{ sx / 8.f, sy / 8.f });
+      a = d; b = m; c = f; d = g; m = h; f = i;
     }
   }
-  // ---- 5 x 5 binomial blur + decimate (cu_image_proc.cpp:134-164): thread = one pixel of the next level (tile origin is even)
-  if (P.out) {
-    const int oy = threadIdx.x >> 5, ox = threadIdx.x & 31;          // 8 rows x 32 columns
-    const int X = (x0 >> 1) + ox, Y = (y0 >> 1) + oy;
-    if (X < OW && Y < OH) {
-      const float B[5] = { 1.f, 4.f, 6.f, 4.f, 1.f };
-      float sum = 0.f, wall = 0.f;
+  // ---- 5 x 5 binomial blur + decimate (cu_image_proc.cpp:134-164): thread = two VERTICALLY adjacent pixels of the next level (they share three of their
+  // five window rows: 35 LDS reads for two pixels instead of 50), lane = output column (unit stride in the even / odd column arrays).  Window column of input
+  // x0 - 4 + c is c; output column ox reads inputs 2 ox - 2 .. 2 ox + 2 = window columns 2 ox + 2 .. 2 ox + 6: even ones at tev[.][ox + 1 .. ox + 3], odd
+  // ones at tod[.][ox + 1 .. ox + 2].  Each pixel is summed in the order of k_blur_down (py outer, px inner): the same bits.
+  if (blur) {
+    const float B[5] = { 1.f, 4.f, 6.f, 4.f, 1.f };
+    const int ox = threadIdx.x & 31, oyp = threadIdx.x >> 5;      // 32 columns x 8 row pairs
+    const int X = (x0 >> 1) + ox;
+    float w[7][5];
 #pragma unroll
-      for (int py = 0; py < 5; ++py) {
+    for (int r = 0; r < 7; ++r) {
+      const int wr = 4 * oyp + r;                                  // window row of input row 2 (2 oyp) - 2 + r
+      w[r][0] = tev[wr][ox + 1]; w[r][1] = tod[wr][ox + 1]; w[r][2] = tev[wr][ox + 2]; w[r][3] = tod[wr][ox + 2]; w[r][4] = tev[wr][ox + 3];
+    }
 #pragma unroll
-        for (int px = 0; px < 5; ++px) {
-          // input (2 X + px - 2, 2 Y + py - 2) with clamped range: the window entry of an (unclamped) coordinate holds the clamped pixel
-          const float k = B[px] * B[py];
-          sum += tile[2 * Y + py - y0][2 * X + px + 2 - x0] * k;
-          wall += k;
+    for (int half = 0; half < 2; ++half) {
+      const int Y = (y0 >> 1) + 2 * oyp + half;
+      if (X < OW && Y < OH) {
+        float sum = 0.f, wall = 0.f;
+#pragma unroll
+        for (int py = 0; py < 5; ++py) {
+#pragma unroll
+          for (int px = 0; px < 5; ++px) {
+            const float k = B[px] * B[py];
+            sum += w[2 * half + py][px] * k;
+            wall += k;
+          }
         }
+        pyr_store<float>((char*)P.out + (size_t)Y * P.pitch_out + (size_t)X * 4, sum / wall);
       }
-      gstore<float>((char*)P.out + (size_t)Y * P.pitch_out + (size_t)X * 4, sum / wall);
     }
   }
 }
