@@ -300,18 +300,20 @@ def small_operator_rooflines(dfx, synth, ctx, dev):
     us = event_time_us(torch, lambda: se3.RunStepBatch(sarr, sitems), reps=60, warm=300)
     kus = kernel_only_us(ctx, lambda: se3.RunStepBatch(sarr, sitems))
     byts = 20 * W * H * P
-    out["se3_step_batch_128pairs"] = dict(us=us, algorithmic_bytes=byts, algorithmic_gbs=byts / us / 1e3, frac=byts / us / 1e3 / HBM_PEAK_GBS,
+    out["se3_step_batch_128pairs"] = dict(kernel="k_se3_step_batch", us=us, algorithmic_bytes=byts, algorithmic_gbs=byts / us / 1e3, frac=byts / us / 1e3 / HBM_PEAK_GBS,
                                           kernel_us=kus, kernel_frac=byts / kus / 1e3 / HBM_PEAK_GBS,
                                           note="k_se3_step_batch + finalize: 128 distinct 640x480 pairs in one launch (786 MB: beyond the 256 MB Infinity Cache); "
                                                "us / frac = the whole call in back-to-back enqueues (reduction kernel + finalize kernel + two launch boundaries), "
-                                               "kernel_us / kernel_frac = the reduction kernel alone (HIP events around it)")
+                                               "kernel_us / kernel_frac = the reduction kernel alone (HIP events around it: they read 2.4 - 3 us more than the kernel's "
+                                               "duration in a rocprofv3 kernel trace, whatever its length; the warmed trace of these kernels -- tools/small_ops_trace.py, "
+                                               "last 30 of 430 dispatches per phase -- is profiles/r05_small_ops_trace.csv)")
     # the same launch at the pairs' true relative poses: what a tracker evaluates from its second iteration on.  At the exact identity (the entry above,
     # kept for continuity with rounds 1-3) the outermost pixel columns / rows project ONTO the view border, where the fast geometry defers to the
     # reference-order evaluation: two of the ten 64-pixel bands take that path on every row
     sarr2 = se3.make_pairs([dict(se3=p["pose10_true"], cam=p["cam"], img0=p["img0"], img1=p["img1"], dpt0=p["dpt0"], grad1=p["grad1"]) for p in prs])
     us = event_time_us(torch, lambda: se3.RunStepBatch(sarr2, sitems), reps=60, warm=150)
     kus = kernel_only_us(ctx, lambda: se3.RunStepBatch(sarr2, sitems))
-    out["se3_step_batch_128pairs_true_pose"] = dict(us=us, algorithmic_bytes=byts, algorithmic_gbs=byts / us / 1e3, frac=byts / us / 1e3 / HBM_PEAK_GBS,
+    out["se3_step_batch_128pairs_true_pose"] = dict(kernel="k_se3_step_batch", us=us, algorithmic_bytes=byts, algorithmic_gbs=byts / us / 1e3, frac=byts / us / 1e3 / HBM_PEAK_GBS,
                                                     kernel_us=kus, kernel_frac=byts / kus / 1e3 / HBM_PEAK_GBS,
                                                     note="as se3_step_batch_128pairs, evaluated at each pair's generating pose instead of the identity")
     earr = al.make_pairs([dict(pose0=p["pose0"], pose1=p["pose1"], cam=p["cam"], img0=p["img0"], img1=p["img1"], dpt0=p["dpt0"], prx0_jac=p["prx_jac"],
@@ -320,7 +322,7 @@ def small_operator_rooflines(dfx, synth, ctx, dev):
     us = event_time_us(torch, lambda: al.EvaluateErrorBatch(earr, eitems), reps=60, warm=300)
     kus = kernel_only_us(ctx, lambda: al.EvaluateErrorBatch(earr, eitems))
     byts = 12 * W * H * P
-    out["sfm_error_batch_128pairs"] = dict(us=us, algorithmic_bytes=byts, algorithmic_gbs=byts / us / 1e3, frac=byts / us / 1e3 / HBM_PEAK_GBS,
+    out["sfm_error_batch_128pairs"] = dict(kernel="k_sfm_error_batch", us=us, algorithmic_bytes=byts, algorithmic_gbs=byts / us / 1e3, frac=byts / us / 1e3 / HBM_PEAK_GBS,
                                            kernel_us=kus, kernel_frac=byts / kus / 1e3 / HBM_PEAK_GBS,
                                            note="k_sfm_error_batch + finalize: 128 distinct 640x480 pairs in one launch (472 MB)")
     return out
