@@ -1509,6 +1509,14 @@ void rot_to_quat(const double* R, float* qout) {   // rotation matrix -> unit qu
   for (int i = 0; i < 4; ++i) qout[i] = (float)(q[i] / qn);
 }
 
+// Workgroups per tracker and iteration: the update kernel behind every step kernel reads one partial row per workgroup, and both are latency-bound
+// (4-6 us each); DFX_TRACK_BLOCKS caps the count (tuning aid; profiles/r05_tracker.txt)
+int track_blocks(uint32_t W, uint32_t H) {
+  static const int cap = [] { const char* ev = std::getenv("DFX_TRACK_BLOCKS"); const int v = ev ? std::atoi(ev) : 0; return v > 0 && v <= dfx::kMaxSimpleBlocks ? v : 512; }();   // 512: 0.235 ms per 640x480 frame (1024: 0.247-0.252, 256: 0.229-0.240, 128: 0.25)
+  const int b = simple_blocks(W, H);
+  return b < cap ? b : cap;
+}
+
 // n independent trackers with a common schedule; levels is candidate-major: levels[k * n_levels + l].
 int track_frames_impl(dfx_ctx* c, int n, const dfx_se3* pose_init, const dfx_track_level* levels, int n_levels, float huber_delta,
                       dfx_track_result* out) {
@@ -1540,7 +1548,7 @@ int track_frames_impl(dfx_ctx* c, int n, const dfx_se3* pose_init, const dfx_tra
         g_last_error = "candidate " + std::to_string(k) + " level " + std::to_string(l) + ": " + g_last_error;
         return rc;
       }
-      const int b = simple_blocks(L.img0.w, L.img0.h);
+      const int b = track_blocks(L.img0.w, L.img0.h);
       if (b > max_blocks) max_blocks = b;
     }
   const size_t pbytes = (size_t)n * max_blocks * dfx::kSimpleRow * sizeof(float);
@@ -1562,7 +1570,7 @@ int track_frames_impl(dfx_ctx* c, int n, const dfx_se3* pose_init, const dfx_tra
   const dfx::SimplePairDev* ddesc = reinterpret_cast<const dfx::SimplePairDev*>((const char*)c->track_state_dev + off_desc);
   for (int l = n_levels - 1; l >= 0; --l) {
     const int W = (int)levels[l].img0.w, H = (int)levels[l].img0.h;
-    const int blocks = simple_blocks(levels[l].img0.w, levels[l].img0.h);
+    const int blocks = track_blocks(levels[l].img0.w, levels[l].img0.h);
     for (int it = 0; it < levels[l].iterations; ++it)
       DFX_HIP(dfx::launch_track_iteration(ddesc + (size_t)l * n, n, c->track_state_dev, W, H, huber_delta, blocks, c->partials, c->stream));
   }
@@ -1664,8 +1672,12 @@ int sparse_geo_batch_impl(dfx_ctx* c, int cs, const dfx_sparse_geo_factor* f, in
                          pts_dev, q.n_points, (int)q.prx0_orig.w, (int)q.prx0_orig.h, rows_base + row_off * nc, huber_delta, avg_dpt);
     row_off += (size_t)q.n_points;
   }
-  DFX_HIP(hipMemcpyAsync(c->sg_dev, host, up, hipMemcpyHostToDevice, c->stream));
-  if ((rc = stage_release(c, slot))) return rc;
+  {   // the slot gets its event whether or not the copy went out (no exit between acquiring a slot and releasing it)
+    const hipError_t ce = hipMemcpyAsync(c->sg_dev, host, up, hipMemcpyHostToDevice, c->stream);
+    rc = stage_release(c, slot);
+    if (ce != hipSuccess) return fail(DFX_E_HIP, "hipMemcpyAsync (descriptors) failed: %s", hipGetErrorString(ce));
+    if (rc) return rc;
+  }
   DFX_HIP(dfx::launch_sparse_geometric_batch(cs, c->sg_dev, n, max_pts, c->stream));
   if (!rows_host) return DFX_OK;
   if (row_bytes <= kDirectResultMax) return fetch_result(c, rows_base, rows_host, row_bytes);
@@ -1947,12 +1959,14 @@ DFX_API int dfx_build_pyramid_batch_async(dfx_ctx* c, const dfx_pyramid* frames,
   void* hdev = nullptr;
   const size_t dbytes = sizeof(dfx::PyrLevelDev) * (size_t)n * L;
   if (n > 4) {
-    if (c->pyr_bytes < dbytes) DFX_HIP(hipStreamSynchronize(c->stream));
+    if (c->pyr_bytes < dbytes) (void)hipStreamSynchronize(c->stream);
     if ((rc = grow_dev((void**)&c->pyr_dev, &c->pyr_bytes, dbytes, c->stream))) { (void)stage_release(c, slot); return rc; }
-    DFX_HIP(hipMemcpyAsync(c->pyr_dev, host, dbytes, hipMemcpyHostToDevice, c->stream));
+    const hipError_t ce = hipMemcpyAsync(c->pyr_dev, host, dbytes, hipMemcpyHostToDevice, c->stream);
+    if (ce != hipSuccess) { (void)stage_release(c, slot); return fail(DFX_E_HIP, "hipMemcpyAsync (descriptors) failed: %s", hipGetErrorString(ce)); }
     hdev = c->pyr_dev;
   } else {
-    DFX_HIP(hipHostGetDevicePointer(&hdev, host, 0));
+    const hipError_t ge = hipHostGetDevicePointer(&hdev, host, 0);
+    if (ge != hipSuccess) { (void)stage_release(c, slot); return fail(DFX_E_HIP, "hipHostGetDevicePointer failed: %s", hipGetErrorString(ge)); }
   }
   for (int i = 0; i < L; ++i) {
     bool any = false;   // (the last level of a batch whose frames all skip its gradient has nothing to do)

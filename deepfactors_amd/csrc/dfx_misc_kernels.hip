@@ -406,13 +406,16 @@ __global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev* __rest
   se3_step_body(p, R, t, e1, e2, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
 }
 
+// MAXQ: partial rows per row group the launch can hold (nblocks <= 32 MAXQ; rows past nblocks add +0.0: every MAXQ gives the same bits) -- the coarse
+// levels of a tracker have 75 / 300 partial rows, not 1024
+template <int MAXQ>
 __global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__ partials_all, const int nblocks, TrackState* __restrict__ states) {
   const float* partials = partials_all + (size_t)blockIdx.x * nblocks * kSimpleRow;
   TrackState* st = states + blockIdx.x;
   __shared__ double red[32][kSimpleRow];
   __shared__ double sum[kSimpleRow];
   const int e = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  double s = strided_sum_f64_wide<32, 32>(partials + e, rg, nblocks, kSimpleRow);
+  double s = strided_sum_f64_wide<32, MAXQ>(partials + e, rg, nblocks, kSimpleRow);
   red[rg][e] = s;
   __syncthreads();
   if (rg == 0) {
@@ -440,8 +443,18 @@ __global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__
   st->last_residual = (float)sum[27];
   st->last_inliers = (float)sum[28];
   st->iterations_done += 1;
-  // LDL^T (no pivoting), forward / diagonal / backward substitution
-  double L[6][6], D[6], yv[6], x[6];
+  // LDL^T (no pivoting), forward / diagonal / backward substitution.  One thread walks ~600 dependent double-precision operations here, and this kernel is
+  // half of a tracker iteration (5.7 us beside a 5 us step kernel, profiles/r05_tracker.txt): the 21 divisions by the pivots are six refined reciprocals
+  // (v_rcp_f64 + three Newton steps: relative error < 2^-52; a compiler division is ~30 instructions each) and the exponential's sin / cos factors are their
+  // Taylor series in theta^2 for the small rotations a tracker update has (|theta| < 1.5: twelve terms, < 1e-16; the library functions beyond)
+  auto rcp = [](double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    return r;
+  };
+  double L[6][6], D[6], Di[6], yv[6], x[6];
   bool ok = sum[28] > 0.0;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -450,12 +463,13 @@ __global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__
     for (int q = 0; q < j; ++q) d -= L[j][q] * L[j][q] * D[q];
     ok = ok && (fabs(d) > 0.0);
     D[j] = d;
+    Di[j] = rcp(d);
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
       double v = A[i][j];
 #pragma unroll
       for (int q = 0; q < j; ++q) v -= L[i][q] * L[j][q] * D[q];
-      L[i][j] = v / d;
+      L[i][j] = v * Di[j];
     }
   }
   if (!ok) { st->solver_failures += 1; return; }
@@ -468,15 +482,29 @@ __global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__
   }
 #pragma unroll
   for (int i = 5; i >= 0; --i) {
-    double v = yv[i] / D[i];
+    double v = yv[i] * Di[i];
 #pragma unroll
     for (int q = i + 1; q < 6; ++q) v -= L[q][i] * x[q];
     x[i] = v;
   }
   // update = -x ; t += update[0:3] ; R = exp(update[3:6]) * R   (lucas_kanade_se3.h:85-95)
   const double w0 = -x[3], w1 = -x[4], w2 = -x[5];
-  const double th2 = w0 * w0 + w1 * w1 + w2 * w2, th = sqrt(th2);
-  const double Ac = th < 1e-9 ? 1.0 - th2 / 6.0 : sin(th) / th, Bc = th < 1e-9 ? 0.5 - th2 / 24.0 : (1.0 - cos(th)) / th2;
+  const double th2 = w0 * w0 + w1 * w1 + w2 * w2;
+  double Ac, Bc;   // sin(theta) / theta, (1 - cos(theta)) / theta^2
+  if (th2 < 2.25) {
+    // sum_k (-1)^k th2^k / (2k+1)!  and  sum_k (-1)^k th2^k / (2k+2)!, Horner from k = 11
+    double sa = 1.0 / 25852016738884976640000.0, sb = 1.0 / 620448401733239439360000.0;   // 1 / 23!, 1 / 24!
+    const double ia[11] = { 1.0 / 51090942171709440000.0, 1.0 / 121645100408832000.0, 1.0 / 355687428096000.0, 1.0 / 1307674368000.0, 1.0 / 6227020800.0, 1.0 / 39916800.0,
+                            1.0 / 362880.0, 1.0 / 5040.0, 1.0 / 120.0, 1.0 / 6.0, 1.0 };   // 1 / 21!, 19!, ... 1!
+    const double ib[11] = { 1.0 / 1124000727777607680000.0, 1.0 / 2432902008176640000.0, 1.0 / 6402373705728000.0, 1.0 / 20922789888000.0, 1.0 / 87178291200.0, 1.0 / 479001600.0,
+                            1.0 / 3628800.0, 1.0 / 40320.0, 1.0 / 720.0, 1.0 / 24.0, 1.0 / 2.0 };   // 1 / 22!, 20!, ... 2!
+#pragma unroll
+    for (int k = 0; k < 11; ++k) { sa = __builtin_fma(-th2, sa, ia[k]); sb = __builtin_fma(-th2, sb, ib[k]); }
+    Ac = sa; Bc = sb;
+  } else {
+    const double th = sqrt(th2);
+    Ac = sin(th) / th; Bc = (1.0 - cos(th)) / th2;
+  }
   const double K[3][3] = { { 0, -w2, w1 }, { w2, 0, -w0 }, { -w1, w0, 0 } };
   double E[3][3], Rn[3][3], Ro[3][3];
 #pragma unroll
@@ -513,7 +541,9 @@ hipError_t launch_track_iteration(const SimplePairDev* descs_dev, int n, void* s
   hipLaunchKernelGGL(k_se3_step_dev, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (const TrackState*)states_dev, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_track_update, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (TrackState*)states_dev);
+  if (blocks <= 128) hipLaunchKernelGGL(k_track_update<4>, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (TrackState*)states_dev);
+  else if (blocks <= 512) hipLaunchKernelGGL(k_track_update<16>, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (TrackState*)states_dev);
+  else hipLaunchKernelGGL(k_track_update<32>, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (TrackState*)states_dev);
   return hipGetLastError();
 }
 
