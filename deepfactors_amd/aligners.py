@@ -652,6 +652,13 @@ class CameraTracker:
     def SetKeyframe(self, pyr_img, pyr_dpt):
         """Keyframe image and depth pyramids (kf->pyr_img, kf->pyr_dpt), finest level first."""
         self.kf_ = (list(pyr_img), list(pyr_dpt))
+        # the keyframe's half of the level records is marshalled once per keyframe, not once per tracked frame
+        n = self.config_.pyramid_levels
+        self._lv = (_lib.TrackLevel * n)()
+        for l in range(n):
+            self._lv[l].cam = _cam(self.camera_pyr_[l])
+            self._lv[l].img0, self._lv[l].dpt0 = _img(self.kf_[0][l], "kf img"), _img(self.kf_[1][l], "kf dpt")
+            self._lv[l].iterations = int(self.config_.iterations_per_level[l])
 
     def SetPoseEstimate(self, pose_ck):
         self.pose_ck_ = np.asarray(pose_ck, np.float32).copy()
@@ -659,13 +666,9 @@ class CameraTracker:
     def TrackFrame(self, pyr_img1, pyr_grad1):
         if self.kf_ is None:
             raise RuntimeError("Calling CameraTracker::TrackFrame before a keyframe was set")   # camera_tracker.cpp:44-45
-        n = self.config_.pyramid_levels
-        lv = (_lib.TrackLevel * n)()
+        n, lv = self.config_.pyramid_levels, self._lv
         for l in range(n):
-            lv[l].cam = _cam(self.camera_pyr_[l])
-            lv[l].img0, lv[l].dpt0 = _img(self.kf_[0][l], "kf img"), _img(self.kf_[1][l], "kf dpt")
             lv[l].img1, lv[l].grad1 = _img(pyr_img1[l], "img1"), _img(pyr_grad1[l], "grad1", 2)
-            lv[l].iterations = int(self.config_.iterations_per_level[l])
         res = _lib.TrackResult()
         s = _se3(self.pose_ck_)
         check(_lib.lib().dfx_track_frame(self.ctx.handle, C.byref(s), lv, n, float(self.config_.huber_delta), C.byref(res)))

@@ -1509,10 +1509,10 @@ void rot_to_quat(const double* R, float* qout) {   // rotation matrix -> unit qu
   for (int i = 0; i < 4; ++i) qout[i] = (float)(q[i] / qn);
 }
 
-// Workgroups per tracker and iteration: the update kernel behind every step kernel reads one partial row per workgroup, and both are latency-bound
-// (4-6 us each); DFX_TRACK_BLOCKS caps the count (tuning aid; profiles/r05_tracker.txt)
+// Workgroups per tracker and iteration: every workgroup of an iteration first folds one partial row per workgroup of the previous one (the update is computed
+// redundantly instead of in a launch of its own), and the evaluation is latency-bound (4-6 us); DFX_TRACK_BLOCKS caps the count (tuning aid; profiles/r05_tracker.txt)
 int track_blocks(uint32_t W, uint32_t H) {
-  static const int cap = [] { const char* ev = std::getenv("DFX_TRACK_BLOCKS"); const int v = ev ? std::atoi(ev) : 0; return v > 0 && v <= dfx::kMaxSimpleBlocks ? v : 512; }();   // 512: 0.235 ms per 640x480 frame (1024: 0.247-0.252, 256: 0.229-0.240, 128: 0.25)
+  static const int cap = [] { const char* ev = std::getenv("DFX_TRACK_BLOCKS"); const int v = ev ? std::atoi(ev) : 0; return v > 0 && v <= dfx::kMaxSimpleBlocks ? v : 256; }();   // 256: 0.209 ms per 640x480 frame (1024: 0.24, 512: 0.222, 384: 0.218, 192: 0.218, 128: 0.23)
   const int b = simple_blocks(W, H);
   return b < cap ? b : cap;
 }
@@ -1526,56 +1526,77 @@ int track_frames_impl(dfx_ctx* c, int n, const dfx_se3* pose_init, const dfx_tra
   int rc;
   if ((rc = ensure_device(c))) return rc;
   if ((rc = ray_table_gc(c))) return rc;
-  // one staged upload: [TrackState x n][SimplePairDev x n_levels x n (level-major)]
+  // one staged upload: [SimplePairDev x n_levels x n (level-major)][TrackState x n]; on the device the states continue as an array over iterations
+  // (iteration k reads states[k - 1] and the partial rows of evaluation k - 1, workgroup 0 writes states[k]; dfx_misc_kernels.hip)
   const size_t sbytes = dfx::track_state_bytes();
-  const size_t off_desc = ((sbytes * (size_t)n + 15) / 16) * 16;
-  const size_t total = off_desc + sizeof(dfx::SimplePairDev) * (size_t)n * n_levels;
+  const size_t off_state = ((sizeof(dfx::SimplePairDev) * (size_t)n * n_levels + 15) / 16) * 16;
+  const size_t total = off_state + sbytes * (size_t)n;
+  int total_iters = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    if (levels[l].iterations < 0) return fail(DFX_E_INVALID, "candidate 0 level %d: negative iteration count", l);
+    if (levels[l].iterations > 4096) return fail(DFX_E_INVALID, "level %d: %d iterations (at most 4096)", l, levels[l].iterations);
+    total_iters += levels[l].iterations;
+  }
+  const size_t dev_total = off_state + sbytes * (size_t)n * ((size_t)total_iters + 1);
   int slot;
   char* host;
   if ((rc = stage_acquire(c, total, &slot, &host))) return rc;
-  dfx::SimplePairDev* hdesc = reinterpret_cast<dfx::SimplePairDev*>(host + off_desc);
+  dfx::SimplePairDev* hdesc = reinterpret_cast<dfx::SimplePairDev*>(host);
   // validate every level of every candidate first (no partial work on a bad argument)
   int max_blocks = 1;
   const dfx_se3 ident{ { 0, 0, 0, 1 }, { 0, 0, 0 } };
+  auto bail = [&](int code) { (void)stage_release(c, slot); return code; };
   for (int k = 0; k < n; ++k)
     for (int l = 0; l < n_levels; ++l) {
       const dfx_track_level& L = levels[(size_t)k * n_levels + l];
       const dfx_track_level& L0 = levels[l];
-      if (L.iterations < 0) return fail(DFX_E_INVALID, "candidate %d level %d: negative iteration count", k, l);
       if (L.iterations != L0.iterations || L.img0.w != L0.img0.w || L.img0.h != L0.img0.h)
-        return fail(DFX_E_INVALID, "candidate %d level %d: schedule / image size differs from candidate 0", k, l);
+        return bail(fail(DFX_E_INVALID, "candidate %d level %d: schedule / image size differs from candidate 0", k, l));
       if ((rc = fill_simple(c, &ident, &L.cam, &L.img0, &L.img1, &L.dpt0, &L.grad1, nullptr, &hdesc[(size_t)l * n + k]))) {
         g_last_error = "candidate " + std::to_string(k) + " level " + std::to_string(l) + ": " + g_last_error;
-        return rc;
+        return bail(rc);
       }
       const int b = track_blocks(L.img0.w, L.img0.h);
       if (b > max_blocks) max_blocks = b;
     }
-  const size_t pbytes = (size_t)n * max_blocks * dfx::kSimpleRow * sizeof(float);
-  if ((rc = grow_partials(c, pbytes))) return rc;
-  if (c->track_bytes < total) {
-    DFX_HIP(hipStreamSynchronize(c->stream));
-    if (c->track_state_dev) DFX_HIP(hipFree(c->track_state_dev));
+  const size_t pfloats = (size_t)n * max_blocks * dfx::kSimpleRow;   // per evaluation; two buffers alternate
+  if ((rc = grow_partials(c, 2 * pfloats * sizeof(float)))) return bail(rc);
+  if (c->track_bytes < dev_total) {
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(fail(DFX_E_HIP, "dfx_track_frame: stream synchronisation failed"));
+    if (c->track_state_dev) (void)hipFree(c->track_state_dev);
     c->track_state_dev = nullptr;
-    DFX_HIP(hipMalloc(&c->track_state_dev, total * 2));
-    c->track_bytes = total * 2;
+    c->track_bytes = 0;
+    if (hipMalloc(&c->track_state_dev, dev_total * 2) != hipSuccess) return bail(fail(DFX_E_HIP, "dfx_track_frame: %zu bytes of tracker state", dev_total * 2));
+    c->track_bytes = dev_total * 2;
   }
   for (int k = 0; k < n; ++k) {
     double R[9], t[3] = { pose_init[k].t[0], pose_init[k].t[1], pose_init[k].t[2] };
     quat_to_R(pose_init[k].q, R);
-    dfx::track_state_init(host + sbytes * (size_t)k, R, t);
+    dfx::track_state_init(host + off_state + sbytes * (size_t)k, R, t);
   }
-  DFX_HIP(hipMemcpyAsync(c->track_state_dev, host, total, hipMemcpyHostToDevice, c->stream));
+  if (hipMemcpyAsync(c->track_state_dev, host, total, hipMemcpyHostToDevice, c->stream) != hipSuccess) return bail(fail(DFX_E_HIP, "dfx_track_frame: descriptor upload failed"));
   if ((rc = stage_release(c, slot))) return rc;
-  const dfx::SimplePairDev* ddesc = reinterpret_cast<const dfx::SimplePairDev*>((const char*)c->track_state_dev + off_desc);
+  const dfx::SimplePairDev* ddesc = reinterpret_cast<const dfx::SimplePairDev*>(c->track_state_dev);
+  char* dstates = (char*)c->track_state_dev + off_state;
+  auto state_at = [&](int k) { return dstates + sbytes * (size_t)n * (size_t)k; };
+  int it_done = 0, blocks_prev = 0;
   for (int l = n_levels - 1; l >= 0; --l) {
     const int W = (int)levels[l].img0.w, H = (int)levels[l].img0.h;
     const int blocks = track_blocks(levels[l].img0.w, levels[l].img0.h);
-    for (int it = 0; it < levels[l].iterations; ++it)
-      DFX_HIP(dfx::launch_track_iteration(ddesc + (size_t)l * n, n, c->track_state_dev, W, H, huber_delta, blocks, c->partials, c->stream));
+    for (int it = 0; it < levels[l].iterations; ++it) {
+      // evaluation `it_done` at states[it_done] (= states[0] as uploaded, or the update this launch computes from evaluation it_done - 1)
+      const void* sin = state_at(it_done > 0 ? it_done - 1 : 0);
+      DFX_HIP(dfx::launch_track_iteration(ddesc + (size_t)l * n, n, sin, state_at(it_done), c->partials + (size_t)((it_done + 1) & 1) * pfloats, blocks_prev, W, H, huber_delta, blocks,
+                                          c->partials + (size_t)(it_done & 1) * pfloats, c->stream));
+      blocks_prev = blocks;
+      ++it_done;
+    }
   }
-  if ((rc = ensure_result_host(c, sbytes * (size_t)n))) return rc;
-  DFX_HIP(hipMemcpyAsync(c->result_host, c->track_state_dev, sbytes * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  // the last update goes straight into the pinned, device-mapped result area (no copy operation behind the kernels)
+  void* rdev = nullptr;
+  if ((rc = result_target(c, sbytes * (size_t)n, &rdev))) return rc;
+  if (it_done > 0) DFX_HIP(dfx::launch_track_final(n, state_at(it_done - 1), rdev, c->partials + (size_t)((it_done + 1) & 1) * pfloats, blocks_prev, c->stream));
+  else DFX_HIP(hipMemcpyAsync(c->result_host, state_at(0), sbytes * (size_t)n, hipMemcpyDeviceToHost, c->stream));
   DFX_HIP(hipStreamSynchronize(c->stream));
   const double area = (double)levels[0].img0.w * levels[0].img0.h;
   for (int k = 0; k < n; ++k) {

@@ -60,7 +60,7 @@ int load_rccl() {
     h = dlopen(name, flags);
     if (h) g_rccl.path = name; else { tried += name; tried += (flags & RTLD_NOLOAD) ? " (loaded?) " : " "; }
   };
-  if (const char* ev = std::getenv("DFX_RCCL_LIB")) {
+  if (const char* ev = std::getenv("DFX_RCCL_LIB"); ev && *ev) {   // an empty value counts as unset (dlopen("") would hand back the main program)
     attempt(ev, RTLD_NOW | RTLD_LOCAL);
     if (!h) return fail(DFX_E_INVALID, std::string("DFX_RCCL_LIB=") + ev + " cannot be loaded: " + dlerror());
   }

@@ -203,9 +203,12 @@ hipError_t launch_depth_aligner_step(int cs, const SfmPairDev* pair_host, int W,
 size_t track_state_bytes();
 void track_state_init(void* host_state, const double* R, const double* t);
 void track_state_read(const void* host_state, double* R, double* t, float* residual, float* inliers, int* failures, int* iters);
-// one Gauss-Newton iteration of `n` independent trackers at one pyramid level: descs_dev[n], states_dev[n], partials [n][blocks][kSimpleRow]
-hipError_t launch_track_iteration(const SimplePairDev* descs_dev, int n, void* states_dev, int W, int H, float huber_delta, int blocks,
-                                  float* partials_dev, hipStream_t stream);
+// one Gauss-Newton iteration of `n` independent trackers at one pyramid level = one launch: the update from the previous evaluation (partials_prev
+// [n][blocks_prev][kSimpleRow] at states_in[n]; blocks_prev 0 = none) -> states_out[n], then the evaluation at it -> partials_dev [n][blocks][kSimpleRow];
+// launch_track_final applies the last evaluation
+hipError_t launch_track_iteration(const SimplePairDev* descs_dev, int n, const void* states_in, void* states_out, const float* partials_prev, int blocks_prev,
+                                  int W, int H, float huber_delta, int blocks, float* partials_dev, hipStream_t stream);
+hipError_t launch_track_final(int n, const void* states_in, void* states_out, const float* partials_prev, int blocks_prev, hipStream_t stream);
 
 // SparseGeometricFactor::linearize, n factors per launch (descriptors in device-visible memory; codes inside the descriptor, points and rows device pointers)
 size_t sparse_geo_desc_bytes();

@@ -382,71 +382,48 @@ __global__ __launch_bounds__(kT) void k_se3_step(const SimplePairDev p, const in
 }
 
 // ---- device-resident tracker (CameraTracker::TrackFrame, reference core/system/camera_tracker.cpp:42-71) -------------
-// The pose lives in device memory between iterations: k_se3_step_dev reads it, k_track_update folds the workgroup
-// partials (double, fixed order), solves the 6x6 normal equations by LDL^T in double and applies the reference's update
-// (t += dt, R = exp(dw) R; lucas_kanade_se3.h:85-95).  A whole coarse-to-fine schedule is enqueued without host syncs.
+// The pose lives in device memory between iterations, and an iteration is ONE launch: every workgroup of k_se3_step_dev first folds the partial rows of the
+// PREVIOUS evaluation (double, fixed order), solves the 6x6 normal equations by LDL^T in double and applies the reference's update (t += dt, R = exp(dw) R;
+// lucas_kanade_se3.h:85-95) -- all workgroups compute the same bits from the same rows -- and then evaluates its rows of the image at the new pose.  Workgroup 0
+// also writes the new state out (states are an array over iterations: nobody overwrites what another workgroup still reads, and the partial rows alternate
+// between two buffers).  k_track_final applies the last evaluation.  Rounds 2-4 ran a separate update kernel behind every step kernel: two dependent launches of
+// 3.5-5.6 us each per iteration (profiles/r05_tracker.txt); a grid-wide hand-over inside one kernel was measured slower in round 3.  A whole coarse-to-fine
+// schedule is enqueued without host syncs.
 struct TrackState {      // device-resident
   double R[9], t[3];     // pose_ck, kept in double across iterations
   float Rf[9], tf[3];    // fp32 copy consumed by the step kernel
   float last_residual; float last_inliers; int solver_failures; int iterations_done;
 };
+struct TrackLds { double red[32][kSimpleRow]; double sum[kSimpleRow]; TrackState st; };
 
-// blockIdx.y = candidate: Relocalize / the loop-closure geometry checks track ONE live frame against N keyframes
-// (deepfactors.cpp:713-743, loop_detector.cpp:146-167); descriptors, states and partials are arrays over candidates.
-__global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev* __restrict__ descs, const TrackState* __restrict__ states, const int W,
-                                                     const int H, const float huber_delta, float* __restrict__ partials_all) {
-  const SimplePairDev& p = descs[blockIdx.y];
-  const TrackState* st = states + blockIdx.y;
-  float* partials = partials_all + (size_t)blockIdx.y * gridDim.x * kSimpleRow;
-  float R[9], t[3], e1, e2;
-#pragma unroll
-  for (int q = 0; q < 9; ++q) R[q] = st->Rf[q];
-  t[0] = st->tf[0]; t[1] = st->tf[1]; t[2] = st->tf[2];
-  fast_band(R, t, p.fc, e1, e2);   // the descriptor's band belongs to the pose it was filled with, not to the state's
-  se3_step_body(p, R, t, e1, e2, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
+__device__ __forceinline__ double bcast(const double v, const int src_lane) {   // wave-uniform copy of lane `src_lane`'s value
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src_lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src_lane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-// MAXQ: partial rows per row group the launch can hold (nblocks <= 32 MAXQ; rows past nblocks add +0.0: every MAXQ gives the same bits) -- the coarse
-// levels of a tracker have 75 / 300 partial rows, not 1024
-template <int MAXQ>
-__global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__ partials_all, const int nblocks, TrackState* __restrict__ states) {
-  const float* partials = partials_all + (size_t)blockIdx.x * nblocks * kSimpleRow;
-  TrackState* st = states + blockIdx.x;
-  __shared__ double red[32][kSimpleRow];
-  __shared__ double sum[kSimpleRow];
-  const int e = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  double s = strided_sum_f64_wide<32, MAXQ>(partials + e, rg, nblocks, kSimpleRow);
-  red[rg][e] = s;
-  __syncthreads();
-  if (rg == 0) {
-    s = 0.0;
+// One WAVE: normal equations in `sum` (the fp64 fold of the partial rows) + the state they were evaluated at -> the next state.
+// reference precision: the item is fp32 (JTJJrReductionItem<float,6>) before the solve (camera_tracker.cpp:59); LDL^T (no pivoting), forward / diagonal /
+// backward substitution in double; update = -x ; t += update[0:3] ; R = exp(update[3:6]) * R   (lucas_kanade_se3.h:85-95).
+// A wave issues one instruction every four cycles whether or not it depends on the last one, so what this costs is its instruction COUNT, and every workgroup of
+// a tracker iteration waits for it: one thread walking the 6x6 system was ~700 double-precision instructions (2 us of a 9 us iteration).  Here lane i holds row i
+// of the matrix (rows below the pivot are eliminated by all lanes at once, pivot rows travel by v_readlane), the substitutions run on wave-uniform values, and lane
+// j holds column j of the rotation for the retraction: ~250 instructions.  Everything is unrolled: the small matrices are REGISTERS (as dynamically indexed private
+// arrays they landed in scratch memory; as LDS arrays every dependent access paid an LDS round trip).  The 6 divisions by the pivots are refined reciprocals
+// (v_rcp_f64 + three Newton steps: relative error < 2^-52), the exponential's sin / cos factors their Taylor series in theta^2 for the small rotations a tracker
+// update has (|theta| < 1.5: twelve terms, < 1e-16; the library functions beyond).
+__device__ __forceinline__ void track_solve_wave(const double* sum, const TrackState* __restrict__ in, TrackState& out) {
+  const int lane = threadIdx.x & 63;
+  const int i = lane < 6 ? lane : 5, jc = lane < 3 ? lane : 2;
+  const double Ro0 = in->R[jc], Ro1 = in->R[3 + jc], Ro2 = in->R[6 + jc], tin = in->t[jc];   // column jc of R, t[jc]
+  double row[6];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) s += red[q][e];
-    sum[e] = s;
+  for (int q = 0; q < 6; ++q) {
+    const int a = i < q ? i : q, b = i < q ? q : i;   // upper triangle, row-major: (a, b) -> a (13 - a) / 2 + b - a
+    row[q] = (double)(float)sum[(a * (13 - a)) / 2 + (b - a)];
   }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  // Thread 0 solves.  Every loop below is fully unrolled so that the small matrices are REGISTERS (as dynamically indexed private
-  // arrays they landed in scratch memory and made this kernel as slow as the step kernel itself; as LDS arrays every dependent
-  // access paid an LDS round trip: 8.3 us for the kernel, most of a tracker iteration).
-  // reference precision: the item is fp32 (JTJJrReductionItem<float,6>) before the solve (camera_tracker.cpp:59)
-  double A[6][6], bvec[6];
-  {
-    int k = 0;
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-      for (int b = a; b < 6; ++b) { const double v = (double)(float)sum[k++]; A[a][b] = v; A[b][a] = v; }
-#pragma unroll
-    for (int a = 0; a < 6; ++a) bvec[a] = (double)(float)sum[21 + a];
-  }
-  st->last_residual = (float)sum[27];
-  st->last_inliers = (float)sum[28];
-  st->iterations_done += 1;
-  // LDL^T (no pivoting), forward / diagonal / backward substitution.  One thread walks ~600 dependent double-precision operations here, and this kernel is
-  // half of a tracker iteration (5.7 us beside a 5 us step kernel, profiles/r05_tracker.txt): the 21 divisions by the pivots are six refined reciprocals
-  // (v_rcp_f64 + three Newton steps: relative error < 2^-52; a compiler division is ~30 instructions each) and the exponential's sin / cos factors are their
-  // Taylor series in theta^2 for the small rotations a tracker update has (|theta| < 1.5: twelve terms, < 1e-16; the library functions beyond)
+  double acc = (double)(float)sum[21 + i];
+  bool ok = sum[28] > 0.0;
   auto rcp = [](double d) {
     double r = __builtin_amdgcn_rcp(d);
     r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
@@ -454,41 +431,42 @@ __global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__
     r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
     return r;
   };
-  double L[6][6], D[6], Di[6], yv[6], x[6];
-  bool ok = sum[28] > 0.0;
+  double D[6], Di[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    double d = A[j][j];
+    // lanes i > j: L[i][j] = (A[i][j] - sum_q L[i][q] L[j][q] D[q]) / d_j ; lane j itself computes d_j by the same expression
+    double v = row[j];
 #pragma unroll
-    for (int q = 0; q < j; ++q) d -= L[j][q] * L[j][q] * D[q];
+    for (int q = 0; q < j; ++q) v = __builtin_fma(-row[q], bcast(row[q], j) * D[q], v);
+    const double d = bcast(v, j);
     ok = ok && (fabs(d) > 0.0);
     D[j] = d;
     Di[j] = rcp(d);
+    row[j] = v * Di[j];
+  }
+  if (!ok) {   // the pose stays (the update of a failed solve is not applied)
+    if (lane == 0) {
+      out.last_residual = (float)sum[27]; out.last_inliers = (float)sum[28];
+      out.iterations_done = in->iterations_done + 1; out.solver_failures = in->solver_failures + 1;
 #pragma unroll
-    for (int i = j + 1; i < 6; ++i) {
-      double v = A[i][j];
+      for (int q = 0; q < 9; ++q) { out.R[q] = in->R[q]; out.Rf[q] = in->Rf[q]; }
 #pragma unroll
-      for (int q = 0; q < j; ++q) v -= L[i][q] * L[j][q] * D[q];
-      L[i][j] = v * Di[j];
+      for (int q = 0; q < 3; ++q) { out.t[q] = in->t[q]; out.tf[q] = in->tf[q]; }
     }
+    return;
   }
-  if (!ok) { st->solver_failures += 1; return; }
+  double z[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    double v = bvec[i];
-#pragma unroll
-    for (int q = 0; q < i; ++q) v -= L[i][q] * yv[q];
-    yv[i] = v;
+  for (int q = 0; q < 6; ++q) {   // forward: y_q is final in lane q once the lanes above it have been subtracted
+    const double y = bcast(acc, q);
+    acc = __builtin_fma(-row[q], y, acc);
+    z[q] = y * Di[q];
   }
 #pragma unroll
-  for (int i = 5; i >= 0; --i) {
-    double v = yv[i] * Di[i];
+  for (int q = 5; q >= 1; --q)    // backward, on uniform values: x_q = z[q] is final, L[q][i] lives in lane q
 #pragma unroll
-    for (int q = i + 1; q < 6; ++q) v -= L[q][i] * x[q];
-    x[i] = v;
-  }
-  // update = -x ; t += update[0:3] ; R = exp(update[3:6]) * R   (lucas_kanade_se3.h:85-95)
-  const double w0 = -x[3], w1 = -x[4], w2 = -x[5];
+    for (int r = 0; r < q; ++r) z[r] = __builtin_fma(-bcast(row[r], q), z[q], z[r]);
+  const double w0 = -z[3], w1 = -z[4], w2 = -z[5];
   const double th2 = w0 * w0 + w1 * w1 + w2 * w2;
   double Ac, Bc;   // sin(theta) / theta, (1 - cos(theta)) / theta^2
   if (th2 < 2.25) {
@@ -505,45 +483,99 @@ __global__ __launch_bounds__(1024) void k_track_update(const float* __restrict__
     const double th = sqrt(th2);
     Ac = sin(th) / th; Bc = (1.0 - cos(th)) / th2;
   }
-  const double K[3][3] = { { 0, -w2, w1 }, { w2, 0, -w0 }, { -w1, w0, 0 } };
-  double E[3][3], Rn[3][3], Ro[3][3];
+  // exp(w) = I + Ac K + Bc K^2 with K = [w]x, K^2 = w w^T - theta^2 I (its diagonal written without the cancellation)
+  const double p01 = Bc * w0 * w1, p02 = Bc * w0 * w2, p12 = Bc * w1 * w2;
+  const double E00 = 1.0 - Bc * (w1 * w1 + w2 * w2), E01 = p01 - Ac * w2, E02 = p02 + Ac * w1;
+  const double E10 = p01 + Ac * w2, E11 = 1.0 - Bc * (w0 * w0 + w2 * w2), E12 = p12 - Ac * w0;
+  const double E20 = p02 - Ac * w1, E21 = p12 + Ac * w0, E22 = 1.0 - Bc * (w0 * w0 + w1 * w1);
+  const double Rn0 = E00 * Ro0 + E01 * Ro1 + E02 * Ro2, Rn1 = E10 * Ro0 + E11 * Ro1 + E12 * Ro2, Rn2 = E20 * Ro0 + E21 * Ro1 + E22 * Ro2;
+  const double tn = tin - (lane == 0 ? z[0] : lane == 1 ? z[1] : z[2]);
+  if (lane < 3) {
+    out.R[lane] = Rn0; out.R[3 + lane] = Rn1; out.R[6 + lane] = Rn2;
+    out.Rf[lane] = (float)Rn0; out.Rf[3 + lane] = (float)Rn1; out.Rf[6 + lane] = (float)Rn2;
+    out.t[lane] = tn; out.tf[lane] = (float)tn;
+  }
+  if (lane == 0) {
+    out.last_residual = (float)sum[27]; out.last_inliers = (float)sum[28];
+    out.iterations_done = in->iterations_done + 1; out.solver_failures = in->solver_failures;
+  }
+}
+
+// All kT threads of a workgroup: fold `nblocks` partial rows (thread = one float4 column of every 32nd row, up to 16 loads in flight; rows ascending within a
+// thread, row groups ascending in the second stage: the same bits in every workgroup and for every grid size), wave 0 solves into l.st.
+__device__ __forceinline__ void track_fold_and_solve(const float* __restrict__ partials, const int nblocks, const TrackState* __restrict__ in, TrackLds& l) {
+  static_assert(kT == 256 && kSimpleRow == 32, "8 float4 columns x 32 row groups");
+  const int c = threadIdx.x & 7, rg = threadIdx.x >> 3;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  for (int b0 = rg; b0 < nblocks; b0 += 32 * 16) {
+    f32x4 v[16];
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      Ro[i][j] = st->R[i * 3 + j];
-      double k2 = 0;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) k2 += K[i][q] * K[q][j];
-      E[i][j] = (i == j ? 1.0 : 0.0) + Ac * K[i][j] + Bc * k2;
+    for (int q = 0; q < 16; ++q) {
+      const int b = b0 + 32 * q;
+      v[q] = b < nblocks ? *reinterpret_cast<const f32x4*>(partials + (size_t)b * kSimpleRow + c * 4) : f32x4{ 0.f, 0.f, 0.f, 0.f };
     }
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+    for (int q = 0; q < 16; ++q) { s0 += (double)v[q][0]; s1 += (double)v[q][1]; s2 += (double)v[q][2]; s3 += (double)v[q][3]; }
+  }
+  l.red[rg][c * 4 + 0] = s0; l.red[rg][c * 4 + 1] = s1; l.red[rg][c * 4 + 2] = s2; l.red[rg][c * 4 + 3] = s3;
+  __syncthreads();
+  if (threadIdx.x < kSimpleRow) {
+    double s = 0.0;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      double v = 0;
+    for (int q = 0; q < 32; ++q) s += l.red[q][threadIdx.x];
+    l.sum[threadIdx.x] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) track_solve_wave(l.sum, in, l.st);
+  __syncthreads();
+}
+
+// blockIdx.y = candidate: Relocalize / the loop-closure geometry checks track ONE live frame against N keyframes
+// (deepfactors.cpp:713-743, loop_detector.cpp:146-167); descriptors, states and partials are arrays over candidates.
+// nblocks_prev == 0: the first evaluation of a frame, at states_in as the host wrote it.
+__global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev* __restrict__ descs, const TrackState* __restrict__ states_in, TrackState* __restrict__ states_out,
+                                                     const float* __restrict__ partials_prev, const int nblocks_prev, const int W, const int H,
+                                                     const float huber_delta, float* __restrict__ partials_all) {
+  const SimplePairDev& p = descs[blockIdx.y];
+  float* partials = partials_all + (size_t)blockIdx.y * gridDim.x * kSimpleRow;
+  __shared__ TrackLds l;
+  float R[9], t[3], e1, e2;
+  if (nblocks_prev > 0) {
+    track_fold_and_solve(partials_prev + (size_t)blockIdx.y * nblocks_prev * kSimpleRow, nblocks_prev, states_in + blockIdx.y, l);
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(TrackState) / 4) reinterpret_cast<uint32_t*>(states_out + blockIdx.y)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&l.st)[threadIdx.x];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) v += E[i][q] * Ro[q][j];
-      Rn[i][j] = v;
-    }
+    for (int q = 0; q < 9; ++q) R[q] = rfl(l.st.Rf[q]);   // wave-uniform: scalar registers, as the loads of the other branch
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+    for (int q = 0; q < 3; ++q) t[q] = rfl(l.st.tf[q]);
+  } else {
+    const TrackState* st = states_in + blockIdx.y;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { st->R[i * 3 + j] = Rn[i][j]; st->Rf[i * 3 + j] = (float)Rn[i][j]; }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) { st->t[i] -= x[i]; st->tf[i] = (float)st->t[i]; }
+    for (int q = 0; q < 9; ++q) R[q] = st->Rf[q];
+    t[0] = st->tf[0]; t[1] = st->tf[1]; t[2] = st->tf[2];
+  }
+  fast_band(R, t, p.fc, e1, e2);   // the descriptor's band belongs to the pose it was filled with, not to the state's
+  se3_step_body(p, R, t, e1, e2, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
+}
+
+// the update behind the last evaluation of a frame
+// (states_out: the caller's mapped host buffer -- the result needs no copy engine behind this kernel)
+__global__ __launch_bounds__(kT) void k_track_final(const float* __restrict__ partials_prev, const int nblocks_prev, const TrackState* __restrict__ states_in,
+                                                    TrackState* __restrict__ states_out) {
+  __shared__ TrackLds l;
+  track_fold_and_solve(partials_prev + (size_t)blockIdx.x * nblocks_prev * kSimpleRow, nblocks_prev, states_in + blockIdx.x, l);
+  if (threadIdx.x < sizeof(TrackState) / 4) reinterpret_cast<uint32_t*>(states_out + blockIdx.x)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&l.st)[threadIdx.x];
 }
 
 size_t track_state_bytes() { return sizeof(TrackState); }
 
-hipError_t launch_track_iteration(const SimplePairDev* descs_dev, int n, void* states_dev, int W, int H, float huber_delta, int blocks,
-                                  float* partials_dev, hipStream_t stream) {
-  hipLaunchKernelGGL(k_se3_step_dev, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (const TrackState*)states_dev, W, H, huber_delta, partials_dev);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  if (blocks <= 128) hipLaunchKernelGGL(k_track_update<4>, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (TrackState*)states_dev);
-  else if (blocks <= 512) hipLaunchKernelGGL(k_track_update<16>, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (TrackState*)states_dev);
-  else hipLaunchKernelGGL(k_track_update<32>, dim3(n), dim3(1024), 0, stream, (const float*)partials_dev, blocks, (TrackState*)states_dev);
+hipError_t launch_track_iteration(const SimplePairDev* descs_dev, int n, const void* states_in, void* states_out, const float* partials_prev, int blocks_prev,
+                                  int W, int H, float huber_delta, int blocks, float* partials_dev, hipStream_t stream) {
+  hipLaunchKernelGGL(k_se3_step_dev, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (const TrackState*)states_in, (TrackState*)states_out, partials_prev, blocks_prev, W, H,
+                     huber_delta, partials_dev);
+  return hipGetLastError();
+}
+hipError_t launch_track_final(int n, const void* states_in, void* states_out, const float* partials_prev, int blocks_prev, hipStream_t stream) {
+  hipLaunchKernelGGL(k_track_final, dim3(n), dim3(kT), 0, stream, partials_prev, blocks_prev, (const TrackState*)states_in, (TrackState*)states_out);
   return hipGetLastError();
 }
 

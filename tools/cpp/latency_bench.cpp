@@ -74,6 +74,37 @@ int main() {
     timeit("SfmAligner<32>::EvaluateError 640x480", 300, [&] { (void)sfm.EvaluateError(p0, p1, cam, v0, v1, vd, vd, vg); });
     timeit("UpdateDepth<32> 640x480", 300, [&] { df::UpdateDepth<float, CS>(code, vd, vj, 2.0f, vo); });
     timeit("SobelGradients 640x480", 300, [&] { df::SobelGradients(v1, vg); });
+    {
+      // CameraTracker::TrackFrame as ONE call (dfx_track_frame: 3 levels, 10 / 5 / 5 iterations from the coarsest -- BASELINE.json configs[0]'s schedule): the
+      // live image is the keyframe image moved by two pixels, levels 1-2 from dfx_build_pyramid (depth: the level-0 depth's top-left quarter, a timing stand-in)
+      dfx_ctx* c = dfx::Context::Default()->get();
+      std::vector<float> moved((size_t)W * H);
+      for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) moved[(size_t)y * W + x] = img[(size_t)y * W + (x + 2 < W ? x + 2 : W - 1)];
+      (void)hipMemcpy(d_img1, moved.data(), moved.size() * 4, hipMemcpyHostToDevice);
+      dfx_pyramid py0{}, py1{};
+      py0.levels = py1.levels = 3;
+      dfx_track_level lv[3];
+      for (int l = 0; l < 3; ++l) {
+        const uint32_t w = W >> l, h = H >> l;
+        float *a = d_img0, *b = d_img1; Grad2* g = d_grad;
+        if (l) { (void)hipMalloc(&a, (size_t)w * h * 4); (void)hipMalloc(&b, (size_t)w * h * 4); }
+        if (l) (void)hipMalloc(&g, (size_t)w * h * 8);
+        py0.img[l] = dfx_img{ a, (size_t)w * 4, w, h }; py1.img[l] = dfx_img{ b, (size_t)w * 4, w, h };
+        py0.grad[l] = dfx_img{ nullptr, 0, 0, 0 }; py1.grad[l] = dfx_img{ g, (size_t)w * 8, w, h };
+        const float sc = 1.f / (float)(1 << l);
+        lv[l].cam = dfx_cam{ cam.fx() * sc, cam.fy() * sc, (cam.u0() + 0.5f) * sc - 0.5f, (cam.v0() + 0.5f) * sc - 0.5f, (float)w, (float)h };
+        lv[l].img0 = py0.img[l]; lv[l].img1 = py1.img[l]; lv[l].grad1 = py1.grad[l];
+        lv[l].dpt0 = dfx_img{ d_dpt, (size_t)W * 4, w, h };
+        lv[l].iterations = l == 2 ? 10 : 5;
+      }
+      if (dfx_build_pyramid(c, &py0) != DFX_OK || dfx_build_pyramid(c, &py1) != DFX_OK) { std::printf("dfx_build_pyramid: %s\n", dfx_last_error()); return 1; }
+      const dfx_se3 init{ { 0, 0, 0, 1 }, { 0, 0, 0 } };
+      dfx_track_result res{};
+      if (dfx_track_frame(c, &init, lv, 3, 0.1f, &res) != DFX_OK) { std::printf("dfx_track_frame: %s\n", dfx_last_error()); return 1; }
+      std::printf("dfx_track_frame: %d iterations, %d failed solves, inliers %.3f, t = (%.4f %.4f %.4f)\n", res.iterations, res.solver_failures, res.inliers_frac, res.pose_ck.t[0],
+                  res.pose_ck.t[1], res.pose_ck.t[2]);
+      timeit("dfx_track_frame 640x480, 3 levels, 20 iterations", 300, [&] { (void)dfx_track_frame(c, &init, lv, 3, 0.1f, &res); });
+    }
   } catch (const std::exception& e) {
     std::printf("exception: %s\n", e.what());
     return 1;

@@ -38,7 +38,7 @@ for spec in "$@"; do
     case "$p" in
       tag=*) tag=_${p#tag=};;
       [A-Z_]*=*) envs+=("$p");;
-      *) args="$args${args:+:}$p";;
+      *) args="$args${args:+:}$p";;   # (arguments of one step are separated by spaces inside the quoted spec, not by colons)
     esac
   done
   case "$step" in
@@ -93,7 +93,7 @@ PY
            tail -c 600 $OUT/bench_rccl_1rank$tag.json | cut -c1-600;;
     gnround) { timeout 200 tests/cpp/gn_round_bench 16 7; timeout 300 tests/cpp/gn_round_bench 64 3 16; } > $OUT/gn_round_cpp$tag.txt 2>&1 < /dev/null; rc=$?; cat $OUT/gn_round_cpp$tag.txt;;
     latency) timeout 120 tests/cpp/latency_bench > $OUT/latency_cpp$tag.txt 2>&1 < /dev/null; rc=$?; tail -14 $OUT/latency_cpp$tag.txt;;
-    cpp) rc=0; for t in shim_test host_test host_logic_test comm_test ref_callers_test; do [ -x tests/cpp/$t ] && { DFX_RCCL_LIB=${DFX_RCCL_LIB:-} timeout 300 tests/cpp/$t 2>&1 | tail -2; r=${PIPESTATUS[0]}; [ $r -ne 0 ] && rc=$r; }; done > $OUT/cpp_tests$tag.txt 2>&1 < /dev/null; cat $OUT/cpp_tests$tag.txt;;
+    cpp) rc=0; for t in shim_test host_test host_logic_test comm_test ref_callers_test; do [ -x tests/cpp/$t ] && { e=(); [ $t = comm_test ] && e=(DFX_RCCL_LIB=$PWD/tests/cpp/librccl_stub.so); env "${e[@]}" timeout 300 tests/cpp/$t 2>&1 | tail -2; r=${PIPESTATUS[0]}; [ $r -ne 0 ] && rc=$r; }; done > $OUT/cpp_tests$tag.txt 2>&1 < /dev/null; cat $OUT/cpp_tests$tag.txt;;
     tracker) timeout 120 python tools/profile_tracker.py > $OUT/tracker$tag.json 2>/dev/null < /dev/null; rc=$?; tail -2 $OUT/tracker$tag.json;;
     clocks) timeout 120 python tools/idle_gap_probe.py --idle-us 0 --seconds 3 > $OUT/clock_power_steady$tag.txt 2>&1 < /dev/null; rc=$?; grep "^idle" $OUT/clock_power_steady$tag.txt;;
     run) env "${envs[@]}" timeout 600 bash -c "$args" > $OUT/run_$n$tag.log 2>&1 < /dev/null; rc=$?; tail -20 $OUT/run_$n$tag.log;;
