@@ -508,9 +508,11 @@ def gauss_newton_round(dfx, synth, ctx, al, kfs, graph, poses, reps=8, serial=Tr
         import contextlib
         blas_limit = contextlib.nullcontext
     stages = dict(marshal_ms=[], gpu_ms=[], d2h_ms=[], host_system_ms=[], host_solve_ms=[], update_ms=[], total_ms=[])
+    arr = pairs_of(poses)                                # images, cameras: once per graph
+    gi, gj = np.asarray(graph.pairs, np.int64)[:, 0], np.asarray(graph.pairs, np.int64)[:, 1]
     for rep in range(reps + 2):
         t = [time.perf_counter()]
-        arr = pairs_of(poses)
+        al.set_poses_all(arr, poses, gi, gj)             # poses: every round
         t.append(time.perf_counter())
         dfx.UpdateDepthBatch(codes, prx, jac, 2.0, dpt, ctx=ctx)
         al.RunStepBatchAssembleAsync(arr, items, neq, 0)
@@ -538,7 +540,7 @@ def gauss_newton_round(dfx, synth, ctx, al, kfs, graph, poses, reps=8, serial=Tr
                 stages[name].append((t[b] - t[a]) * 1e3)
     out = {k: float(np.median(v)) for k, v in stages.items()}
     out.update(keyframes=K, pairs=n_pairs, unknowns=int(keep.sum()), system_bytes=int(neq.buf.numel() * 4),
-               note="one Gauss-Newton iteration end to end (median of %d): pair descriptors (host) | batched UpdateDepth + batched RunStep + assembly (GPU, to sync) | D2H of the "
+               note="one Gauss-Newton iteration end to end (median of %d): the round's poses into the pair descriptors (host; images marshalled once per graph) | batched UpdateDepth + batched RunStep + assembly (GPU, to sync) | D2H of the "
                     "block-sparse system | dense host system | scipy Cholesky (LAPACK, 8 threads) | retract" % reps)
     if serial:
         # the reference's per-factor pattern over the same factor set

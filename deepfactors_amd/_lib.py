@@ -119,6 +119,8 @@ _PROTOS = {
     "dfx_debug_read_partials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "dfx_img_alloc": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t, C.POINTER(Img)]),
     "dfx_img_free": (C.c_int, [C.c_void_p, C.POINTER(Img)]),
+    "dfx_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "dfx_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dfx_img_upload": (C.c_int, [C.c_void_p, C.POINTER(Img), C.c_void_p, C.c_size_t, C.c_size_t]),
     "dfx_img_download": (C.c_int, [C.c_void_p, C.POINTER(Img), C.c_void_p, C.c_size_t, C.c_size_t]),
     "dfx_img_fill_f32": (C.c_int, [C.c_void_p, C.POINTER(Img), C.c_float]),

@@ -389,6 +389,17 @@ class SfmAligner:
     def set_poses(self, arr, k, pose0, pose1):
         arr[k].pose0, arr[k].pose1 = _se3(pose0), _se3(pose1)
 
+    @staticmethod
+    def set_poses_all(arr, poses, idx0, idx1):
+        """A relinearisation round moves poses, not images: rewrite pose0 = poses[idx0[k]], pose1 = poses[idx1[k]] of EVERY record of a make_pairs()
+        array in place (numpy views over the ctypes array, no per-pair Python) -- the image half of the records is marshalled once per graph.
+        poses: [K][7] (x y z w tx ty tz), idx0 / idx1: [n] keyframe indices (e.g. the two columns of PairGraph.pairs)."""
+        n = len(arr)
+        P = np.ascontiguousarray(np.asarray(poses, np.float32).reshape(-1, 7))
+        raw = np.frombuffer(arr, dtype=np.uint8).reshape(n, C.sizeof(SfmPair))
+        for field, idx in ((SfmPair.pose0, idx0), (SfmPair.pose1, idx1)):
+            raw[:, field.offset:field.offset + 28] = P[np.asarray(idx, np.int64)].view(np.uint8).reshape(n, 28)
+
     def RunStepBatchAsync(self, pair_array, out_items_dev):
         """Enqueue one batched launch; results land in `out_items_dev` (uint8 CUDA tensor, n*item_size bytes)."""
         n = len(pair_array)

@@ -820,6 +820,25 @@ DFX_API int dfx_img_alloc(dfx_ctx* c, uint32_t w, uint32_t h, size_t elem_bytes,
   return DFX_OK;
 }
 
+DFX_API int dfx_host_alloc(dfx_ctx* c, size_t bytes, void** out) {
+  if (!c || !out || bytes == 0) return fail(DFX_E_INVALID, "dfx_host_alloc: null argument / zero size");
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  void* p = nullptr;
+  DFX_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+  *out = p;
+  return DFX_OK;
+}
+DFX_API int dfx_host_free(dfx_ctx* c, void* ptr) {
+  if (!c) return fail(DFX_E_INVALID, "dfx_host_free: null context");
+  if (!ptr) return DFX_OK;
+  int rc;
+  if ((rc = ensure_device(c))) return rc;
+  DFX_HIP(hipStreamSynchronize(c->stream));   // a copy into it may still be in flight
+  DFX_HIP(hipHostFree(ptr));
+  return DFX_OK;
+}
+
 DFX_API int dfx_img_free(dfx_ctx* c, dfx_img* img) {
   if (!c || !img) return fail(DFX_E_INVALID, "dfx_img_free: null argument");
   int rc;

@@ -186,10 +186,18 @@ class NormalEquations:
         M = np.zeros((K * D, K * D), np.float64)
         for k in range(K):
             M[k * D:(k + 1) * D, k * D:(k + 1) * D] = Hd[k]
-        for p, (a, c) in enumerate(self.graph.pairs):
-            a, c = int(a), int(c)
-            M[a * D:(a + 1) * D, c * D:c * D + 6] += Ho[p]
-            M[c * D:c * D + 6, a * D:(a + 1) * D] += Ho[p].T
+        pr = np.asarray(self.graph.pairs, np.int64).reshape(P, 2)
+        if len({(int(a), int(c)) for a, c in pr}) == P:
+            # every directed pair once: the [D x 6] blocks of one statement do not overlap each other, so two indexed += place them all
+            rows = (pr[:, 0, None] * D + np.arange(D))[:, :, None]          # [P][D][1]
+            cols = (pr[:, 1, None] * D + np.arange(6))[:, None, :]          # [P][1][6]
+            M[rows, cols] += Ho
+            M[cols.transpose(0, 2, 1), rows.transpose(0, 2, 1)] += Ho.transpose(0, 2, 1)
+        else:
+            for p, (a, c) in enumerate(pr):
+                a, c = int(a), int(c)
+                M[a * D:(a + 1) * D, c * D:c * D + 6] += Ho[p]
+                M[c * D:c * D + 6, a * D:(a + 1) * D] += Ho[p].T
         return M, b[nd + no:].astype(np.float64)
 
     def dense(self):

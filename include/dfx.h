@@ -214,6 +214,11 @@ DFX_API int dfx_img_free(dfx_ctx* ctx, dfx_img* img);
 DFX_API int dfx_img_upload(dfx_ctx* ctx, const dfx_img* dst, const void* host, size_t host_pitch_bytes, size_t elem_bytes);
 DFX_API int dfx_img_download(dfx_ctx* ctx, const dfx_img* src, void* host, size_t host_pitch_bytes, size_t elem_bytes);
 DFX_API int dfx_img_fill_f32(dfx_ctx* ctx, const dfx_img* dst, float value);
+/* Page-locked host memory for LARGE results (no reference counterpart: its host buffers are pageable and its results are 100-byte items).  The rows of a
+ * whole graph's SparseGeometricFactors are 150 MB per round at 1024 factors; into pageable memory that copy runs at ~5 GB/s and costs more than every kernel
+ * of the round together, into a buffer from here at link speed.  Any host pointer is accepted by the blocking entries; this only makes the copy fast. */
+DFX_API int dfx_host_alloc(dfx_ctx* ctx, size_t bytes, void** out);
+DFX_API int dfx_host_free(dfx_ctx* ctx, void* ptr);
 /* Debug / tests: copies the valid0 shadow of a library-owned image to the host (one uint64 per 64 pixels of the linear index y*w + x,
  * bit = pixel known to hold 1.0).  *n_words = 0 when the image has no shadow (foreign memory, or never used as valid0). */
 DFX_API int dfx_debug_read_valid0_shadow(dfx_ctx* ctx, const dfx_img* img, uint64_t* host_words, size_t cap_words, size_t* n_words);

@@ -475,4 +475,42 @@ std::vector<float> SparseGeometricLinearizeAll(const std::vector<SparseGeometric
   return rows;
 }
 
+// Page-locked host memory (dfx_host_alloc) for large results that come back every round: the rows of a 1024-factor graph are 150 MB, and a fresh pageable
+// std::vector per round costs more in page faults and a 5 GB/s copy than every kernel of the round.
+template <typename T>
+class PinnedBuffer {
+ public:
+  PinnedBuffer(std::size_t n, std::shared_ptr<Context> c) : ctx_(std::move(c)), n_(n) { void* p = nullptr; check(dfx_host_alloc(ctx_->get(), n * sizeof(T), &p)); p_ = static_cast<T*>(p); }
+  ~PinnedBuffer() { (void)dfx_host_free(ctx_->get(), p_); }
+  PinnedBuffer(const PinnedBuffer&) = delete;
+  PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+  T* data() { return p_; }
+  const T* data() const { return p_; }
+  std::size_t size() const { return n_; }
+  T& operator[](std::size_t i) { return p_[i]; }
+  const T& operator[](std::size_t i) const { return p_[i]; }
+
+ private:
+  std::shared_ptr<Context> ctx_;
+  T* p_ = nullptr;
+  std::size_t n_;
+};
+
+// the round's rows into a buffer the caller keeps across rounds (factor k's rows start at (points of the factors before it) * kCols); returns the row count
+template <int CS>
+std::size_t SparseGeometricLinearizeAll(const std::vector<SparseGeometricFactor<CS>*>& factors, const std::vector<GeoValues<CS>>& values, PinnedBuffer<float>& rows_host) {
+  if (factors.empty() || factors.size() != values.size()) throw Error(DFX_E_INVALID, "SparseGeometricLinearizeAll: one value tuple per factor");
+  std::vector<dfx_sparse_geo_factor> d;
+  std::size_t total = 0;
+  for (std::size_t k = 0; k < factors.size(); ++k) {
+    if (factors[k]->huber_delta() != factors[0]->huber_delta() || factors[k]->avg_dpt() != factors[0]->avg_dpt() || factors[k]->ctx() != factors[0]->ctx())
+      throw Error(DFX_E_INVALID, "SparseGeometricLinearizeAll: the factors of a round share huber_delta, avg_dpt and the context");
+    d.push_back(factors[k]->Describe(values[k].pose0, values[k].pose1, values[k].code0, values[k].code1));
+    total += (std::size_t)factors[k]->n_points();
+  }
+  if (rows_host.size() < total * SparseGeometricFactor<CS>::kCols) throw Error(DFX_E_INVALID, "SparseGeometricLinearizeAll: row buffer too small");
+  check(dfx_sparse_geometric_linearize_batch(factors[0]->ctx(), CS, d.data(), (int)d.size(), factors[0]->huber_delta(), factors[0]->avg_dpt(), rows_host.data()));
+  return total;
+}
+
 }  // namespace dfx
