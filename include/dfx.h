@@ -242,8 +242,10 @@ DFX_API int dfx_se3_warp(dfx_ctx* ctx, const dfx_se3* pose_10, const dfx_cam* ca
 
 /* ---- CameraTracker::TrackFrame (core/system/camera_tracker.cpp:42-71), device-resident -------
  * The reference loops on the host: RunStep (kernel + finalize + sync + 120-byte copy) -> 6x6 ldlt().solve -> retract, per
- * iteration.  Here the whole coarse-to-fine schedule is enqueued at once: the pose stays in device memory, the solve
- * (LDL^T in double) and the update (t += dt, R = exp(dw) R) run in the finalize kernel; one copy back at the end.
+ * iteration.  Here the whole coarse-to-fine schedule is enqueued at once, one launch per iteration: the pose stays in device memory, and
+ * every workgroup of an iteration first folds the previous evaluation's partial sums (double, fixed order), solves the 6x6 system (LDL^T
+ * in double) and applies the update (t += dt, R = exp(dw) R) -- all workgroups compute the same bits, so nothing is handed over across the
+ * grid --, then evaluates its rows at the new pose.  The last update is stored into mapped host memory; the call returns after one stream wait.
  * levels[0] is the finest level; levels are processed from n_levels-1 down to 0 with levels[l].iterations steps each. */
 typedef struct dfx_track_level {
   dfx_cam cam;
