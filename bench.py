@@ -935,10 +935,23 @@ def main():
 
     # The exchange.  cabi (default): the library's own collectives -- a dfx_comm created over RCCL from a unique id that rank 0 hands to the others over the
     # process group, then per step dfx_comm_reduce_f32_async on the context's exchange stream (what dfx_graph_reduce_async issues for the graph's system).
-    comm = None
+    comm, exchange_note = None, None
     if dist is not None and a.exchange == "cabi":
         from deepfactors_amd.dist import Comm
-        comm = Comm.create(ctx, dist, rank, world, dev)
+        try:
+            comm = Comm.create(ctx, dist, rank, world, dev)
+            err = ""
+        except Exception as e:   # noqa: BLE001 -- e.g. an RCCL without an entry point dfx_comm.cpp resolves
+            err = f"{type(e).__name__}: {e}"
+        # the ranks agree: one rank without a communicator puts every rank on the process group's exchange (said in config.exchange), instead of N - 1 ranks
+        # waiting in a collective the last one never joins
+        okf = torch.tensor([0.0 if err else 1.0], device=dev)
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if float(okf.item()) < 1.0:
+            if comm is not None:
+                comm.close()
+            comm, exchange_note = None, "torch (dfx_comm_create failed on a rank" + (": " + err[:200] if err else "") + ")"
+            print(f"[rank {rank}] C-ABI communicator unavailable, exchanging through torch.distributed {err}", file=sys.stderr)
 
     # Deferred tail: consecutive steps are independent batches, so the reduction tail of step k (the tail kernel with the graph assembly, and the RCCL reduce of
     # its system) can run on a second stream beside the 1 ms step kernel of step k + 1 (dfx_set_tail_stream).  Opt-in for one rank (--deferred-tail: -0.5 % step time
@@ -1031,7 +1044,7 @@ def main():
                                    + ("; the reduction tail of step k (finalize, assembly" + (", reduce" if world > 1 else "") + ") runs on a second stream beside the kernel of step k + 1"
                                       if tail is not None else ""),
                        "pairs_per_gpu": P, "width": W, "height": H, "code_size": CS,
-                       "parallelism": f"pairs sharded over {world} GPU(s)", "exchange": ("cabi" if comm is not None else ("torch" if dist is not None else "none"))},
+                       "parallelism": f"pairs sharded over {world} GPU(s)", "exchange": ("cabi" if comm is not None else ((exchange_note or "torch") if dist is not None else "none"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": f"k_sfm_step<NCB={CS // 16}, {'bf16x3' if mode_ran == _dl.DFX_MFMA_BF16X3 else 'f32 chain'}, {'dynamic' if dyn_ran else 'static'}>",
                          "kernel_us": kern_s * 1e6, "kernel_us_min": pr["kern_min_ms"] * 1e3, "kernel_us_max": pr["kern_max_ms"] * 1e3, "launches": n_launch,

@@ -231,14 +231,24 @@ class Comm:
         """Collective over the ranks of `dist` (None: a world of one)."""
         from . import _lib
         L = _lib.lib()
-        uid = torch.zeros(_lib.DFX_COMM_ID_BYTES, dtype=torch.uint8, device=device)
+        # the id travels with a status byte: a rank 0 that cannot draw an id (no RCCL to load) tells the others instead of leaving them in the broadcast
+        uid = torch.zeros(_lib.DFX_COMM_ID_BYTES + 1, dtype=torch.uint8, device=device)
+        err = None
         if rank == 0:
             raw = (C.c_ubyte * _lib.DFX_COMM_ID_BYTES)()
-            _lib.check(L.dfx_comm_get_unique_id(raw))
-            uid.copy_(torch.tensor(list(raw), dtype=torch.uint8))
+            try:
+                _lib.check(L.dfx_comm_get_unique_id(raw))
+                uid.copy_(torch.tensor(list(raw) + [1], dtype=torch.uint8))
+            except Exception as e:   # noqa: BLE001
+                err = e
         if dist is not None and world > 1:
             dist.broadcast(uid, 0)
-        raw = (C.c_ubyte * _lib.DFX_COMM_ID_BYTES)(*[int(v) for v in uid.cpu().tolist()])
+        host = [int(v) for v in uid.cpu().tolist()]
+        if err is not None:
+            raise err
+        if host[-1] != 1:
+            raise _lib.DfxError(_lib.DFX_E_HIP, "rank 0 could not draw a communicator id (dfx_comm_get_unique_id failed there)")
+        raw = (C.c_ubyte * _lib.DFX_COMM_ID_BYTES)(*host[:-1])
         h = C.c_void_p()
         _lib.check(L.dfx_comm_create(getattr(ctx, "handle", None), raw, int(rank), int(world), C.byref(h)))
         return Comm(h, rank, world)

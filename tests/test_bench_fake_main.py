@@ -246,8 +246,8 @@ def _stub():
     return STUB
 
 
-def _rank(rank, world, port, outdir, exchange):
-    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DFX_RCCL_LIB=STUB)
+def _rank(rank, world, port, outdir, exchange, rccl=STUB):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DFX_RCCL_LIB=rccl)
     _run_main(["--gpus", str(world), "--window", "--exchange", exchange] + ARGS, os.path.join(outdir, f"rank{rank}.txt"))
 
 
@@ -266,6 +266,16 @@ def test_main_two_ranks_over_gloo(tmp_path, exchange):
     assert "not collected for N > 1" in d["roofline"]["traffic_source"] and "cpu_baseline" not in d
     w = d["configs"]["configs3_window64"]                               # --window: BASELINE configs[3] sharded over the two ranks
     assert w["keyframes"] == 64 and w["pairs"] == 1024 and w["pairs_per_rank"] == 512 and w["evals_per_s"] > 0
+
+
+def test_main_two_ranks_fall_back_together_when_the_communicator_cannot_be_created(tmp_path):
+    """A rank whose dfx_comm_create fails (here: an RCCL library that cannot be loaded) must not leave the others waiting in a collective: the ranks agree over
+    the process group, all of them exchange through torch.distributed, and the line says so."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_rank, args=(2, port, str(tmp_path), "cabi", "/nonexistent/librccl.so"), nprocs=2, join=True)
+    d = json.loads((tmp_path / "rank0.txt").read_text().strip().splitlines()[-1])
+    assert d["config"]["exchange"].startswith("torch (dfx_comm_create failed") and d["n_gpus"] == 2 and d["value"] > 0
+    assert "C ABI" not in d["config"]["workload"]
 
 
 def test_main_with_the_secondary_configurations(tmp_path, monkeypatch):
