@@ -129,6 +129,12 @@ struct dfx_ctx {
   int stage_next = 0;
   char* result_host = nullptr;
   size_t result_bytes = 0;
+  // blocking single-result calls: the call's last kernel stores done_seq behind the result and the host polls the word (dfx_kernels.hpp, DoneFlag)
+  uint32_t* done_flag_host = nullptr;   // pinned, mapped, coherent
+  uint32_t* done_flag_dev = nullptr;
+  unsigned* done_counter = nullptr;     // device: arrivals of a multi-workgroup finalize kernel, zero between calls
+  uint32_t done_seq = 0;
+  dfx::DoneFlag* done_armed = nullptr;        // set by a blocking entry around the one impl call whose finalize kernel is to signal
   void* track_state_dev = nullptr;   // [TrackState x n][SimplePairDev x levels x n]
   size_t track_bytes = 0;
   char* sg_dev = nullptr;      // sparse geometric: codes + points + rows
@@ -270,6 +276,45 @@ int result_target(dfx_ctx* c, size_t bytes, void** dev_ptr) {
 }
 int finish_result(dfx_ctx* c, void* host_out, size_t bytes) {
   DFX_HIP(hipStreamSynchronize(c->stream));
+  std::memcpy(host_out, c->result_host, bytes);
+  return DFX_OK;
+}
+// The polled form (DoneFlag in dfx_kernels.hpp; DFX_POLL_RESULT=0 turns it off: every blocking call then waits for the stream as above).
+bool poll_results() {
+  static const bool on = [] { const char* ev = std::getenv("DFX_POLL_RESULT"); return !(ev && ev[0] == '0'); }();
+  return on;
+}
+// a flag for one call: *d stays empty when polling is off (the launchers then signal nothing and finish_result_polled waits for the stream)
+int new_done_flag(dfx_ctx* c, dfx::DoneFlag* d) {
+  *d = dfx::DoneFlag{};
+  if (!poll_results()) return DFX_OK;
+  if (!c->done_flag_host) {
+    DFX_HIP(hipHostMalloc((void**)&c->done_flag_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    c->done_flag_host[0] = 0;
+    void* dp = nullptr;
+    DFX_HIP(hipHostGetDevicePointer(&dp, c->done_flag_host, 0));
+    c->done_flag_dev = static_cast<uint32_t*>(dp);
+    DFX_HIP(hipMalloc((void**)&c->done_counter, 64));
+    DFX_HIP(hipMemsetAsync(c->done_counter, 0, 64, c->stream));
+  }
+  if (++c->done_seq == 0) c->done_seq = 1;
+  d->flag = c->done_flag_dev; d->seq = c->done_seq; d->counter = c->done_counter;
+  return DFX_OK;
+}
+int finish_result_polled(dfx_ctx* c, void* host_out, size_t bytes, const dfx::DoneFlag& d) {
+  if (!d.flag) return finish_result(c, host_out, bytes);
+  const uint32_t* f = c->done_flag_host;
+  for (unsigned spins = 1;; ++spins) {
+    if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == d.seq) break;
+    if ((spins & 0x3fff) == 0) {   // every 16384 polls (a few hundred microseconds): a failed launch or a faulted queue never writes the flag
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q == hipSuccess) {
+        if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == d.seq) break;
+        return fail(DFX_E_HIP, "the stream drained without the result flag (sequence %u)", d.seq);
+      }
+      if (q != hipErrorNotReady) return fail(DFX_E_HIP, "stream failed while waiting for a result: %s", hipGetErrorString(q));
+    }
+  }
   std::memcpy(host_out, c->result_host, bytes);
   return DFX_OK;
 }
@@ -643,6 +688,8 @@ DFX_API void dfx_ctx_destroy(dfx_ctx* c) {
   if (c->qhead) (void)hipFree(c->qhead);
   if (c->node_cnt) (void)hipFree(c->node_cnt);
   if (c->track_state_dev) (void)hipFree(c->track_state_dev);
+  if (c->done_flag_host) (void)hipHostFree(c->done_flag_host);
+  if (c->done_counter) (void)hipFree(c->done_counter);
   if (c->sg_dev) (void)hipFree(c->sg_dev);
   if (c->pyr_dev) (void)hipFree(c->pyr_dev);
   for (auto& t : c->ray_tabs) (void)hipFree(t.dev);
@@ -1132,9 +1179,12 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
   }
   hipStream_t const fin_stream = defer ? c->tail_stream : c->stream;
   bool assembled = false;
+  dfx::DoneFlag* dn = c->done_armed;   // (blocking single-pair entries; launch_sfm_step clears the flag when the launch has no signalling tail)
+  if (dn && (graph || defer)) { dn->flag = nullptr; dn = nullptr; }
   DFX_HIP(dfx::launch_sfm_step(cs, dd, n, (int)W, (int)H, prm, bpp, partials, out_items_dev, dfx_item_size(12 + cs), c->stream,
                                jac_dense, resolve_mfma(c, cs), eb, ee, n == 1 ? &one : nullptr, dyn.qhead ? &dyn : nullptr, dyn_grid, vsh,
-                               fin_stream, defer ? c->ev_mid[par] : nullptr, map_dev, total_blocks, graph ? &tg : nullptr, node_wgs, &assembled));
+                               fin_stream, defer ? c->ev_mid[par] : nullptr, map_dev, total_blocks, graph ? &tg : nullptr, node_wgs, &assembled,
+                               dn));
   c->qhead_dirty = false;   // both kernels are enqueued: the finalize kernel rewinds the heads
   if (graph) {
     c->node_cnt_dirty = false;   // the tail kernel rewinds the counters it used
@@ -1273,8 +1323,13 @@ DFX_API int dfx_sfm_step_batch(dfx_ctx* c, int cs, const dfx_sfm_params* params,
   if (bytes <= kDirectResultMax) {
     void* tgt;
     if ((rc = result_target(c, bytes, &tgt))) return rc;
-    if ((rc = sfm_step_batch_impl(c, cs, params, pairs, n, tgt, false))) return rc;
-    return finish_result(c, out_items_host, bytes);
+    dfx::DoneFlag done;
+    if (n == 1 && (rc = new_done_flag(c, &done))) return rc;   // a single pair (the reference's per-factor call): the finalize kernel signals, the host polls
+    c->done_armed = done.flag ? &done : nullptr;
+    rc = sfm_step_batch_impl(c, cs, params, pairs, n, tgt, false);
+    c->done_armed = nullptr;
+    if (rc) return rc;
+    return finish_result_polled(c, out_items_host, bytes, done);
   }
   if (c->items_bytes < bytes) DFX_HIP(hipStreamSynchronize(c->stream));
   if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, bytes, c->stream))) return rc;
@@ -1315,8 +1370,10 @@ DFX_API int dfx_sfm_error(dfx_ctx* c, const dfx_se3* pose0, const dfx_se3* pose1
   if ((rc = grow_partials(c, pbytes))) return rc;
   void* tgt;
   if ((rc = result_target(c, sizeof(dfx_corr_item), &tgt))) return rc;
-  DFX_HIP(dfx::launch_sfm_error(d, (int)img0->w, (int)img0->h, params->huber_delta, blocks, c->partials, tgt, c->stream));
-  return finish_result(c, out, sizeof(dfx_corr_item));
+  dfx::DoneFlag done;
+  if ((rc = new_done_flag(c, &done))) return rc;
+  DFX_HIP(dfx::launch_sfm_error(d, (int)img0->w, (int)img0->h, params->huber_delta, blocks, c->partials, tgt, c->stream, done));
+  return finish_result_polled(c, out, sizeof(dfx_corr_item), done);
 }
 
 // ---- batched EvaluateError / SE3 step -------------------------------------------------------------------------------
@@ -1494,8 +1551,10 @@ DFX_API int dfx_se3_step(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam,
   if ((rc = grow_partials(c, pbytes))) return rc;
   void* tgt;
   if ((rc = result_target(c, dfx_item_size(6), &tgt))) return rc;
-  DFX_HIP(dfx::launch_se3_step(d, (int)img0->w, (int)img0->h, huber_delta, blocks, c->partials, tgt, c->stream));
-  return finish_result(c, out_item, dfx_item_size(6));
+  dfx::DoneFlag done;
+  if ((rc = new_done_flag(c, &done))) return rc;
+  DFX_HIP(dfx::launch_se3_step(d, (int)img0->w, (int)img0->h, huber_delta, blocks, c->partials, tgt, c->stream, done));
+  return finish_result_polled(c, out_item, dfx_item_size(6), done);
 }
 
 DFX_API int dfx_se3_warp(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam, const dfx_img* img0, const dfx_img* img1,
@@ -1512,8 +1571,10 @@ DFX_API int dfx_se3_warp(dfx_ctx* c, const dfx_se3* pose_10, const dfx_cam* cam,
   if ((rc = grow_partials(c, pbytes))) return rc;
   void* tgt;
   if ((rc = result_target(c, sizeof(dfx_corr_item), &tgt))) return rc;
-  DFX_HIP(dfx::launch_se3_warp(d, (int)img0->w, (int)img0->h, blocks, c->partials, tgt, c->stream));
-  return finish_result(c, out, sizeof(dfx_corr_item));
+  dfx::DoneFlag done;
+  if ((rc = new_done_flag(c, &done))) return rc;
+  DFX_HIP(dfx::launch_se3_warp(d, (int)img0->w, (int)img0->h, blocks, c->partials, tgt, c->stream, done));
+  return finish_result_polled(c, out, sizeof(dfx_corr_item), done);
 }
 
 namespace {
@@ -1614,9 +1675,14 @@ int track_frames_impl(dfx_ctx* c, int n, const dfx_se3* pose_init, const dfx_tra
   // the last update goes straight into the pinned, device-mapped result area (no copy operation behind the kernels)
   void* rdev = nullptr;
   if ((rc = result_target(c, sbytes * (size_t)n, &rdev))) return rc;
-  if (it_done > 0) DFX_HIP(dfx::launch_track_final(n, state_at(it_done - 1), rdev, c->partials + (size_t)((it_done + 1) & 1) * pfloats, blocks_prev, c->stream));
-  else DFX_HIP(hipMemcpyAsync(c->result_host, state_at(0), sbytes * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-  DFX_HIP(hipStreamSynchronize(c->stream));
+  dfx::DoneFlag done;
+  if (it_done > 0) {
+    if (n == 1 && (rc = new_done_flag(c, &done))) return rc;
+    DFX_HIP(dfx::launch_track_final(n, state_at(it_done - 1), rdev, c->partials + (size_t)((it_done + 1) & 1) * pfloats, blocks_prev, c->stream, done));
+  } else DFX_HIP(hipMemcpyAsync(c->result_host, state_at(0), sbytes * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  if (done.flag) {
+    if ((rc = finish_result_polled(c, c->result_host, 0, done))) return rc;   // (the records are read in place below)
+  } else DFX_HIP(hipStreamSynchronize(c->stream));
   const double area = (double)levels[0].img0.w * levels[0].img0.h;
   for (int k = 0; k < n; ++k) {
     double R[9], t[3];
@@ -1913,8 +1979,13 @@ DFX_API int dfx_sfm_linearize_batch(dfx_ctx* c, int cs, const dfx_sfm_params* pa
   if (bytes <= kDirectResultMax) {
     void* tgt;
     if ((rc = result_target(c, bytes, &tgt))) return rc;
-    if ((rc = sfm_linearize_batch_impl(c, cs, params, pairs, prx0_orig, codes0, n, tgt, false))) return rc;
-    return finish_result(c, out_items_host, bytes);
+    dfx::DoneFlag done;
+    if (n == 1 && (rc = new_done_flag(c, &done))) return rc;
+    c->done_armed = done.flag ? &done : nullptr;
+    rc = sfm_linearize_batch_impl(c, cs, params, pairs, prx0_orig, codes0, n, tgt, false);
+    c->done_armed = nullptr;
+    if (rc) return rc;
+    return finish_result_polled(c, out_items_host, bytes, done);
   }
   if (c->items_bytes < bytes) DFX_HIP(hipStreamSynchronize(c->stream));
   if ((rc = grow_dev((void**)&c->items_dev, &c->items_bytes, bytes, c->stream))) return rc;
@@ -2037,9 +2108,11 @@ DFX_API int dfx_squared_error(dfx_ctx* c, const dfx_img* a, const dfx_img* b, fl
   if ((rc = grow_partials(c, pbytes))) return rc;
   void* tgt;
   if ((rc = result_target(c, sizeof(float), &tgt))) return rc;
+  dfx::DoneFlag done;
+  if ((rc = new_done_flag(c, &done))) return rc;
   DFX_HIP(dfx::launch_squared_error((const float*)a->ptr, (uint32_t)a->pitch_bytes, (const float*)b->ptr, (uint32_t)b->pitch_bytes,
-                                    (int)a->w, (int)a->h, blocks, c->partials, (float*)tgt, c->stream));
-  return finish_result(c, out, sizeof(float));
+                                    (int)a->w, (int)a->h, blocks, c->partials, (float*)tgt, c->stream, done));
+  return finish_result_polled(c, out, sizeof(float), done);
 }
 
 DFX_API int dfx_depth_aligner_step(dfx_ctx* c, int cs, const float* code, const dfx_img* target_dpt, const dfx_img* prx_orig,
@@ -2077,9 +2150,11 @@ DFX_API int dfx_depth_aligner_step(dfx_ctx* c, int cs, const float* code, const 
   const size_t ibytes = dfx_item_size(cs);
   void* tgt;
   if ((rc = result_target(c, ibytes, &tgt))) return rc;
+  dfx::DoneFlag done;
+  if ((rc = new_done_flag(c, &done))) return rc;
   DFX_HIP(dfx::launch_depth_aligner_step(cs, hd, (int)W, (int)H, avg_dpt, bpp, c->partials, tgt, c->stream,
-                                         prx_jac->pitch_bytes == (size_t)W * cs * 4, resolve_mfma(c, cs)));
-  return finish_result(c, out_item, ibytes);
+                                         prx_jac->pitch_bytes == (size_t)W * cs * 4, resolve_mfma(c, cs), done.flag ? &done : nullptr));
+  return finish_result_polled(c, out_item, ibytes, done);
 }
 
 }  // extern "C"

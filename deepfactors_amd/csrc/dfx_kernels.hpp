@@ -156,6 +156,38 @@ struct SimplePairDev {   // SE3Aligner / EvaluateError / Warp
 inline int sfm_nacc(int ncb) { return ncb * (ncb - 1) / 2 + ncb + 2 * ((ncb + 1) / 2); }
 inline int sfm_zdim(int ncb) { return (1 + sfm_nacc(ncb)) * 256; }
 
+// A blocking call's result lands in pinned, device-mapped host memory, written by the call's LAST kernel.  With a DoneFlag that kernel also stores the call's
+// sequence number behind the result (system-scope release), and the host polls that word instead of waiting for the stream: hipStreamSynchronize learns of
+// the end of a kernel 5.4 us after a polling host reads the flag (tools/ubench/sync_latency.cpp: 11.8 against 6.3 us for one kernel, 15.5 against 10.0 for two;
+// a command-processor write behind the kernel, hipStreamWriteValue32, only gains 2.4) -- a quarter of an SE3Aligner::RunStep.  Kernels of several workgroups
+// count arrivals in `counter` (device memory, zero between calls); flag == nullptr: no signal (batched and *_async entries).
+struct DoneFlag { uint32_t* flag = nullptr; uint32_t seq = 0; unsigned* counter = nullptr; };
+#if defined(__HIPCC__)
+// the result was stored by lanes of the calling wave only
+__device__ __forceinline__ void signal_done_wave(const DoneFlag& d) {
+  if (!d.flag) return;
+  __builtin_amdgcn_s_waitcnt(0);                    // this wave's stores have completed
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");     // system scope
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(d.flag, d.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// every thread of every workgroup of the grid calls this once its stores of the result are issued (the protocol of k_sfm_tail_b3's arrival counters)
+__device__ __forceinline__ void signal_done_grid(const DoneFlag& d, const unsigned total_wgs) {
+  if (!d.flag) return;
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  if (total_wgs > 1) {
+    const unsigned got = __hip_atomic_fetch_add(d.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (got != total_wgs) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // rewound for the next call
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  }
+  __hip_atomic_store(d.flag, d.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
+
 // All launchers enqueue on `stream` and return the HIP status of the launch.
 // ev_begin/ev_end (optional) bracket the step kernel only.
 hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int W, int H, const SfmParamsDev& prm,
@@ -169,16 +201,17 @@ hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int 
                                                                                            // blkmap[g] >> 16 as its block blkmap[g] & 0xffff (of SfmPairDev::nblk);
                                                                                            // W, H = the largest width / height (ray-table LDS); blocks_per_pair unused
                            const TailGraphDev* tail_graph = nullptr, int node_wgs = 0,    // graph assembly inside the reduction tail (k_sfm_tail_b3) where the
-                           bool* assembled = nullptr);                                    // launch has one: *assembled tells; node_wgs = 0 or the graph's nodes
+                           bool* assembled = nullptr,                                     // launch has one: *assembled tells; node_wgs = 0 or the graph's nodes
+                           DoneFlag* done = nullptr);   // one_host launches: the finalize kernel signals *done; cleared (flag = nullptr) when the launch cannot
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair);
 // system layout (floats): Hd [n_nodes][D][D], Ho [n_pairs][D][6], g [n_nodes][D]; contributions of the pairs [first_pair, first_pair + n_local)
 hipError_t launch_graph_assemble(int cs, const GraphDev& G, const void* items_dev, size_t item_stride, int first_pair, int n_local, float* sys_dev,
                                  hipStream_t stream);
 
 hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
-                           void* item_dev, hipStream_t stream);
+                           void* item_dev, hipStream_t stream, const DoneFlag& done = DoneFlag{});
 hipError_t launch_sfm_error(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
-                            void* corr_item_dev, hipStream_t stream);
+                            void* corr_item_dev, hipStream_t stream, const DoneFlag& done = DoneFlag{});
 // batched forms: descs_dev[n], partials [n][blocks][kSimpleRow], results packed (16 bytes per dfx_corr_item, 120 per JTJJrReductionItem<float,6>)
 // ev_begin / ev_end (optional) bracket the reduction kernel only
 hipError_t launch_sfm_error_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
@@ -186,7 +219,7 @@ hipError_t launch_sfm_error_batch(const SimplePairDev* descs_dev, int n, int W, 
 hipError_t launch_se3_step_batch(const SimplePairDev* descs_dev, int n, int W, int H, float huber_delta, int blocks, float* partials_dev,
                                  void* items_dev, hipStream_t stream, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 hipError_t launch_se3_warp(const SimplePairDev& p, int W, int H, int blocks, float* partials_dev, void* corr_item_dev,
-                           hipStream_t stream);
+                           hipStream_t stream, const DoneFlag& done = DoneFlag{});
 hipError_t launch_update_depth(int cs, const float* code_dev, const float* prx_orig, uint32_t pitch_prx, const float* jac,
                                uint32_t pitch_jac, float avg_dpt, float* dpt_out, uint32_t pitch_out, int W, int H,
                                hipStream_t stream);
@@ -195,9 +228,9 @@ hipError_t launch_sobel(const float* img, uint32_t pitch, float* grad, uint32_t 
 hipError_t launch_blur_down(const float* in, uint32_t pitch, int W, int H, float* out, uint32_t opitch, int OW, int OH,
                             hipStream_t stream);
 hipError_t launch_squared_error(const float* a, uint32_t pitch_a, const float* b, uint32_t pitch_b, int W, int H, int blocks,
-                                float* partials_dev, float* out_dev, hipStream_t stream);
+                                float* partials_dev, float* out_dev, hipStream_t stream, const DoneFlag& done = DoneFlag{});
 hipError_t launch_depth_aligner_step(int cs, const SfmPairDev* pair_host, int W, int H, float avg_dpt, int blocks,
-                                     float* partials_dev, void* item_dev, hipStream_t stream, bool jac_dense, int prec);
+                                     float* partials_dev, void* item_dev, hipStream_t stream, bool jac_dense, int prec, DoneFlag* done = nullptr);
 
 // device-resident tracker
 size_t track_state_bytes();
@@ -208,7 +241,8 @@ void track_state_read(const void* host_state, double* R, double* t, float* resid
 // launch_track_final applies the last evaluation
 hipError_t launch_track_iteration(const SimplePairDev* descs_dev, int n, const void* states_in, void* states_out, const float* partials_prev, int blocks_prev,
                                   int W, int H, float huber_delta, int blocks, float* partials_dev, hipStream_t stream);
-hipError_t launch_track_final(int n, const void* states_in, void* states_out, const float* partials_prev, int blocks_prev, hipStream_t stream);
+hipError_t launch_track_final(int n, const void* states_in, void* states_out, const float* partials_prev, int blocks_prev, hipStream_t stream,
+                              const DoneFlag& done = DoneFlag{});   // (n == 1)
 
 // SparseGeometricFactor::linearize, n factors per launch (descriptors in device-visible memory; codes inside the descriptor, points and rows device pointers)
 size_t sparse_geo_desc_bytes();

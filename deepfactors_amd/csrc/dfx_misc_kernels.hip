@@ -560,10 +560,12 @@ __global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev* __rest
 // the update behind the last evaluation of a frame
 // (states_out: the caller's mapped host buffer -- the result needs no copy engine behind this kernel)
 __global__ __launch_bounds__(kT) void k_track_final(const float* __restrict__ partials_prev, const int nblocks_prev, const TrackState* __restrict__ states_in,
-                                                    TrackState* __restrict__ states_out) {
+                                                    TrackState* __restrict__ states_out, const DoneFlag done) {
   __shared__ TrackLds l;
   track_fold_and_solve(partials_prev + (size_t)blockIdx.x * nblocks_prev * kSimpleRow, nblocks_prev, states_in + blockIdx.x, l);
+  static_assert(sizeof(TrackState) / 4 <= 64, "the state is stored by wave 0");
   if (threadIdx.x < sizeof(TrackState) / 4) reinterpret_cast<uint32_t*>(states_out + blockIdx.x)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&l.st)[threadIdx.x];
+  if (threadIdx.x < 64) signal_done_wave(done);
 }
 
 size_t track_state_bytes() { return sizeof(TrackState); }
@@ -574,8 +576,8 @@ hipError_t launch_track_iteration(const SimplePairDev* descs_dev, int n, const v
                      huber_delta, partials_dev);
   return hipGetLastError();
 }
-hipError_t launch_track_final(int n, const void* states_in, void* states_out, const float* partials_prev, int blocks_prev, hipStream_t stream) {
-  hipLaunchKernelGGL(k_track_final, dim3(n), dim3(kT), 0, stream, partials_prev, blocks_prev, (const TrackState*)states_in, (TrackState*)states_out);
+hipError_t launch_track_final(int n, const void* states_in, void* states_out, const float* partials_prev, int blocks_prev, hipStream_t stream, const DoneFlag& done) {
+  hipLaunchKernelGGL(k_track_final, dim3(n), dim3(kT), 0, stream, partials_prev, blocks_prev, (const TrackState*)states_in, (TrackState*)states_out, n == 1 ? done : DoneFlag{});
   return hipGetLastError();
 }
 
@@ -797,7 +799,7 @@ enum FinalKind { kFinalItem6 = 0, kFinalCorr = 1, kFinalScalar = 2 };
 // batched reductions run 24 - 60 workgroups per pair and take MAXQ = 2 (2 loads per thread instead of 32: 4.7 -> ~3 us per 128 pairs).
 template <int MAXQ>
 __global__ __launch_bounds__(1024) void k_finalize_rows(const float* __restrict__ partials_all, const int nblocks, const int kind,
-                                                        char* __restrict__ out_all, const size_t out_stride) {
+                                                        char* __restrict__ out_all, const size_t out_stride, const DoneFlag done) {
   // blockIdx.x = pair of a batched launch (0 for the single-pair operators)
   const float* partials = partials_all + (size_t)blockIdx.x * nblocks * kSimpleRow;
   char* out = out_all + (size_t)blockIdx.x * out_stride;
@@ -820,6 +822,7 @@ __global__ __launch_bounds__(1024) void k_finalize_rows(const float* __restrict_
   } else {
     if (e == 0) reinterpret_cast<float*>(out)[0] = (float)s;
   }
+  signal_done_wave(done);   // (single-pair launches: the result was stored by lanes 0..31 of this wave)
 }
 
 // ---- UpdateDepth: dpt = a / (prx0 + jac . code) - a  (the code-Jacobian decoder, GEMV, 8 + 4 CS bytes / pixel) ---
@@ -1059,27 +1062,29 @@ hipError_t launch_pyr_level(const PyrLevelDev* descs_dev, int n, int W, int H, h
 // ---------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------
-static void launch_finalize_rows(int n, int blocks, int kind, const float* partials_dev, void* out_dev, size_t stride, hipStream_t stream) {
-  if (blocks <= 64) hipLaunchKernelGGL(k_finalize_rows<2>, dim3(n), dim3(1024), 0, stream, partials_dev, blocks, kind, (char*)out_dev, stride);
-  else if (blocks <= 256) hipLaunchKernelGGL(k_finalize_rows<8>, dim3(n), dim3(1024), 0, stream, partials_dev, blocks, kind, (char*)out_dev, stride);
-  else hipLaunchKernelGGL(k_finalize_rows<32>, dim3(n), dim3(1024), 0, stream, partials_dev, blocks, kind, (char*)out_dev, stride);
+static void launch_finalize_rows(int n, int blocks, int kind, const float* partials_dev, void* out_dev, size_t stride, hipStream_t stream,
+                                 const DoneFlag& done_in = DoneFlag{}) {
+  const DoneFlag done = n == 1 ? done_in : DoneFlag{};   // one workgroup per pair: only a single-pair launch has ONE last writer
+  if (blocks <= 64) hipLaunchKernelGGL(k_finalize_rows<2>, dim3(n), dim3(1024), 0, stream, partials_dev, blocks, kind, (char*)out_dev, stride, done);
+  else if (blocks <= 256) hipLaunchKernelGGL(k_finalize_rows<8>, dim3(n), dim3(1024), 0, stream, partials_dev, blocks, kind, (char*)out_dev, stride, done);
+  else hipLaunchKernelGGL(k_finalize_rows<32>, dim3(n), dim3(1024), 0, stream, partials_dev, blocks, kind, (char*)out_dev, stride, done);
 }
 
 hipError_t launch_se3_step(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
-                           void* item_dev, hipStream_t stream) {
+                           void* item_dev, hipStream_t stream, const DoneFlag& done) {
   hipLaunchKernelGGL(k_se3_step, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  launch_finalize_rows(1, blocks, (int)kFinalItem6, (const float*)partials_dev, item_dev, (size_t)0, stream);
+  launch_finalize_rows(1, blocks, (int)kFinalItem6, (const float*)partials_dev, item_dev, (size_t)0, stream, done);
   return hipGetLastError();
 }
 
 hipError_t launch_sfm_error(const SimplePairDev& p, int W, int H, float huber_delta, int blocks, float* partials_dev,
-                            void* corr_item_dev, hipStream_t stream) {
+                            void* corr_item_dev, hipStream_t stream, const DoneFlag& done) {
   hipLaunchKernelGGL(k_sfm_error, dim3(blocks), dim3(kT), 0, stream, p, W, H, huber_delta, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  launch_finalize_rows(1, blocks, (int)kFinalCorr, (const float*)partials_dev, corr_item_dev, (size_t)0, stream);
+  launch_finalize_rows(1, blocks, (int)kFinalCorr, (const float*)partials_dev, corr_item_dev, (size_t)0, stream, done);
   return hipGetLastError();
 }
 
@@ -1106,20 +1111,20 @@ hipError_t launch_se3_step_batch(const SimplePairDev* descs_dev, int n, int W, i
 }
 
 hipError_t launch_se3_warp(const SimplePairDev& p, int W, int H, int blocks, float* partials_dev, void* corr_item_dev,
-                           hipStream_t stream) {
+                           hipStream_t stream, const DoneFlag& done) {
   hipLaunchKernelGGL(k_se3_warp, dim3(blocks), dim3(kT), 0, stream, p, W, H, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  launch_finalize_rows(1, blocks, (int)kFinalCorr, (const float*)partials_dev, corr_item_dev, (size_t)0, stream);
+  launch_finalize_rows(1, blocks, (int)kFinalCorr, (const float*)partials_dev, corr_item_dev, (size_t)0, stream, done);
   return hipGetLastError();
 }
 
 hipError_t launch_squared_error(const float* a, uint32_t pitch_a, const float* b, uint32_t pitch_b, int W, int H, int blocks,
-                                float* partials_dev, float* out_dev, hipStream_t stream) {
+                                float* partials_dev, float* out_dev, hipStream_t stream, const DoneFlag& done) {
   hipLaunchKernelGGL(k_squared_error, dim3(blocks), dim3(kT), 0, stream, a, pitch_a, b, pitch_b, W, H, partials_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  launch_finalize_rows(1, blocks, (int)kFinalScalar, (const float*)partials_dev, out_dev, (size_t)0, stream);
+  launch_finalize_rows(1, blocks, (int)kFinalScalar, (const float*)partials_dev, out_dev, (size_t)0, stream, done);
   return hipGetLastError();
 }
 

@@ -941,9 +941,9 @@ __device__ __forceinline__ void rebuild_valid0_shadow(const SfmPairDev& P, int W
 // grid = (1 + NACC + 2 ND, npairs), 1024 threads: thread = (element of one 256-float block, 1 of 4 partial groups); groups
 // stride over the pair's `bpp` partials (1 KB coalesced reads, 8 loads in flight) and are folded in fixed order.
 template <int NCB, int NPOSE, bool BYVAL>
-__global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs, const SfmPairDev one,
-                                                       char* __restrict__ items, const size_t item_stride, unsigned* __restrict__ qhead,
-                                                       const int Wk, const int Hk, const unsigned launch_id, const int ragged) {
+__device__ __forceinline__ void sfm_finalize_body(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs, const SfmPairDev& one,
+                                                  char* __restrict__ items, const size_t item_stride, unsigned* __restrict__ qhead,
+                                                  const int Wk, const int Hk, const unsigned launch_id, const int ragged) {
   constexpr int CS = 16 * NCB;
   constexpr int NP = NPOSE + CS;
   constexpr int NX = NCB * (NCB - 1) / 2, ND = (NCB + 1) / 2;
@@ -1204,9 +1204,17 @@ __device__ __forceinline__ void b3_scatter(int blk, int t, const double* S, cons
 }
 
 template <int NCB, int NPOSE, bool BYVAL>
+__global__ __launch_bounds__(1024) void k_sfm_finalize(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs, const SfmPairDev one,
+                                                       char* __restrict__ items, const size_t item_stride, unsigned* __restrict__ qhead,
+                                                       const int Wk, const int Hk, const unsigned launch_id, const int ragged, const DoneFlag done) {
+  sfm_finalize_body<NCB, NPOSE, BYVAL>(partials, bpp, pairs, one, items, item_stride, qhead, Wk, Hk, launch_id, ragged);
+  if (BYVAL) signal_done_grid(done, gridDim.x * gridDim.y);   // a blocking single-pair call: the host polls the flag behind the item (dfx_kernels.hpp)
+}
+
+template <int NCB, int NPOSE, bool BYVAL>
 __global__ __launch_bounds__(1024) void k_sfm_finalize_b3(const float* __restrict__ partials, const int bpp, const SfmPairDev* __restrict__ pairs, const SfmPairDev one,
                                                           char* __restrict__ items, const size_t item_stride, unsigned* __restrict__ qhead,
-                                                          const int Wk, const int Hk, const unsigned launch_id, const int ragged) {
+                                                          const int Wk, const int Hk, const unsigned launch_id, const int ragged, const DoneFlag done) {
   constexpr int NT3 = b3_tiles(NCB);
   constexpr int ZDIM = b3_blocks(NCB) * 256;
   __shared__ double red[4][256];
@@ -1243,6 +1251,7 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize_b3(const float* __restric
   }
   float* item = reinterpret_cast<float*>(items + (size_t)pair * item_stride);
   b3_scatter<NCB, NPOSE>(blk, (int)threadIdx.x, red[0], T, item);
+  if (BYVAL) signal_done_grid(done, gridDim.x * gridDim.y);
 }
 
 // ---- the reduction tail of a batched bf16-split launch in ONE kernel: workgroup p sums ALL blocks of pair p's partials (same order as
@@ -1482,8 +1491,11 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
                            hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, const SfmPairDev* one_host = nullptr,
                            const DynDev* dyn = nullptr, int dyn_grid = 0, bool vsh = false, hipStream_t fin_stream = nullptr, hipEvent_t ev_mid = nullptr,
                            const unsigned* blkmap = nullptr, int total_blocks = 0, const TailGraphDev* tail_graph = nullptr, int node_wgs = 0,
-                           bool* assembled = nullptr) {
+                           bool* assembled = nullptr, DoneFlag* done_io = nullptr) {
   if (assembled) *assembled = false;
+  // only the by-value (single pair) finalize kernels signal; a launch that takes another tail clears the caller's flag, and the caller waits for the stream
+  const DoneFlag done = (done_io && one_host && !dyn) ? *done_io : DoneFlag{};
+  if (done_io && !done.flag) done_io->flag = nullptr;
   const TailGraphDev tg = tail_graph ? *tail_graph : TailGraphDev{};
   constexpr int NACC = NCB * (NCB - 1) / 2 + NCB + 2 * ((NCB + 1) / 2);   // 256-float blocks after block 0 (16x16x4 and 4x4x1 accumulators)
   hipError_t e;
@@ -1537,9 +1549,9 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
         if (assembled) *assembled = tg.sys != nullptr;
       } else if (b3) {
         hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, 12, false>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
-                           (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0);
+                           (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0, DoneFlag{});
       } else hipLaunchKernelGGL((k_sfm_finalize<NCB, 12, false>), dim3(1 + NACC, npairs), dim3(1024), 0, fstream,
-                              (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0);
+                              (const float*)partials_dev, dyn->team, pairs_dev, one, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0, DoneFlag{});
       return hipGetLastError();
     }
   }
@@ -1566,7 +1578,7 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   const SfmPairDev* fpairs = byval ? (const SfmPairDev*)nullptr : pairs_dev;
   if (b3) {
     if (byval) hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, true>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
-                                  (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged);
+                                  (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged, done);
     else if (MODE == 0 && use_tail) {   // batched launches: one workgroup per pair, the graph assembly folded in
       if (tg.sys && tail_ordered()) hipLaunchKernelGGL((k_sfm_tail_b3<NCB, true, true>), dim3(npairs + node_wgs), dim3(1024), 0, fstream,
                                      (const float*)partials_dev, bpp, fpairs, npairs, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged, tg);
@@ -1576,12 +1588,12 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
                               (const float*)partials_dev, bpp, fpairs, npairs, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged, tg);
       if (assembled) *assembled = tg.sys != nullptr;
     } else hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, false>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
-                              (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged);
+                              (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged, DoneFlag{});
   } else {
     if (byval) hipLaunchKernelGGL((k_sfm_finalize<NCB, NPOSE, true>), dim3(1 + NACC, npairs), dim3(1024), 0, fstream,
-                                  (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged);
+                                  (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged, done);
     else hipLaunchKernelGGL((k_sfm_finalize<NCB, NPOSE, false>), dim3(1 + NACC, npairs), dim3(1024), 0, fstream,
-                            (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged);
+                            (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged, DoneFlag{});
   }
   return hipGetLastError();
 }
@@ -1590,23 +1602,23 @@ hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int 
                            int blocks_per_pair, float* partials_dev, void* items_dev, size_t item_stride,
                            hipStream_t stream, bool jac_dense, int prec, hipEvent_t eb, hipEvent_t ee, const SfmPairDev* one_host,
                            const DynDev* dyn, int dyn_grid, bool vsh, hipStream_t fin_stream, hipEvent_t ev_mid, const unsigned* blkmap_dev, int total_blocks,
-                           const TailGraphDev* tail_graph, int node_wgs, bool* assembled) {
+                           const TailGraphDev* tail_graph, int node_wgs, bool* assembled, DoneFlag* done) {
   switch (cs) {
-    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled);
-    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled);
-    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled);
+    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled, done);
+    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled, done);
+    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled, done);
     default: return hipErrorInvalidValue;
   }
 }
 
 // DepthAligner::RunStep: `pair_host` describes ONE pseudo-pair with img0 = target depth, dpt0 = current depth, jac (passed by value).
 hipError_t launch_depth_aligner_step(int cs, const SfmPairDev* pair_host, int W, int H, float avg_dpt, int blocks,
-                                     float* partials_dev, void* item_dev, hipStream_t stream, bool jac_dense, int prec) {
+                                     float* partials_dev, void* item_dev, hipStream_t stream, bool jac_dense, int prec, DoneFlag* done) {
   SfmParamsDev prm{ 0.f, avg_dpt, 0.f, 0.f, 0u };
   switch (cs) {
-    case 16: return launch_t<1, 1>(nullptr, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec, nullptr, nullptr, pair_host);
-    case 32: return launch_t<2, 1>(nullptr, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec, nullptr, nullptr, pair_host);
-    case 64: return launch_t<4, 1>(nullptr, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec, nullptr, nullptr, pair_host);
+    case 16: return launch_t<1, 1>(nullptr, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec, nullptr, nullptr, pair_host, nullptr, 0, false, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, done);
+    case 32: return launch_t<2, 1>(nullptr, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec, nullptr, nullptr, pair_host, nullptr, 0, false, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, done);
+    case 64: return launch_t<4, 1>(nullptr, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec, nullptr, nullptr, pair_host, nullptr, 0, false, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, done);
     default: return hipErrorInvalidValue;
   }
 }

@@ -240,6 +240,12 @@ DFX_API int dfx_se3_step(dfx_ctx* ctx, const dfx_se3* pose_10, const dfx_cam* ca
 DFX_API int dfx_se3_warp(dfx_ctx* ctx, const dfx_se3* pose_10, const dfx_cam* cam, const dfx_img* img0,
                          const dfx_img* img1, const dfx_img* dpt0, const dfx_img* img2_out, dfx_corr_item* out);
 
+/* How the blocking single-result entries return (dfx_se3_step, dfx_se3_warp, dfx_sfm_error, dfx_sfm_step / dfx_sfm_step_batch and dfx_sfm_linearize_batch
+ * with n = 1, dfx_depth_aligner_step, dfx_squared_error, dfx_track_frame): the call's last kernel stores the result into pinned, device-mapped host memory
+ * and, behind it (system-scope release), the call's sequence number; the host polls that word and copies the result out -- it does NOT wait for the stream
+ * to report idle, which the runtime learns 1-5 us later (profiles/r05_poll_result.txt).  Everything the call enqueued in front of that kernel has completed
+ * when the call returns; the stream itself may show busy for a few more microseconds.  A stream error or a launch that never writes the word is detected
+ * (the stream is queried every few hundred microseconds of polling).  DFX_POLL_RESULT=0 in the environment restores hipStreamSynchronize. */
 /* ---- CameraTracker::TrackFrame (core/system/camera_tracker.cpp:42-71), device-resident -------
  * The reference loops on the host: RunStep (kernel + finalize + sync + 120-byte copy) -> 6x6 ldlt().solve -> retract, per
  * iteration.  Here the whole coarse-to-fine schedule is enqueued at once, one launch per iteration: the pose stays in device memory, and
