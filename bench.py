@@ -738,6 +738,23 @@ def tracker_and_geometric_configs(dfx, synth, ctx, dev):
                 out[key] = {"error": (r.stdout + r.stderr)[-300:]}
         except Exception as e:   # noqa: BLE001 -- an extra figure, never the line
             out[key] = {"error": f"{type(e).__name__}: {e}"}
+    # blocking-call latencies as a C++ call site sees them (tools/cpp/latency_bench.cpp through include/dfx_shim.hpp), incl. dfx_track_frame without the Python wrapper
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "cpp", "latency_bench")
+    if os.path.exists(exe):
+        try:
+            r = subprocess.run([exe], capture_output=True, text=True, timeout=120, stdin=subprocess.DEVNULL)
+            lat = {}
+            for line in r.stdout.splitlines():
+                if " mean " in line and " us " in line:
+                    name, rest = line.split(" mean ", 1)
+                    lat[name.strip()] = float(rest.split()[0])
+            if r.returncode == 0 and lat:
+                out["blocking_call_latency_cpp_us"] = lat
+                trk = [v for k, v in lat.items() if k.startswith("dfx_track_frame")]
+                if trk and "configs0_se3_tracker_3level" in out:
+                    out["configs0_se3_tracker_3level"]["cpp_ms_per_frame"] = trk[0] * 1e-3
+        except Exception as e:   # noqa: BLE001
+            out["blocking_call_latency_cpp_us"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 
