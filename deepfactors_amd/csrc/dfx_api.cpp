@@ -134,6 +134,7 @@ struct dfx_ctx {
   uint32_t* done_flag_dev = nullptr;
   unsigned* done_counter = nullptr;     // device: arrivals of a multi-workgroup finalize kernel, zero between calls
   uint32_t done_seq = 0;
+  bool poll = true;                     // dfx_set_result_wait; initialised from DFX_POLL_RESULT
   dfx::DoneFlag* done_armed = nullptr;        // set by a blocking entry around the one impl call whose finalize kernel is to signal
   void* track_state_dev = nullptr;   // [TrackState x n][SimplePairDev x levels x n]
   size_t track_bytes = 0;
@@ -274,47 +275,66 @@ int result_target(dfx_ctx* c, size_t bytes, void** dev_ptr) {
   DFX_HIP(hipHostGetDevicePointer(dev_ptr, c->result_host, 0));
   return DFX_OK;
 }
+int wait_stream(dfx_ctx* c);
 int finish_result(dfx_ctx* c, void* host_out, size_t bytes) {
-  DFX_HIP(hipStreamSynchronize(c->stream));
+  int rc;
+  if ((rc = wait_stream(c))) return rc;
   std::memcpy(host_out, c->result_host, bytes);
   return DFX_OK;
 }
 // The polled form (DoneFlag in dfx_kernels.hpp; DFX_POLL_RESULT=0 turns it off: every blocking call then waits for the stream as above).
-bool poll_results() {
+bool poll_default() {
   static const bool on = [] { const char* ev = std::getenv("DFX_POLL_RESULT"); return !(ev && ev[0] == '0'); }();
   return on;
 }
 // a flag for one call: *d stays empty when polling is off (the launchers then signal nothing and finish_result_polled waits for the stream)
+int ensure_done_flag(dfx_ctx* c) {
+  if (c->done_flag_host) return DFX_OK;
+  DFX_HIP(hipHostMalloc((void**)&c->done_flag_host, 128, hipHostMallocMapped | hipHostMallocCoherent));
+  std::memset(c->done_flag_host, 0, 128);
+  void* dp = nullptr;
+  DFX_HIP(hipHostGetDevicePointer(&dp, c->done_flag_host, 0));
+  c->done_flag_dev = static_cast<uint32_t*>(dp);
+  DFX_HIP(hipMalloc((void**)&c->done_counter, 64));
+  DFX_HIP(hipMemsetAsync(c->done_counter, 0, 64, c->stream));
+  return DFX_OK;
+}
 int new_done_flag(dfx_ctx* c, dfx::DoneFlag* d) {
   *d = dfx::DoneFlag{};
-  if (!poll_results()) return DFX_OK;
-  if (!c->done_flag_host) {
-    DFX_HIP(hipHostMalloc((void**)&c->done_flag_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
-    c->done_flag_host[0] = 0;
-    void* dp = nullptr;
-    DFX_HIP(hipHostGetDevicePointer(&dp, c->done_flag_host, 0));
-    c->done_flag_dev = static_cast<uint32_t*>(dp);
-    DFX_HIP(hipMalloc((void**)&c->done_counter, 64));
-    DFX_HIP(hipMemsetAsync(c->done_counter, 0, 64, c->stream));
-  }
+  if (!c->poll) return DFX_OK;
+  int rc;
+  if ((rc = ensure_done_flag(c))) return rc;
   if (++c->done_seq == 0) c->done_seq = 1;
   d->flag = c->done_flag_dev; d->seq = c->done_seq; d->counter = c->done_counter;
   return DFX_OK;
 }
-int finish_result_polled(dfx_ctx* c, void* host_out, size_t bytes, const dfx::DoneFlag& d) {
-  if (!d.flag) return finish_result(c, host_out, bytes);
-  const uint32_t* f = c->done_flag_host;
+// spins until *f == seq; every 16384 polls (a few hundred microseconds) the stream is queried: a failed launch or a faulted queue never writes the word.
+// an idle stream without the word is an error (the kernel that was to write it did not run to its end)
+int poll_word(dfx_ctx* c, const uint32_t* f, uint32_t seq) {
   for (unsigned spins = 1;; ++spins) {
-    if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == d.seq) break;
-    if ((spins & 0x3fff) == 0) {   // every 16384 polls (a few hundred microseconds): a failed launch or a faulted queue never writes the flag
+    if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == seq) return DFX_OK;
+    if ((spins & 0x3fff) == 0) {
       const hipError_t q = hipStreamQuery(c->stream);
       if (q == hipSuccess) {
-        if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == d.seq) break;
-        return fail(DFX_E_HIP, "the stream drained without the result flag (sequence %u)", d.seq);
+        if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == seq) return DFX_OK;
+        return fail(DFX_E_HIP, "the stream drained without the result flag (sequence %u)", seq);
       }
       if (q != hipErrorNotReady) return fail(DFX_E_HIP, "stream failed while waiting for a result: %s", hipGetErrorString(q));
     }
   }
+}
+// The end of a blocking call that has no kernel of its own to signal (no result, or many last writers).  A word written by the command processor behind the
+// stream's work (hipStreamWriteValue32) and polled by the host was measured here too, interleaved with this in one process: the best case is 2.5 us sooner,
+// the mean is not (UpdateDepth 22.5-24.0 against 22.5-24.4 us, SobelGradients 14.2 against 12.5-13.4, a 16-pair RunStepBatch 156 against 149;
+// profiles/r05_poll_result.txt) -- so these calls wait for the stream.
+int wait_stream(dfx_ctx* c) {
+  DFX_HIP(hipStreamSynchronize(c->stream));
+  return DFX_OK;
+}
+int finish_result_polled(dfx_ctx* c, void* host_out, size_t bytes, const dfx::DoneFlag& d) {
+  if (!d.flag) return finish_result(c, host_out, bytes);
+  int rc;
+  if ((rc = poll_word(c, c->done_flag_host, d.seq))) return rc;
   std::memcpy(host_out, c->result_host, bytes);
   return DFX_OK;
 }
@@ -532,7 +552,7 @@ int fetch_result(dfx_ctx* c, const void* dev, void* host_out, size_t bytes) {
   int rc;
   if ((rc = ensure_result_host(c, bytes))) return rc;
   DFX_HIP(hipMemcpyAsync(c->result_host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
-  DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = wait_stream(c))) return rc;
   std::memcpy(host_out, c->result_host, bytes);
   return DFX_OK;
 }
@@ -641,6 +661,7 @@ DFX_API int dfx_ctx_create(int device, void* stream, dfx_ctx** out) {
   dfx_ctx* c = new dfx_ctx();
   c->device = device;
   c->cu_count = prop.multiProcessorCount;
+  c->poll = poll_default();
   // Testing aids (documented in include/dfx.h): the INITIAL evaluation mode / schedule of every context of the process.  They change
   // result bits (the two MFMA modes agree to fp32 accuracy, not bit for bit), so a value that is not understood is an error, never
   // silently the default; dfx_set_mfma_mode / dfx_set_schedule override them.
@@ -722,7 +743,7 @@ DFX_API int dfx_ctx_device(dfx_ctx* c) { return c ? c->device : -1; }
 
 DFX_API int dfx_sync(dfx_ctx* c) {
   if (!c) return fail(DFX_E_INVALID, "null context");
-  DFX_HIP(hipStreamSynchronize(c->stream));
+  { int rc; if ((rc = wait_stream(c))) return rc; }
   if (c->tail_stream) DFX_HIP(hipStreamSynchronize(c->tail_stream));
   return DFX_OK;
 }
@@ -800,6 +821,13 @@ DFX_API int dfx_set_schedule(dfx_ctx* c, int mode) {
   if (!c) return fail(DFX_E_INVALID, "null context");
   if (mode != DFX_SCHEDULE_AUTO && mode != DFX_SCHEDULE_STATIC && mode != DFX_SCHEDULE_DYNAMIC) return fail(DFX_E_INVALID, "unknown schedule %d", mode);
   c->schedule = mode;
+  return DFX_OK;
+}
+
+DFX_API int dfx_set_result_wait(dfx_ctx* c, int mode) {
+  if (!c) return fail(DFX_E_INVALID, "null context");
+  if (mode != DFX_WAIT_STREAM && mode != DFX_WAIT_POLL) return fail(DFX_E_INVALID, "unknown wait mode %d", mode);
+  c->poll = mode == DFX_WAIT_POLL;
   return DFX_OK;
 }
 
@@ -1682,7 +1710,7 @@ int track_frames_impl(dfx_ctx* c, int n, const dfx_se3* pose_init, const dfx_tra
   } else DFX_HIP(hipMemcpyAsync(c->result_host, state_at(0), sbytes * (size_t)n, hipMemcpyDeviceToHost, c->stream));
   if (done.flag) {
     if ((rc = finish_result_polled(c, c->result_host, 0, done))) return rc;   // (the records are read in place below)
-  } else DFX_HIP(hipStreamSynchronize(c->stream));
+  } else if ((rc = wait_stream(c))) return rc;
   const double area = (double)levels[0].img0.w * levels[0].img0.h;
   for (int k = 0; k < n; ++k) {
     double R[9], t[3];
@@ -1789,7 +1817,7 @@ int sparse_geo_batch_impl(dfx_ctx* c, int cs, const dfx_sparse_geo_factor* f, in
   if (row_bytes <= kDirectResultMax) return fetch_result(c, rows_base, rows_host, row_bytes);
   // a whole round of rows (18 MB for 120 factors x 500 points at CS = 32): straight into the caller's memory, no bounce through the result area
   DFX_HIP(hipMemcpyAsync(rows_host, rows_base, row_bytes, hipMemcpyDeviceToHost, c->stream));
-  DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = wait_stream(c))) return rc;
   return DFX_OK;
 }
 }  // namespace
@@ -1854,7 +1882,7 @@ DFX_API int dfx_update_depth(dfx_ctx* c, int cs, const float* code, const dfx_im
                                    (const float*)prx_jac->ptr, (uint32_t)prx_jac->pitch_bytes, avg_dpt, (float*)dpt_out->ptr,
                                    (uint32_t)dpt_out->pitch_bytes, (int)W, (int)H, c->stream));
   // the reference's UpdateDepth returns after CudaCheckLastError = cudaDeviceSynchronize (cu_image_proc.cpp:276)
-  DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = wait_stream(c))) return rc;
   return DFX_OK;
 }
 
@@ -2004,7 +2032,7 @@ DFX_API int dfx_sobel_gradients(dfx_ctx* c, const dfx_img* img, const dfx_img* g
   if (((uintptr_t)grad_out->ptr | grad_out->pitch_bytes) & 7) return fail(DFX_E_INVALID, "grad: pointer/pitch must be 8-byte aligned");
   DFX_HIP(dfx::launch_sobel((const float*)img->ptr, (uint32_t)img->pitch_bytes, (float*)grad_out->ptr, (uint32_t)grad_out->pitch_bytes,
                             (int)img->w, (int)img->h, c->stream));
-  DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = wait_stream(c))) return rc;
   return DFX_OK;
 }
 
@@ -2018,7 +2046,7 @@ DFX_API int dfx_gaussian_blur_down(dfx_ctx* c, const dfx_img* in, const dfx_img*
   if ((rc = img_note_write(c, out))) return rc;
   DFX_HIP(dfx::launch_blur_down((const float*)in->ptr, (uint32_t)in->pitch_bytes, (int)in->w, (int)in->h, (float*)out->ptr,
                                 (uint32_t)out->pitch_bytes, (int)out->w, (int)out->h, c->stream));
-  DFX_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = wait_stream(c))) return rc;
   return DFX_OK;
 }
 
@@ -2092,7 +2120,7 @@ DFX_API int dfx_build_pyramid_batch_async(dfx_ctx* c, const dfx_pyramid* frames,
 DFX_API int dfx_build_pyramid(dfx_ctx* c, const dfx_pyramid* frame) {
   int rc;
   if ((rc = dfx_build_pyramid_batch_async(c, frame, 1))) return rc;
-  DFX_HIP(hipStreamSynchronize(c->stream));   // like the reference's per-level calls (CudaCheckLastError = cudaDeviceSynchronize, cu_image_proc.cpp:111,185)
+  if ((rc = wait_stream(c))) return rc;   // like the reference's per-level calls (CudaCheckLastError = cudaDeviceSynchronize, cu_image_proc.cpp:111,185)
   return DFX_OK;
 }
 

@@ -185,6 +185,11 @@ DFX_API int dfx_last_mfma_mode(dfx_ctx* ctx, int* mode);
 #define DFX_SCHEDULE_DYNAMIC 2
 DFX_API int dfx_set_schedule(dfx_ctx* ctx, int mode);
 DFX_API int dfx_last_schedule(dfx_ctx* ctx, int* dynamic);
+/* How the context's blocking calls wait (see "How the blocking single-result entries return" below): DFX_WAIT_POLL = the host polls a word in mapped memory
+ * (the default unless DFX_POLL_RESULT=0 is in the environment), DFX_WAIT_STREAM = hipStreamSynchronize. */
+#define DFX_WAIT_STREAM 0
+#define DFX_WAIT_POLL 1
+DFX_API int dfx_set_result_wait(dfx_ctx* ctx, int mode);
 /* Measurement hook (no reference counterpart; the reference times with std::clock around blocking calls,
  * tools/kernel_benchmark.cpp:145-180): when enabled, every SfM step launch -- and every batched SE3-step / EvaluateError launch
  * (dfx_se3_step_batch*, dfx_sfm_error_batch*) -- is bracketed by HIP events on the context's stream: around the step (reduction)
@@ -243,7 +248,7 @@ DFX_API int dfx_se3_warp(dfx_ctx* ctx, const dfx_se3* pose_10, const dfx_cam* ca
 /* How the blocking single-result entries return (dfx_se3_step, dfx_se3_warp, dfx_sfm_error, dfx_sfm_step / dfx_sfm_step_batch and dfx_sfm_linearize_batch
  * with n = 1, dfx_depth_aligner_step, dfx_squared_error, dfx_track_frame): the call's last kernel stores the result into pinned, device-mapped host memory
  * and, behind it (system-scope release), the call's sequence number; the host polls that word and copies the result out -- it does NOT wait for the stream
- * to report idle, which the runtime learns 1-5 us later (profiles/r05_poll_result.txt).  Everything the call enqueued in front of that kernel has completed
+ * to report idle, which the runtime learns 3-6 us later (profiles/r05_poll_result.txt; dfx_set_result_wait switches per context).  Everything the call enqueued in front of that kernel has completed
  * when the call returns; the stream itself may show busy for a few more microseconds.  A stream error or a launch that never writes the word is detected
  * (the stream is queried every few hundred microseconds of polling).  DFX_POLL_RESULT=0 in the environment restores hipStreamSynchronize. */
 /* ---- CameraTracker::TrackFrame (core/system/camera_tracker.cpp:42-71), device-resident -------

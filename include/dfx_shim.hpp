@@ -119,6 +119,7 @@ class Context {
   // DFX_MFMA_F32_CHAIN pins the fmaf-chain bits) and which launch schedule batched steps use (DFX_SCHEDULE_*), see include/dfx.h
   void SetMfmaMode(int mode) { check(dfx_set_mfma_mode(ctx_, mode)); }
   void SetSchedule(int mode) { check(dfx_set_schedule(ctx_, mode)); }
+  void SetResultWait(int mode) { check(dfx_set_result_wait(ctx_, mode)); }   // DFX_WAIT_POLL (default) / DFX_WAIT_STREAM
   // The thread's default context: created on first use on the thread's CURRENT device (one process per GPU: this rank's GPU),
   // default stream.  SetDefault installs another one (other device / stream) for the aligners and free functions constructed or
   // called afterwards on this thread.

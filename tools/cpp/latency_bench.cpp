@@ -16,17 +16,26 @@ using dfx::pod::Image2DView;
 using dfx::pod::PinholeCamera;
 using dfx::pod::SE3f;
 
+// Per operator: the two ways a blocking call can wait (DFX_WAIT_POLL, the default, and DFX_WAIT_STREAM = hipStreamSynchronize), INTERLEAVED in blocks of n / 4
+// calls so that both see the same box in the same state; mean / min microseconds over n calls each.
 template <typename F>
 static void timeit(const char* name, int n, F&& f) {
-  for (int i = 0; i < 5; ++i) f();
-  double tot = 0, mn = 1e30;
-  for (int i = 0; i < n; ++i) {
-    const auto t0 = std::chrono::steady_clock::now();
-    f();
-    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    tot += us; mn = us < mn ? us : mn;
+  auto ctx = dfx::Context::Default();
+  double tot[2] = { 0, 0 }, mn[2] = { 1e30, 1e30 };
+  for (int block = 0; block < 8; ++block) {
+    const int mode = block & 1;   // 0: poll, 1: stream
+    ctx->SetResultWait(mode == 0 ? DFX_WAIT_POLL : DFX_WAIT_STREAM);
+    for (int i = 0; i < 5; ++i) f();
+    for (int i = 0; i < n / 4; ++i) {
+      const auto t0 = std::chrono::steady_clock::now();
+      f();
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      tot[mode] += us; mn[mode] = us < mn[mode] ? us : mn[mode];
+    }
   }
-  std::printf("%-44s mean %7.1f us   min %7.1f us   (%d blocking calls)\n", name, tot / n, mn, n);
+  ctx->SetResultWait(DFX_WAIT_POLL);
+  const int m = (n / 4) * 4;
+  std::printf("%-44s mean %7.1f us   min %7.1f us   (%d blocking calls; waiting for the stream instead: mean %7.1f  min %7.1f)\n", name, tot[0] / m, mn[0], m, tot[1] / m, mn[1]);
 }
 
 int main() {
