@@ -1646,14 +1646,18 @@ int track_frames_impl(dfx_ctx* c, int n, const dfx_se3* pose_init, const dfx_tra
     total_iters += levels[l].iterations;
   }
   const size_t dev_total = off_state + sbytes * (size_t)n * ((size_t)total_iters + 1);
-  int slot;
-  char* host;
-  if ((rc = stage_acquire(c, total, &slot, &host))) return rc;
+  // one tracker (the camera-rate case): descriptors and the initial state travel in the kernel arguments -- no staging slot, no upload in front of the first kernel
+  const bool byval = n == 1 && total_iters > 0;
+  alignas(16) char local[16 * sizeof(dfx::SimplePairDev) + 512];
+  static_assert(sizeof(local) >= 16 * sizeof(dfx::SimplePairDev) + 16 + 256, "n_levels <= 16 descriptors + one state");
+  int slot = -1;
+  char* host = local;
+  if (!byval && (rc = stage_acquire(c, total, &slot, &host))) return rc;
   dfx::SimplePairDev* hdesc = reinterpret_cast<dfx::SimplePairDev*>(host);
   // validate every level of every candidate first (no partial work on a bad argument)
   int max_blocks = 1;
   const dfx_se3 ident{ { 0, 0, 0, 1 }, { 0, 0, 0 } };
-  auto bail = [&](int code) { (void)stage_release(c, slot); return code; };
+  auto bail = [&](int code) { if (slot >= 0) (void)stage_release(c, slot); return code; };
   for (int k = 0; k < n; ++k)
     for (int l = 0; l < n_levels; ++l) {
       const dfx_track_level& L = levels[(size_t)k * n_levels + l];
@@ -1682,8 +1686,10 @@ int track_frames_impl(dfx_ctx* c, int n, const dfx_se3* pose_init, const dfx_tra
     quat_to_R(pose_init[k].q, R);
     dfx::track_state_init(host + off_state + sbytes * (size_t)k, R, t);
   }
-  if (hipMemcpyAsync(c->track_state_dev, host, total, hipMemcpyHostToDevice, c->stream) != hipSuccess) return bail(fail(DFX_E_HIP, "dfx_track_frame: descriptor upload failed"));
-  if ((rc = stage_release(c, slot))) return rc;
+  if (!byval) {
+    if (hipMemcpyAsync(c->track_state_dev, host, total, hipMemcpyHostToDevice, c->stream) != hipSuccess) return bail(fail(DFX_E_HIP, "dfx_track_frame: descriptor upload failed"));
+    if ((rc = stage_release(c, slot))) return rc;
+  }
   const dfx::SimplePairDev* ddesc = reinterpret_cast<const dfx::SimplePairDev*>(c->track_state_dev);
   char* dstates = (char*)c->track_state_dev + off_state;
   auto state_at = [&](int k) { return dstates + sbytes * (size_t)n * (size_t)k; };
@@ -1695,7 +1701,8 @@ int track_frames_impl(dfx_ctx* c, int n, const dfx_se3* pose_init, const dfx_tra
       // evaluation `it_done` at states[it_done] (= states[0] as uploaded, or the update this launch computes from evaluation it_done - 1)
       const void* sin = state_at(it_done > 0 ? it_done - 1 : 0);
       DFX_HIP(dfx::launch_track_iteration(ddesc + (size_t)l * n, n, sin, state_at(it_done), c->partials + (size_t)((it_done + 1) & 1) * pfloats, blocks_prev, W, H, huber_delta, blocks,
-                                          c->partials + (size_t)(it_done & 1) * pfloats, c->stream));
+                                          c->partials + (size_t)(it_done & 1) * pfloats, c->stream, byval ? &hdesc[l] : nullptr,
+                                          byval && it_done == 0 ? host + off_state : nullptr));
       blocks_prev = blocks;
       ++it_done;
     }

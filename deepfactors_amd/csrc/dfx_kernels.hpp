@@ -240,7 +240,9 @@ void track_state_read(const void* host_state, double* R, double* t, float* resid
 // [n][blocks_prev][kSimpleRow] at states_in[n]; blocks_prev 0 = none) -> states_out[n], then the evaluation at it -> partials_dev [n][blocks][kSimpleRow];
 // launch_track_final applies the last evaluation
 hipError_t launch_track_iteration(const SimplePairDev* descs_dev, int n, const void* states_in, void* states_out, const float* partials_prev, int blocks_prev,
-                                  int W, int H, float huber_delta, int blocks, float* partials_dev, hipStream_t stream);
+                                  int W, int H, float huber_delta, int blocks, float* partials_dev, hipStream_t stream,
+                                  const SimplePairDev* one_host = nullptr,    // n == 1: the level's descriptor by value (descs_dev unused) and, for the first
+                                  const void* state0_host = nullptr);         // evaluation of a frame (blocks_prev == 0), the initial state by value
 hipError_t launch_track_final(int n, const void* states_in, void* states_out, const float* partials_prev, int blocks_prev, hipStream_t stream,
                               const DoneFlag& done = DoneFlag{});   // (n == 1)
 

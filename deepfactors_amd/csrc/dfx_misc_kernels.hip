@@ -533,10 +533,15 @@ __device__ __forceinline__ void track_fold_and_solve(const float* __restrict__ p
 // blockIdx.y = candidate: Relocalize / the loop-closure geometry checks track ONE live frame against N keyframes
 // (deepfactors.cpp:713-743, loop_detector.cpp:146-167); descriptors, states and partials are arrays over candidates.
 // nblocks_prev == 0: the first evaluation of a frame, at states_in as the host wrote it.
-__global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev* __restrict__ descs, const TrackState* __restrict__ states_in, TrackState* __restrict__ states_out,
+// BYVAL (one tracker, the camera-rate case): the level's descriptor and -- for the first evaluation -- the initial state travel in the kernel arguments, so a
+// frame has no host-to-device copy in front of its first kernel (a 4 us blit kernel and a launch boundary); workgroup 0 of the first evaluation writes the
+// initial state to states_out, where the second evaluation's update reads it.
+template <bool BYVAL>
+__global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev* __restrict__ descs, const SimplePairDev one, const TrackState st0,
+                                                     const TrackState* __restrict__ states_in, TrackState* __restrict__ states_out,
                                                      const float* __restrict__ partials_prev, const int nblocks_prev, const int W, const int H,
                                                      const float huber_delta, float* __restrict__ partials_all) {
-  const SimplePairDev& p = descs[blockIdx.y];
+  const SimplePairDev& p = BYVAL ? one : descs[blockIdx.y];
   float* partials = partials_all + (size_t)blockIdx.y * gridDim.x * kSimpleRow;
   __shared__ TrackLds l;
   float R[9], t[3], e1, e2;
@@ -548,10 +553,11 @@ __global__ __launch_bounds__(kT) void k_se3_step_dev(const SimplePairDev* __rest
 #pragma unroll
     for (int q = 0; q < 3; ++q) t[q] = rfl(l.st.tf[q]);
   } else {
-    const TrackState* st = states_in + blockIdx.y;
+    const TrackState* st = BYVAL ? &st0 : states_in + blockIdx.y;
 #pragma unroll
     for (int q = 0; q < 9; ++q) R[q] = st->Rf[q];
     t[0] = st->tf[0]; t[1] = st->tf[1]; t[2] = st->tf[2];
+    if (BYVAL && blockIdx.x == 0 && threadIdx.x == 0) states_out[blockIdx.y] = st0;
   }
   fast_band(R, t, p.fc, e1, e2);   // the descriptor's band belongs to the pose it was filled with, not to the state's
   se3_step_body(p, R, t, e1, e2, W, H, huber_delta, partials + (size_t)blockIdx.x * kSimpleRow);
@@ -571,9 +577,17 @@ __global__ __launch_bounds__(kT) void k_track_final(const float* __restrict__ pa
 size_t track_state_bytes() { return sizeof(TrackState); }
 
 hipError_t launch_track_iteration(const SimplePairDev* descs_dev, int n, const void* states_in, void* states_out, const float* partials_prev, int blocks_prev,
-                                  int W, int H, float huber_delta, int blocks, float* partials_dev, hipStream_t stream) {
-  hipLaunchKernelGGL(k_se3_step_dev, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, (const TrackState*)states_in, (TrackState*)states_out, partials_prev, blocks_prev, W, H,
-                     huber_delta, partials_dev);
+                                  int W, int H, float huber_delta, int blocks, float* partials_dev, hipStream_t stream, const SimplePairDev* one_host,
+                                  const void* state0_host) {
+  if (one_host && n == 1) {
+    TrackState st0{};
+    if (state0_host) st0 = *static_cast<const TrackState*>(state0_host);
+    hipLaunchKernelGGL(k_se3_step_dev<true>, dim3(blocks, 1), dim3(kT), 0, stream, (const SimplePairDev*)nullptr, *one_host, st0, (const TrackState*)states_in,
+                       (TrackState*)states_out, partials_prev, blocks_prev, W, H, huber_delta, partials_dev);
+  } else {
+    hipLaunchKernelGGL(k_se3_step_dev<false>, dim3(blocks, n), dim3(kT), 0, stream, descs_dev, SimplePairDev{}, TrackState{}, (const TrackState*)states_in,
+                       (TrackState*)states_out, partials_prev, blocks_prev, W, H, huber_delta, partials_dev);
+  }
   return hipGetLastError();
 }
 hipError_t launch_track_final(int n, const void* states_in, void* states_out, const float* partials_prev, int blocks_prev, hipStream_t stream, const DoneFlag& done) {
