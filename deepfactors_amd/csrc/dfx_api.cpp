@@ -135,6 +135,8 @@ struct dfx_ctx {
   unsigned* done_counter = nullptr;     // device: arrivals of a multi-workgroup finalize kernel, zero between calls
   uint32_t done_seq = 0;
   bool poll = true;                     // dfx_set_result_wait; initialised from DFX_POLL_RESULT
+  double* fin_scratch = nullptr;        // a single pair's four-workgroups-per-tile finalize kernel (k_sfm_finalize_b3_split): dfx::kSplitScratchBytes
+  unsigned* fin_cnt = nullptr;          // + 64 arrival counters, zero between calls
   dfx::DoneFlag* done_armed = nullptr;        // set by a blocking entry around the one impl call whose finalize kernel is to signal
   void* track_state_dev = nullptr;   // [TrackState x n][SimplePairDev x levels x n]
   size_t track_bytes = 0;
@@ -297,6 +299,13 @@ int ensure_done_flag(dfx_ctx* c) {
   c->done_flag_dev = static_cast<uint32_t*>(dp);
   DFX_HIP(hipMalloc((void**)&c->done_counter, 64));
   DFX_HIP(hipMemsetAsync(c->done_counter, 0, 64, c->stream));
+  return DFX_OK;
+}
+int ensure_fin_scratch(dfx_ctx* c) {
+  if (c->fin_scratch) return DFX_OK;
+  DFX_HIP(hipMalloc((void**)&c->fin_cnt, 64 * sizeof(unsigned)));
+  DFX_HIP(hipMemsetAsync(c->fin_cnt, 0, 64 * sizeof(unsigned), c->stream));
+  DFX_HIP(hipMalloc((void**)&c->fin_scratch, dfx::kSplitScratchBytes));
   return DFX_OK;
 }
 int new_done_flag(dfx_ctx* c, dfx::DoneFlag* d) {
@@ -711,6 +720,8 @@ DFX_API void dfx_ctx_destroy(dfx_ctx* c) {
   if (c->track_state_dev) (void)hipFree(c->track_state_dev);
   if (c->done_flag_host) (void)hipHostFree(c->done_flag_host);
   if (c->done_counter) (void)hipFree(c->done_counter);
+  if (c->fin_scratch) (void)hipFree(c->fin_scratch);
+  if (c->fin_cnt) (void)hipFree(c->fin_cnt);
   if (c->sg_dev) (void)hipFree(c->sg_dev);
   if (c->pyr_dev) (void)hipFree(c->pyr_dev);
   for (auto& t : c->ray_tabs) (void)hipFree(t.dev);
@@ -1209,10 +1220,12 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
   bool assembled = false;
   dfx::DoneFlag* dn = c->done_armed;   // (blocking single-pair entries; launch_sfm_step clears the flag when the launch has no signalling tail)
   if (dn && (graph || defer)) { dn->flag = nullptr; dn = nullptr; }
+  const bool split_fin = n == 1 && uniform && !defer;   // a single pair on the context's stream: the finalize kernel with four workgroups per tile
+  if (split_fin && (rc = ensure_fin_scratch(c))) return rc;
   DFX_HIP(dfx::launch_sfm_step(cs, dd, n, (int)W, (int)H, prm, bpp, partials, out_items_dev, dfx_item_size(12 + cs), c->stream,
                                jac_dense, resolve_mfma(c, cs), eb, ee, n == 1 ? &one : nullptr, dyn.qhead ? &dyn : nullptr, dyn_grid, vsh,
                                fin_stream, defer ? c->ev_mid[par] : nullptr, map_dev, total_blocks, graph ? &tg : nullptr, node_wgs, &assembled,
-                               dn));
+                               dn, split_fin ? c->fin_scratch : nullptr, split_fin ? c->fin_cnt : nullptr));
   c->qhead_dirty = false;   // both kernels are enqueued: the finalize kernel rewinds the heads
   if (graph) {
     c->node_cnt_dirty = false;   // the tail kernel rewinds the counters it used
@@ -2187,8 +2200,9 @@ DFX_API int dfx_depth_aligner_step(dfx_ctx* c, int cs, const float* code, const 
   if ((rc = result_target(c, ibytes, &tgt))) return rc;
   dfx::DoneFlag done;
   if ((rc = new_done_flag(c, &done))) return rc;
+  if ((rc = ensure_fin_scratch(c))) return rc;
   DFX_HIP(dfx::launch_depth_aligner_step(cs, hd, (int)W, (int)H, avg_dpt, bpp, c->partials, tgt, c->stream,
-                                         prx_jac->pitch_bytes == (size_t)W * cs * 4, resolve_mfma(c, cs), done.flag ? &done : nullptr));
+                                         prx_jac->pitch_bytes == (size_t)W * cs * 4, resolve_mfma(c, cs), done.flag ? &done : nullptr, c->fin_scratch, c->fin_cnt));
   return finish_result_polled(c, out_item, ibytes, done);
 }
 

@@ -202,7 +202,9 @@ hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int 
                                                                                            // W, H = the largest width / height (ray-table LDS); blocks_per_pair unused
                            const TailGraphDev* tail_graph = nullptr, int node_wgs = 0,    // graph assembly inside the reduction tail (k_sfm_tail_b3) where the
                            bool* assembled = nullptr,                                     // launch has one: *assembled tells; node_wgs = 0 or the graph's nodes
-                           DoneFlag* done = nullptr);   // one_host launches: the finalize kernel signals *done; cleared (flag = nullptr) when the launch cannot
+                           DoneFlag* done = nullptr,   // one_host launches: the finalize kernel signals *done; cleared (flag = nullptr) when the launch cannot
+                           double* split_scratch = nullptr, unsigned* split_cnt = nullptr);   // one_host, bf16 split: kSplitScratchBytes of device scratch + 64 zeroed
+                                                                                              // counters -> the four-workgroups-per-tile finalize kernel
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair);
 // system layout (floats): Hd [n_nodes][D][D], Ho [n_pairs][D][6], g [n_nodes][D]; contributions of the pairs [first_pair, first_pair + n_local)
 hipError_t launch_graph_assemble(int cs, const GraphDev& G, const void* items_dev, size_t item_stride, int first_pair, int n_local, float* sys_dev,
@@ -230,7 +232,9 @@ hipError_t launch_blur_down(const float* in, uint32_t pitch, int W, int H, float
 hipError_t launch_squared_error(const float* a, uint32_t pitch_a, const float* b, uint32_t pitch_b, int W, int H, int blocks,
                                 float* partials_dev, float* out_dev, hipStream_t stream, const DoneFlag& done = DoneFlag{});
 hipError_t launch_depth_aligner_step(int cs, const SfmPairDev* pair_host, int W, int H, float avg_dpt, int blocks,
-                                     float* partials_dev, void* item_dev, hipStream_t stream, bool jac_dense, int prec, DoneFlag* done = nullptr);
+                                     float* partials_dev, void* item_dev, hipStream_t stream, bool jac_dense, int prec, DoneFlag* done = nullptr,
+                                     double* split_scratch = nullptr, unsigned* split_cnt = nullptr);
+constexpr size_t kSplitScratchBytes = 64 * 4 * 512 * sizeof(double);   // b3_tiles(4) = 15 tiles <= 64, four groups, 256 + 256 doubles each
 
 // device-resident tracker
 size_t track_state_bytes();

@@ -1254,6 +1254,62 @@ __global__ __launch_bounds__(1024) void k_sfm_finalize_b3(const float* __restric
   if (BYVAL) signal_done_grid(done, gridDim.x * gridDim.y);
 }
 
+// ---- a SINGLE pair's finalize (the reference's per-factor pattern: one blocking RunStep per linearisation) on more than b3_tiles compute units --------------
+// k_sfm_finalize_b3 gives a pair one workgroup per tile: 6 at CS = 32, each folding 240-480 KB of partial rows through ONE compute unit's 64 B / clock --
+// 10 us behind a 14 us step kernel (rocprofv3 kernel trace of tests/cpp/gn_round_bench's serial pattern).  Here a tile has FOUR workgroups of 256 threads:
+// workgroup (tile, g) sums the rows g, g + 4, ... (the row group `rg` of k_sfm_finalize_b3: the same chain of additions), parks its 256 (+ 256) doubles,
+// and counts itself in; the workgroup that arrives last folds the four groups ((g0 + g1) + g2) + g3 -- the same bits as the one-workgroup form --, unpacks
+// and scatters.  Arrival protocol of k_sfm_tail_b3 (stores complete, barrier, one release fence + one relaxed read-modify-write, acquire in the last arriver).
+template <int NCB, int NPOSE>
+__global__ __launch_bounds__(256) void k_sfm_finalize_b3_split(const float* __restrict__ partials, const int nparts, const SfmPairDev one, char* __restrict__ item_bytes,
+                                                               const int W, const int H, const unsigned launch_id, double* __restrict__ scratch,
+                                                               unsigned* __restrict__ tile_cnt, const DoneFlag done) {
+  constexpr int NT3 = b3_tiles(NCB);
+  constexpr int ZDIM = b3_blocks(NCB) * 256;
+  __shared__ double red[256], redn[256];
+  __shared__ double T[12][6];
+  __shared__ int last_s;
+  const int blk = blockIdx.x, g = blockIdx.y, el = threadIdx.x;
+  if (NPOSE == 12) rebuild_valid0_shadow(one, W, H, launch_id, blk * 4 + g, (int)gridDim.x * 4, valid0_shadow_stamp(one, launch_id));
+  const int dtile = b3_dtile<NCB>(blk);
+  double* mine = scratch + ((size_t)blk * 4 + g) * 512;
+  mine[el] = strided_sum_f64<4, 16>(partials + blk * 256 + el, g, nparts, ZDIM);
+  if (dtile >= 0) mine[256 + el] = strided_sum_f64<4, 16>(partials + (NT3 + dtile) * 256 + el, g, nparts, ZDIM);
+  __builtin_amdgcn_s_waitcnt(0);   // this wave's stores have completed
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const bool last = __hip_atomic_fetch_add(&tile_cnt[blk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3u;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(&tile_cnt[blk], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // rewound for the next call
+    }
+    last_s = last ? 1 : 0;
+  }
+  __syncthreads();
+  if (!last_s) return;
+  {
+    const double* t0 = scratch + (size_t)blk * 4 * 512;
+    auto ld = [](const double* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };   // written by other workgroups of this kernel
+    red[el] = ((ld(t0 + el) + ld(t0 + 512 + el)) + ld(t0 + 1024 + el)) + ld(t0 + 1536 + el);
+    if (dtile >= 0) redn[el] = ((ld(t0 + 256 + el) + ld(t0 + 768 + el)) + ld(t0 + 1280 + el)) + ld(t0 + 1792 + el);
+  }
+  if (NPOSE == 12 && threadIdx.x < 72) {
+    const int n = threadIdx.x / 6, i = threadIdx.x - n * 6;
+    T[n][i] = b3_T_entry(one.M, one.HM, n, i);
+  }
+  __syncthreads();
+  {
+    bool keep = false;
+    const double v = b3_unpack<NCB>(blk, dtile, el, red, redn, keep);
+    __syncthreads();
+    if (keep) red[el] = v;
+    __syncthreads();
+  }
+  b3_scatter<NCB, NPOSE>(blk, el, red, T, reinterpret_cast<float*>(item_bytes));
+  signal_done_grid(done, gridDim.x);   // the last arrivers of the tiles count themselves in; the last of THEM tells the host
+}
+
 // ---- the reduction tail of a batched bf16-split launch in ONE kernel: workgroup p sums ALL blocks of pair p's partials (same order as
 // k_sfm_finalize_b3: four interleaved groups of partials, folded ((g0 + g1) + g2) + g3 in double), writes the item, and -- when the
 // launch assembles a keyframe graph (dfx_sfm_step_batch_assemble_async) -- the workgroup that completes a node (the last of the
@@ -1491,7 +1547,7 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
                            hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, const SfmPairDev* one_host = nullptr,
                            const DynDev* dyn = nullptr, int dyn_grid = 0, bool vsh = false, hipStream_t fin_stream = nullptr, hipEvent_t ev_mid = nullptr,
                            const unsigned* blkmap = nullptr, int total_blocks = 0, const TailGraphDev* tail_graph = nullptr, int node_wgs = 0,
-                           bool* assembled = nullptr, DoneFlag* done_io = nullptr) {
+                           bool* assembled = nullptr, DoneFlag* done_io = nullptr, double* split_scratch = nullptr, unsigned* split_cnt = nullptr) {
   if (assembled) *assembled = false;
   // only the by-value (single pair) finalize kernels signal; a launch that takes another tail clears the caller's flag, and the caller waits for the stream
   const DoneFlag done = (done_io && one_host && !dyn) ? *done_io : DoneFlag{};
@@ -1577,7 +1633,9 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
   constexpr int NPOSE = MODE == 0 ? 12 : 0;
   const SfmPairDev* fpairs = byval ? (const SfmPairDev*)nullptr : pairs_dev;
   if (b3) {
-    if (byval) hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, true>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
+    if (byval && split_scratch && !ragged) hipLaunchKernelGGL((k_sfm_finalize_b3_split<NCB, NPOSE>), dim3(b3_tiles(NCB), 4), dim3(256), 0, fstream,
+                                  (const float*)partials_dev, bpp, one, (char*)items_dev, W, H, prm.launch_id, split_scratch, split_cnt, done);
+    else if (byval) hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, true>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
                                   (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged, done);
     else if (MODE == 0 && use_tail) {   // batched launches: one workgroup per pair, the graph assembly folded in
       if (tg.sys && tail_ordered()) hipLaunchKernelGGL((k_sfm_tail_b3<NCB, true, true>), dim3(npairs + node_wgs), dim3(1024), 0, fstream,
@@ -1602,23 +1660,23 @@ hipError_t launch_sfm_step(int cs, const SfmPairDev* pairs_dev, int npairs, int 
                            int blocks_per_pair, float* partials_dev, void* items_dev, size_t item_stride,
                            hipStream_t stream, bool jac_dense, int prec, hipEvent_t eb, hipEvent_t ee, const SfmPairDev* one_host,
                            const DynDev* dyn, int dyn_grid, bool vsh, hipStream_t fin_stream, hipEvent_t ev_mid, const unsigned* blkmap_dev, int total_blocks,
-                           const TailGraphDev* tail_graph, int node_wgs, bool* assembled, DoneFlag* done) {
+                           const TailGraphDev* tail_graph, int node_wgs, bool* assembled, DoneFlag* done, double* split_scratch, unsigned* split_cnt) {
   switch (cs) {
-    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled, done);
-    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled, done);
-    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled, done);
+    case 16: return launch_t<1, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled, done, split_scratch, split_cnt);
+    case 32: return launch_t<2, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled, done, split_scratch, split_cnt);
+    case 64: return launch_t<4, 0>(pairs_dev, npairs, W, H, prm, blocks_per_pair, partials_dev, items_dev, item_stride, stream, jac_dense, prec, eb, ee, one_host, dyn, dyn_grid, vsh, fin_stream, ev_mid, blkmap_dev, total_blocks, tail_graph, node_wgs, assembled, done, split_scratch, split_cnt);
     default: return hipErrorInvalidValue;
   }
 }
 
 // DepthAligner::RunStep: `pair_host` describes ONE pseudo-pair with img0 = target depth, dpt0 = current depth, jac (passed by value).
 hipError_t launch_depth_aligner_step(int cs, const SfmPairDev* pair_host, int W, int H, float avg_dpt, int blocks,
-                                     float* partials_dev, void* item_dev, hipStream_t stream, bool jac_dense, int prec, DoneFlag* done) {
+                                     float* partials_dev, void* item_dev, hipStream_t stream, bool jac_dense, int prec, DoneFlag* done, double* split_scratch, unsigned* split_cnt) {
   SfmParamsDev prm{ 0.f, avg_dpt, 0.f, 0.f, 0u };
   switch (cs) {
-    case 16: return launch_t<1, 1>(nullptr, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec, nullptr, nullptr, pair_host, nullptr, 0, false, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, done);
-    case 32: return launch_t<2, 1>(nullptr, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec, nullptr, nullptr, pair_host, nullptr, 0, false, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, done);
-    case 64: return launch_t<4, 1>(nullptr, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec, nullptr, nullptr, pair_host, nullptr, 0, false, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, done);
+    case 16: return launch_t<1, 1>(nullptr, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec, nullptr, nullptr, pair_host, nullptr, 0, false, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, done, split_scratch, split_cnt);
+    case 32: return launch_t<2, 1>(nullptr, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec, nullptr, nullptr, pair_host, nullptr, 0, false, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, done, split_scratch, split_cnt);
+    case 64: return launch_t<4, 1>(nullptr, 1, W, H, prm, blocks, partials_dev, item_dev, 0, stream, jac_dense, prec, nullptr, nullptr, pair_host, nullptr, 0, false, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, done, split_scratch, split_cnt);
     default: return hipErrorInvalidValue;
   }
 }
