@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/dfx_shim.hpp"
@@ -73,6 +74,15 @@ int main() {
     df::SfmAligner<float, CS> sfm;
     float code[CS] = { 0 };
     timeit("SfmAligner<32>::RunStep 640x480", 300, [&] { (void)sfm.RunStep(p0, p1, code, cam, v0, v1, vd, vd, vv, vj, vg); });
+    if (std::getenv("DFX_LATENCY_SWEEP")) {   // workgroups of the single pair's step kernel (0 = the library's choice)
+      for (int blocks : { 0, 160, 200, 240, 300, 400, 480, 600, 800 }) {
+        sfm.SetStepThreadsBlocks(256, blocks);
+        char name[96];
+        std::snprintf(name, sizeof name, "SfmAligner<32>::RunStep, step_blocks %d", blocks);
+        timeit(name, 200, [&] { (void)sfm.RunStep(p0, p1, code, cam, v0, v1, vd, vd, vv, vj, vg); });
+      }
+      sfm.SetStepThreadsBlocks(256, 0);
+    }
     {
       std::vector<dfx_sfm_pair> batch(16, df::SfmAligner<float, CS>::MakePair(p0, p1, cam, v0, v1, vd, vv, vj, vg));
       const auto items = sfm.RunStepBatch(batch);
