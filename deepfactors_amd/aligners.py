@@ -238,6 +238,11 @@ class Context:
         DFX_SCHEDULE_DYNAMIC (opt-in per-pair item queues for batches of >= 128 pairs); see include/dfx.h."""
         check(_lib.lib().dfx_set_schedule(self._h, int(mode)))
 
+    def set_result_wait(self, mode):
+        """_lib.DFX_WAIT_POLL (default: blocking single-result calls poll the word their last kernel stores behind the result) or
+        _lib.DFX_WAIT_STREAM (hipStreamSynchronize); see include/dfx.h."""
+        check(_lib.lib().dfx_set_result_wait(self._h, int(mode)))
+
     def last_schedule_dynamic(self):
         """True when the last batched SfM step of this context ran on the dynamic item queues."""
         d = C.c_int(0)

@@ -303,8 +303,10 @@ int ensure_done_flag(dfx_ctx* c) {
 }
 int ensure_fin_scratch(dfx_ctx* c) {
   if (c->fin_scratch) return DFX_OK;
-  DFX_HIP(hipMalloc((void**)&c->fin_cnt, 64 * sizeof(unsigned)));
-  DFX_HIP(hipMemsetAsync(c->fin_cnt, 0, 64 * sizeof(unsigned), c->stream));
+  if (!c->fin_cnt) {
+    DFX_HIP(hipMalloc((void**)&c->fin_cnt, 64 * sizeof(unsigned)));
+    DFX_HIP(hipMemsetAsync(c->fin_cnt, 0, 64 * sizeof(unsigned), c->stream));
+  }
   DFX_HIP(hipMalloc((void**)&c->fin_scratch, dfx::kSplitScratchBytes));
   return DFX_OK;
 }

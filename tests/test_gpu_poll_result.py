@@ -61,3 +61,19 @@ def test_depth_aligner_and_tracker(dfx):
         trk[k].Reset()
         return trk[k].TrackFrame([prs[k]["img1"]], [prs[k]["grad1"]]).tobytes() + np.float32(trk[k].GetError()).tobytes()
     _alternate(frame, reps=150)
+
+
+def test_both_waits_give_the_same_bytes_and_bad_modes_are_refused(dfx):
+    from deepfactors_amd import _lib
+    prs = _pairs(32)
+    ctx = dfx.Context(0)
+    al, se3 = dfx.SfmAligner(code_size=32, ctx=ctx), dfx.SE3Aligner(ctx=ctx)
+    out = {}
+    for mode in (_lib.DFX_WAIT_POLL, _lib.DFX_WAIT_STREAM, _lib.DFX_WAIT_POLL):
+        ctx.set_result_wait(mode)
+        p = prs[0]
+        got = (al.RunStep(p["pose0"], p["pose1"], None, p["cam"], p["img0"], p["img1"], p["dpt0"], None, p["valid0"], p["prx_jac"], p["grad1"]).raw.tobytes(),
+               se3.RunStep(p["pose10_true"], p["cam"], p["img0"], p["img1"], p["dpt0"], p["grad1"]).raw.tobytes())
+        assert out.setdefault("first", got) == got
+    with pytest.raises(dfx.DfxError):
+        ctx.set_result_wait(7)
