@@ -236,6 +236,28 @@ __device__ __forceinline__ double strided_sum_f64_wide(const float* __restrict__
   return s;
 }
 
+// Two strided sums whose loads are in flight TOGETHER (TWO = false: only a): the diagonal tiles of a pair's normal equations fold two blocks of every partial
+// row, and a single pair's finalize kernel is nothing but these dependent round trips (0.55 us per batch of 16 rows: 4.5 us for the two sums one after the
+// other, timestamps in profiles/r05_poll_result.txt).  Same order of additions per source as strided_sum_f64 (ascending rows, one chain): the same bits.
+template <int STEP, int DEPTH, bool TWO>
+__device__ __forceinline__ void strided_sum2_f64(const float* __restrict__ a, const float* __restrict__ b, int first, int n, size_t stride, double& sa_out, double& sb_out) {
+  double sa = 0.0, sb = 0.0;
+  for (int r0 = first; r0 < n; r0 += DEPTH * STEP) {
+    float va[DEPTH], vb[DEPTH];
+#pragma unroll
+    for (int q = 0; q < DEPTH; ++q) {
+      const int r = r0 + q * STEP;
+      const size_t off = (size_t)(r < n ? r : r0) * stride;   // unconditional loads of existing rows (a conditional one is a branch + a wait each), +0.0 past n
+      const float ta = a[off];
+      va[q] = r < n ? ta : 0.0f;
+      if constexpr (TWO) { const float tb = b[off]; vb[q] = r < n ? tb : 0.0f; }
+    }
+#pragma unroll
+    for (int q = 0; q < DEPTH; ++q) { sa += (double)va[q]; if constexpr (TWO) sb += (double)vb[q]; }
+  }
+  sa_out = sa; sb_out = sb;
+}
+
 // 64-lane sum via shuffles (wave = 64 on gfx950)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -176,14 +176,14 @@ __device__ __forceinline__ void signal_done_grid(const DoneFlag& d, const unsign
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (threadIdx.x != 0) return;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   if (total_wgs > 1) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // into the count; the last arriver's system-scope release below carries every workgroup's stores to the host
     const unsigned got = __hip_atomic_fetch_add(d.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     if (got != total_wgs) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // rewound for the next call
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   __hip_atomic_store(d.flag, d.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 #endif

@@ -105,6 +105,9 @@ namespace dfx {
 // spill put scratch loads into the in-order vmcnt queue of the pipelined loop: 1367-1415 us against 995-1007 us.  The half-size ring alone
 // (+0.6 %) and the two-part fold alone (+-0) at three waves change nothing.
 #ifndef DFX_TAIL_KERNEL
+#ifndef DFX_FIN_TRACE
+#define DFX_FIN_TRACE 0   // debug builds (tools/variants.sh fintrace:"-DDFX_FIN_TRACE=1"): timestamps of the single-pair finalize kernel through printf
+#endif
 #define DFX_TAIL_KERNEL 1    // batched bf16-split launches: 1 = k_sfm_tail_b3 (a workgroup per pair, graph assembly folded in), 0 = k_sfm_finalize_b3 (a workgroup
 #endif                       // per tile of a pair) and a separate assembly kernel -- the A/B switch of DESIGN.md 3.7
 #ifndef DFX_TAIL_MAX_KB
@@ -1270,13 +1273,27 @@ __global__ __launch_bounds__(256) void k_sfm_finalize_b3_split(const float* __re
   __shared__ double T[12][6];
   __shared__ int last_s;
   const int blk = blockIdx.x, g = blockIdx.y, el = threadIdx.x;
+#if DFX_FIN_TRACE
+  const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
   if (NPOSE == 12) rebuild_valid0_shadow(one, W, H, launch_id, blk * 4 + g, (int)gridDim.x * 4, valid0_shadow_stamp(one, launch_id));
+#if DFX_FIN_TRACE
+  const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int dtile = b3_dtile<NCB>(blk);
   double* mine = scratch + ((size_t)blk * 4 + g) * 512;
-  mine[el] = strided_sum_f64<4, 16>(partials + blk * 256 + el, g, nparts, ZDIM);
-  if (dtile >= 0) mine[256 + el] = strided_sum_f64<4, 16>(partials + (NT3 + dtile) * 256 + el, g, nparts, ZDIM);
+  {
+    double sa, sb;
+    if (dtile >= 0) strided_sum2_f64<4, 32, true>(partials + blk * 256 + el, partials + (NT3 + dtile) * 256 + el, g, nparts, ZDIM, sa, sb);
+    else strided_sum2_f64<4, 32, false>(partials + blk * 256 + el, nullptr, g, nparts, ZDIM, sa, sb);
+    mine[el] = sa;
+    if (dtile >= 0) mine[256 + el] = sb;
+  }
   __builtin_amdgcn_s_waitcnt(0);   // this wave's stores have completed
   __syncthreads();
+#if DFX_FIN_TRACE
+  const unsigned long long tr2 = __builtin_amdgcn_s_memrealtime();
+#endif
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     const bool last = __hip_atomic_fetch_add(&tile_cnt[blk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3u;
@@ -1287,6 +1304,10 @@ __global__ __launch_bounds__(256) void k_sfm_finalize_b3_split(const float* __re
     last_s = last ? 1 : 0;
   }
   __syncthreads();
+#if DFX_FIN_TRACE
+  const unsigned long long tr3 = __builtin_amdgcn_s_memrealtime();
+  if (!last_s) { if (threadIdx.x == 0) printf("fin blk %d g %d  shadow %llu fold %llu arrive %llu (x10 ns) start %llu\n", blk, g, tr1 - tr0, tr2 - tr1, tr3 - tr2, tr0 % 1000000ull); return; }
+#endif
   if (!last_s) return;
   {
     const double* t0 = scratch + (size_t)blk * 4 * 512;
@@ -1307,7 +1328,14 @@ __global__ __launch_bounds__(256) void k_sfm_finalize_b3_split(const float* __re
     __syncthreads();
   }
   b3_scatter<NCB, NPOSE>(blk, el, red, T, reinterpret_cast<float*>(item_bytes));
+#if DFX_FIN_TRACE
+  const unsigned long long tr4 = __builtin_amdgcn_s_memrealtime();
+#endif
   signal_done_grid(done, gridDim.x);   // the last arrivers of the tiles count themselves in; the last of THEM tells the host
+#if DFX_FIN_TRACE
+  if (threadIdx.x == 0) printf("fin blk %d g %d LAST shadow %llu fold %llu arrive %llu gather+scatter %llu signal %llu (x10 ns) start %llu\n", blk, g, tr1 - tr0, tr2 - tr1, tr3 - tr2, tr4 - tr3,
+                               __builtin_amdgcn_s_memrealtime() - tr4, tr0 % 1000000ull);
+#endif
 }
 
 // ---- the reduction tail of a batched bf16-split launch in ONE kernel: workgroup p sums ALL blocks of pair p's partials (same order as
