@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -230,19 +231,27 @@ bool desc_zerocopy() {
 }
 
 // Pinned staging ring: returns a host slot whose previous upload has completed.
+// Slots of at least `bytes`.  Growing frees the old ring: never while a slot is handed out and not yet released -- a caller that acquires a second slot before
+// releasing the first (dfx_sfm_linearize_batch: the decoder's job list inside the step's preparation) reserves the second one's size up front.
+int stage_reserve(dfx_ctx* c, size_t bytes) {
+  if (bytes <= c->stage_slot_bytes) return DFX_OK;
+  // drain and regrow
+  DFX_HIP(hipStreamSynchronize(c->stream));
+  if (c->copy_stream) DFX_HIP(hipStreamSynchronize(c->copy_stream));
+  if (c->tail_stream) DFX_HIP(hipStreamSynchronize(c->tail_stream));
+  if (c->stage_host) DFX_HIP(hipHostFree(c->stage_host));
+  c->stage_host = nullptr;
+  c->stage_slot_bytes = 0;
+  size_t n = bytes * 2;
+  if (n < 4096) n = 4096;
+  DFX_HIP(hipHostMalloc((void**)&c->stage_host, n * kStageSlots, hipHostMallocDefault));
+  c->stage_slot_bytes = n;
+  for (int i = 0; i < kStageSlots; ++i) c->stage_used[i] = false;
+  return DFX_OK;
+}
 int stage_acquire(dfx_ctx* c, size_t bytes, int* slot, char** host) {
-  if (bytes > c->stage_slot_bytes) {
-    // drain and regrow
-    DFX_HIP(hipStreamSynchronize(c->stream));
-    if (c->copy_stream) DFX_HIP(hipStreamSynchronize(c->copy_stream));
-    if (c->stage_host) DFX_HIP(hipHostFree(c->stage_host));
-    c->stage_host = nullptr;
-    size_t n = bytes * 2;
-    if (n < 4096) n = 4096;
-    DFX_HIP(hipHostMalloc((void**)&c->stage_host, n * kStageSlots, hipHostMallocDefault));
-    c->stage_slot_bytes = n;
-    for (int i = 0; i < kStageSlots; ++i) c->stage_used[i] = false;
-  }
+  int rc;
+  if ((rc = stage_reserve(c, bytes))) return rc;
   const int s = c->stage_next;
   c->stage_next = (s + 1) % kStageSlots;
   if (c->stage_used[s]) DFX_HIP(hipEventSynchronize(c->stage_ev[s]));
@@ -1004,8 +1013,12 @@ DFX_API int dfx_debug_read_valid0_shadow(dfx_ctx* c, const dfx_img* img, uint64_
 
 // ---- SfmAligner ------------------------------------------------------------------------------------------------
 struct dfx_graph;
+// before_launch (optional): enqueued work the step kernel depends on (the decoder launches of dfx_sfm_linearize_batch), issued once the step's own host work --
+// validation, descriptors, launch shape -- is done, right in front of the step kernel: the GPU then runs the two back to back instead of idling through the
+// step's preparation (5.6 us between a single pair's decode and its step in the kernel trace).
 static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n, void* out_items_dev, bool allow_defer,
-                               const dfx_graph* graph = nullptr, int first_pair = 0, float* sys_dev = nullptr);
+                               const dfx_graph* graph = nullptr, int first_pair = 0, float* sys_dev = nullptr, const std::function<int()>* before_launch = nullptr,
+                               const std::function<int()>* after_launch = nullptr);   // after_launch: behind the step's launches (runs on every exit once before_launch has)
 
 DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n,
                                      void* out_items_dev) {
@@ -1016,7 +1029,7 @@ DFX_API int dfx_sfm_step_batch_async(dfx_ctx* c, int cs, const dfx_sfm_params* p
 static int graph_tail(dfx_ctx* c, int cs, const dfx_graph* g, int first_pair, int n, float* sys_dev, dfx::TailGraphDev* tg, int* node_wgs);
 
 static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, int n, void* out_items_dev, bool allow_defer,
-                               const dfx_graph* graph, int first_pair, float* sys_dev) {
+                               const dfx_graph* graph, int first_pair, float* sys_dev, const std::function<int()>* before_launch, const std::function<int()>* after_launch) {
   if (!c || !params || !pairs || !out_items_dev) return fail(DFX_E_INVALID, "dfx_sfm_step_batch: null argument");
   if (!cs_supported(cs)) return fail(DFX_E_INVALID, "unsupported code size %d (16, 32, 64)", cs);
   if (n <= 0 || n > 65535) return fail(DFX_E_INVALID, "batch size %d out of range [1,65535]", n);
@@ -1209,6 +1222,17 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
   if (dyn.qhead) dyn.qhead = c->qhead + (size_t)par * c->qhead_cap;
 
   dfx::SfmParamsDev prm{ params->huber_delta, params->avg_dpt, params->min_dpt, (float)params->valid_border, next_launch_id() };
+  if (before_launch && (rc = (*before_launch)())) {
+    const std::string why = g_last_error;
+    if (after_launch) (void)(*after_launch)();
+    if (slot >= 0) (void)stage_release(c, slot);
+    g_last_error = why;
+    return rc;
+  }
+  struct AfterGuard {   // the hook runs on every exit below
+    const std::function<int()>* f;
+    ~AfterGuard() { if (f) (void)(*f)(); }
+  } after_guard{ before_launch ? after_launch : nullptr };
   hipEvent_t eb = nullptr, ee = nullptr;
   if ((rc = prof_events(c, &eb, &ee))) return rc;
   if (dyn.qhead) {
@@ -1911,7 +1935,10 @@ DFX_API int dfx_update_depth(dfx_ctx* c, int cs, const float* code, const dfx_im
 // ---- batched decoder + the reference's real hot entry -----------------------------------------------------------------------
 namespace {
 // jobs: host-side list of decode jobs of one image size; uploads the descriptors through the staging ring and enqueues ONE launch
-int update_depth_jobs(dfx_ctx* c, int cs, const std::vector<dfx::DepthJobDev>& jobs, float avg_dpt, uint32_t W, uint32_t H) {
+// held_slots (optional, zero-copy job lists only): the slot is NOT released here -- its event would sit between this launch and the caller's next kernel, and a
+// marker between two dependent kernels costs the GPU 4-5 us (5.6 us between a pair's decode and its step in the kernel trace) -- the caller releases it behind
+// its own launches.
+int update_depth_jobs(dfx_ctx* c, int cs, const std::vector<dfx::DepthJobDev>& jobs, float avg_dpt, uint32_t W, uint32_t H, std::vector<int>* held_slots = nullptr) {
   const int n = (int)jobs.size();
   if (n == 0) return DFX_OK;
   int rc, slot;
@@ -1923,6 +1950,7 @@ int update_depth_jobs(dfx_ctx* c, int cs, const std::vector<dfx::DepthJobDev>& j
     void* hdev = nullptr;
     DFX_HIP(hipHostGetDevicePointer(&hdev, host, 0));
     DFX_HIP(dfx::launch_update_depth_batch(cs, reinterpret_cast<const dfx::DepthJobDev*>(hdev), n, avg_dpt, (int)W, (int)H, c->stream));
+    if (held_slots) { held_slots->push_back(slot); return DFX_OK; }
     return stage_release(c, slot);
   }
   if (c->jobs_cap < (size_t)n) {
@@ -2014,9 +2042,32 @@ static int sfm_linearize_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* pa
         return fail(DFX_E_INVALID, "pairs %d and %d write the same depth map from different codes / decoder images", q, p);
     }
   }
-  for (auto& lv : jobs)
-    if ((rc = update_depth_jobs(c, cs, lv.second, params->avg_dpt, lv.first.first, lv.first.second))) return rc;
-  return sfm_step_batch_impl(c, cs, params, pairs, n, out_items_dev, allow_defer);
+  {   // the decoder's job lists take staging slots while the step holds its own: size the ring now (see stage_reserve)
+    size_t most = 0;
+    for (auto& lv : jobs) most = std::max(most, lv.second.size());
+    if ((rc = stage_reserve(c, sizeof(dfx::DepthJobDev) * most))) return rc;
+  }
+  std::vector<int> held;
+  const std::function<int()> decode = [&]() -> int {
+    for (auto& lv : jobs) {
+      const int r = update_depth_jobs(c, cs, lv.second, params->avg_dpt, lv.first.first, lv.first.second, &held);
+      if (r) return r;
+    }
+    return DFX_OK;
+  };
+  const std::function<int()> release = [&]() -> int {   // the job lists' slots get their events behind the step's kernels
+    int r = DFX_OK;
+    for (int sl : held) { const int q = stage_release(c, sl); if (q) r = q; }
+    held.clear();
+    return r;
+  };
+  if ((int)jobs.size() > kStageSlots - 2) {   // one staging slot per image size + the step's own must fit the ring: otherwise decode first, as before
+    rc = decode();
+    const int r2 = release();
+    if (rc || r2) return rc ? rc : r2;
+    return sfm_step_batch_impl(c, cs, params, pairs, n, out_items_dev, allow_defer);
+  }
+  return sfm_step_batch_impl(c, cs, params, pairs, n, out_items_dev, allow_defer, nullptr, 0, nullptr, &decode, &release);
 }
 
 DFX_API int dfx_sfm_linearize_batch(dfx_ctx* c, int cs, const dfx_sfm_params* params, const dfx_sfm_pair* pairs, const dfx_img* prx0_orig,

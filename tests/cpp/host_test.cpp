@@ -200,6 +200,7 @@ int main() {
       dfx_comm_destroy(comm);
     }
     std::printf("host_test OK (%d factors, %d relinearised after moving one node)\n", n, expect);
+    std::fflush(stdout);   // the verdict reaches the pipe before the destructors and the GPU runtime's teardown run
   } catch (const std::exception& e) {
     std::printf("exception: %s\n", e.what());
     return 1;

@@ -277,5 +277,6 @@ int main() {
     return 1;
   }
   std::printf("ref_callers_test OK\n");
+  std::fflush(stdout);   // the verdict reaches the pipe before the process tears the GPU runtime down
   return 0;
 }
