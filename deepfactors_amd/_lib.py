@@ -141,6 +141,8 @@ _PROTOS = {
                                                  C.POINTER(Img), C.POINTER(Img), C.c_float, C.c_float, C.POINTER(C.c_float)]),
     "dfx_sparse_geometric_linearize_batch_async": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SparseGeoFactor), C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "dfx_sparse_geometric_linearize_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SparseGeoFactor), C.c_int, C.c_float, C.c_float, C.POINTER(C.c_float)]),
+    "dfx_sparse_geometric_gram_batch_async": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SparseGeoFactor), C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "dfx_sparse_geometric_gram_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SparseGeoFactor), C.c_int, C.c_float, C.c_float, C.POINTER(C.c_float)]),
     "dfx_sfm_step": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SE3), C.POINTER(SE3), C.POINTER(Cam), C.POINTER(SfmParams),
                                C.POINTER(Img), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img), C.POINTER(Img),
                                C.POINTER(Img), C.c_void_p]),

@@ -811,6 +811,51 @@ class SparseGeometricFactor:
         return arr
 
     @staticmethod
+    def _marshal(factors, values):
+        """(array, factor objects, first factor) for a round: an array from prepare() gets poses and codes only."""
+        if hasattr(factors, "_factors"):
+            arr, factors = factors, factors._factors
+            for k, v in enumerate(values):
+                arr[k].pose0, arr[k].pose1 = _se3(v[0]), _se3(v[1])
+                arr._codes[k, 0], arr._codes[k, 1] = v[2], v[3]
+            return arr, factors, factors[0]
+        factors = list(factors)
+        f0 = factors[0]
+        if any(f.CS != f0.CS or f.huber_delta_ != f0.huber_delta_ or f.avg_dpt_ != f0.avg_dpt_ or f.ctx is not f0.ctx for f in factors):
+            raise ValueError("the factors of a batch share code size, huber_delta, avg_dpt and context")
+        arr = (_lib.SparseGeoFactor * len(factors))()
+        arr._keep = []
+        for k, (f, v) in enumerate(zip(factors, values)):
+            f._fill(arr[k], *v, arr._keep)
+        return arr, factors, f0
+
+    @staticmethod
+    def gram_all(factors, values, gram_dev=None):
+        """The round's NORMAL EQUATIONS instead of its rows (dfx_sparse_geometric_gram_batch[_async]): per factor the upper triangle (row-major) of
+        [A | b]^T [A | b], NC (NC + 1) / 2 floats with NC = 12 + 2 CS + 1 -- what gtsam's elimination forms from the JacobianFactor on the host, formed on the
+        device (a 1024-factor round returns 12 MB instead of 157 MB of rows).  `gram_dev`: float32 CUDA tensor [n][NC (NC + 1) / 2] (enqueue only); otherwise
+        a host array of that shape is returned.  `gram_dense(G[k], CS)` unpacks one factor's block."""
+        arr, factors, f0 = SparseGeometricFactor._marshal(factors, values)
+        n, nc = len(factors), 12 + 2 * f0.CS + 1
+        ne = nc * (nc + 1) // 2
+        if gram_dev is not None:
+            if gram_dev.dtype != torch.float32 or gram_dev.numel() < n * ne or not gram_dev.is_contiguous():
+                raise ValueError("gram_dev: contiguous float32 CUDA tensor of n x NC (NC + 1) / 2 required")
+            check(_lib.lib().dfx_sparse_geometric_gram_batch_async(f0.ctx.handle, f0.CS, arr, n, f0.huber_delta_, f0.avg_dpt_, C.c_void_p(gram_dev.data_ptr())))
+            return None
+        out = np.zeros((n, ne), np.float32)
+        check(_lib.lib().dfx_sparse_geometric_gram_batch(f0.ctx.handle, f0.CS, arr, n, f0.huber_delta_, f0.avg_dpt_, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    @staticmethod
+    def gram_dense(packed, code_size):
+        """[NC][NC] symmetric matrix from one factor's packed upper triangle (see gram_all); [:-1, :-1] = A^T A, [:-1, -1] = A^T b, [-1, -1] = b^T b."""
+        nc = 12 + 2 * int(code_size) + 1
+        M = np.zeros((nc, nc), np.float64)
+        M[np.triu_indices(nc)] = np.asarray(packed, np.float64)
+        return M + np.triu(M, 1).T
+
+    @staticmethod
     def linearize_all(factors, values, rows_dev=None):
         """Every factor of a relinearisation round in ONE launch (dfx_sparse_geometric_linearize_batch[_async]); the reference linearises them one
         after the other inside ISAM2::update.  `factors`: the factor objects, or the array prepare() made of them (the per-round marshalling is then

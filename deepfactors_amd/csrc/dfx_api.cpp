@@ -1789,8 +1789,10 @@ DFX_API int dfx_track_frame_batch(dfx_ctx* c, int n, const dfx_se3* pose_init, c
 // ---- SparseGeometricFactor::linearize: all factors of a round in ONE launch ------------------------------------------------------------
 namespace {
 // rows_dev != null: rows stay on the device (enqueue only); rows_host != null: one device-to-host copy of all rows, blocking
-int sparse_geo_batch_impl(dfx_ctx* c, int cs, const dfx_sparse_geo_factor* f, int n, float huber_delta, float avg_dpt, float* rows_dev, float* rows_host) {
-  if (!c || !f || (!rows_dev && !rows_host)) return fail(DFX_E_INVALID, "dfx_sparse_geometric_linearize_batch: null argument");
+// gram_dev / gram_host (one of them, with rows_dev = rows_host = null): the rows stay in the context's scratch and their Gram blocks are the result
+int sparse_geo_batch_impl(dfx_ctx* c, int cs, const dfx_sparse_geo_factor* f, int n, float huber_delta, float avg_dpt, float* rows_dev, float* rows_host,
+                          float* gram_dev = nullptr, float* gram_host = nullptr) {
+  if (!c || !f || (!rows_dev && !rows_host && !gram_dev && !gram_host)) return fail(DFX_E_INVALID, "dfx_sparse_geometric_linearize_batch: null argument");
   if (!cs_supported(cs)) return fail(DFX_E_INVALID, "unsupported code size %d (16, 32, 64)", cs);
   if (n <= 0 || n > 65535) return fail(DFX_E_INVALID, "factor count %d out of range [1,65535]", n);
   int rc;
@@ -1827,7 +1829,10 @@ int sparse_geo_batch_impl(dfx_ctx* c, int cs, const dfx_sparse_geo_factor* f, in
   const size_t up = off_pts + host_pts * 8;
   const size_t off_rows = (up + 255) & ~(size_t)255;
   const size_t row_bytes = total_pts * nc * sizeof(float);
-  const size_t need = off_rows + (rows_dev ? 0 : row_bytes);
+  const size_t ne = nc * (nc + 1) / 2;
+  const size_t off_gram = (off_rows + (rows_dev ? 0 : row_bytes) + 255) & ~(size_t)255;
+  const size_t gram_bytes = (size_t)n * ne * sizeof(float);
+  const size_t need = (gram_host ? off_gram + gram_bytes : off_rows + (rows_dev ? 0 : row_bytes));
   if (c->sg_bytes < need) DFX_HIP(hipStreamSynchronize(c->stream));
   if ((rc = grow_dev((void**)&c->sg_dev, &c->sg_bytes, need, c->stream))) return rc;
   float* const rows_base = rows_dev ? rows_dev : reinterpret_cast<float*>(c->sg_dev + off_rows);
@@ -1859,6 +1864,14 @@ int sparse_geo_batch_impl(dfx_ctx* c, int cs, const dfx_sparse_geo_factor* f, in
     if (rc) return rc;
   }
   DFX_HIP(dfx::launch_sparse_geometric_batch(cs, c->sg_dev, n, max_pts, c->stream));
+  if (gram_dev || gram_host) {
+    float* const g = gram_dev ? gram_dev : reinterpret_cast<float*>(c->sg_dev + off_gram);
+    DFX_HIP(dfx::launch_rows_gram(cs, c->sg_dev, n, g, c->stream));
+    if (!gram_host) return DFX_OK;
+    if (gram_bytes <= kDirectResultMax) return fetch_result(c, g, gram_host, gram_bytes);
+    DFX_HIP(hipMemcpyAsync(gram_host, g, gram_bytes, hipMemcpyDeviceToHost, c->stream));
+    return wait_stream(c);
+  }
   if (!rows_host) return DFX_OK;
   if (row_bytes <= kDirectResultMax) return fetch_result(c, rows_base, rows_host, row_bytes);
   // a whole round of rows (18 MB for 120 factors x 500 points at CS = 32): straight into the caller's memory, no bounce through the result area
@@ -1881,6 +1894,15 @@ DFX_API int dfx_sparse_geometric_linearize_batch(dfx_ctx* c, int cs, const dfx_s
 }
 
 // one factor per blocking call (the reference's pattern): the same kernel with a batch of one
+DFX_API int dfx_sparse_geometric_gram_batch_async(dfx_ctx* c, int cs, const dfx_sparse_geo_factor* factors, int n, float huber_delta, float avg_dpt, float* gram_dev) {
+  if (!gram_dev) return fail(DFX_E_INVALID, "dfx_sparse_geometric_gram_batch_async: null output");
+  return sparse_geo_batch_impl(c, cs, factors, n, huber_delta, avg_dpt, nullptr, nullptr, gram_dev, nullptr);
+}
+DFX_API int dfx_sparse_geometric_gram_batch(dfx_ctx* c, int cs, const dfx_sparse_geo_factor* factors, int n, float huber_delta, float avg_dpt, float* gram_host) {
+  if (!gram_host) return fail(DFX_E_INVALID, "dfx_sparse_geometric_gram_batch: null output");
+  return sparse_geo_batch_impl(c, cs, factors, n, huber_delta, avg_dpt, nullptr, nullptr, nullptr, gram_host);
+}
+
 DFX_API int dfx_sparse_geometric_linearize(dfx_ctx* c, int cs, const dfx_se3* pose0, const dfx_se3* pose1, const float* code0,
                                            const float* code1, const dfx_cam* cam, const int32_t* points_xy, int n_points,
                                            const dfx_img* prx0_orig, const dfx_img* prx0_jac, const dfx_img* prx1_orig,

@@ -252,6 +252,8 @@ hipError_t launch_track_final(int n, const void* states_in, void* states_out, co
 
 // SparseGeometricFactor::linearize, n factors per launch (descriptors in device-visible memory; codes inside the descriptor, points and rows device pointers)
 size_t sparse_geo_desc_bytes();
+// [A | b]^T [A | b] of every factor's rows (upper triangle, row-major, NC (NC + 1) / 2 floats per factor, NC = 12 + 2 CS + 1); descs_dev as launched above
+hipError_t launch_rows_gram(int cs, const void* descs_dev, int n_factors, float* gram_dev, hipStream_t stream);
 void sparse_geo_fill(void* desc, const float* R, const float* t, const float* M, const float* HM, const float* cam6, const float* code0, const float* code1, int cs,
                      const float* prx0, uint32_t pp0, const float* jac0, uint32_t pj0, const float* prx1, uint32_t pp1, const float* jac1, uint32_t pj1,
                      const float* dgrad1, uint32_t pg1, const int* pts_dev, int npts, int W, int H, float* rows_dev, float huber_delta, float avg_dpt);

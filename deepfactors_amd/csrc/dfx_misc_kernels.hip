@@ -717,6 +717,57 @@ void sparse_geo_fill(void* desc, const float* R, const float* t, const float* M,
   d->pitch_prx0 = pp0; d->pitch_jac0 = pj0; d->pitch_prx1 = pp1; d->pitch_jac1 = pj1; d->pitch_dgrad1 = pg1;
   d->huber_delta = huber_delta; d->avg_dpt = avg_dpt;
 }
+// ---- the factors' normal equations on the device: G = [A | b]^T [A | b] per factor (upper triangle, row-major) ---------------------------------------------
+// gtsam eliminates a JacobianFactor by forming exactly this product on the host; the rows of a 1024-factor graph are 157 MB per round (3 ms into pinned
+// memory, 32 into pageable), their Gram blocks 12 MB.  One workgroup per factor: tiles of 32 rows are staged in LDS (the rows are contiguous in memory: a flat,
+// coalesced copy), thread t owns the entries t, t + 256, ... of the triangle and adds row after row in ascending order (fp32 fma; deterministic).  Rows of
+// invalid points are zero rows (k_sparse_geometric_batch writes them so) and add nothing.
+template <int CS>
+__global__ __launch_bounds__(256) void k_rows_gram(const SparseGeoDev* __restrict__ descs, float* __restrict__ gram_all) {
+  constexpr int NC = 12 + 2 * CS + 1, NE = NC * (NC + 1) / 2, EPT = (NE + 255) / 256, TR = 32, LD = NC + 1;
+  __shared__ float tile[TR * LD];
+  const SparseGeoDev& d = descs[blockIdx.x];
+  const float* __restrict__ rows = d.rows;
+  const int n = d.npts;
+  int oi[EPT], oj[EPT];   // LDS offsets of the entry's two columns
+  float acc[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    int e = (int)threadIdx.x + 256 * k, i = 0;
+    if (e >= NE) e = NE - 1;                       // (padding entries recompute the last one; never stored)
+    while (e >= NC - i) { e -= NC - i; ++i; }      // row-major upper triangle: row i holds NC - i entries
+    oi[k] = i; oj[k] = i + e; acc[k] = 0.f;
+  }
+  for (int r0 = 0; r0 < n; r0 += TR) {
+    const int nr = n - r0 < TR ? n - r0 : TR;
+    for (int idx = threadIdx.x; idx < TR * NC; idx += 256) {
+      const int r = idx / NC, c = idx - r * NC;
+      tile[r * LD + c] = r < nr ? rows[(size_t)r0 * NC + idx] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < TR; ++r) {
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) acc[k] = __builtin_fmaf(tile[r * LD + oi[k]], tile[r * LD + oj[k]], acc[k]);
+    }
+    __syncthreads();
+  }
+  float* out = gram_all + (size_t)blockIdx.x * NE;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) { const int e = (int)threadIdx.x + 256 * k; if (e < NE) out[e] = acc[k]; }
+}
+
+hipError_t launch_rows_gram(int cs, const void* descs_dev, int n_factors, float* gram_dev, hipStream_t stream) {
+  const SparseGeoDev* d = (const SparseGeoDev*)descs_dev;
+  switch (cs) {
+    case 16: hipLaunchKernelGGL(k_rows_gram<16>, dim3(n_factors), dim3(256), 0, stream, d, gram_dev); break;
+    case 32: hipLaunchKernelGGL(k_rows_gram<32>, dim3(n_factors), dim3(256), 0, stream, d, gram_dev); break;
+    case 64: hipLaunchKernelGGL(k_rows_gram<64>, dim3(n_factors), dim3(256), 0, stream, d, gram_dev); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_sparse_geometric_batch(int cs, const void* descs_dev, int n_factors, int max_points, hipStream_t stream) {
   const int ppb = (kT / 64) * (64 / (cs / 4));        // points per workgroup step
   int bx = (max_points + ppb - 1) / ppb;

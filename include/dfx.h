@@ -475,6 +475,13 @@ DFX_API int dfx_sparse_geometric_linearize_batch_async(dfx_ctx* ctx, int cs, con
                                                        float avg_dpt, float* rows_dev);
 DFX_API int dfx_sparse_geometric_linearize_batch(dfx_ctx* ctx, int cs, const dfx_sparse_geo_factor* factors, int n, float huber_delta,
                                                  float avg_dpt, float* rows_host);
+/* The same round with the factors' NORMAL EQUATIONS as the result: per factor the upper triangle (row-major) of [A | b]^T [A | b], NC (NC + 1) / 2 floats with
+ * NC = 12 + 2 CS + 1 -- entry (i, j), i <= j, at i NC - i (i - 1) / 2 + (j - i); columns 0..11 the two poses, 12..12+2CS-1 the two codes, column NC - 1 = b, so the last
+ * column holds A^T b and b^T b.  It is what gtsam's Cholesky elimination forms from the JacobianFactor on the host (the reference hands it the rows,
+ * sparse_geometric_factor.cpp:262-275); formed here on the device (fp32, rows added in ascending order: deterministic), a 1024-factor round returns 12 MB instead
+ * of 157 MB.  The rows themselves stay in the context's scratch.  _async: gram_dev is device memory, enqueue only; the blocking form copies to the host. */
+DFX_API int dfx_sparse_geometric_gram_batch_async(dfx_ctx* ctx, int cs, const dfx_sparse_geo_factor* factors, int n, float huber_delta, float avg_dpt, float* gram_dev);
+DFX_API int dfx_sparse_geometric_gram_batch(dfx_ctx* ctx, int cs, const dfx_sparse_geo_factor* factors, int n, float huber_delta, float avg_dpt, float* gram_host);
 
 /* ---- DepthAligner<float,CS>::RunStep (cuda/cu_depthaligner.cpp:32-110); avg_dpt is 2 in the reference. */
 DFX_API int dfx_depth_aligner_step(dfx_ctx* ctx, int cs, const float* code, const dfx_img* target_dpt,

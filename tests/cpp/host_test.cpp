@@ -187,6 +187,25 @@ int main() {
       dfx::DeviceImage<float> rows_dev(all.size(), 1, ctx);
       (void)dfx::SparseGeometricLinearizeAll<CS>(gf, gv, rows_dev.ptr());
       REQUIRE(rows_dev.Download() == all);
+      // the round's normal equations formed on the device == [A | b]^T [A | b] of the fetched rows (double on the host), factor by factor
+      const std::vector<float> gram = dfx::SparseGeometricGramAll<CS>(gf, gv);
+      constexpr int NC = dfx::SparseGeometricFactor<CS>::kCols, NE = NC * (NC + 1) / 2;
+      REQUIRE(gram.size() == gf.size() * (std::size_t)NE);
+      off = 0;
+      for (std::size_t k = 0; k < gf.size(); ++k) {
+        const std::size_t np = (std::size_t)gf[k]->n_points();
+        std::vector<double> diag((std::size_t)NC, 0.0);
+        for (std::size_t r = 0; r < np; ++r) for (int i = 0; i < NC; ++i) { const double a = all[off + r * NC + i]; diag[(std::size_t)i] += a * a; }
+        int e = 0;
+        for (int i = 0; i < NC; ++i)
+          for (int j = i; j < NC; ++j, ++e) {
+            double want = 0.0;
+            for (std::size_t r = 0; r < np; ++r) want += (double)all[off + r * NC + i] * (double)all[off + r * NC + j];
+            const double scale = std::sqrt(diag[(std::size_t)i] * diag[(std::size_t)j]) + 1e-30;
+            REQUIRE(std::fabs((double)gram[k * NE + (std::size_t)e] - want) <= 5e-5 * scale);
+          }
+        off += np * NC;
+      }
     }
     {   // keyframe replication over the multi-GPU C ABI (real RCCL, a world of one): the root's content stays, the call orders on the stream
       unsigned char id[DFX_COMM_ID_BYTES];

@@ -102,3 +102,40 @@ def test_all_factors_of_a_round_in_one_launch(dfx, oracle, cs):
     worse = dfx.SparseGeometricFactor(facs[0].cam_, [[256, 3]], facs[0].kf0_, facs[0].kf1_, 0.1, code_size=cs)
     with pytest.raises(dfx.DfxError, match="outside"):
         dfx.SparseGeometricFactor.linearize_all([facs[1], worse], [vals[1], vals[0]])
+
+
+@pytest.mark.parametrize("cs", [16, 32, 64])
+def test_gram_of_a_round_equals_the_rows_products(dfx, cs):
+    """dfx_sparse_geometric_gram_batch: per factor the upper triangle of [A | b]^T [A | b] of EXACTLY the rows dfx_sparse_geometric_linearize_batch returns
+    (fp32 on the device against float64 numpy of those rows; factors of different point counts, incl. one that is not a multiple of the 32-row tile and one
+    smaller than a tile), on the host and left on the device."""
+    import torch
+    from deepfactors_amd import synth
+    rng = np.random.default_rng(17 + cs)
+    W, H = 160, 120
+    kfs = []
+    for k in range(3):
+        p = synth.make_pair(W, H, cs, seed=0x9100 + k, device="cuda")
+        dg = torch.empty((H, W, 2), dtype=torch.float32, device="cuda")
+        dfx.SobelGradients(p["dpt0"], dg)
+        kfs.append(dict(prx_orig=p["prx_orig"], prx_jac=p["prx_jac"], dpt_grad=dg, code=p["code"], cam=p["cam"]))
+    facs, vals = [], []
+    for (i, j, npts) in ((0, 1, 500), (1, 2, 77), (2, 0, 19), (0, 2, 256)):
+        pts = np.stack([rng.integers(0, W, npts), rng.integers(0, H, npts)], 1).astype(np.int32)
+        facs.append(dfx.SparseGeometricFactor(kfs[i]["cam"], pts, kfs[i], kfs[j], 0.1, code_size=cs))
+        vals.append((synth.pose_qt(synth.so3_exp(rng.normal(0, 0.01, 3)), rng.normal(0, 0.02, 3)), synth.pose_qt(synth.so3_exp(rng.normal(0, 0.01, 3)), rng.normal(0, 0.02, 3)),
+                     kfs[i]["code"], kfs[j]["code"]))
+    rows = dfx.SparseGeometricFactor.linearize_all(facs, vals)
+    G = dfx.SparseGeometricFactor.gram_all(facs, vals)
+    nc = 12 + 2 * cs + 1
+    assert G.shape == (4, nc * (nc + 1) // 2)
+    for k, A in enumerate(rows):
+        want = A.astype(np.float64).T @ A.astype(np.float64)
+        got = dfx.SparseGeometricFactor.gram_dense(G[k], cs)
+        scale = np.sqrt(np.outer(np.diag(want), np.diag(want))) + 1e-30
+        assert np.count_nonzero(np.any(A != 0, axis=1)) > len(A) // 2          # the factors are not degenerate
+        assert np.max(np.abs(got - want) / scale) < 5e-5, (k, np.max(np.abs(got - want) / scale))
+    # device-resident form, and prepare()d marshalling: the same bits
+    gd = torch.zeros((4, nc * (nc + 1) // 2), dtype=torch.float32, device="cuda")
+    dfx.SparseGeometricFactor.gram_all(dfx.SparseGeometricFactor.prepare(facs), vals, gd)
+    assert np.array_equal(gd.cpu().numpy(), G)

@@ -112,7 +112,7 @@ int main(int argc, char** argv) {
       if (rep >= 2) { cold.push_back(c); batched.push_back(b); warmed.push_back(w); }
     }
     // the geometric half
-    std::vector<double> g_dev, g_host, g_pinned, g_serial;
+    std::vector<double> g_dev, g_host, g_pinned, g_serial, g_gram;
     dfx::PinnedBuffer<float> rows_pinned((std::size_t)n * kGeoPoints * dfx::SparseGeometricFactor<CS>::kCols, ctx);
     dfx::DeviceImage<float> rows_dev((std::size_t)n * kGeoPoints * dfx::SparseGeometricFactor<CS>::kCols / 64 + 1, 64, ctx);
     for (int rep = 0; rep < REPS + 2; ++rep) {
@@ -127,6 +127,10 @@ int main(int argc, char** argv) {
       t0 = now_ms();
       const std::size_t nrows = dfx::SparseGeometricLinearizeAll<CS>(gfac, gval, rows_pinned);
       const double bp = now_ms() - t0;
+      t0 = now_ms();
+      const std::vector<float> gram = dfx::SparseGeometricGramAll<CS>(gfac, gval);
+      const double bg = now_ms() - t0;
+      sink += gram[gram.size() / 2];
       if (std::memcmp(rows.data(), rows_pinned.data(), nrows * dfx::SparseGeometricFactor<CS>::kCols * sizeof(float)) != 0) { std::printf("pinned rows differ from the pageable copy\n"); return 1; }
       double c = 0;
       if (rep < 4) {   // (the per-factor pattern is slow: a few rounds suffice)
@@ -134,12 +138,13 @@ int main(int argc, char** argv) {
         for (int k = 0; k < n; ++k) sink += gfac[(std::size_t)k]->Linearize(gval[(std::size_t)k].pose0, gval[(std::size_t)k].pose1, gval[(std::size_t)k].code0, gval[(std::size_t)k].code1)[5];
         c = now_ms() - t0;
       }
-      if (rep >= 2) { g_dev.push_back(a); g_host.push_back(b); g_pinned.push_back(bp); if (rep < 4) g_serial.push_back(c); }
+      if (rep >= 2) { g_dev.push_back(a); g_host.push_back(b); g_pinned.push_back(bp); g_gram.push_back(bg); if (rep < 4) g_serial.push_back(c); }
     }
     std::printf("gn_round_bench keyframes %d factors %d (640x480, cs %d), median of %d rounds\n", K, n, CS, REPS);
     std::printf("geometric_batched_rows_on_device_ms %.3f  per_factor_us %.1f\n", median(g_dev), median(g_dev) / n * 1e3);
     std::printf("geometric_batched_rows_to_host_ms %.3f  per_factor_us %.1f\n", median(g_host), median(g_host) / n * 1e3);
     std::printf("geometric_batched_rows_to_pinned_host_ms %.3f  per_factor_us %.1f\n", median(g_pinned), median(g_pinned) / n * 1e3);
+    std::printf("geometric_batched_gram_to_host_ms %.3f  per_factor_us %.1f\n", median(g_gram), median(g_gram) / n * 1e3);
     std::printf("geometric_serial_ms %.3f  per_factor_us %.1f\n", median(g_serial), median(g_serial) / n * 1e3);
     std::printf("serial_cold_ms %.3f  per_factor_us %.1f\n", median(cold), median(cold) / n * 1e3);
     std::printf("batched_ms %.3f  per_factor_us %.1f\n", median(batched), median(batched) / n * 1e3);
