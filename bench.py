@@ -699,6 +699,13 @@ def tracker_and_geometric_configs(dfx, synth, ctx, dev):
     for _ in range(5):
         dfx.SparseGeometricFactor.linearize_all(gbatch, gvals)
     host_round = (time.perf_counter() - t0) / 5
+    gram_fn = getattr(dfx.SparseGeometricFactor, "gram_all", None)    # the round's normal equations formed on the device (dfx_sparse_geometric_gram_batch)
+    if gram_fn is not None:
+        gram_fn(gbatch, gvals)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            gram_fn(gbatch, gvals)
+        out["configs2_sparse_geometric_500pts"]["batched_round_ms_normal_equations_to_host"] = (time.perf_counter() - t0) / 5 * 1e3
     out["configs2_sparse_geometric_500pts"].update(batched_round_ms_rows_on_device=dev_round * 1e3, batched_gpu_ms=e0.elapsed_time(e1), batched_round_ms_rows_to_host=host_round * 1e3,
                                                    batched_equals_per_factor_bits=bool(same), rows_bytes=int(rows_dev.numel() * 4),
                                                    batched_note="the 120 factors in ONE launch: rows_on_device = wall clock per round of back-to-back enqueues incl. the Python marshalling of "
