@@ -300,14 +300,18 @@ bool poll_default() {
 }
 // a flag for one call: *d stays empty when polling is off (the launchers then signal nothing and finish_result_polled waits for the stream)
 int ensure_done_flag(dfx_ctx* c) {
-  if (c->done_flag_host) return DFX_OK;
-  DFX_HIP(hipHostMalloc((void**)&c->done_flag_host, 128, hipHostMallocMapped | hipHostMallocCoherent));
-  std::memset(c->done_flag_host, 0, 128);
+  if (c->done_flag_dev) return DFX_OK;   // (set last: a half-made set is completed by the next call)
+  if (!c->done_counter) {
+    DFX_HIP(hipMalloc((void**)&c->done_counter, 64));
+    DFX_HIP(hipMemsetAsync(c->done_counter, 0, 64, c->stream));
+  }
+  if (!c->done_flag_host) {
+    DFX_HIP(hipHostMalloc((void**)&c->done_flag_host, 128, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->done_flag_host, 0, 128);
+  }
   void* dp = nullptr;
   DFX_HIP(hipHostGetDevicePointer(&dp, c->done_flag_host, 0));
   c->done_flag_dev = static_cast<uint32_t*>(dp);
-  DFX_HIP(hipMalloc((void**)&c->done_counter, 64));
-  DFX_HIP(hipMemsetAsync(c->done_counter, 0, 64, c->stream));
   return DFX_OK;
 }
 int ensure_fin_scratch(dfx_ctx* c) {
