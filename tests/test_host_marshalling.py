@@ -44,3 +44,17 @@ def test_dense_from_vectorised_equals_block_loop():
         R[c * D:c * D + 6, a * D:(a + 1) * D] += Ho[p].T
     assert np.array_equal(M, R)
     assert np.array_equal(grad, buf[K * D * D + P * D * 6:].astype(np.float64))
+
+
+def test_gram_dense_unpacks_the_row_major_upper_triangle():
+    """The packing dfx_sparse_geometric_gram_batch documents (include/dfx.h): entry (i, j), i <= j, at i NC - i (i - 1) / 2 + (j - i)."""
+    from deepfactors_amd.aligners import SparseGeometricFactor
+    cs = 16
+    nc = 12 + 2 * cs + 1
+    A = np.random.default_rng(1).standard_normal((50, nc))
+    G = A.T @ A
+    packed = np.empty(nc * (nc + 1) // 2)
+    for i in range(nc):
+        for j in range(i, nc):
+            packed[i * nc - i * (i - 1) // 2 + (j - i)] = G[i, j]
+    assert np.allclose(SparseGeometricFactor.gram_dense(packed, cs), G, rtol=0, atol=1e-12)
