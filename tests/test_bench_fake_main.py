@@ -268,6 +268,28 @@ def test_main_two_ranks_over_gloo(tmp_path, exchange):
     assert w["keyframes"] == 64 and w["pairs"] == 1024 and w["pairs_per_rank"] == 512 and w["evals_per_s"] > 0
 
 
+def test_main_four_ranks_over_the_c_abi_exchange(tmp_path):
+    """N = 4 through the shipped collectives (host-memory RCCL stand-in): the graph spans 4 x 48 pairs, every rank assembles its shard into the common
+    system, rank 0's checksum of the reduced system equals the checksum of all ranks' items (asserted inside main())."""
+    _stub()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_rank, args=(4, port, str(tmp_path), "cabi"), nprocs=4, join=True)
+    for r in (1, 2, 3):
+        assert (tmp_path / f"rank{r}.txt").read_text().strip() == ""
+    d = _check_line((tmp_path / "rank0.txt").read_text(), 4)
+    assert d["config"]["exchange"] == "cabi" and d["n_gpus"] == 4
+    assert d["configs"]["configs3_window64"]["pairs_per_rank"] == 256
+
+
+def test_main_eight_ranks_over_the_c_abi_exchange(tmp_path):
+    """N = 8: the node size the driver's scaling run ends at."""
+    _stub()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_rank, args=(8, port, str(tmp_path), "cabi"), nprocs=8, join=True)
+    d = _check_line((tmp_path / "rank0.txt").read_text(), 8)
+    assert d["config"]["exchange"] == "cabi" and d["n_gpus"] == 8 and d["configs"]["configs3_window64"]["pairs_per_rank"] == 128
+
+
 def test_main_two_ranks_fall_back_together_when_the_communicator_cannot_be_created(tmp_path):
     """A rank whose dfx_comm_create fails (here: an RCCL library that cannot be loaded) must not leave the others waiting in a collective: the ranks agree over
     the process group, all of them exchange through torch.distributed, and the line says so."""
