@@ -13,6 +13,7 @@ import os
 import numpy as np
 import pytest
 
+from helpers import assert_item_close, block_errors, format_block_errors
 from test_oracle_kat import load_fixture, scenenet_cam
 
 ref = pytest.importorskip("oracle.dfx_ref")
@@ -33,14 +34,8 @@ def _pair(w, h, cs, seed, **kw):
 
 
 def _close(got, want, w, h, rel=2e-5):
-    flips = abs(int(got.inliers) - int(want.inliers))
-    assert flips <= max(1, int(1e-5 * w * h)), (got.inliers, want.inliers)
-    slack = 1.0 + 4.0 * flips
-    sj = float(np.abs(want.JtJ).max())
-    assert np.abs(np.asarray(got.JtJ, np.float64) - want.JtJ).max() <= rel * sj * slack
-    sr = max(float(np.abs(want.Jtr).max()), float(np.sqrt(sj * max(want.residual, 0.0))))
-    assert np.abs(np.asarray(got.Jtr, np.float64) - want.Jtr).max() <= rel * sr * slack
-    assert abs(got.residual - want.residual) <= rel * want.residual * slack
+    """Per entry, at the entry's own Cauchy-Schwarz scale (tests/helpers.py) -- pose-code / code-code / code gradient included."""
+    assert_item_close(got, want, w, h, rel=rel, what="oracle vs reference code")
 
 
 @pytest.mark.parametrize("w,h,cs,seed", [(160, 120, 32, 11), (96, 64, 16, 12), (128, 96, 64, 13), (320, 240, 32, 14), (100, 77, 32, 15)])
@@ -87,9 +82,13 @@ def test_single_pixel_items_match(oracle, refl):
         assert got.inliers == want.inliers, (x, y)
         nvalid += want.inliers
         if want.inliers:
-            s = max(float(np.abs(want.JtJ).max()), 1e-12)
-            assert np.abs(got.JtJ - want.JtJ).max() <= 5e-5 * s, (x, y)
-            assert np.abs(got.Jtr - want.Jtr).max() <= 5e-5 * max(float(np.abs(want.Jtr).max()), np.sqrt(s * want.residual), 1e-12), (x, y)
+            # one pixel: sqrt(JtJ_ii JtJ_jj) = |J_i J_j| would be a relative check of single products, and a row entry that is itself
+            # a cancelling sum (-g C J1) legitimately differs by 1e-4 of ITS value between two fp32 evaluation orders -- so here each of
+            # the nine blocks is compared at the block's own maximum instead (still never at the whole matrix's)
+            errs = block_errors(got, want)
+            assert all(v["blk"] <= 5e-5 for v in errs.values()), ((x, y), format_block_errors(errs))
+            # r = img0 - bilinear(img1) carries a few ulp(1) whatever its size: d(r^2) <= 2 |r| * 8 ulp
+            assert abs(got.residual - want.residual) <= 5e-5 * want.residual + 16 * np.finfo(np.float32).eps * np.sqrt(want.residual)
     assert 20 <= nvalid < len(pix)   # both valid and invalid pixels were exercised
 
 
@@ -214,10 +213,7 @@ def test_depth_aligner_oracle_equals_reference_code(oracle, refl, w, h, seed):
     got = oracle.depth_aligner_step(code, tgt, n["prx_orig"], n["prx_jac"], 2.0, accum_f64=True)
     assert got.inliers == want.inliers == w * h
     # the reference accumulates w*h terms in float in pixel order: 1e-4 of the scale is its own rounding
-    sj = float(np.abs(want.JtJ).max())
-    assert np.abs(got.JtJ - want.JtJ).max() <= 2e-4 * sj
-    assert np.abs(got.Jtr - want.Jtr).max() <= 2e-4 * max(float(np.abs(want.Jtr).max()), float(np.sqrt(sj * want.residual)))
-    assert abs(got.residual - want.residual) <= 2e-4 * want.residual
+    assert_item_close(got, want, w, h, rel=2e-4, what="depth aligner, oracle vs reference kernel body")
 
 
 @pytest.mark.parametrize("w,h,seed", [(160, 120, 51), (101, 67, 52), (64, 48, 53)])
