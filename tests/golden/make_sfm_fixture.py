@@ -7,6 +7,7 @@ Inputs (stored RAW so the file stays small; tests/sfm_fixture.py redoes the prep
     img0, img1     data/testimg/0.jpg, 25.jpg   uint8 grayscale (ut_sfmaligner.cpp:42-43)
     dpt0_mm/dpt1_mm data/testimg/0.png, 25.png   uint16 millimetres; 0.png has 124 zero pixels, kept
     jac_grid       [16][21][32] float32 ~ N(0, 0.05), numpy default_rng(0x5F25): the seeded stand-in for the decoder's prx_jac
+    code_neg       [32] float32 ~ N(0, 2): the code of the 'decoded' depth variant (drives the proximity through zero)
 Outputs, per case of tests/sfm_fixture.py:CASES x DEPTH_VARIANTS, from oracle/_ref/libdfx_ref.so (the reference's unmodified
 warping.h / dense_sfm.h / lucas_kanade_se3.h / pinhole_camera_impl.h / m_estimators.h and the kernel_warp_calculate body):
     sfm_{JtJ,Jtr,residual,inliers,valid0}   SfmAligner::RunStep       host loop of ut_sfmaligner.cpp:299-315
@@ -44,7 +45,8 @@ def main():
     raw = dict(img0=gray(os.path.join(REF_IMG, "0.jpg")), img1=gray(os.path.join(REF_IMG, "25.jpg")),
                dpt0_mm=np.asarray(Image.open(os.path.join(REF_IMG, "0.png"))).astype(np.uint16),
                dpt1_mm=np.asarray(Image.open(os.path.join(REF_IMG, "25.png"))).astype(np.uint16),
-               jac_grid=(rng.standard_normal((fx.H // fx.GRID + 1, fx.W // fx.GRID + 1, fx.CS)) * 0.05).astype(np.float32))
+               jac_grid=(rng.standard_normal((fx.H // fx.GRID + 1, fx.W // fx.GRID + 1, fx.CS)) * 0.05).astype(np.float32),
+               code_neg=(rng.standard_normal(fx.CS) * 2.0).astype(np.float32))
     assert raw["img0"].shape == raw["img1"].shape == raw["dpt0_mm"].shape == (fx.H, fx.W) and int((raw["dpt0_mm"] == 0).sum()) == 124
     tmp = os.path.join(HERE, "_tmp_inputs.npz")
     np.savez(tmp, **raw)

@@ -11,7 +11,8 @@ It re-creates ut_sfmaligner::FullJacobianCompareWithCpu (/root/reference/tests/u
   * prx_jac: the network is a download too, so the Jacobian is a SEEDED smooth field: a 16 x 21 x 32 float32 grid stored in the fixture,
     upsampled bilinearly with float32 ufuncs only (bit-deterministic on any machine);
   * poses of :254-268: pose0 = I, pose1 = inverse(SE3(exp(0.1, 0.1, 0), (-0.5, -0.5, 0))); huber_delta 0.5 (:69); plus scaled / forward
-    variants and depth maps with degenerate entries (0, < 0, +-inf, NaN, 1e-30, 1e4), see CASES / DEPTH_VARIANTS.
+    variants, depth maps with degenerate entries (0, < 0, +-inf, NaN, 1e-30, 65.535 m) and a depth map DECODED from a code that drives the
+    proximity through zero (14 % of the pixels get a negative depth, ~1000 a depth beyond 100 m), see CASES / DEPTH_VARIANTS.
 
 The expected outputs stored in the fixture come from oracle/_ref (the reference's own DenseSfm / LucasKanadeSE3 / kernel_warp_calculate)."""
 import os
@@ -61,7 +62,8 @@ CASES = {
     "fwd": ((0.004, -0.006, 0.003), (0.02, -0.01, 0.10), 0.1),   # pose_10 = SE3(exp(rot), trs) has t.z > 0, so depth-0 pixels (q = t) are VALID
                                                                  # correspondences in FindCorrespondence (warping.h:204-241)
 }
-DEPTH_VARIANTS = ("raw", "mixed")
+DEPTH_VARIANTS = ("raw", "mixed", "decoded")
+FAR_DEPTH = 65.535   # the largest value a 16-bit millimetre depth image holds
 
 
 def upsample_jac(grid, w=W, h=H):
@@ -83,7 +85,9 @@ def upsample_jac(grid, w=W, h=H):
 
 
 def degenerate_depth(dpt):
-    """The 'mixed' variant: rectangles of depth 0, negative, +inf, NaN, -inf, denormal-small and 10 km inside the real depth map."""
+    """The 'mixed' variant: rectangles of depth 0, negative, +inf, NaN, -inf, denormal-small and 65.535 m inside the real depth map.
+    (Farther than that the reference's own fp32 row is noise: dpix/dd = D R ray cancels to O(t / d), and a 10 km pixel moves the
+    code-code block by 5e-5 between two evaluation orders of the same formulas -- measured oracle vs oracle/_ref -- so it pins nothing.)"""
     d = np.array(dpt, np.float32, copy=True)
     d[20:40, 30:60] = 0.0
     d[60:80, 100:140] = -1.5
@@ -91,7 +95,7 @@ def degenerate_depth(dpt):
     d[150:160, 40:80] = np.nan
     d[180:190, 150:200] = -np.inf
     d[200:210, 250:300] = 1e-30
-    d[215:225, 20:60] = 1e4
+    d[215:225, 20:60] = FAR_DEPTH
     return d
 
 
@@ -105,13 +109,15 @@ def load(path=GOLDEN):
     a = np.float32(AVG_DPT)
     prx_orig = (a / (a + d0)).astype(np.float32)                                                          # DepthToProx, warping.h:37-42
     return dict(img0=img0, img1=img1, dpt_raw=d0, dpt1_raw=d1, prx_orig=prx_orig, prx_jac=upsample_jac(z["jac_grid"]), cam=scenenet_cam(),
-                code=np.zeros(CS, np.float32)), z
+                code=np.zeros(CS, np.float32), code_neg=z["code_neg"].astype(np.float32)), z
 
 
 def depth_variant(inp, variant, update_depth):
     """dpt0 as the reference test builds it -- UpdateDepth(code = 0) of the proximity image (ut_sfmaligner.cpp:279-283) -- then the
-    degenerate rectangles for 'mixed'.  `update_depth(code, prx_orig, prx_jac, avg_dpt)` is the decoder under test or the oracle's."""
-    d = update_depth(inp["code"], inp["prx_orig"], inp["prx_jac"], AVG_DPT)
+    degenerate rectangles for 'mixed'; 'decoded' = UpdateDepth(code_neg): prx = prx_orig + j . c crosses zero, so dpt = a / prx - a
+    (warping.h:30-35) comes out negative (prx < 0) or enormous (prx -> 0+).  `update_depth(code, prx_orig, prx_jac, avg_dpt)` is the
+    decoder under test or the oracle's."""
+    d = update_depth(inp["code_neg"] if variant == "decoded" else inp["code"], inp["prx_orig"], inp["prx_jac"], AVG_DPT)
     return degenerate_depth(d) if variant == "mixed" else d
 
 
