@@ -75,6 +75,10 @@ def parse():
                     help="how the ranks' normal equations are summed when the script runs under torch.distributed.run: cabi (default) = the SHIPPED exchange, "
                          "dfx_comm_* of the C ABI (deepfactors_amd/csrc/dfx_comm.cpp: ncclReduce enqueued on the context's exchange stream; the communicator is created "
                          "from a unique id handed round over the process group that launched the ranks); torch = torch.distributed's collectives on the same buffers (A/B)")
+    ap.add_argument("--workload", choices=["truth", "perturbed", "unrelated"], default="truth",
+                    help="what the timed pairs look like: truth = every pair at its generating pose (residual ~ 0, Huber never active, taps maximally coherent); "
+                         "perturbed = pose1 of every pair moved by N(0, 5 mm) / N(0, 0.3 deg) per axis (SURVEY 8d cfg 3: what a relinearisation sees); "
+                         "unrelated = perturbed poses AND img1 / grad1 of ANOTHER scene (Huber active on most pixels).  The line's `config.workload` names it")
     ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -137,6 +141,47 @@ def cpu_baseline(w, h, cs):
     return out
 
 
+def parity_probe(dfx, synth, ctx, dev, W, H, CS):
+    """GPU side of `parity_blocks`: ONE pair of the headline geometry (seed 0xDF02, pose1 moved by 1 cm so that the gradient is not ~0) through
+    SfmAligner::RunStep in BOTH evaluation modes.  No oracle here -- the items are compared in the cpu_baseline leg (parity_blocks)."""
+    from deepfactors_amd import _lib
+    p = synth.make_pair(W, H, CS, seed=0xDF02, device=dev)
+    pose1 = np.asarray(p["pose1"], np.float32).copy()
+    pose1[4] += 0.01
+    got = {}
+    try:
+        for name, mode in (("f32_chain", _lib.DFX_MFMA_F32_CHAIN), ("bf16x3", _lib.DFX_MFMA_BF16X3)):
+            ctx.set_mfma_mode(mode)
+            al = dfx.SfmAligner(code_size=CS, ctx=ctx)
+            it = al.RunStep(p["pose0"], pose1, None, p["cam"], p["img0"], p["img1"], p["dpt0"], None, None, p["prx_jac"], p["grad1"])
+            got[name] = dict(JtJ=np.array(it.JtJ, np.float64), Jtr=np.array(it.Jtr, np.float64), residual=float(it.residual), inliers=int(it.inliers))
+    finally:
+        ctx.set_mfma_mode(_lib.DFX_MFMA_AUTO)
+    return dict(items=got, pose1=pose1, w=W, h=H, cs=CS)
+
+
+def parity_blocks(probe):
+    """cpu_baseline leg: the probe's GPU items against the fp64-accumulating oracle on the same seeded pair, PER BLOCK of the 12 + CS system
+    (the six G blocks and three gradients GTSAM receives, photometric_factor.cpp:135-161).  `cs` = max over the block's entries of
+    |got_ij - ref_ij| / sqrt(ref_ii ref_jj) (Jtr: / sqrt(ref_ii * sum r^2)); `blk` = max|got - ref| / max|ref| over the block -- the
+    comparison of tests/helpers.py, whose tolerance is 1e-4 per entry."""
+    from types import SimpleNamespace
+    from deepfactors_amd import synth
+    from oracle import dfx_oracle as orc   # cpu_baseline leg only
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import block_errors
+    W, H, CS = probe["w"], probe["h"], probe["cs"]
+    n = synth.to_numpy(synth.make_pair(W, H, CS, seed=0xDF02, device="cpu"))
+    ref = orc.sfm_step(n["pose0"], probe["pose1"], n["cam"], n["img0"], n["img1"], n["dpt0"], n["prx_jac"], n["grad1"], accum_f64=True, threads=min(orc.max_threads(), 16))
+    out = {"tolerance": 1e-4, "pair": f"{W}x{H} cs={CS} seed 0xDF02, pose1.tx + 1 cm", "oracle_inliers": int(ref.inliers)}
+    for mode, it in probe["items"].items():
+        e = block_errors(SimpleNamespace(**it), ref)
+        out[mode] = {k: {"cs": float(f"{v['cs']:.3g}"), "blk": float(f"{v['blk']:.3g}"), "scale": float(f"{v['scale']:.4g}")} for k, v in e.items()}
+        out[mode]["inliers"] = it["inliers"]
+        out[mode]["worst_cs"] = max(v["cs"] for v in e.values())
+    return out
+
+
 def build_pairs(dfx, synth, dev, rank, P, W, H, CS, same=False, ctx=None):
     """P synthetic pairs.  With `ctx` every keyframe's valid map (kf->pyr_vld) is an image owned through the library, as the host layer's
     keyframes keep it (include/dfx_host.hpp, Keyframe::pyr_vld): zero-filled, so the first step writes 1.0 at every inlier and the
@@ -152,7 +197,28 @@ def build_pairs(dfx, synth, dev, rank, P, W, H, CS, same=False, ctx=None):
     return pairs, keep
 
 
-def pmc_traffic(a):
+def apply_workload(al, synth, pairs, kind, seed=0x5EED):
+    """Turn the truth-pose batch into the `perturbed` / `unrelated` workload IN PLACE (no new device memory) and return the pair array.
+    perturbed: pose1 <- (t + N(0, 5 mm), exp(N(0, 0.3 deg)) R) per pair, seeded (SURVEY 8d cfg 3).  unrelated: additionally pair k reads the
+    img1 / grad1 of pair k + 1 -- every pair has its own texture seed, so that is another scene: residuals of order 0.1-0.5, the Huber branch
+    on most pixels, and gradients uncorrelated with the residual."""
+    if kind == "truth":
+        return al.make_pairs(pairs)
+    rng = np.random.default_rng(seed)
+    out = []
+    for k, q in enumerate(pairs):
+        q = dict(q)
+        p1 = np.asarray(q["pose1"], np.float64)
+        R = synth.so3_exp(rng.normal(0.0, np.deg2rad(0.3), 3)) @ synth.quat_to_R(p1[:4])
+        q["pose1"] = synth.pose_qt(R, p1[4:] + rng.normal(0.0, 0.005, 3))
+        if kind == "unrelated":
+            o = pairs[(k + 1) % len(pairs)]
+            q["img1"], q["grad1"] = o["img1"], o["grad1"]
+        out.append(q)
+    return al.make_pairs(out)
+
+
+def pmc_traffic(a, workload=None):
     """Memory-side traffic of the step kernel from the TCC request counters by size (rocprofv3, counters only, own process so that
     the timed run above is never profiled).  Returns (bytes per launch or None, detail dict)."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
@@ -161,7 +227,7 @@ def pmc_traffic(a):
     out = tempfile.mkdtemp(prefix="dfx_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     worker = [sys.executable, os.path.abspath(__file__), "--pmc-worker", "--pairs", str(a.pairs), "--width", str(a.width), "--height", str(a.height),
-              "--cs", str(a.cs), "--step-blocks", str(a.step_blocks), "--schedule", a.schedule, "--mfma", a.mfma] + (["--foreign-valid0"] if a.foreign_valid0 else [])
+              "--cs", str(a.cs), "--step-blocks", str(a.step_blocks), "--schedule", a.schedule, "--mfma", a.mfma, "--workload", workload or a.workload] + (["--foreign-valid0"] if a.foreign_valid0 else [])
     passes = {"rd": ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"],
               "wr": ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"]}
     vals = {}
@@ -438,32 +504,37 @@ def secondary_configs(dfx, synth, ctx, dev):
     # factor of a 16-keyframe window): UpdateDepth once per keyframe whose code moved + one batched RunStep over the 120 pairs
     from deepfactors_amd.dist import PairGraph
     W, H, CS, K = 640, 480, 32, 16
-    graph = PairGraph.all_pairs(K, both_directions=False)
     al2 = dfx.SfmAligner(code_size=CS, ctx=ctx)
     kfs = [synth.make_pair(W, H, CS, seed=0x1600 + k, device=dev) for k in range(K)]
-    plist, prx, codes = [], [], []
-    for (i, j) in graph.pairs:
-        a, b = kfs[int(i)], kfs[int(j)]
-        plist.append(dict(pose0=a["pose0"], pose1=b["pose1"], cam=a["cam"], img0=a["img0"], img1=b["img0"], dpt0=a["dpt0"], valid0=a["valid0"],
-                          prx0_jac=a["prx_jac"], grad1=b["grad1"]))
-        prx.append(a["prx_orig"])
-        codes.append(np.asarray(a["code"].cpu() if hasattr(a["code"], "cpu") else a["code"], np.float32))
-    arr = al2.make_pairs(plist)
-    items = torch.zeros(len(plist) * dfx.item_size(12 + CS), dtype=torch.uint8, device=dev)
-    codes = np.stack(codes)
-    for _ in range(200):
-        al2.LinearizeBatch(arr, prx, codes, items)
-    ctx.sync()
-    reps = 40
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        al2.LinearizeBatch(arr, prx, codes, items)
-    ctx.sync()
-    dt = (time.perf_counter() - t0) / reps
-    byts = ((8 + 4 * CS) * K + (20 + 4 * CS) * len(plist)) * W * H
-    out["configs2_linearize_16kf_120pairs"] = dict(round_us=dt * 1e6, evals_per_s=len(plist) / dt, algorithmic_gbs=byts / dt / 1e9, frac=byts / dt / 1e9 / HBM_PEAK_GBS,
-                                                   note="UpdateDepth of the 16 keyframes (136 B/px each) + one batched RunStep of the 120 pairs (148 B/px each) per round, wall clock "
-                                                        "of enqueue-to-completion; the 16 Jacobian images (630 MB) are shared by the pairs, so part of the stream is Infinity-Cache/L2 traffic")
+    # 120 pairs i < j (BASELINE's count), and the 240 DIRECTED pairs the mapper actually links: every keyframe pair gets a photometric factor in
+    # both directions (core/mapping/mapper.cpp:308-311)
+    for both, key in ((False, "configs2_linearize_16kf_120pairs"), (True, "configs2_linearize_16kf_240pairs_both_directions")):
+        graph = PairGraph.all_pairs(K, both_directions=both)
+        plist, prx, codes = [], [], []
+        for (i, j) in graph.pairs:
+            a, b = kfs[int(i)], kfs[int(j)]
+            plist.append(dict(pose0=a["pose0"], pose1=b["pose1"], cam=a["cam"], img0=a["img0"], img1=b["img0"], dpt0=a["dpt0"], valid0=a["valid0"],
+                              prx0_jac=a["prx_jac"], grad1=b["grad1"]))
+            prx.append(a["prx_orig"])
+            codes.append(np.asarray(a["code"].cpu() if hasattr(a["code"], "cpu") else a["code"], np.float32))
+        arr = al2.make_pairs(plist)
+        items = torch.zeros(len(plist) * dfx.item_size(12 + CS), dtype=torch.uint8, device=dev)
+        codes = np.stack(codes)
+        for _ in range(200):
+            al2.LinearizeBatch(arr, prx, codes, items)
+        ctx.sync()
+        reps = 40
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            al2.LinearizeBatch(arr, prx, codes, items)
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / reps
+        byts = ((8 + 4 * CS) * K + (20 + 4 * CS) * len(plist)) * W * H
+        out[key] = dict(round_us=dt * 1e6, pairs=len(plist), evals_per_s=len(plist) / dt, algorithmic_gbs=byts / dt / 1e9, frac=byts / dt / 1e9 / HBM_PEAK_GBS,
+                        note=f"UpdateDepth of the 16 keyframes (136 B/px each) + one batched RunStep of the {len(plist)} pairs (148 B/px each) per round, wall clock "
+                             "of enqueue-to-completion; the 16 Jacobian images (630 MB) are shared by the pairs, so part of the stream is Infinity-Cache/L2 traffic"
+                             + ("; both directions of every keyframe pair, as Mapper links them (mapper.cpp:308-311)" if both else ""))
+        del arr, items
     return out
 
 
@@ -947,7 +1018,7 @@ def main():
 
     # ---- synthetic, device-resident input: P distinct keyframe->frame pairs per rank
     pairs, keep = build_pairs(dfx, synth, dev, rank, P, W, H, CS, same=bool(os.environ.get("DFX_BENCH_SAME")), ctx=None if a.foreign_valid0 else ctx)
-    arr = al.make_pairs(pairs)
+    arr = apply_workload(al, synth, pairs, a.workload)
     isz = dfx.item_size(12 + CS)
     items = torch.zeros(P * isz, dtype=torch.uint8, device=dev)
 
@@ -1062,12 +1133,14 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1] geometry in the batch size of configs[3] (1k pairs / 8 GPUs): {P} independent {W}x{H} pairs per GPU per step, "
+            "config": {"workload": {"truth": "every pair evaluated at its generating pose (residual ~ 0); ", "perturbed": "pose1 of every pair perturbed by N(0, 5 mm) / N(0, 0.3 deg) per axis (SURVEY 8d cfg 3); ",
+                                    "unrelated": "perturbed poses and img1 / grad1 of another scene (Huber active); "}[a.workload]
+                                   + f"BASELINE configs[1] geometry in the batch size of configs[3] (1k pairs / 8 GPUs): {P} independent {W}x{H} pairs per GPU per step, "
                                    f"CS={CS}, SfmAligner::RunStep (SE3+code Jacobians, JtJ/Jtr) in one launch, level 0; "
                                    "+ block-sparse normal-equation assembly" + ((" + RCCL reduce to rank 0 through " + ("the C ABI (dfx_comm_reduce_f32_async)" if comm is not None else "torch.distributed")) if dist is not None else "")
                                    + ("; the reduction tail of step k (finalize, assembly" + (", reduce" if world > 1 else "") + ") runs on a second stream beside the kernel of step k + 1"
                                       if tail is not None else ""),
-                       "pairs_per_gpu": P, "width": W, "height": H, "code_size": CS,
+                       "pairs_per_gpu": P, "width": W, "height": H, "code_size": CS, "poses": a.workload,
                        "parallelism": f"pairs sharded over {world} GPU(s)", "exchange": ("cabi" if comm is not None else ((exchange_note or "torch") if dist is not None else "none"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": f"k_sfm_step<NCB={CS // 16}, {'bf16x3' if mode_ran == _dl.DFX_MFMA_BF16X3 else 'f32 chain'}, {'dynamic' if dyn_ran else 'static'}>",
@@ -1087,6 +1160,19 @@ def main():
         # the timed workload once more, pinned to the evaluation mode the line did NOT run
         other = _dl.DFX_MFMA_F32_CHAIN if mode_ran == _dl.DFX_MFMA_BF16X3 else _dl.DFX_MFMA_BF16X3
         configs["headline_workload_other_mode"] = mode_kernel_us(ctx, lambda: al.RunStepBatchAsync(arr, items), (20 + 4 * CS) * W * H * P, warm=150, steps=30, mode=other)
+        # the same 128 pairs as the OTHER workloads (--workload): perturbed poses (what a relinearisation sees) and unrelated textures (Huber active)
+        for kind in ("truth", "perturbed", "unrelated"):
+            if kind == a.workload:
+                continue
+            arr_k = apply_workload(al, synth, pairs, kind)
+            r = mode_kernel_us(ctx, lambda: al.RunStepBatchAsync(arr_k, items), (20 + 4 * CS) * W * H * P, warm=150, steps=30, mode=_dl.DFX_MFMA_AUTO)
+            ctx.sync()
+            its_k = al.items_from_bytes(items.cpu().numpy(), CS)
+            r.update(mean_inliers_frac=float(np.mean([it.inliers for it in its_k]) / (W * H)),
+                     mean_residual_per_inlier=float(np.mean([it.residual / max(it.inliers, 1) for it in its_k])))
+            configs["headline_" + kind] = r
+            del arr_k
+    probe = parity_probe(dfx, synth, ctx, dev, W, H, CS) if (world == 1 and rank == 0 and not a.no_cpu_baseline) else None
     del keep, pairs, arr
     torch.cuda.empty_cache()
     if world == 1 and not a.no_configs:
@@ -1117,8 +1203,17 @@ def main():
                 out["roofline"]["traffic"] = traffic
                 out["roofline"]["traffic_source"] = detail.pop("source")
                 out["roofline"].update({f"traffic_{k}": v for k, v in detail.items()})
+            if not a.no_traffic and not a.no_configs:
+                for kind in ("truth", "perturbed", "unrelated"):
+                    if "headline_" + kind in configs and "kernel_us" in configs["headline_" + kind]:
+                        tr_k, det_k = pmc_traffic(a, workload=kind)
+                        configs["headline_" + kind].update(traffic=tr_k, traffic_ratio=(tr_k / ((20 + 4 * CS) * W * H * P) if tr_k else None), traffic_source=det_k.get("source"))
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(W, H, CS)
+                try:
+                    out["parity_blocks"] = parity_blocks(probe)
+                except Exception as e:   # noqa: BLE001 -- a reported check, never the line
+                    out["parity_blocks"] = {"error": f"{type(e).__name__}: {e}"}
                 if "configs0_se3_tracker_3level" in configs:
                     configs["configs0_se3_tracker_3level"]["cpu_baseline"] = cpu_baseline_se3()
         else:

