@@ -20,6 +20,7 @@ DFX_MFMA_BF16X3 = 1
 DFX_MFMA_AUTO = 2
 DFX_COMM_ID_BYTES = 128
 DFX_WAIT_STREAM, DFX_WAIT_POLL = 0, 1
+DFX_OPT_SIMPLE_DESC_ZEROCOPY, DFX_OPT_STEP_DESC_ZEROCOPY = 1, 2
 
 
 class DfxError(RuntimeError):
@@ -114,6 +115,7 @@ _PROTOS = {
     "dfx_debug_read_valid0_shadow": (C.c_int, [C.c_void_p, C.POINTER(Img), C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]),
     "dfx_set_schedule": (C.c_int, [C.c_void_p, C.c_int]),
     "dfx_set_result_wait": (C.c_int, [C.c_void_p, C.c_int]),
+    "dfx_ctx_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "dfx_last_schedule": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "dfx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "dfx_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),

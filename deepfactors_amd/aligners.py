@@ -243,6 +243,10 @@ class Context:
         _lib.DFX_WAIT_STREAM (hipStreamSynchronize); see include/dfx.h."""
         check(_lib.lib().dfx_set_result_wait(self._h, int(mode)))
 
+    def configure(self, option, value):
+        """dfx_ctx_configure: _lib.DFX_OPT_SIMPLE_DESC_ZEROCOPY / _lib.DFX_OPT_STEP_DESC_ZEROCOPY (0 / 1); result bits never change."""
+        check(_lib.lib().dfx_ctx_configure(self._h, int(option), int(value)))
+
     def last_schedule_dynamic(self):
         """True when the last batched SfM step of this context ran on the dynamic item queues."""
         d = C.c_int(0)

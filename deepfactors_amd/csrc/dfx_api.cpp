@@ -14,6 +14,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -135,7 +136,9 @@ struct dfx_ctx {
   uint32_t* done_flag_dev = nullptr;
   unsigned* done_counter = nullptr;     // device: arrivals of a multi-workgroup finalize kernel, zero between calls
   uint32_t done_seq = 0;
-  bool poll = true;                     // dfx_set_result_wait; initialised from DFX_POLL_RESULT
+  bool poll = true;                     // dfx_set_result_wait
+  bool simple_zerocopy = true;          // dfx_ctx_configure(DFX_OPT_SIMPLE_DESC_ZEROCOPY)
+  bool step_zerocopy = false;           // dfx_ctx_configure(DFX_OPT_STEP_DESC_ZEROCOPY)
   double* fin_scratch = nullptr;        // a single pair's four-workgroups-per-tile finalize kernel (k_sfm_finalize_b3_split): dfx::kSplitScratchBytes
   unsigned* fin_cnt = nullptr;          // + 64 arrival counters, zero between calls
   dfx::DoneFlag* done_armed = nullptr;        // set by a blocking entry around the one impl call whose finalize kernel is to signal
@@ -219,20 +222,16 @@ int grow_partials(dfx_ctx* c, size_t need, bool for_step = false) {
 // Zero-copy descriptors: the kernels of a batched launch read their descriptor array straight out of the pinned staging slot (host memory,
 // mapped) instead of a device copy -- no copy, no event between the copy stream and the launch stream; the slot is free again behind the
 // kernels.  Measured (profiles/r04_launch_gaps.txt): the batched SE3 step / EvaluateError gain 7 / 3.5 us per call (165.8 -> 158.7,
-// 93.0 -> 89.7 us per 128 pairs) -> default for them (DFX_SIMPLE_DESC_ZEROCOPY=0 restores the device copy); the batched SfM step gains
-// 8 us outside its kernel and loses 4 inside it (3840 long-lived workgroups read 1.5 MB over PCIe) -> opt-in (DFX_STEP_DESC_ZEROCOPY=1).
-bool simple_zerocopy() {
-  static const bool v = [] { const char* ev = std::getenv("DFX_SIMPLE_DESC_ZEROCOPY"); return !ev || std::atoi(ev) != 0; }();
-  return v;
-}
-bool desc_zerocopy() {
-  static const bool v = [] { const char* ev = std::getenv("DFX_STEP_DESC_ZEROCOPY"); return ev && std::atoi(ev) != 0; }();
-  return v;
-}
+// 93.0 -> 89.7 us per 128 pairs) -> default for them; the batched SfM step gains 8 us outside its kernel and loses 4 inside it (3840 long-lived
+// workgroups read 1.5 MB over PCIe) -> off by default.  Both are per-context options (dfx_ctx_configure: DFX_OPT_SIMPLE_DESC_ZEROCOPY,
+// DFX_OPT_STEP_DESC_ZEROCOPY); the two descriptor paths give the same bytes (tests/test_gpu_desc_paths.py).
+bool simple_zerocopy(const dfx_ctx* c) { return c->simple_zerocopy; }
+bool desc_zerocopy(const dfx_ctx* c) { return c->step_zerocopy; }
 
 // Pinned staging ring: returns a host slot whose previous upload has completed.
 // Slots of at least `bytes`.  Growing frees the old ring: never while a slot is handed out and not yet released -- a caller that acquires a second slot before
 // releasing the first (dfx_sfm_linearize_batch: the decoder's job list inside the step's preparation) reserves the second one's size up front.
+constexpr size_t kStageSlotMaxBytes = size_t(64) << 20;   // x kStageSlots = 512 MiB of pinned memory at the very most
 int stage_reserve(dfx_ctx* c, size_t bytes) {
   if (bytes <= c->stage_slot_bytes) return DFX_OK;
   // drain and regrow
@@ -242,8 +241,14 @@ int stage_reserve(dfx_ctx* c, size_t bytes) {
   if (c->stage_host) DFX_HIP(hipHostFree(c->stage_host));
   c->stage_host = nullptr;
   c->stage_slot_bytes = 0;
-  size_t n = bytes * 2;
+  // growth headroom: double small slots (descriptor arrays grow with the batch), at most 1 MiB of slack on large ones; and a ceiling -- the ring is
+  // kStageSlots slots of PINNED host memory, so one oversized call (65535 sparse-geometric factors with host-resident points ~ 50 MB) must not pin
+  // gigabytes for the life of the context: split such a batch
+  if (bytes > kStageSlotMaxBytes)
+    return fail(DFX_E_INVALID, "a single call stages %zu bytes of descriptors / host payload; the pinned ring takes at most %zu per call: split the batch", bytes, kStageSlotMaxBytes);
+  size_t n = bytes + (bytes < (size_t(1) << 20) ? bytes : (size_t(1) << 20));
   if (n < 4096) n = 4096;
+  if (n > kStageSlotMaxBytes) n = kStageSlotMaxBytes;
   DFX_HIP(hipHostMalloc((void**)&c->stage_host, n * kStageSlots, hipHostMallocDefault));
   c->stage_slot_bytes = n;
   for (int i = 0; i < kStageSlots; ++i) c->stage_used[i] = false;
@@ -293,11 +298,7 @@ int finish_result(dfx_ctx* c, void* host_out, size_t bytes) {
   std::memcpy(host_out, c->result_host, bytes);
   return DFX_OK;
 }
-// The polled form (DoneFlag in dfx_kernels.hpp; DFX_POLL_RESULT=0 turns it off: every blocking call then waits for the stream as above).
-bool poll_default() {
-  static const bool on = [] { const char* ev = std::getenv("DFX_POLL_RESULT"); return !(ev && ev[0] == '0'); }();
-  return on;
-}
+// The polled form (DoneFlag in dfx_kernels.hpp) is the default; dfx_set_result_wait(ctx, DFX_WAIT_STREAM) makes every blocking call wait for the stream as above.
 // a flag for one call: *d stays empty when polling is off (the launchers then signal nothing and finish_result_polled waits for the stream)
 int ensure_done_flag(dfx_ctx* c) {
   if (c->done_flag_dev) return DFX_OK;   // (set last: a half-made set is completed by the next call)
@@ -332,19 +333,33 @@ int new_done_flag(dfx_ctx* c, dfx::DoneFlag* d) {
   d->flag = c->done_flag_dev; d->seq = c->done_seq; d->counter = c->done_counter;
   return DFX_OK;
 }
-// spins until *f == seq; every 16384 polls (a few hundred microseconds) the stream is queried: a failed launch or a faulted queue never writes the word.
-// an idle stream without the word is an error (the kernel that was to write it did not run to its end)
+// Spins until *f == seq -- politely: a `pause` per poll (the SMT sibling keeps its issue slots), and for at most kPollSpinUs.  A call that lands behind a queue
+// of *_async work (millisecond step kernels) would otherwise hold a core at 100 % for the whole queue time; past the bound the wait turns into
+// hipStreamSynchronize, which also surfaces a failed launch or a faulted queue (they never write the word).  A drained stream without the word is an error:
+// the kernel that was to write it did not run to its end.
+constexpr long long kPollSpinUs = 200;
+inline void cpu_relax() {
+#if defined(__x86_64__)
+  __asm__ __volatile__("pause" ::: "memory");
+#elif defined(__aarch64__)
+  __asm__ __volatile__("yield" ::: "memory");
+#endif
+}
 int poll_word(dfx_ctx* c, const uint32_t* f, uint32_t seq) {
+  using clk = std::chrono::steady_clock;
+  clk::time_point t0{};
+  bool timed = false;
   for (unsigned spins = 1;; ++spins) {
     if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == seq) return DFX_OK;
-    if ((spins & 0x3fff) == 0) {
-      const hipError_t q = hipStreamQuery(c->stream);
-      if (q == hipSuccess) {
-        if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == seq) return DFX_OK;
-        return fail(DFX_E_HIP, "the stream drained without the result flag (sequence %u)", seq);
-      }
-      if (q != hipErrorNotReady) return fail(DFX_E_HIP, "stream failed while waiting for a result: %s", hipGetErrorString(q));
-    }
+    cpu_relax();
+    if ((spins & 0xff) != 0) continue;
+    const clk::time_point now = clk::now();
+    if (!timed) { t0 = now; timed = true; continue; }
+    if (std::chrono::duration_cast<std::chrono::microseconds>(now - t0).count() < kPollSpinUs) continue;
+    const hipError_t q = hipStreamSynchronize(c->stream);
+    if (q != hipSuccess) return fail(DFX_E_HIP, "stream failed while waiting for a result: %s", hipGetErrorString(q));
+    if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == seq) return DFX_OK;
+    return fail(DFX_E_HIP, "the stream drained without the result flag (sequence %u)", seq);
   }
 }
 // The end of a blocking call that has no kernel of its own to signal (no result, or many last writers).  A word written by the command processor behind the
@@ -490,10 +505,8 @@ int fill_sfm_pair(dfx_ctx* c, int cs, const dfx_se3* pose0, const dfx_se3* pose1
 // 48 pairs -2.3 %, 128 pairs -1.0 % incl. 3 us less reduction tail, 256 pairs -0.5 %, three pyramid levels in one launch -0.5 %, 64 pairs and
 // CS = 16 +-0).  Batches whose pairs SHARE a keyframe's Jacobian (a relinearisation round: 120 pairs of 16 keyframes) live on the pairs of a
 // keyframe running side by side through the L2 / Infinity Cache, and there the shorter waves are 8 % faster (917 vs 990 us): they keep 30,
-// and so does CS = 64.  DFX_CPW_MAX overrides (tuning aid).
+// and so does CS = 64.
 int chunks_per_wave_max(int cs, bool b3, bool distinct_jacobians) {
-  static const int env = [] { const char* ev = std::getenv("DFX_CPW_MAX"); const int v = ev ? std::atoi(ev) : 0; return v > 0 && v <= 1000 ? v : 0; }();
-  if (env) return env;
   return (b3 && cs < 64 && distinct_jacobians) ? 40 : 30;
 }
 
@@ -618,7 +631,7 @@ int img_note_write(dfx_ctx* c, const dfx_img* im, bool uniform, float value) {
   return DFX_OK;
 }
 int img_note_write(dfx_ctx* c, const dfx_img* im) { return img_note_write(c, im, false, 0.f); }
-// many images written by one call (a pyramid build): one pass under the lock
+// many images written by one call (a pyramid build): skipped outright while the library owns no image, else one registry lookup (one lock) per image
 int img_note_writes(dfx_ctx* c, const std::vector<const void*>& ptrs) {
   if (g_img_count.load(std::memory_order_relaxed) == 0) return DFX_OK;
   for (const void* p : ptrs) {
@@ -685,22 +698,7 @@ DFX_API int dfx_ctx_create(int device, void* stream, dfx_ctx** out) {
   dfx_ctx* c = new dfx_ctx();
   c->device = device;
   c->cu_count = prop.multiProcessorCount;
-  c->poll = poll_default();
-  // Testing aids (documented in include/dfx.h): the INITIAL evaluation mode / schedule of every context of the process.  They change
-  // result bits (the two MFMA modes agree to fp32 accuracy, not bit for bit), so a value that is not understood is an error, never
-  // silently the default; dfx_set_mfma_mode / dfx_set_schedule override them.
-  if (const char* ev = std::getenv("DFX_MFMA")) {
-    if (std::strcmp(ev, "bf16x3") == 0) c->mfma_mode = DFX_MFMA_BF16X3;
-    else if (std::strcmp(ev, "f32") == 0 || std::strcmp(ev, "f32_chain") == 0) c->mfma_mode = DFX_MFMA_F32_CHAIN;
-    else if (std::strcmp(ev, "auto") == 0) c->mfma_mode = DFX_MFMA_AUTO;
-    else { delete c; return fail(DFX_E_INVALID, "environment DFX_MFMA=%s: expected auto, f32 or bf16x3", ev); }
-  }
-  if (const char* ev = std::getenv("DFX_SCHEDULE")) {
-    if (std::strcmp(ev, "static") == 0) c->schedule = DFX_SCHEDULE_STATIC;
-    else if (std::strcmp(ev, "dynamic") == 0) c->schedule = DFX_SCHEDULE_DYNAMIC;
-    else if (std::strcmp(ev, "auto") == 0) c->schedule = DFX_SCHEDULE_AUTO;
-    else { delete c; return fail(DFX_E_INVALID, "environment DFX_SCHEDULE=%s: expected auto, static or dynamic", ev); }
-  }
+  // (no environment variable steers a context: evaluation mode, schedule, wait mode and descriptor paths are set through dfx_set_* / dfx_ctx_configure only)
   // NULL = the device's default stream, on which the reference runs everything (cuda/launch_utils.h:26-32): work is
   // then ordered with any other default-stream producer of the images (e.g. PyTorch ops on its default stream).
   c->stream = (hipStream_t)stream;
@@ -855,6 +853,16 @@ DFX_API int dfx_set_result_wait(dfx_ctx* c, int mode) {
   if (mode != DFX_WAIT_STREAM && mode != DFX_WAIT_POLL) return fail(DFX_E_INVALID, "unknown wait mode %d", mode);
   c->poll = mode == DFX_WAIT_POLL;
   return DFX_OK;
+}
+
+DFX_API int dfx_ctx_configure(dfx_ctx* c, int option, int value) {
+  if (!c) return fail(DFX_E_INVALID, "null context");
+  if (value != 0 && value != 1) return fail(DFX_E_INVALID, "dfx_ctx_configure: option %d takes 0 or 1, got %d", option, value);
+  switch (option) {
+    case DFX_OPT_SIMPLE_DESC_ZEROCOPY: c->simple_zerocopy = value != 0; return DFX_OK;
+    case DFX_OPT_STEP_DESC_ZEROCOPY: c->step_zerocopy = value != 0; return DFX_OK;
+    default: return fail(DFX_E_INVALID, "dfx_ctx_configure: unknown option %d", option);
+  }
 }
 
 DFX_API int dfx_last_schedule(dfx_ctx* c, int* dynamic) {
@@ -1150,14 +1158,14 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
       for (int i = 0; i < kStageSlots; ++i) c->slot_busy[i] = false;
     }
     char* region = reinterpret_cast<char*>(c->pairs_dev) + (size_t)slot * c->pairs_cap;
-    if (desc_zerocopy()) {
+    if (desc_zerocopy(c)) {
       void* hdev = nullptr;
       DFX_HIP(hipHostGetDevicePointer(&hdev, hd, 0));
       region = reinterpret_cast<char*>(hdev);   // the staging slot itself; stage_ev[slot] is recorded behind the kernels below
     }
     dd = reinterpret_cast<dfx::SfmPairDev*>(region);
     if (!uniform) map_dev = reinterpret_cast<unsigned*>(region + desc_bytes);
-    if (!desc_zerocopy()) {
+    if (!desc_zerocopy(c)) {
       if (c->slot_busy[slot]) DFX_HIP(hipStreamWaitEvent(c->copy_stream, c->slot_done[slot], 0));
       DFX_HIP(hipMemcpyAsync(region, hd, desc_bytes + map_bytes, hipMemcpyHostToDevice, c->copy_stream));
       DFX_HIP(hipEventRecord(c->stage_ev[slot], c->copy_stream));
@@ -1191,7 +1199,6 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
         W / 64 <= 64 && dyn_lds <= 40 * 1024 && (size_t)W * H < (1u << 26)) {
       const int vs = (int)(W / 64);
       int R = (int)(((long long)H * vs) / ((long long)team * 24));
-      if (const char* ev = std::getenv("DFX_DYN_ROWS")) R = std::atoi(ev);   // tuning aid
       if (R < 2) R = 2;
       if (R > 32) R = 32;
       dyn.items_per_pair = vs * (int)((H + R - 1) / R);
@@ -1267,7 +1274,7 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
   }
   if (c->tail_stream) c->tail_parity ^= 1;
   if (n > 1) {   // the finalize kernel reads the descriptors too
-    if (desc_zerocopy()) {   // the kernels read the staging slot itself: it is free again behind them
+    if (desc_zerocopy(c)) {   // the kernels read the staging slot itself: it is free again behind them
       DFX_HIP(hipEventRecord(c->stage_ev[slot], fin_stream));
       c->stage_used[slot] = true;
     } else {
@@ -1470,7 +1477,7 @@ int upload_simple(dfx_ctx* c, const std::vector<dfx::SimplePairDev>& descs, cons
     c->sdesc_cap = cap;
     for (int i = 0; i < kStageSlots; ++i) c->sdesc_busy[i] = false;
   }
-  if (simple_zerocopy()) {
+  if (simple_zerocopy(c)) {
     void* hdev = nullptr;
     DFX_HIP(hipHostGetDevicePointer(&hdev, host, 0));
     *dev_out = reinterpret_cast<const dfx::SimplePairDev*>(hdev);
@@ -1490,7 +1497,7 @@ int upload_simple(dfx_ctx* c, const std::vector<dfx::SimplePairDev>& descs, cons
 
 // behind the kernels that read the slot's device copy
 int simple_launched(dfx_ctx* c, int slot) {
-  if (simple_zerocopy()) return stage_release(c, slot);   // the kernels read the staging slot itself: free again behind them
+  if (simple_zerocopy(c)) return stage_release(c, slot);   // the kernels read the staging slot itself: free again behind them
   DFX_HIP(hipEventRecord(c->sdesc_done[slot], c->stream));
   c->sdesc_busy[slot] = true;
   return DFX_OK;
@@ -1502,8 +1509,7 @@ int simple_launched(dfx_ctx* c, int slot) {
 // gave 19 segments of 26 rows with a short last one (profiles/r04_launch_shape.txt: SE3 step 165 -> 160 us, EvaluateError 92 -> 88).
 int batch_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int n) {
   int b = simple_blocks(W, H);
-  static const int k_env = [] { const char* ev = std::getenv("DFX_BATCH_WGS_PER_CU"); const int v = ev ? std::atoi(ev) : 0; return v > 0 && v <= 256 ? v : 0; }();   // tuning aid
-  const int cap = ((k_env ? k_env : 20) * c->cu_count + n - 1) / n;
+  const int cap = (20 * c->cu_count + n - 1) / n;
   if (b > cap) b = cap;
   return b < 1 ? 1 : b;
 }
@@ -1661,9 +1667,9 @@ void rot_to_quat(const double* R, float* qout) {   // rotation matrix -> unit qu
 }
 
 // Workgroups per tracker and iteration: every workgroup of an iteration first folds one partial row per workgroup of the previous one (the update is computed
-// redundantly instead of in a launch of its own), and the evaluation is latency-bound (4-6 us); DFX_TRACK_BLOCKS caps the count (tuning aid; profiles/r05_tracker.txt)
+// redundantly instead of in a launch of its own), and the evaluation is latency-bound (4-6 us); the count is capped at 256 (sweep: profiles/r05_tracker.txt)
 int track_blocks(uint32_t W, uint32_t H) {
-  static const int cap = [] { const char* ev = std::getenv("DFX_TRACK_BLOCKS"); const int v = ev ? std::atoi(ev) : 0; return v > 0 && v <= dfx::kMaxSimpleBlocks ? v : 256; }();   // 256: 0.209 ms per 640x480 frame (1024: 0.24, 512: 0.222, 384: 0.218, 192: 0.218, 128: 0.23)
+  const int cap = 256;   // 256: 0.209 ms per 640x480 frame (1024: 0.24, 512: 0.222, 384: 0.218, 192: 0.218, 128: 0.23; profiles/r05_tracker.txt)
   const int b = simple_blocks(W, H);
   return b < cap ? b : cap;
 }
@@ -1972,7 +1978,7 @@ int update_depth_jobs(dfx_ctx* c, int cs, const std::vector<dfx::DepthJobDev>& j
   const size_t bytes = sizeof(dfx::DepthJobDev) * (size_t)n;
   if ((rc = stage_acquire(c, bytes, &slot, &host))) return rc;
   std::memcpy(host, jobs.data(), bytes);
-  if (simple_zerocopy()) {   // the kernel reads the job list out of the pinned slot (see simple_zerocopy)
+  if (simple_zerocopy(c)) {   // the kernel reads the job list out of the pinned slot (see simple_zerocopy)
     void* hdev = nullptr;
     DFX_HIP(hipHostGetDevicePointer(&hdev, host, 0));
     DFX_HIP(dfx::launch_update_depth_batch(cs, reinterpret_cast<const dfx::DepthJobDev*>(hdev), n, avg_dpt, (int)W, (int)H, c->stream));

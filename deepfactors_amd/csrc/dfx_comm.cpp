@@ -11,8 +11,10 @@
 // (PyTorch ships its own copy) keeps using that one instead of a second copy with its own state, and single-GPU users never load it.
 // DFX_RCCL_LIB names a specific library (tests/cpp/comm_test.cpp runs two ranks over a host-memory stand-in through this hook).
 #include "../../include/dfx.h"
+#include "dfx_rccl_abi.hpp"
 
 #include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -29,20 +31,20 @@ extern "C" int dfx_internal_note_write(dfx_ctx* ctx, void* ptr);
 
 namespace {
 
-// the subset of rccl.h (ROCm 7.x: /opt/rocm/include/rccl/rccl.h:40-43,187,220,448-466,550,590,611,678) this file needs
-struct NcclUniqueId { char internal[128]; };
-typedef void* NcclComm;
-enum { kNcclSuccess = 0, kNcclSum = 0, kNcclUint8 = 1, kNcclFloat = 7 };
+// the subset of rccl.h this file needs: dfx_rccl_abi.hpp (checked against the real header by tests/cpp/rccl_abi_check.cpp)
+using NcclUniqueId = dfx_rccl::UniqueId;
+using NcclComm = dfx_rccl::Comm;
+enum { kNcclSuccess = dfx_rccl::kSuccess, kNcclSum = dfx_rccl::kSum, kNcclUint8 = dfx_rccl::kUint8, kNcclFloat = dfx_rccl::kFloat };
 struct Rccl {
   void* handle = nullptr;
-  int (*GetUniqueId)(NcclUniqueId*) = nullptr;
-  int (*CommInitRank)(NcclComm*, int, NcclUniqueId, int) = nullptr;
-  int (*CommDestroy)(NcclComm) = nullptr;
-  int (*Reduce)(const void*, void*, size_t, int, int, int, NcclComm, void*) = nullptr;
-  int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, void*) = nullptr;
-  int (*AllGather)(const void*, void*, size_t, int, NcclComm, void*) = nullptr;
-  int (*Broadcast)(const void*, void*, size_t, int, int, NcclComm, void*) = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
+  dfx_rccl::GetUniqueId_t GetUniqueId = nullptr;
+  dfx_rccl::CommInitRank_t CommInitRank = nullptr;
+  dfx_rccl::CommDestroy_t CommDestroy = nullptr;
+  dfx_rccl::Reduce_t Reduce = nullptr;
+  dfx_rccl::AllReduce_t AllReduce = nullptr;
+  dfx_rccl::AllGather_t AllGather = nullptr;
+  dfx_rccl::Broadcast_t Broadcast = nullptr;
+  dfx_rccl::GetErrorString_t GetErrorString = nullptr;
   std::string path;
 };
 Rccl g_rccl;
@@ -75,14 +77,14 @@ int load_rccl() {
   r.handle = h; r.path = g_rccl.path;
   bool ok = true;
   auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) ok = false; return p; };
-  r.GetUniqueId = reinterpret_cast<int (*)(NcclUniqueId*)>(sym("ncclGetUniqueId"));
-  r.CommInitRank = reinterpret_cast<int (*)(NcclComm*, int, NcclUniqueId, int)>(sym("ncclCommInitRank"));
-  r.CommDestroy = reinterpret_cast<int (*)(NcclComm)>(sym("ncclCommDestroy"));
-  r.Reduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, int, NcclComm, void*)>(sym("ncclReduce"));
-  r.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, NcclComm, void*)>(sym("ncclAllReduce"));
-  r.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, NcclComm, void*)>(sym("ncclAllGather"));
-  r.Broadcast = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, NcclComm, void*)>(sym("ncclBroadcast"));
-  r.GetErrorString = reinterpret_cast<const char* (*)(int)>(sym("ncclGetErrorString"));
+  r.GetUniqueId = reinterpret_cast<dfx_rccl::GetUniqueId_t>(sym("ncclGetUniqueId"));
+  r.CommInitRank = reinterpret_cast<dfx_rccl::CommInitRank_t>(sym("ncclCommInitRank"));
+  r.CommDestroy = reinterpret_cast<dfx_rccl::CommDestroy_t>(sym("ncclCommDestroy"));
+  r.Reduce = reinterpret_cast<dfx_rccl::Reduce_t>(sym("ncclReduce"));
+  r.AllReduce = reinterpret_cast<dfx_rccl::AllReduce_t>(sym("ncclAllReduce"));
+  r.AllGather = reinterpret_cast<dfx_rccl::AllGather_t>(sym("ncclAllGather"));
+  r.Broadcast = reinterpret_cast<dfx_rccl::Broadcast_t>(sym("ncclBroadcast"));
+  r.GetErrorString = reinterpret_cast<dfx_rccl::GetErrorString_t>(sym("ncclGetErrorString"));
   if (!ok) return fail(DFX_E_HIP, r.path + " lacks an RCCL entry point this library needs");
   g_rccl = r;
   return DFX_OK;
@@ -122,7 +124,14 @@ DFX_API int dfx_comm_create(dfx_ctx* ctx, const void* id, int rank, int world, d
   std::memcpy(&uid, id, sizeof(uid));
   dfx_comm* c = new dfx_comm();
   c->rank = rank; c->world = world;
-  c->device = ctx ? dfx_internal_ctx_device(ctx) : -1;   // ncclCommInitRank binds to the calling thread's current device: the context's
+  // ncclCommInitRank binds the communicator to the CALLING THREAD's current device.  dfx_internal_ctx_device() makes the context's device current
+  // (hipSetDevice, like every entry point of the library that takes a context) -- the device whose streams the collectives are enqueued on --
+  // whatever device the caller's thread had current; checked here rather than assumed
+  c->device = ctx ? dfx_internal_ctx_device(ctx) : -1;
+  if (c->device >= 0) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != c->device) { delete c; return fail(DFX_E_HIP, "dfx_comm_create: device " + std::to_string(c->device) + " of the context is not current"); }
+  }
   const int e = g_rccl.CommInitRank(&c->comm, world, uid, rank);
   if (e != kNcclSuccess) { delete c; return nccl_fail("ncclCommInitRank", e); }
   *out = c;

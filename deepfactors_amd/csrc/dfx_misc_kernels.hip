@@ -57,7 +57,7 @@ __device__ __forceinline__ Geo geo_from(const SimplePairDev& p) {
 //    inlier set is still EXACTLY the reference's: a wave with a pixel whose margin is within the error bound E of zero re-evaluates those
 //    pixels in the reference's operation order (find_correspondence_ray<true>) -- a wave-uniform branch taken for a ~1e-3-pixel band
 //    along the view border.  The sums are within a few ulp per pixel of the reference-order arithmetic (the parity tests' tolerance is
-//    1e-4 of the block scale against the fp64 oracle);
+//    1e-4 of each entry's own Cauchy-Schwarz scale sqrt(JtJ_ii JtJ_jj) against the fp64 oracle, tests/helpers.py);
 //  * the Huber weight is folded into 1 / q.z before the pose row (J = [a | (R p) x a], a = -w grad D: warping.h:156-164 restated), the
 //    inlier count rides the scalar unit (s_bcnt1 of the validity mask), and the 28 + 1 sums of a wave are folded with
 //    v_permlane32_swap / v_permlane16_swap + four DPP row shifts (70 vector-ALU instructions instead of 29 64-lane shuffle ladders).

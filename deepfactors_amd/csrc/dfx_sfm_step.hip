@@ -1509,7 +1509,7 @@ __global__ __launch_bounds__(1024) void k_sfm_tail_b3(const float* __restrict__ 
   // therefore ran the counter relaxed).  Reader: the workgroup whose arrival completes a node issues one ACQUIRE fence at device scope behind
   // its read-modify-write (it read the last link of the chain of arrivals, each behind its writer's release fence), the barrier hands the
   // order to the rest of the workgroup, and the items are read with device-scope loads.  ORD = false keeps the relaxed counter of rounds 3-4 for A/B
-  // runs (DFX_TAIL_ORDERED=0): same bits.
+  // ran: same bits.
   if (ASM) {
     __builtin_amdgcn_s_waitcnt(0);   // vmcnt = lgkmcnt = expcnt = 0: this wave's stores have completed
     __syncthreads();
@@ -1555,12 +1555,6 @@ __global__ __launch_bounds__(1024) void k_sfm_tail_b3(const float* __restrict__ 
   }
   // ---- the pair's valid0 shadow, when a wave of this launch changed the map (never in the steady state)
   rebuild_valid0_shadow(PD, W, H, launch_id, 0, 1, stamp);
-}
-
-// A/B aid: DFX_TAIL_ORDERED=0 runs the assembling tail kernel with the relaxed arrival counter of rounds 3-4 (same bits)
-static bool tail_ordered() {
-  static const bool v = [] { const char* ev = getenv("DFX_TAIL_ORDERED"); return !ev || atoi(ev) != 0; }();
-  return v;
 }
 
 size_t sfm_step_partials_bytes(int cs, int npairs, int blocks_per_pair) {
@@ -1624,9 +1618,7 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
       if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
       if ((e = to_fin_stream()) != hipSuccess) return e;
       if (b3 && use_tail) {
-        if (tg.sys && tail_ordered()) hipLaunchKernelGGL((k_sfm_tail_b3<NCB, true, true>), dim3(npairs + node_wgs), dim3(1024), 0, fstream,
-                                       (const float*)partials_dev, dyn->team, pairs_dev, npairs, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0, tg);
-        else if (tg.sys) hipLaunchKernelGGL((k_sfm_tail_b3<NCB, true, false>), dim3(npairs + node_wgs), dim3(1024), 0, fstream,
+        if (tg.sys) hipLaunchKernelGGL((k_sfm_tail_b3<NCB, true, true>), dim3(npairs + node_wgs), dim3(1024), 0, fstream,
                                        (const float*)partials_dev, dyn->team, pairs_dev, npairs, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0, tg);
         else hipLaunchKernelGGL((k_sfm_tail_b3<NCB, false>), dim3(npairs), dim3(1024), 0, fstream,
                                 (const float*)partials_dev, dyn->team, pairs_dev, npairs, (char*)items_dev, item_stride, dyn->qhead, W, H, prm.launch_id, 0, tg);
@@ -1666,9 +1658,7 @@ static hipError_t launch_t(const SfmPairDev* pairs_dev, int npairs, int W, int H
     else if (byval) hipLaunchKernelGGL((k_sfm_finalize_b3<NCB, NPOSE, true>), dim3(b3_tiles(NCB), npairs), dim3(1024), 0, fstream,
                                   (const float*)partials_dev, bpp, fpairs, one, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged, done);
     else if (MODE == 0 && use_tail) {   // batched launches: one workgroup per pair, the graph assembly folded in
-      if (tg.sys && tail_ordered()) hipLaunchKernelGGL((k_sfm_tail_b3<NCB, true, true>), dim3(npairs + node_wgs), dim3(1024), 0, fstream,
-                                     (const float*)partials_dev, bpp, fpairs, npairs, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged, tg);
-      else if (tg.sys) hipLaunchKernelGGL((k_sfm_tail_b3<NCB, true, false>), dim3(npairs + node_wgs), dim3(1024), 0, fstream,
+      if (tg.sys) hipLaunchKernelGGL((k_sfm_tail_b3<NCB, true, true>), dim3(npairs + node_wgs), dim3(1024), 0, fstream,
                                      (const float*)partials_dev, bpp, fpairs, npairs, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged, tg);
       else hipLaunchKernelGGL((k_sfm_tail_b3<NCB, false>), dim3(npairs), dim3(1024), 0, fstream,
                               (const float*)partials_dev, bpp, fpairs, npairs, (char*)items_dev, item_stride, (unsigned*)nullptr, W, H, prm.launch_id, ragged, tg);

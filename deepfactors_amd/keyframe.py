@@ -45,20 +45,22 @@ class Frame:
     def IsKeyframe(self):
         return False
 
-    def FillPyramids(self, img, pyrlevels=None):
-        """frame.h:80-94: level 0 = img, level i = GaussianBlurDown(level i-1); Sobel gradient on every level."""
+    def FillPyramids(self, img, pyrlevels=None, blocking=True):
+        """frame.h:80-94: level 0 = img, level i = GaussianBlurDown(level i-1); Sobel gradient on every level.  BLOCKING by default, like the
+        reference (its image operators each end in cudaDeviceSynchronize, launch_utils.h:26-32): the pyramids are complete -- readable from any
+        stream, launch errors raised here -- on return.  blocking=False only enqueues on the context's stream (FillPyramidsBatch always does)."""
         n = self.levels if pyrlevels is None else int(pyrlevels)
         img = torch.as_tensor(img, dtype=torch.float32)
         if tuple(img.shape) != (self.height, self.width):
             raise _al.DfxError(-1, f"image is {tuple(img.shape)}, frame is {(self.height, self.width)}")
         self.pyr_img[0].copy_(img)   # H2D (or D2D) upload on the current stream
         # one enqueue: a launch per level, each reading its level once (Sobel + blur-down from one LDS tile); same bits as the per-level operators
-        _al.BuildPyramids([self.pyr_img[:n]], [self.pyr_grad[:n]], self.ctx)
+        _al.BuildPyramids([self.pyr_img[:n]], [self.pyr_grad[:n]], self.ctx, blocking=blocking)
 
     @staticmethod
     def FillPyramidsBatch(frames, imgs=None, pyrlevels=None):
         """FillPyramids of several frames in ONE enqueue (one launch per pyramid level over all frames).  `imgs[k]` (optional) is uploaded into
-        frame k's level 0 first."""
+        frame k's level 0 first.  ENQUEUE ONLY: the pyramids are complete when the context's stream reaches this point."""
         frames = list(frames)
         n = frames[0].levels if pyrlevels is None else int(pyrlevels)
         if imgs is not None:

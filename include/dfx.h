@@ -166,10 +166,10 @@ DFX_API int dfx_device_cu_count(dfx_ctx* ctx);
 DFX_API int dfx_set_mfma_mode(dfx_ctx* ctx, int mode);
 /* *mode = the evaluation mode (DFX_MFMA_F32_CHAIN / DFX_MFMA_BF16X3) the context's last SfM / DepthAligner step resolved to. */
 DFX_API int dfx_last_mfma_mode(dfx_ctx* ctx, int* mode);
-/* Testing aids: the environment variables DFX_MFMA = auto | f32 | bf16x3 and DFX_SCHEDULE = auto | static | dynamic set the INITIAL mode of
- * every context this process creates (e.g. to run a whole test suite in one mode); any other value makes dfx_ctx_create fail.
- * Tuning aid: DFX_CPW_MAX = n overrides the longest wave (64-pixel chunks) the launch shape of a batched step hands out -- 30, or 40 for the
- * bf16 split at CS < 64 when every pair of the batch streams its own Jacobian image; results stay bit-reproducible for a given shape. */
+/* No environment variable steers a context: evaluation mode, schedule, wait mode and descriptor paths are set through dfx_set_mfma_mode /
+ * dfx_set_schedule / dfx_set_result_wait / dfx_ctx_configure only, so a drop-in build cannot change result bits behind its caller's back.
+ * (Rounds 3-5 read DFX_MFMA, DFX_SCHEDULE, DFX_POLL_RESULT, DFX_*_DESC_ZEROCOPY and five tuning aids from the environment; removed in round 6.
+ * The one variable left is DFX_RCCL_LIB, the path of the RCCL library to load -- deployment, not numerics; see "multi-GPU exchange".) */
 /* Launch schedule of the batched SfM step (no reference counterpart: the reference has one fixed 11 x 32 grid, cu_sfmaligner.cpp:60).
  *  DFX_SCHEDULE_AUTO     (default) the library's choice -- today always the static partition.
  *  DFX_SCHEDULE_STATIC   the static partition: bit-reproducible for a given launch shape, like the reference's fixed grid.
@@ -186,10 +186,19 @@ DFX_API int dfx_last_mfma_mode(dfx_ctx* ctx, int* mode);
 DFX_API int dfx_set_schedule(dfx_ctx* ctx, int mode);
 DFX_API int dfx_last_schedule(dfx_ctx* ctx, int* dynamic);
 /* How the context's blocking calls wait (see "How the blocking single-result entries return" below): DFX_WAIT_POLL = the host polls a word in mapped memory
- * (the default unless DFX_POLL_RESULT=0 is in the environment), DFX_WAIT_STREAM = hipStreamSynchronize. */
+ * (the default), DFX_WAIT_STREAM = hipStreamSynchronize. */
 #define DFX_WAIT_STREAM 0
 #define DFX_WAIT_POLL 1
 DFX_API int dfx_set_result_wait(dfx_ctx* ctx, int mode);
+/* Per-context switches that survived their A/B (value 0 / 1; an unknown option or value is an error).  Neither changes a result bit
+ * (tests/test_gpu_desc_paths.py): they choose where a batched launch reads its descriptor array from.
+ *  DFX_OPT_SIMPLE_DESC_ZEROCOPY (default 1)  batched SE3 step / EvaluateError / UpdateDepth / pyramid: the kernels read the descriptors straight
+ *                                            out of the pinned, mapped staging slot instead of a device copy (-7 / -3.5 us per call of 128 pairs)
+ *  DFX_OPT_STEP_DESC_ZEROCOPY   (default 0)  the same for the batched SfM step: -8 us outside the kernel, +4 us inside it (3840 long-lived
+ *                                            workgroups read 1.5 MB over PCIe); pays only when the tail runs on its own stream */
+#define DFX_OPT_SIMPLE_DESC_ZEROCOPY 1
+#define DFX_OPT_STEP_DESC_ZEROCOPY 2
+DFX_API int dfx_ctx_configure(dfx_ctx* ctx, int option, int value);
 /* Measurement hook (no reference counterpart; the reference times with std::clock around blocking calls,
  * tools/kernel_benchmark.cpp:145-180): when enabled, every SfM step launch -- and every batched SE3-step / EvaluateError launch
  * (dfx_se3_step_batch*, dfx_sfm_error_batch*) -- is bracketed by HIP events on the context's stream: around the step (reduction)
@@ -250,7 +259,7 @@ DFX_API int dfx_se3_warp(dfx_ctx* ctx, const dfx_se3* pose_10, const dfx_cam* ca
  * and, behind it (system-scope release), the call's sequence number; the host polls that word and copies the result out -- it does NOT wait for the stream
  * to report idle, which the runtime learns 3-6 us later (profiles/r05_poll_result.txt; dfx_set_result_wait switches per context).  Everything the call enqueued in front of that kernel has completed
  * when the call returns; the stream itself may show busy for a few more microseconds.  A stream error or a launch that never writes the word is detected
- * (the stream is queried every few hundred microseconds of polling).  DFX_POLL_RESULT=0 in the environment restores hipStreamSynchronize. */
+ * (the stream is queried every few hundred microseconds of polling).  dfx_set_result_wait(ctx, DFX_WAIT_STREAM) restores hipStreamSynchronize. */
 /* ---- CameraTracker::TrackFrame (core/system/camera_tracker.cpp:42-71), device-resident -------
  * The reference loops on the host: RunStep (kernel + finalize + sync + 120-byte copy) -> 6x6 ldlt().solve -> retract, per
  * iteration.  Here the whole coarse-to-fine schedule is enqueued at once, one launch per iteration: the pose stays in device memory, and

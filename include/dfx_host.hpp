@@ -102,9 +102,17 @@ struct Frame {
   virtual bool IsKeyframe() const { return false; }
 
   // frame.h:80-94: level 0 = img (HOST, w x h floats), level i = GaussianBlurDown(level i-1), Sobel / 8 gradient on every level
-  // One enqueue (dfx_build_pyramid_batch_async: a launch per level, each level read once) instead of the reference's 2 L - 1 blocking single-image
-  // calls; same bits as df::GaussianBlurDown / df::SobelGradients level by level.
+  // One call (dfx_build_pyramid: a launch per level, each level read once) instead of the reference's 2 L - 1 blocking single-image calls; same bits as
+  // df::GaussianBlurDown / df::SobelGradients level by level.  BLOCKING like the reference, whose image operators each end in cudaDeviceSynchronize
+  // (launch_utils.h:26-32): the pyramids are complete -- readable from any stream, any launch error raised HERE -- when it returns.
   void FillPyramids(const float* img_host, std::size_t pyrlevels) {
+    pyr_img[0].Upload(img_host);
+    const dfx_pyramid p = Describe(pyrlevels);
+    check(dfx_build_pyramid(ctx->get(), &p));
+  }
+  // The enqueue-only form for a caller that orders its own work on the context's stream (a frame ring fed at camera rate): returns at once, the
+  // pyramids are complete when the context's stream reaches this point; errors of the launches surface at the next blocking call.
+  void FillPyramidsAsync(const float* img_host, std::size_t pyrlevels) {
     pyr_img[0].Upload(img_host);
     const dfx_pyramid p = Describe(pyrlevels);
     check(dfx_build_pyramid_batch_async(ctx->get(), &p, 1));
@@ -131,7 +139,8 @@ struct Frame {
   bool marginalized = false;
 };
 
-// FillPyramids of many frames whose level 0 is already on the device (e.g. uploaded by the camera driver's stream): one launch per level over all frames
+// FillPyramids of many frames whose level 0 is already on the device (e.g. uploaded by the camera driver's stream): one launch per level over all frames.
+// ENQUEUE ONLY (like Frame::FillPyramidsAsync): complete when the context's stream reaches this point
 inline void FillPyramidsBatch(const std::vector<Frame*>& frames, std::size_t pyrlevels) {
   if (frames.empty()) return;
   std::vector<dfx_pyramid> d;

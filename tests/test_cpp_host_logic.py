@@ -26,3 +26,20 @@ def test_cpp_exchange_step_two_ranks_over_a_stub_rccl():
     out = subprocess.run([os.path.join(d, "comm_test")], capture_output=True, text=True, timeout=60, stdin=subprocess.DEVNULL, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "comm_test OK" in out.stdout
+
+
+def _rccl_abi_check(*args):
+    d = os.path.join(ROOT, "tests", "cpp")
+    exe = os.path.join(d, "rccl_abi_check")
+    if not os.path.exists(exe) and os.path.exists("/opt/rocm/include/rccl/rccl.h"):
+        subprocess.check_call(["make", "-C", d, "rccl_abi_check"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return subprocess.run([exe, *args], capture_output=True, text=True, timeout=120, stdin=subprocess.DEVNULL)
+
+
+def test_hand_declared_rccl_subset_matches_the_real_header_and_library():
+    """Pre-flight of the exchange that needs no second GPU (tests/cpp/rccl_abi_check.cpp): the prototypes and enumerator values dfx_comm.cpp
+    declares by hand (deepfactors_amd/csrc/dfx_rccl_abi.hpp) are checked against the REAL <rccl/rccl.h> by static_asserts -- the binary exists only
+    if they hold -- and every entry point resolves in the real librccl.  (No collective runs here: there is no device.)"""
+    out = _rccl_abi_check()
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rccl_abi_check OK" in out.stdout

@@ -64,3 +64,23 @@ def test_comm_world_of_one_reduce_and_gather_follow_the_step(dfx):
     with pytest.raises(dfx.DfxError):
         _lib.check(L.dfx_comm_broadcast_async(ctx.handle, comm, C.c_void_p(kfimg.data_ptr()), kfimg.numel() * 4, 1))
     L.dfx_comm_destroy(comm)
+
+
+def test_rccl_abi_preflight_on_the_real_library():
+    """tests/cpp/rccl_abi_check: the hand-declared RCCL subset of dfx_comm.cpp against the real header (static_asserts, at build time) and, here,
+    against the real libraries at run time -- the system's librccl and the copy PyTorch ships (the one dfx_comm.cpp finds already loaded in a
+    torch process): every entry point resolves, and a world of one runs all-reduce / reduce / all-gather / broadcast through the product's own
+    typedefs (id by value, enumerator values, argument order) with the data intact."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "rccl_abi_check")
+    assert os.path.exists(exe), "tests/cpp/rccl_abi_check not built: run __graft_entry__.build()"
+    libs = [None]
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    if os.path.exists(cand):
+        libs.append(cand)
+    for lib in libs:
+        out = subprocess.run([exe] + ([lib] if lib else []), capture_output=True, text=True, timeout=300, stdin=subprocess.DEVNULL)
+        assert out.returncode == 0, (lib, out.stdout + out.stderr)
+        assert "rccl_abi_check OK" in out.stdout and "world-1 collectives" in out.stdout, out.stdout

@@ -6,7 +6,7 @@
   the global-ray-table kernel variant at a realistic height; image regions that leave the view (whole chunks without a
   correspondence) with bit-determinism over many runs.
 Reference: tests/ut_sfmaligner.cpp:235-327 (GPU vs host evaluation of the same inputs: inliers equal, |dJtJ| <= 1e-1); the
-tolerance here is tests/helpers.py (1e-4 of the block scale against the fp64-accumulating oracle)."""
+tolerance here is tests/helpers.py: every entry within 1e-4 of its own Cauchy-Schwarz scale sqrt(JtJ_ii JtJ_jj) against the fp64-accumulating oracle."""
 import numpy as np
 import pytest
 import torch

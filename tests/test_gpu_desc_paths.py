@@ -1,7 +1,8 @@
 """The descriptor array of a batched launch reaches the kernels in one of two ways (dfx_api.cpp: simple_zerocopy / desc_zerocopy): read straight
 out of the pinned staging slot (default for the batched SE3 step / EvaluateError / decoder, opt-in for the batched SfM step) or through a device
-copy made on the context's copy stream (the other way round).  Both must give the same bytes.  The switches are read once per process, so each
-setting runs in its own interpreter."""
+copy made on the context's copy stream (the other way round).  Both must give the same bytes.  The switches are per-context options
+(dfx_ctx_configure: DFX_OPT_SIMPLE_DESC_ZEROCOPY / DFX_OPT_STEP_DESC_ZEROCOPY; environment variables until round 5); each setting still runs in its own
+interpreter so that no allocation of one run can serve another."""
 import hashlib
 import os
 import subprocess
@@ -18,8 +19,10 @@ import hashlib, sys
 import numpy as np, torch
 sys.path.insert(0, %r)
 import deepfactors_amd as dfx
-from deepfactors_amd import synth
+from deepfactors_amd import synth, _lib
 ctx = dfx.Context(0)
+for opt, val in (OPTIONS):
+    ctx.configure(getattr(_lib, opt), val)
 w, h, cs, n = 192, 144, 32, 9
 al, se3 = dfx.SfmAligner(code_size=cs, ctx=ctx), dfx.SE3Aligner(ctx=ctx)
 plist, slist, keep = [], [], []
@@ -45,9 +48,9 @@ print("DIGEST", hsh.hexdigest())
 ''' % ROOT
 
 
-def _run(env_extra):
-    env = dict(os.environ, **env_extra)
-    r = subprocess.run([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
+def _run(options):
+    env = dict(os.environ)
+    r = subprocess.run([sys.executable, "-c", WORKER.replace("(OPTIONS)", repr(tuple(options.items())))], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST ")]
     assert lines, r.stdout[-500:]
@@ -56,7 +59,7 @@ def _run(env_extra):
 
 def test_zero_copy_and_copied_descriptors_give_the_same_bytes():
     default = _run({})
-    copied = _run({"DFX_SIMPLE_DESC_ZEROCOPY": "0"})
-    step_zero = _run({"DFX_STEP_DESC_ZEROCOPY": "1"})
+    copied = _run({"DFX_OPT_SIMPLE_DESC_ZEROCOPY": 0})
+    step_zero = _run({"DFX_OPT_STEP_DESC_ZEROCOPY": 1})
     assert default == copied == step_zero
     assert len(default) == len(hashlib.sha256().hexdigest())
