@@ -2167,6 +2167,8 @@ DFX_API int dfx_build_pyramid_batch_async(dfx_ctx* c, const dfx_pyramid* frames,
   char* host;
   if ((rc = stage_acquire(c, sizeof(dfx::PyrLevelDev) * (size_t)n * L, &slot, &host))) return rc;
   dfx::PyrLevelDev* hd = reinterpret_cast<dfx::PyrLevelDev*>(host);
+  bool rows_ok[DFX_MAX_PYR_LEVELS];
+  for (int i = 0; i < DFX_MAX_PYR_LEVELS; ++i) rows_ok[i] = true;
   std::vector<const void*> written;
   for (int k = 0; k < n && !rc; ++k) {
     const dfx_pyramid& f = frames[k];
@@ -2192,6 +2194,10 @@ DFX_API int dfx_build_pyramid_batch_async(dfx_ctx* c, const dfx_pyramid* frames,
         d.out = (float*)f.img[i + 1].ptr; d.pitch_out = (uint32_t)f.img[i + 1].pitch_bytes; d.OW = (int)f.img[i + 1].w; d.OH = (int)f.img[i + 1].h;
         written.push_back(f.img[i + 1].ptr);
       }
+      // the row-streaming kernel (k_pyr_rows): 8-byte image loads, 16-byte gradient stores, 32-bit row offsets
+      if ((((uintptr_t)d.in | d.pitch_in) & 7) || (d.grad && (((uintptr_t)d.grad | d.pitch_grad) & 15)) || (d.out && (((uintptr_t)d.out | d.pitch_out) & 3)) ||
+          (uint64_t)d.pitch_in * H >= (1ull << 31) || (uint64_t)d.pitch_grad * H >= (1ull << 31))
+        rows_ok[i] = false;
     }
     if (rc) g_last_error = "frame " + std::to_string(k) + ": " + g_last_error;
   }
@@ -2200,6 +2206,9 @@ DFX_API int dfx_build_pyramid_batch_async(dfx_ctx* c, const dfx_pyramid* frames,
   // Few frames (the per-frame latency path): the kernels read the pinned staging slot (zero-copy descriptors, see simple_zerocopy).  Many frames: a
   // device copy first -- every one of the ~10^4 workgroups of a level starts with its descriptor (levels 1-3 of a 64-frame build: 17.8 / 10.0 / 8.6 ->
   // 15.8 / 8.4 / 6.3 us; level 0 unchanged).
+  // (Measured and dropped in round 6: issuing level 0 twice -- blur-down only in front of the level 1.. chain, gradient only on a second stream beside it -- to hide
+  // the chain's launch latencies behind the 157 MB of gradient stores.  The blur-only kernel still takes 46 us of the combined kernel's 52 (a wave's walk is bound
+  // by load latency per row, not by its bytes), and the cross-stream hand-over costs more than the chain: 88 -> 111 us per 64-frame build; profiles/r06_pyramid.txt.)
   void* hdev = nullptr;
   const size_t dbytes = sizeof(dfx::PyrLevelDev) * (size_t)n * L;
   if (n > 4) {
@@ -2212,11 +2221,12 @@ DFX_API int dfx_build_pyramid_batch_async(dfx_ctx* c, const dfx_pyramid* frames,
     const hipError_t ge = hipHostGetDevicePointer(&hdev, host, 0);
     if (ge != hipSuccess) { (void)stage_release(c, slot); return fail(DFX_E_HIP, "hipHostGetDevicePointer failed: %s", hipGetErrorString(ge)); }
   }
+  const dfx::PyrLevelDev* ddev = reinterpret_cast<const dfx::PyrLevelDev*>(hdev);
   for (int i = 0; i < L; ++i) {
     bool any = false;   // (the last level of a batch whose frames all skip its gradient has nothing to do)
     for (int k = 0; k < n; ++k) any = any || hd[(size_t)i * n + k].grad || hd[(size_t)i * n + k].out;
     if (!any) continue;
-    hipError_t e = dfx::launch_pyr_level(reinterpret_cast<const dfx::PyrLevelDev*>(hdev) + (size_t)i * n, n, (int)frames[0].img[i].w, (int)frames[0].img[i].h, c->stream);
+    hipError_t e = dfx::launch_pyr_level(ddev + (size_t)i * n, n, (int)frames[0].img[i].w, (int)frames[0].img[i].h, c->stream, rows_ok[i]);
     if (e != hipSuccess) { (void)stage_release(c, slot); return fail(DFX_E_HIP, "k_pyr_level launch failed: %s", hipGetErrorString(e)); }
   }
   return stage_release(c, slot);

@@ -265,7 +265,8 @@ struct PyrLevelDev {
   uint32_t pitch_in, pitch_grad, pitch_out;
   int W, H, OW, OH;
 };
-hipError_t launch_pyr_level(const PyrLevelDev* descs_dev, int n, int W, int H, hipStream_t stream);
+// rows_ok: every frame's rows are aligned for the row-streaming kernel (image 8-byte, gradient 16-byte pointer and pitch); else the LDS-tile kernel
+hipError_t launch_pyr_level(const PyrLevelDev* descs_dev, int n, int W, int H, hipStream_t stream, bool rows_ok);
 
 constexpr int kSimpleRow = 32;       // floats per block partial of the VALU reduction kernels
 constexpr int kMaxSimpleBlocks = 1024;

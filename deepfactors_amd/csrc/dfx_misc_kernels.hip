@@ -1119,7 +1119,177 @@ __global__ __launch_bounds__(kT) void k_pyr_level(const PyrLevelDev* __restrict_
   }
 }
 
-hipError_t launch_pyr_level(const PyrLevelDev* descs_dev, int n, int W, int H, hipStream_t stream) {
+// ---- the same level, ROW-STREAMING (round 6): no LDS, no barrier, no per-pixel address arithmetic ---------------------------------------------------
+// A WAVE owns a strip of 128 columns (two pixels per lane: one 8-byte load, one 16-byte gradient store per lane and row -> 512-byte reads and
+// 1-KB write runs per wave and row) and a segment of R rows, and walks down the rows with everything it needs in registers:
+//   * the horizontal neighbours of a lane's two pixels (columns c0 - 2, c0 - 1, c1 + 1) come from the adjacent lanes by DPP wavefront shifts
+//     (v_mov_b32_dpp wave_shr:1 / wave_shl:1); lanes 0 and 63 get theirs from ONE extra 8-byte load per row in which only those two lanes carry
+//     an in-range offset; the clamped columns of getWithClampedRange (cu_image_proc.cpp:66-70,141-146) are selects;
+//   * Sobel of row y needs rows y - 1, y, y + 1: a three-row window rotates through registers;
+//   * the 5 x 5 blur-down is accumulated AS THE ROWS ARRIVE, in the tap order of k_blur_down (py outer, px inner): input row v carries the taps
+//     py = v - 2 Y + 2 of the output rows Y it touches -- three accumulators in flight on even rows (py = 4, 2, 0), two on odd ones (py = 3, 1) -- so
+//     every output pixel is the same chain of 25 fused multiply-adds as in the per-level operator: the same bits;
+//   * addressing is a buffer resource of ONE ROW (loads past the row end return 0 and stores are dropped: no column predicate), re-based from row to
+//     row on the SCALAR unit (s_add_u32 / s_addc_u32 on the descriptor's base; a scalar row OFFSET would not do: gfx950 range-checks vector + scalar
+//     offset against the row length): no vector-ALU address arithmetic at all;
+//   * the next two rows are requested before the current two are worked on.
+// Work items are (frame, row segment, strip); a workgroup is four consecutive strips / segments.  Requires an even width and 8 / 16-byte aligned
+// image / gradient rows (the host checks; anything else takes k_pyr_level above).
+__device__ __forceinline__ float dpp_wave_shr1(float old, float src) {   // lane i <- src of lane i - 1; lane 0 keeps `old`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_wave_shl1(float old, float src) {   // lane i <- src of lane i + 1; lane 63 keeps `old`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x130, 0xf, 0xf, false));
+}
+struct PyrWin { float L1, A, B, R1; };   // columns c0 - 1, c0, c1, c1 + 1 of one row
+__device__ __forceinline__ f32x2 pyr_sobel(const float a, const float b, const float c, const float d, const float f, const float g, const float h, const float i) {
+  float sx = 0.f, sy = 0.f;   // the tap order of k_sobel (the reference loop, zero taps skipped)
+  sx += a * -1.f; sy += a * -1.f;
+  sy += b * -2.f;
+  sx += c * 1.f;  sy += c * -1.f;
+  sx += d * -2.f;
+  sx += f * 2.f;
+  sx += g * -1.f; sy += g * 1.f;
+  sy += h * 2.f;
+  sx += i * 1.f;  sy += i * 1.f;
+  return f32x2{ sx / 8.f, sy / 8.f };
+}
+// one row of taps.  EXPLICIT fused multiply-adds: k_blur_down's `sum += r[nx] * k` contracts to v_fma_f32 (each product has one use); here a pixel
+// feeds up to three accumulators, equal products (k = 6 for py = 0 and py = 4, ...) would be shared as ONE rounded v_mul_f32 + two adds: one ulp off
+template <int PY>
+__device__ __forceinline__ void pyr_blur_taps(float& sum, const float L2, const PyrWin& r) {
+  const float B[5] = { 1.f, 4.f, 6.f, 4.f, 1.f };
+  sum = __builtin_fmaf(L2, B[0] * B[PY], sum);
+  sum = __builtin_fmaf(r.L1, B[1] * B[PY], sum);
+  sum = __builtin_fmaf(r.A, B[2] * B[PY], sum);
+  sum = __builtin_fmaf(r.B, B[3] * B[PY], sum);
+  sum = __builtin_fmaf(r.R1, B[4] * B[PY], sum);
+}
+constexpr int kPyrStrip = 128;
+constexpr unsigned kBufAux = 0;
+template <int NP>
+__global__ __launch_bounds__(512) void k_pyr_rows(const PyrLevelDev* __restrict__ descs, const int nstrips, const int nsegs, const int R) {
+  const PyrLevelDev& P = descs[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  // a workgroup = the `wpg` strips side by side of one row segment (wpg = blockDim.x / 64 divides into nstrips groups): its waves walk down the same rows, so
+  // the workgroup writes whole image rows (5 KB at 640 pixels) rather than 1-KB pieces of four different places
+  const int wpg = (int)(blockDim.x >> 6), gps = (nstrips + wpg - 1) / wpg;   // strip groups per segment
+  const int seg = (int)blockIdx.x / gps, strip = ((int)blockIdx.x - seg * gps) * wpg + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (strip >= nstrips || seg >= nsegs) return;
+  const int W = P.W, H = P.H, OH = P.OH;
+  const int xs = strip * kPyrStrip, ys = seg * R;
+  const int c0 = xs + 2 * lane;
+  const bool has_left = xs >= 2, blur = P.out != nullptr, grad = P.grad != nullptr;
+  // one ROW per resource
+  auto row_rsrc = [](const void* base, int row, uint32_t pitch, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(base) + (size_t)row * pitch), 0, bytes, 0x00020000);
+  };
+  const int voff = c0 * 4;                                                                  // own two pixels (past the row end: zeros, no access)
+  const int eoff = lane == 0 ? (has_left ? (xs - 2) * 4 : -1) : (lane == 63 ? (xs + kPyrStrip) * 4 : -1);   // lanes 0 / 63: the neighbouring strip's pixels
+  const bool right_in = c0 + 2 < W;                                                         // column c1 + 1 exists (else it clamps to c1)
+  auto fetch = [&](int v, f32x2& own, f32x2& edge) {
+    const __amdgpu_buffer_rsrc_t rin = row_rsrc(P.in, min(max(v, 0), H - 1), P.pitch_in, W * 4);
+    own = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rin, voff, 0, kBufAux));
+    edge = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rin, eoff, 0, kBufAux));
+  };
+  auto store_grad = [&](int y, const f32x2 g0, const f32x2 g1) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{ g0.x, g0.y, g1.x, g1.y }), row_rsrc(P.grad, y, P.pitch_grad, W * 8), c0 * 8, 0, kBufAux);
+  };
+  auto window = [&](const f32x2 own, const f32x2 edge, float& L2, PyrWin& w) {
+    w.A = own.x; w.B = own.y;
+    w.L1 = dpp_wave_shr1(has_left ? edge.y : own.x, own.y);
+    L2 = dpp_wave_shr1(has_left ? edge.x : own.x, own.x);
+    const float r = dpp_wave_shl1(edge.x, own.x);
+    w.R1 = right_in ? r : own.y;
+  };
+  const int y_end = min(ys + R, H);                 // Sobel rows [ys, y_end)
+  const int Y0 = ys >> 1, Y1 = min((ys + R) >> 1, OH);   // blur rows [Y0, Y1)
+  const int v_last = min(ys + R, H + 1);            // last virtual row anything of this segment reads
+  PyrWin rm{}, r0{};
+  float accA = 0.f, accB = 0.f, accC = 0.f;
+  auto do_pair = [&](const int v, const f32x2 own0, const f32x2 edge0, const f32x2 own1, const f32x2 edge1) {   // rows v (even) and v + 1
+    {
+      float L2; PyrWin cur;
+      window(own0, edge0, L2, cur);
+      const int y = v - 1;
+      if (grad && y >= ys && y < y_end) {
+        const f32x2 g0 = pyr_sobel(rm.L1, rm.A, rm.B, r0.L1, r0.B, cur.L1, cur.A, cur.B);
+        const f32x2 g1 = pyr_sobel(rm.A, rm.B, rm.R1, r0.A, r0.R1, cur.A, cur.B, cur.R1);
+        store_grad(y, g0, g1);
+      }
+      if (blur) {
+        pyr_blur_taps<4>(accA, L2, cur);            // output row v / 2 - 1 is complete
+        const int Y = (v >> 1) - 1;
+        if (Y >= Y0 && Y < Y1) {
+          float wall = 0.f;
+          const float B[5] = { 1.f, 4.f, 6.f, 4.f, 1.f };
+#pragma unroll
+          for (int py = 0; py < 5; ++py)
+#pragma unroll
+            for (int px = 0; px < 5; ++px) wall += B[px] * B[py];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, accA / wall), row_rsrc(P.out, Y, P.pitch_out, P.OW * 4), (xs / 2 + lane) * 4, 0, kBufAux);
+        }
+        pyr_blur_taps<2>(accB, L2, cur);
+        accC = 0.f;
+        pyr_blur_taps<0>(accC, L2, cur);
+      }
+      rm = r0; r0 = cur;
+    }
+    if (v + 1 <= v_last) {
+      float L2; PyrWin cur;
+      window(own1, edge1, L2, cur);
+      const int y = v;
+      if (grad && y >= ys && y < y_end) {
+        const f32x2 g0 = pyr_sobel(rm.L1, rm.A, rm.B, r0.L1, r0.B, cur.L1, cur.A, cur.B);
+        const f32x2 g1 = pyr_sobel(rm.A, rm.B, rm.R1, r0.A, r0.R1, cur.A, cur.B, cur.R1);
+        store_grad(y, g0, g1);
+      }
+      if (blur) {
+        pyr_blur_taps<3>(accB, L2, cur);
+        pyr_blur_taps<1>(accC, L2, cur);
+      }
+      rm = r0; r0 = cur;
+    }
+    accA = accB; accB = accC;
+  };
+  // NP row pairs per iteration, and the NP pairs of the NEXT iteration requested before the current ones are worked on: 2 NP rows (1 KB each incl. the
+  // edge load) in flight per wave -- the loop is bound by memory latency x requests in flight, not by its ~60 vector-ALU instructions per row
+  f32x2 own[2 * NP], edge[2 * NP];
+#pragma unroll
+  for (int j = 0; j < 2 * NP; ++j) fetch(ys - 2 + j, own[j], edge[j]);
+  for (int v = ys - 2; v <= v_last; v += 2 * NP) {
+    f32x2 nown[2 * NP], nedge[2 * NP];
+#pragma unroll
+    for (int j = 0; j < 2 * NP; ++j) fetch(v + 2 * NP + j, nown[j], nedge[j]);   // (clamped rows past the end are re-reads of the last row: harmless)
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+      if (v + 2 * q <= v_last) do_pair(v + 2 * q, own[2 * q], edge[2 * q], own[2 * q + 1], edge[2 * q + 1]);
+#pragma unroll
+    for (int j = 0; j < 2 * NP; ++j) { own[j] = nown[j]; edge[j] = nedge[j]; }
+  }
+}
+
+hipError_t launch_pyr_level(const PyrLevelDev* descs_dev, int n, int W, int H, hipStream_t stream, bool rows_ok) {
+  if (rows_ok && (W & 1) == 0) {
+    const int nstrips = (W + kPyrStrip - 1) / kPyrStrip;
+    // rows per segment: ~4096 waves per launch (16 per CU) when there is that much work, segments of at least 4 rows (a segment re-reads 3 rows of its
+    // neighbours), at most 64
+    // rows per segment: ~4096 waves per launch (16 per CU) when there is that much work; at least 4 rows (a segment re-reads 3 rows of its neighbours), at most 64.
+    // Swept on MI355X (profiles/r06_pyramid.txt): 4096 / 8192 / 16384 waves and 2 / 4 / 8 rows in flight per wave all land level 0 of a 64-frame build at
+    // 51-56 us = 5.3 TB/s of reads + writes, the rate of a device-to-device copy of the same volume on this box: the memory system, not the launch shape
+    const long long total = (long long)H * nstrips * n;
+    int R = (int)((total + 4095) / 4096);
+    R = (R + 1) & ~1;
+    if (R < 4) R = 4;
+    if (R > 64) R = 64;
+    const int nsegs = (H + R - 1) / R;
+    // a workgroup = the strips side by side of one row segment (at most 8 waves): whole image rows per workgroup (51.6 against 55.2 us with four-wave groups)
+    int wpg = nstrips;
+    if (wpg > 8) wpg = (nstrips + ((nstrips + 7) / 8) - 1) / ((nstrips + 7) / 8);
+    const int gps = (nstrips + wpg - 1) / wpg;
+    hipLaunchKernelGGL(k_pyr_rows<1>, dim3(gps * nsegs, n), dim3(64 * wpg), 0, stream, descs_dev, nstrips, nsegs, R);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_pyr_level, dim3((W + kPyrTW - 1) / kPyrTW, (H + kPyrTH - 1) / kPyrTH, n), dim3(kT), 0, stream, descs_dev);
   return hipGetLastError();
 }

@@ -21,7 +21,11 @@ def _alloc(levels, w, h, ch=None, pad=0):
     return out
 
 
-@pytest.mark.parametrize("w,h,levels,pad", [(640, 480, 4, 0), (320, 240, 3, 0), (333, 217, 3, 0), (70, 50, 2, 3), (64, 16, 1, 0), (9, 7, 2, 0), (1280, 960, 4, 4)])
+# even widths with 8 / 16-byte aligned rows take the row-streaming kernel (k_pyr_rows: strips of 128 columns, segments of >= 4 rows), everything else the
+# LDS-tile kernel (k_pyr_level): odd widths, odd pitches; (130, 66): a strip with ONE active lane, then an odd level; (2, 2): one pixel pair; (256, 100): strip seams
+# at x = 128 and segment seams every 4 rows; (386, 131): odd height, partial last strip, padded rows
+@pytest.mark.parametrize("w,h,levels,pad", [(640, 480, 4, 0), (320, 240, 3, 0), (333, 217, 3, 0), (70, 50, 2, 3), (64, 16, 1, 0), (9, 7, 2, 0), (1280, 960, 4, 4),
+                                            (256, 100, 3, 0), (130, 66, 2, 0), (2, 2, 1, 0), (128, 4, 2, 0), (386, 131, 2, 2), (644, 484, 3, 0)])
 def test_pyramid_build_equals_the_per_level_operators_and_the_oracle(dfx, oracle, w, h, levels, pad):
     rng = np.random.default_rng(w * 7 + h)
     n = 3
@@ -97,3 +101,34 @@ def test_pyramid_build_rejects_inconsistent_levels_and_keyframe_store_uses_it(df
     for q in fs:
         for i in range(3):
             assert torch.equal(q.pyr_img[i], f.pyr_img[i]) and torch.equal(q.pyr_grad[i], f.pyr_grad[i])
+
+
+
+def test_large_build_same_bits(dfx):
+    """Nine frames of 640x480 (the size from which a build's launches carry thousands of waves each): every output equals the per-level operators', repeated
+    builds included."""
+    rng = np.random.default_rng(11)
+    n, w, h, levels = 9, 640, 480, 3
+    imgs = [torch.from_numpy(rng.random((h, w), dtype=np.float32)).cuda() for _ in range(n)]
+    pyr_i = [_alloc(levels, w, h) for _ in range(n)]
+    pyr_g = [_alloc(levels, w, h, ch=2) for _ in range(n)]
+    for k in range(n):
+        pyr_i[k][0].copy_(imgs[k])
+    arr = dfx.make_pyramids(pyr_i, pyr_g)
+    for rep in range(3):
+        for k in range(n):
+            for t in pyr_i[k][1:] + pyr_g[k]:
+                t.fill_(float("nan"))
+        dfx.BuildPyramids(arr)
+    torch.cuda.synchronize()
+    for k in range(n):
+        ref = imgs[k]
+        for i in range(levels):
+            if i > 0:
+                nxt = torch.empty((h >> i, w >> i), device="cuda")
+                dfx.GaussianBlurDown(ref, nxt)
+                ref = nxt
+                assert torch.equal(pyr_i[k][i], ref), (k, i)
+            g = torch.empty((h >> i, w >> i, 2), device="cuda")
+            dfx.SobelGradients(ref, g)
+            assert torch.equal(pyr_g[k][i], g), (k, i)

@@ -33,6 +33,12 @@ def main():
     byts = sum((W >> i) * (H >> i) * (12 + (1 if i + 1 < LV else 0)) for i in range(LV)) * F
     print(f"build_pyramid_batch {F} frames x {LV} levels: {us:.1f} us per enqueue = {byts / us / 1e3:.0f} GB/s = {byts / us / 1e3 / 8000:.3f} of 8 TB/s ({us / F:.2f} us per frame)")
 
+    # the yardstick: a device-to-device copy moving the volume of the level-0 launch (F x (4 B read + 8 + 1 B written) per pixel ~ half read, half written)
+    vol = F * W * H * 13
+    a = torch.empty(vol // 8, dtype=torch.float32, device=dev); b = torch.empty_like(a)
+    cus = timed(lambda: b.copy_(a), 50, 50)
+    print(f"torch copy_ of {vol / 2e6:.0f} MB -> {vol / 2e6:.0f} MB (the level-0 launch's volume): {cus:.1f} us = {vol / cus / 1e3:.0f} GB/s read + written")
+
     def per_level():
         for k in range(min(F, 8)):
             for i in range(LV):
@@ -40,7 +46,7 @@ def main():
                     dfx.GaussianBlurDown(pyr_i[k][i - 1], pyr_i[k][i], ctx)
                 dfx.SobelGradients(pyr_i[k][i], pyr_g[k][i], ctx)
     us8 = timed(per_level, 5, 3)
-    print(f"per-level blocking operators, 8 frames: {us8 / 8:.1f} us per frame")
+    print(f"per-level blocking operators: {us8 / min(F, 8):.1f} us per frame")
 
 
 if __name__ == "__main__":
