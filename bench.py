@@ -75,10 +75,11 @@ def parse():
                     help="how the ranks' normal equations are summed when the script runs under torch.distributed.run: cabi (default) = the SHIPPED exchange, "
                          "dfx_comm_* of the C ABI (deepfactors_amd/csrc/dfx_comm.cpp: ncclReduce enqueued on the context's exchange stream; the communicator is created "
                          "from a unique id handed round over the process group that launched the ranks); torch = torch.distributed's collectives on the same buffers (A/B)")
-    ap.add_argument("--workload", choices=["truth", "perturbed", "unrelated"], default="truth",
-                    help="what the timed pairs look like: truth = every pair at its generating pose (residual ~ 0, Huber never active, taps maximally coherent); "
-                         "perturbed = pose1 of every pair moved by N(0, 5 mm) / N(0, 0.3 deg) per axis (SURVEY 8d cfg 3: what a relinearisation sees); "
-                         "unrelated = perturbed poses AND img1 / grad1 of ANOTHER scene (Huber active on most pixels).  The line's `config.workload` names it")
+    ap.add_argument("--workload", choices=["truth", "perturbed", "unrelated"], default="perturbed",
+                    help="what the timed pairs look like: perturbed (default since round 6) = pose1 of every pair moved by N(0, 5 mm) / N(0, 0.3 deg) per axis "
+                         "(SURVEY 8d cfg 3: what a relinearisation sees); truth = every pair at its generating pose (residual ~ 0, Huber never active, taps maximally "
+                         "coherent: the line of rounds 1-5); unrelated = perturbed poses AND img1 / grad1 of ANOTHER scene (residuals of the order of huber_delta).  "
+                         "The line's `config.workload` names it and `configs.headline_<other>` carry the two it did not run: they differ by < 1 % on MI355X")
     ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -200,8 +201,8 @@ def build_pairs(dfx, synth, dev, rank, P, W, H, CS, same=False, ctx=None):
 def apply_workload(al, synth, pairs, kind, seed=0x5EED):
     """Turn the truth-pose batch into the `perturbed` / `unrelated` workload IN PLACE (no new device memory) and return the pair array.
     perturbed: pose1 <- (t + N(0, 5 mm), exp(N(0, 0.3 deg)) R) per pair, seeded (SURVEY 8d cfg 3).  unrelated: additionally pair k reads the
-    img1 / grad1 of pair k + 1 -- every pair has its own texture seed, so that is another scene: residuals of order 0.1-0.5, the Huber branch
-    on most pixels, and gradients uncorrelated with the residual."""
+    img1 / grad1 of pair k + 1 -- every pair has its own texture seed, so that is another scene: residuals of the order of huber_delta (the synthetic
+    textures are low-contrast: rms 0.1), the Huber branch on part of the pixels, gradients uncorrelated with the residual."""
     if kind == "truth":
         return al.make_pairs(pairs)
     rng = np.random.default_rng(seed)

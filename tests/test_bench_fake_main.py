@@ -312,7 +312,13 @@ def test_main_with_the_secondary_configurations(tmp_path, monkeypatch):
     c = d["configs"]
     assert set(c) >= {"headline_workload_other_mode", "configs1_single_pair_blocking", "configs1_pyramid3_128pairs", "configs4_1280x960_cs64", "configs2_linearize_16kf_120pairs",
                       "update_depth_batch_64kf", "se3_step_batch_128pairs", "sfm_error_batch_128pairs", "configs3_window64",
-                      "configs0_se3_tracker_3level", "configs2_sparse_geometric_500pts", "configs2_gauss_newton_round_16kf_120pairs"}
+                      "configs0_se3_tracker_3level", "configs2_sparse_geometric_500pts", "configs2_gauss_newton_round_16kf_120pairs",
+                      "headline_truth", "headline_unrelated", "configs2_linearize_16kf_240pairs_both_directions"}
+    # the default workload is the perturbed one (round 6); the two it did not run are measured beside it, each with its inlier fraction
+    assert d["config"]["poses"] == "perturbed" and "headline_perturbed" not in c and "perturbed" in d["config"]["workload"]
+    for k in ("headline_truth", "headline_unrelated"):
+        assert c[k]["kernel_us"] > 0 and 0 <= c[k]["mean_inliers_frac"] <= 1
+    assert c["configs2_linearize_16kf_240pairs_both_directions"]["pairs"] == 240
     assert "gauss_newton_round" in c["configs3_window64"]
     assert c["headline_workload_other_mode"]["kernel_us"] > 0 and "error" not in c["headline_workload_other_mode"] and "fp32 fmaf chain" in c["headline_workload_other_mode"]["mfma"]
     assert c["configs4_1280x960_cs64"]["f32_chain"]["kernel_us"] > 0 and "error" not in c["configs4_1280x960_cs64"]["f32_chain"]
