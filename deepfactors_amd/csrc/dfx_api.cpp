@@ -231,6 +231,7 @@ bool desc_zerocopy(const dfx_ctx* c) { return c->step_zerocopy; }
 // Pinned staging ring: returns a host slot whose previous upload has completed.
 // Slots of at least `bytes`.  Growing frees the old ring: never while a slot is handed out and not yet released -- a caller that acquires a second slot before
 // releasing the first (dfx_sfm_linearize_batch: the decoder's job list inside the step's preparation) reserves the second one's size up front.
+constexpr size_t kPyrTailMaxPixels = 160 * 120;   // a pyramid level up to this size starts the one-launch tail of a build (k_pyr_tail)
 constexpr size_t kStageSlotMaxBytes = size_t(64) << 20;   // x kStageSlots = 512 MiB of pinned memory at the very most
 int stage_reserve(dfx_ctx* c, size_t bytes) {
   if (bytes <= c->stage_slot_bytes) return DFX_OK;
@@ -2222,12 +2223,28 @@ DFX_API int dfx_build_pyramid_batch_async(dfx_ctx* c, const dfx_pyramid* frames,
     if (ge != hipSuccess) { (void)stage_release(c, slot); return fail(DFX_E_HIP, "hipHostGetDevicePointer failed: %s", hipGetErrorString(ge)); }
   }
   const dfx::PyrLevelDev* ddev = reinterpret_cast<const dfx::PyrLevelDev*>(hdev);
-  for (int i = 0; i < L; ++i) {
+  // The small levels as ONE launch (k_pyr_tail: a few bands per frame, each workgroup with its rows of those levels in LDS): from the first level k0 >= 1 whose
+  // image is at most kPyrTailMaxPixels (160 x 120 of a 640 x 480 build), when that is at least two levels: 6.0 + 4.4 us of launches and a boundary become one
+  int k0 = L, tail_nb = 0, tail_rp = 0;
+  size_t tail_lds = 0;
+  for (int i = 1; i + 1 < L; ++i)
+    if ((size_t)frames[0].img[i].w * frames[0].img[i].h <= kPyrTailMaxPixels) { k0 = i; break; }
+  if (k0 < L) {
+    int Hs[DFX_MAX_PYR_LEVELS], Ws[DFX_MAX_PYR_LEVELS];
+    for (int i = k0; i < L; ++i) { Hs[i - k0] = (int)frames[0].img[i].h; Ws[i - k0] = (int)frames[0].img[i].w; }
+    tail_nb = dfx::pyr_tail_plan(Hs, Ws, L - k0, n, &tail_rp, &tail_lds);
+    if (tail_nb == 0) k0 = L;
+  }
+  for (int i = 0; i < k0; ++i) {
     bool any = false;   // (the last level of a batch whose frames all skip its gradient has nothing to do)
     for (int k = 0; k < n; ++k) any = any || hd[(size_t)i * n + k].grad || hd[(size_t)i * n + k].out;
     if (!any) continue;
     hipError_t e = dfx::launch_pyr_level(ddev + (size_t)i * n, n, (int)frames[0].img[i].w, (int)frames[0].img[i].h, c->stream, rows_ok[i]);
     if (e != hipSuccess) { (void)stage_release(c, slot); return fail(DFX_E_HIP, "k_pyr_level launch failed: %s", hipGetErrorString(e)); }
+  }
+  if (k0 < L) {
+    const hipError_t e = dfx::launch_pyr_tail(ddev, n, k0, L, tail_nb, tail_rp, tail_lds, c->stream);
+    if (e != hipSuccess) { (void)stage_release(c, slot); return fail(DFX_E_HIP, "k_pyr_tail launch failed: %s", hipGetErrorString(e)); }
   }
   return stage_release(c, slot);
 }

@@ -267,6 +267,11 @@ struct PyrLevelDev {
 };
 // rows_ok: every frame's rows are aligned for the row-streaming kernel (image 8-byte, gradient 16-byte pointer and pitch); else the LDS-tile kernel
 hipError_t launch_pyr_level(const PyrLevelDev* descs_dev, int n, int W, int H, hipStream_t stream, bool rows_ok);
+// levels k0 .. L-1 of every frame in one launch: `nb` bands (workgroups) per frame, each with its rows of those levels in LDS (descs: level-major [L][n]).
+// pyr_tail_plan: Hs / Ws = the levels' sizes, nl = L - k0; returns the bands per frame (0: does not qualify), the band height at the last level and the LDS bytes.
+constexpr size_t kPyrTailMaxLds = 144 * 1024;
+int pyr_tail_plan(const int* Hs, const int* Ws, int nl, int n, int* rows_per, size_t* lds_bytes);
+hipError_t launch_pyr_tail(const PyrLevelDev* descs_dev, int n, int k0, int L, int nb, int rows_per, size_t lds_bytes, hipStream_t stream);
 
 constexpr int kSimpleRow = 32;       // floats per block partial of the VALU reduction kernels
 constexpr int kMaxSimpleBlocks = 1024;

@@ -1166,7 +1166,15 @@ __device__ __forceinline__ void pyr_blur_taps(float& sum, const float L2, const 
   sum = __builtin_fmaf(r.R1, B[4] * B[PY], sum);
 }
 constexpr int kPyrStrip = 128;
-constexpr unsigned kBufAux = 0;
+#ifndef DFX_PYR_LD_AUX
+#define DFX_PYR_LD_AUX 0   // cache policy of k_pyr_rows' image loads (bit 0 = sc0, bit 1 = nt)
+#endif
+#ifndef DFX_PYR_ST_AUX
+#define DFX_PYR_ST_AUX 0   // ... of its next-level image stores (re-read by the next launch of the build)
+#endif
+#ifndef DFX_PYR_GRAD_AUX
+#define DFX_PYR_GRAD_AUX 2 // ... and of its gradient stores (nt: written once, not read by the build)
+#endif
 template <int NP>
 __global__ __launch_bounds__(512) void k_pyr_rows(const PyrLevelDev* __restrict__ descs, const int nstrips, const int nsegs, const int R) {
   const PyrLevelDev& P = descs[blockIdx.y];
@@ -1189,11 +1197,11 @@ __global__ __launch_bounds__(512) void k_pyr_rows(const PyrLevelDev* __restrict_
   const bool right_in = c0 + 2 < W;                                                         // column c1 + 1 exists (else it clamps to c1)
   auto fetch = [&](int v, f32x2& own, f32x2& edge) {
     const __amdgpu_buffer_rsrc_t rin = row_rsrc(P.in, min(max(v, 0), H - 1), P.pitch_in, W * 4);
-    own = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rin, voff, 0, kBufAux));
-    edge = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rin, eoff, 0, kBufAux));
+    own = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rin, voff, 0, DFX_PYR_LD_AUX));
+    edge = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rin, eoff, 0, DFX_PYR_LD_AUX));
   };
   auto store_grad = [&](int y, const f32x2 g0, const f32x2 g1) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{ g0.x, g0.y, g1.x, g1.y }), row_rsrc(P.grad, y, P.pitch_grad, W * 8), c0 * 8, 0, kBufAux);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{ g0.x, g0.y, g1.x, g1.y }), row_rsrc(P.grad, y, P.pitch_grad, W * 8), c0 * 8, 0, DFX_PYR_GRAD_AUX);
   };
   auto window = [&](const f32x2 own, const f32x2 edge, float& L2, PyrWin& w) {
     w.A = own.x; w.B = own.y;
@@ -1227,7 +1235,7 @@ __global__ __launch_bounds__(512) void k_pyr_rows(const PyrLevelDev* __restrict_
           for (int py = 0; py < 5; ++py)
 #pragma unroll
             for (int px = 0; px < 5; ++px) wall += B[px] * B[py];
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, accA / wall), row_rsrc(P.out, Y, P.pitch_out, P.OW * 4), (xs / 2 + lane) * 4, 0, kBufAux);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, accA / wall), row_rsrc(P.out, Y, P.pitch_out, P.OW * 4), (xs / 2 + lane) * 4, 0, DFX_PYR_ST_AUX);
         }
         pyr_blur_taps<2>(accB, L2, cur);
         accC = 0.f;
@@ -1267,6 +1275,166 @@ __global__ __launch_bounds__(512) void k_pyr_rows(const PyrLevelDev* __restrict_
 #pragma unroll
     for (int j = 0; j < 2 * NP; ++j) { own[j] = nown[j]; edge[j] = nedge[j]; }
   }
+}
+
+// ---- the SMALL levels of a build in ONE launch (round 6): a few workgroups per frame keep their bands of the levels in LDS ----------------------------------------
+// From the first level k0 >= 1 from which everything below is small (160 x 120 and 80 x 60 of a 640 x 480 input), the chain of launches -- each a few microseconds
+// of latency-bound work plus a launch boundary -- becomes one.  A frame is cut into `nb` horizontal BANDS; a workgroup owns one band of every level (band rows of
+// level l = twice those of level l + 1) and holds, per level, the rows it needs in LDS: its own rows +- 1 for the Sobel window, and whatever the blur-down into the
+// rows it holds of the NEXT level reads -- so the halo rows of a level are RECOMPUTED by the neighbouring bands from the level above (identical arithmetic on identical
+// inputs: identical bits), and nothing is exchanged between workgroups.  Per level: Sobel / 8 of the own rows from LDS to global memory; blur-down of the held rows of the
+// next level into LDS, the own ones also to global memory; barrier.  Taps, order and arithmetic are k_sobel's / k_blur_down's (explicit fmaf chain, py outer, px
+// inner): the same bits.  Any width, pitch and alignment.
+constexpr int kPyrTailThreads = 512;
+constexpr int kPyrTailMaxLevels = 4;   // instantiated for 2, 3, 4 levels (the row tables must unroll into registers: with a run-time level count they live in scratch memory)
+struct PyrTailRows { int own_lo[kPyrTailMaxLevels], own_hi[kPyrTailMaxLevels], hold_lo[kPyrTailMaxLevels], hold_hi[kPyrTailMaxLevels]; };
+// rows of levels k0 .. L-1 (index l - k0) that band `band` of `nb` owns and holds; Hs[l - k0] = height of level l; rows_per = band height at the LAST level
+template <int NL>
+__host__ __device__ inline void pyr_tail_rows(const int* Hs, int band, int nb, int rows_per, PyrTailRows& r) {
+  constexpr int nl = NL, last = nl - 1;
+  r.own_lo[last] = band * rows_per;
+  r.own_hi[last] = (band == nb - 1) ? Hs[last] : (band + 1) * rows_per;
+#pragma unroll
+  for (int l = last - 1; l >= 0; --l) {
+    r.own_lo[l] = 2 * r.own_lo[l + 1];
+    r.own_hi[l] = (band == nb - 1) ? Hs[l] : 2 * r.own_hi[l + 1];
+  }
+#pragma unroll
+  for (int l = last; l >= 0; --l) {
+    int lo = r.own_lo[l] - 1, hi = r.own_hi[l] + 1;                       // the Sobel window of the own rows
+    if (l < last) {                                                       // the 5 x 5 windows of the rows held of the next level
+      const int blo = 2 * r.hold_lo[l + 1] - 2, bhi = 2 * (r.hold_hi[l + 1] - 1) + 3;
+      lo = blo < lo ? blo : lo; hi = bhi > hi ? bhi : hi;
+    }
+    r.hold_lo[l] = lo < 0 ? 0 : lo;
+    r.hold_hi[l] = hi > Hs[l] ? Hs[l] : hi;
+  }
+}
+template <int NL>
+__global__ __launch_bounds__(1024) void k_pyr_tail(const PyrLevelDev* __restrict__ descs, const int n, const int k0, const int nb, const int rows_per) {
+  extern __shared__ float pyr_lds[];
+  constexpr int nl = NL;
+  const int f = blockIdx.y, band = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  int Hs[NL];
+#pragma unroll
+  for (int l = 0; l < nl; ++l) Hs[l] = descs[(size_t)(k0 + l) * n + f].H;
+  PyrTailRows R;
+  pyr_tail_rows<NL>(Hs, band, nb, rows_per, R);
+  float* cur = pyr_lds;
+  // p -> (row, column) of a W-wide block without an integer division: (p + 0.5) / W is at least 0.5 / W away from an integer, float rounding is 1e-7 of it
+  auto split = [](int p, float invW, int W, int& r, int& x) { r = (int)(((float)p + 0.5f) * invW); x = p - r * W; };
+  {
+    const PyrLevelDev& P = descs[(size_t)k0 * n + f];
+    const int W = P.W, lo = R.hold_lo[0], npx = (R.hold_hi[0] - lo) * W;
+    const float invW = 1.0f / (float)W;
+    constexpr int NB = 8;     // every load of a batch is issued before the first LDS store (a plain loop is a chain of dependent global round trips)
+    for (int base = 0; base < npx; base += NB * nthr) {
+      float v[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int p = base + j * nthr + tid;
+        int r, x;
+        split(p < npx ? p : 0, invW, W, r, x);
+        v[j] = gload<float>((const char*)P.in + (size_t)(lo + r) * P.pitch_in + (size_t)x * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int p = base + j * nthr + tid;
+        if (p < npx) cur[p] = v[j];
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int l = 0; l < nl; ++l) {
+    const PyrLevelDev& P = descs[(size_t)(k0 + l) * n + f];
+    const int W = P.W, H = P.H, lo = R.hold_lo[l];
+    const float invW = 1.0f / (float)W;
+    float* nxt = cur + (R.hold_hi[l] - lo) * W;
+    if (P.grad) {
+      const int y0 = R.own_lo[l], npx = (R.own_hi[l] - y0) * W;
+      for (int p = tid; p < npx; p += nthr) {
+        int r, x;
+        split(p, invW, W, r, x);
+        const int y = y0 + r;
+        const int xm = max(x - 1, 0), xp = min(x + 1, W - 1);
+        const float* r0 = cur + (max(y - 1, 0) - lo) * W;
+        const float* r1 = cur + (y - lo) * W;
+        const float* r2 = cur + (min(y + 1, H - 1) - lo) * W;
+        const f32x2 g = pyr_sobel(r0[xm], r0[x], r0[xp], r1[xm], r1[xp], r2[xm], r2[x], r2[xp]);
+        gstore<f32x2>((char*)P.grad + (size_t)y * P.pitch_grad + (size_t)x * 8, g);
+      }
+    }
+    if (P.out && l + 1 < nl) {
+      const int OW = P.OW, Y0 = R.hold_lo[l + 1], npx = (R.hold_hi[l + 1] - Y0) * OW;
+      const int oY0 = R.own_lo[l + 1], oY1 = R.own_hi[l + 1];
+      const float invOW = 1.0f / (float)OW;
+      const float B[5] = { 1.f, 4.f, 6.f, 4.f, 1.f };
+      for (int p = tid; p < npx; p += nthr) {
+        int r, X;
+        split(p, invOW, OW, r, X);
+        const int Y = Y0 + r;
+        float sum = 0.f, wall = 0.f;
+#pragma unroll
+        for (int py = 0; py < 5; ++py) {
+          const float* row = cur + (min(max(2 * Y + py - 2, 0), H - 1) - lo) * W;
+#pragma unroll
+          for (int px = 0; px < 5; ++px) {
+            const float k = B[px] * B[py];
+            sum = __builtin_fmaf(row[min(max(2 * X + px - 2, 0), W - 1)], k, sum);
+            wall += k;
+          }
+        }
+        const float v = sum / wall;
+        if (Y >= oY0 && Y < oY1) gstore<float>((char*)P.out + (size_t)Y * P.pitch_out + (size_t)X * 4, v);
+        nxt[p] = v;
+      }
+    }
+    __syncthreads();
+    cur = nxt;
+  }
+}
+// bands per frame and the LDS a workgroup needs; 0 bands = the levels do not qualify
+int pyr_tail_plan(const int* Hs, const int* Ws, int nl, int n, int* rows_per, size_t* lds_bytes) {
+  if (nl < 2 || nl > kPyrTailMaxLevels) return 0;
+  auto rows = [&](int b, int nbb, int rp, PyrTailRows& r) { if (nl == 2) pyr_tail_rows<2>(Hs, b, nbb, rp, r); else if (nl == 3) pyr_tail_rows<3>(Hs, b, nbb, rp, r); else pyr_tail_rows<4>(Hs, b, nbb, rp, r); };
+  int nb = 512 / (n > 0 ? n : 1);                     // ~two workgroups per CU when there are that many frames; up to 8 bands for a single frame
+  if (nb > 8) nb = 8;
+  if (nb < 1) nb = 1;
+  const int Hl = Hs[nl - 1];
+  if (nb > Hl / 2) nb = Hl / 2 > 0 ? Hl / 2 : 1;      // at least two rows of the last level per band
+  const int rp = (Hl + nb - 1) / nb;
+  nb = (Hl + rp - 1) / rp;                            // no empty band
+  size_t worst = 0;
+  for (int b = 0; b < nb; ++b) {
+    PyrTailRows r;
+    rows(b, nb, rp, r);
+    size_t px = 0;
+    for (int l = 0; l < nl; ++l) px += (size_t)(r.hold_hi[l] - r.hold_lo[l]) * Ws[l];
+    worst = px > worst ? px : worst;
+  }
+  *rows_per = rp;
+  *lds_bytes = 4 * worst;
+  return worst * 4 <= kPyrTailMaxLds ? nb : 0;
+}
+hipError_t launch_pyr_tail(const PyrLevelDev* descs_dev, int n, int k0, int L, int nb, int rows_per, size_t lds_bytes, hipStream_t stream) {
+  static bool attr_set = false;   // (one process-wide function attribute: the largest request this kernel may get)
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_tail<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPyrTailMaxLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_tail<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPyrTailMaxLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_tail<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPyrTailMaxLds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  // 2 - 16 bands x 256 - 1024 threads all measure 9 - 10 us for the 64-frame tail (profiles/r06_pyramid.txt): ~4 us of launch and a chain of short phases, not the shape
+  const dim3 grid(nb, n), block(kPyrTailThreads);
+  switch (L - k0) {
+    case 2: hipLaunchKernelGGL(k_pyr_tail<2>, grid, block, lds_bytes, stream, descs_dev, n, k0, nb, rows_per); break;
+    case 3: hipLaunchKernelGGL(k_pyr_tail<3>, grid, block, lds_bytes, stream, descs_dev, n, k0, nb, rows_per); break;
+    case 4: hipLaunchKernelGGL(k_pyr_tail<4>, grid, block, lds_bytes, stream, descs_dev, n, k0, nb, rows_per); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 hipError_t launch_pyr_level(const PyrLevelDev* descs_dev, int n, int W, int H, hipStream_t stream, bool rows_ok) {
