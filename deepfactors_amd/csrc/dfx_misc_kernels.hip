@@ -1362,7 +1362,7 @@ __global__ __launch_bounds__(1024) void k_pyr_tail(const PyrLevelDev* __restrict
         const float* r1 = cur + (y - lo) * W;
         const float* r2 = cur + (min(y + 1, H - 1) - lo) * W;
         const f32x2 g = pyr_sobel(r0[xm], r0[x], r0[xp], r1[xm], r1[xp], r2[xm], r2[x], r2[xp]);
-        gstore<f32x2>((char*)P.grad + (size_t)y * P.pitch_grad + (size_t)x * 8, g);
+        __builtin_nontemporal_store(g, (DFX_GLOBAL f32x2*)(void*)((char*)P.grad + (size_t)y * P.pitch_grad + (size_t)x * 8));   // written once, not read by the build (see k_pyr_rows)
       }
     }
     if (P.out && l + 1 < nl) {
