@@ -944,7 +944,7 @@ __device__ __forceinline__ void update_depth_body(const float* __restrict__ code
     if (rows_are_chunks || base + lane < npx) {
       const float p0 = reinterpret_cast<const float*>((const char*)prx + (size_t)y * pitch_prx)[x];
       const float pr = p0 + mine;
-      reinterpret_cast<float*>((char*)out + (size_t)y * pitch_out)[x] = avg_dpt / pr - avg_dpt;
+      reinterpret_cast<float*>((char*)out + (size_t)y * pitch_out)[x] = avg_dpt / pr - avg_dpt;   // (default policy: the step reads it next; nt here, or on prx, costs 2 - 4 %)
     }
   }
 }
@@ -1550,7 +1550,10 @@ hipError_t launch_update_depth(int cs, const float* code_dev, const float* prx_o
 hipError_t launch_update_depth_batch(int cs, const DepthJobDev* jobs_dev, int njobs, float avg_dpt, int W, int H, hipStream_t stream) {
   const int nchunks = (W * H + 63) / 64;
   int blocks = (nchunks + 3) / 4;
-  const int cap = (8192 + njobs - 1) / njobs;   // ~8 workgroups per CU over the whole batch
+  // 32768 workgroups over the whole batch = two or three 64-pixel chunks per wave.  Swept on MI355X for 64 keyframes of 640x480 (2.7 GB; tools/decoder_bench.py, two
+  // interleaved rounds): 4096 -> 469-472 us, 8192 (rounds 2-5) -> 452-456, 16384 -> 443-444, 32768 -> 433-436 = 0.77 of 8 TB/s, 65536 -> 433-434, 131072 -> 436-438.  A streaming form
+  // (contiguous chunk range per wave, next chunk prefetched) measured 500 us: the 90 registers it needs cost three of the eight waves per SIMD
+  const int cap = (32768 + njobs - 1) / njobs;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   const dim3 grid(blocks, njobs);
