@@ -24,11 +24,13 @@ def _alloc(levels, w, h, ch=None, pad=0):
 # even widths with 8 / 16-byte aligned rows take the row-streaming kernel (k_pyr_rows: strips of 128 columns, segments of >= 4 rows), everything else the
 # LDS-tile kernel (k_pyr_level): odd widths, odd pitches; from the first level of at most 160 x 120 pixels on (when at least two levels are left) ONE launch does the rest
 # (k_pyr_tail: bands of a frame in LDS, halo rows recomputed): (640, 480, 4) levels 2-3, (320, 240, 3 / 4) levels 1.., (640, 480, 5) and (1280, 960, 6) three levels,
-# (600, 440, 4) 150 x 110 and 75 x 55 (odd widths inside the tail), (320, 240, 4, pad 3) unaligned rows inside the tail; (130, 66): a strip with ONE active lane, then an odd level; (2, 2): one pixel pair; (256, 100): strip seams
+# (600, 440, 4) 150 x 110 and 75 x 55 (odd widths inside the tail), (320, 240, 4, pad 3) unaligned rows inside the tail, (16, 12, 3) and (40, 30, 4) tails of one band
+# (a last level of 3 rows), (444, 444, 4) an ODD height (111) in the middle of the tail; (130, 66): a strip with ONE active lane, then an odd level; (2, 2): one pixel pair; (256, 100): strip seams
 # at x = 128 and segment seams every 4 rows; (386, 131): odd height, partial last strip, padded rows
 @pytest.mark.parametrize("w,h,levels,pad", [(640, 480, 4, 0), (320, 240, 3, 0), (333, 217, 3, 0), (70, 50, 2, 3), (64, 16, 1, 0), (9, 7, 2, 0), (1280, 960, 4, 4),
                                             (256, 100, 3, 0), (130, 66, 2, 0), (2, 2, 1, 0), (128, 4, 2, 0), (386, 131, 2, 2), (644, 484, 3, 0),
-                                            (640, 480, 5, 0), (1280, 960, 6, 0), (600, 440, 4, 0), (320, 240, 4, 3)])
+                                            (640, 480, 5, 0), (1280, 960, 6, 0), (600, 440, 4, 0), (320, 240, 4, 3),
+                                            (16, 12, 3, 0), (40, 30, 4, 0), (444, 444, 4, 0)])
 def test_pyramid_build_equals_the_per_level_operators_and_the_oracle(dfx, oracle, w, h, levels, pad):
     rng = np.random.default_rng(w * 7 + h)
     n = 3
