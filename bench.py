@@ -65,7 +65,7 @@ def parse():
                     help="run the reduction tail of every step (tail kernel with the graph assembly) on a second stream beside the next step's kernel (dfx_set_tail_stream) "
                          "instead of in order on the launch stream.  Measured on MI355X in interleaved windows of one process (tools/ab_tail_modes.py, profiles/r05_step_gap.txt): "
                          "step time - kernel time falls from 39 to 15-21 us, but the step kernel beside which the tail runs takes 13-19 us longer (the tail's 47 MB of "
-                         "partials and its issue slots are paid there): 985-990 vs 991 us per step, -0.5 %, at a roofline fraction 1.9 % lower.  So the single-GPU line keeps "
+                         "partials and its issue slots are paid there): 985-990 vs 991 us per step, -0.5 %%, at a roofline fraction 1.9 %% lower.  So the single-GPU line keeps "
                          "the tail in order; with the C-ABI exchange and N > 1 the mode is on (it is how the collective leaves the launch stream)")
     ap.add_argument("--two-call-tail", action="store_true", help="issue the step and the graph assembly as two library calls (dfx_sfm_step_batch_async + "
                     "dfx_graph_assemble_async: two tail kernels) instead of dfx_sfm_step_batch_assemble_async (the assembly inside the launch's tail kernel)")
@@ -79,7 +79,7 @@ def parse():
                     help="what the timed pairs look like: perturbed (default since round 6) = pose1 of every pair moved by N(0, 5 mm) / N(0, 0.3 deg) per axis "
                          "(SURVEY 8d cfg 3: what a relinearisation sees); truth = every pair at its generating pose (residual ~ 0, Huber never active, taps maximally "
                          "coherent: the line of rounds 1-5); unrelated = perturbed poses AND img1 / grad1 of ANOTHER scene (residuals of the order of huber_delta).  "
-                         "The line's `config.workload` names it and `configs.headline_<other>` carry the two it did not run: they differ by < 1 % on MI355X")
+                         "The line's `config.workload` names it and `configs.headline_<other>` carry the two it did not run: they differ by < 1 %% on MI355X")
     ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 

@@ -127,6 +127,8 @@ struct dfx_ctx {
   char* stage_host = nullptr;
   size_t stage_slot_bytes = 0;
   hipEvent_t stage_ev[kStageSlots] = {};
+  hipEvent_t stage_rel_ev[kStageSlots] = {};   // stage_release's events: they only tell the HOST that the kernels / copies in front of them have read a slot -- no
+  bool stage_rel[kStageSlots] = {};            // device-written data travels behind them, so they carry no system-scope fence (DFX_STAGE_EVENT_FLAGS); true = the slot's last guard
   bool stage_used[kStageSlots] = {};
   int stage_next = 0;
   char* result_host = nullptr;
@@ -168,6 +170,9 @@ int ensure_device(dfx_ctx* c) {
 
 // Grows a device scratch buffer; callers drain the stream first when the old buffer may still be in use.
 // The clear is enqueued on the context's stream so that it is ordered before the kernels that use the buffer.
+#ifndef DFX_STAGE_EVENT_FLAGS
+#define DFX_STAGE_EVENT_FLAGS (hipEventDisableTiming | hipEventDisableSystemFence)
+#endif
 int grow_dev(void** p, size_t* cap, size_t need, hipStream_t stream) {
   if (*cap >= need) return DFX_OK;
   if (*p) DFX_HIP(hipFree(*p));
@@ -260,15 +265,16 @@ int stage_acquire(dfx_ctx* c, size_t bytes, int* slot, char** host) {
   if ((rc = stage_reserve(c, bytes))) return rc;
   const int s = c->stage_next;
   c->stage_next = (s + 1) % kStageSlots;
-  if (c->stage_used[s]) DFX_HIP(hipEventSynchronize(c->stage_ev[s]));
+  if (c->stage_used[s]) DFX_HIP(hipEventSynchronize(c->stage_rel[s] ? c->stage_rel_ev[s] : c->stage_ev[s]));
   *slot = s;
   *host = c->stage_host + (size_t)s * c->stage_slot_bytes;
   return DFX_OK;
 }
 
 int stage_release(dfx_ctx* c, int slot) {
-  DFX_HIP(hipEventRecord(c->stage_ev[slot], c->stream));
+  DFX_HIP(hipEventRecord(c->stage_rel_ev[slot], c->stream));
   c->stage_used[slot] = true;
+  c->stage_rel[slot] = true;
   return DFX_OK;
 }
 
@@ -705,6 +711,7 @@ DFX_API int dfx_ctx_create(int device, void* stream, dfx_ctx** out) {
   c->stream = (hipStream_t)stream;
   for (int i = 0; i < kStageSlots; ++i) {
     e = hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->stage_rel_ev[i], DFX_STAGE_EVENT_FLAGS);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->slot_done[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->sdesc_done[i], hipEventDisableTiming);
     if (e != hipSuccess) { dfx_ctx_destroy(c); return fail(DFX_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(e)); }   // destroys what exists so far
@@ -743,6 +750,7 @@ DFX_API void dfx_ctx_destroy(dfx_ctx* c) {
   if (c->result_host) (void)hipHostFree(c->result_host);
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   for (int i = 0; i < kStageSlots; ++i) if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
+  for (int i = 0; i < kStageSlots; ++i) if (c->stage_rel_ev[i]) (void)hipEventDestroy(c->stage_rel_ev[i]);
   for (int i = 0; i < kStageSlots; ++i) if (c->slot_done[i]) (void)hipEventDestroy(c->slot_done[i]);
   for (int i = 0; i < kStageSlots; ++i) if (c->sdesc_done[i]) (void)hipEventDestroy(c->sdesc_done[i]);
   for (auto& pr : c->prof_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1171,6 +1179,7 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
       DFX_HIP(hipMemcpyAsync(region, hd, desc_bytes + map_bytes, hipMemcpyHostToDevice, c->copy_stream));
       DFX_HIP(hipEventRecord(c->stage_ev[slot], c->copy_stream));
       c->stage_used[slot] = true;
+      c->stage_rel[slot] = false;
       DFX_HIP(hipStreamWaitEvent(c->stream, c->stage_ev[slot], 0));
     }
   }
@@ -1278,6 +1287,7 @@ static int sfm_step_batch_impl(dfx_ctx* c, int cs, const dfx_sfm_params* params,
     if (desc_zerocopy(c)) {   // the kernels read the staging slot itself: it is free again behind them
       DFX_HIP(hipEventRecord(c->stage_ev[slot], fin_stream));
       c->stage_used[slot] = true;
+      c->stage_rel[slot] = false;
     } else {
       DFX_HIP(hipEventRecord(c->slot_done[slot], fin_stream));
       c->slot_busy[slot] = true;
@@ -1490,6 +1500,7 @@ int upload_simple(dfx_ctx* c, const std::vector<dfx::SimplePairDev>& descs, cons
   DFX_HIP(hipMemcpyAsync(dd, host, bytes, hipMemcpyHostToDevice, c->copy_stream));
   DFX_HIP(hipEventRecord(c->stage_ev[slot], c->copy_stream));   // the host slot is free again once the copy has run
   c->stage_used[slot] = true;
+  c->stage_rel[slot] = false;
   DFX_HIP(hipStreamWaitEvent(c->stream, c->stage_ev[slot], 0));
   *dev_out = reinterpret_cast<const dfx::SimplePairDev*>(dd);
   *slot_out = slot;
@@ -2204,25 +2215,27 @@ DFX_API int dfx_build_pyramid_batch_async(dfx_ctx* c, const dfx_pyramid* frames,
   }
   if (!rc) rc = img_note_writes(c, written);
   if (rc) { (void)stage_release(c, slot); return rc; }
-  // Few frames (the per-frame latency path): the kernels read the pinned staging slot (zero-copy descriptors, see simple_zerocopy).  Many frames: a
-  // device copy first -- every one of the ~10^4 workgroups of a level starts with its descriptor (levels 1-3 of a 64-frame build: 17.8 / 10.0 / 8.6 ->
-  // 15.8 / 8.4 / 6.3 us; level 0 unchanged).
+  // Descriptors: no copy command in front of the build.  The FIRST launch reads the pinned staging slot itself (zero-copy) and its workgroup 0 mirrors the
+  // descriptors of its own and all later levels into device memory, where the launches behind it read them (every one of the ~10^4 workgroups of a level
+  // starts with its descriptor: levels 1-3 of a 64-frame build out of host memory measured 17.8 / 10.0 / 8.6 us against 15.8 / 8.4 / 6.3 out of device
+  // memory, level 0 the same either way).  Rounds 5-6 uploaded them with hipMemcpyAsync on the stream: a 4.4 us blit kernel and 6.3 us of idle GPU in front of
+  // it per 64-frame build (rocprofv3 timeline, profiles/r06_pyramid.txt) -- 10.7 of 72.4 us.
   // (Measured and dropped in round 6: issuing level 0 twice -- blur-down only in front of the level 1.. chain, gradient only on a second stream beside it -- to hide
   // the chain's launch latencies behind the 157 MB of gradient stores.  The blur-only kernel still takes 46 us of the combined kernel's 52 (a wave's walk is bound
   // by load latency per row, not by its bytes), and the cross-stream hand-over costs more than the chain: 88 -> 111 us per 64-frame build; profiles/r06_pyramid.txt.)
   void* hdev = nullptr;
   const size_t dbytes = sizeof(dfx::PyrLevelDev) * (size_t)n * L;
-  if (n > 4) {
-    if (c->pyr_bytes < dbytes) (void)hipStreamSynchronize(c->stream);
-    if ((rc = grow_dev((void**)&c->pyr_dev, &c->pyr_bytes, dbytes, c->stream))) { (void)stage_release(c, slot); return rc; }
-    const hipError_t ce = hipMemcpyAsync(c->pyr_dev, host, dbytes, hipMemcpyHostToDevice, c->stream);
-    if (ce != hipSuccess) { (void)stage_release(c, slot); return fail(DFX_E_HIP, "hipMemcpyAsync (descriptors) failed: %s", hipGetErrorString(ce)); }
-    hdev = c->pyr_dev;
-  } else {
+  {
     const hipError_t ge = hipHostGetDevicePointer(&hdev, host, 0);
     if (ge != hipSuccess) { (void)stage_release(c, slot); return fail(DFX_E_HIP, "hipHostGetDevicePointer failed: %s", hipGetErrorString(ge)); }
   }
-  const dfx::PyrLevelDev* ddev = reinterpret_cast<const dfx::PyrLevelDev*>(hdev);
+  if (L > 1) {
+    if (c->pyr_bytes < dbytes) (void)hipStreamSynchronize(c->stream);
+    if ((rc = grow_dev((void**)&c->pyr_dev, &c->pyr_bytes, dbytes, c->stream))) { (void)stage_release(c, slot); return rc; }
+  }
+  const dfx::PyrLevelDev* hostdev = reinterpret_cast<const dfx::PyrLevelDev*>(hdev);
+  dfx::PyrLevelDev* mirror = L > 1 ? reinterpret_cast<dfx::PyrLevelDev*>(c->pyr_dev) : nullptr;
+  bool mirrored = false;   // a launch has left the descriptors in device memory
   // The small levels as ONE launch (k_pyr_tail: a few bands per frame, each workgroup with its rows of those levels in LDS): from the first level k0 >= 1 whose
   // image is at most kPyrTailMaxPixels (160 x 120 of a 640 x 480 build), when that is at least two levels: 6.0 + 4.4 us of launches and a boundary become one
   int k0 = L, tail_nb = 0, tail_rp = 0;
@@ -2239,11 +2252,14 @@ DFX_API int dfx_build_pyramid_batch_async(dfx_ctx* c, const dfx_pyramid* frames,
     bool any = false;   // (the last level of a batch whose frames all skip its gradient has nothing to do)
     for (int k = 0; k < n; ++k) any = any || hd[(size_t)i * n + k].grad || hd[(size_t)i * n + k].out;
     if (!any) continue;
-    hipError_t e = dfx::launch_pyr_level(ddev + (size_t)i * n, n, (int)frames[0].img[i].w, (int)frames[0].img[i].h, c->stream, rows_ok[i]);
+    const bool first = !mirrored && mirror;
+    hipError_t e = dfx::launch_pyr_level((mirrored ? mirror : hostdev) + (size_t)i * n, n, (int)frames[0].img[i].w, (int)frames[0].img[i].h, c->stream, rows_ok[i],
+                                         first ? mirror + (size_t)i * n : nullptr, first ? (L - i) * n : 0);
     if (e != hipSuccess) { (void)stage_release(c, slot); return fail(DFX_E_HIP, "k_pyr_level launch failed: %s", hipGetErrorString(e)); }
+    mirrored = mirrored || first;
   }
   if (k0 < L) {
-    const hipError_t e = dfx::launch_pyr_tail(ddev, n, k0, L, tail_nb, tail_rp, tail_lds, c->stream);
+    const hipError_t e = dfx::launch_pyr_tail(mirrored ? mirror : hostdev, n, k0, L, tail_nb, tail_rp, tail_lds, c->stream);   // (not mirrored: level 0 had nothing to do)
     if (e != hipSuccess) { (void)stage_release(c, slot); return fail(DFX_E_HIP, "k_pyr_tail launch failed: %s", hipGetErrorString(e)); }
   }
   return stage_release(c, slot);

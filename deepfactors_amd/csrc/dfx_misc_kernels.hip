@@ -1030,7 +1030,19 @@ template <typename T>
 __device__ __forceinline__ void pyr_store(void* p, const T& v) {
   if (DFX_PYR_NT) __builtin_nontemporal_store(v, (DFX_GLOBAL T*)p); else gstore<T>(p, v);
 }
-__global__ __launch_bounds__(kT) void k_pyr_level(const PyrLevelDev* __restrict__ descs) {
+// The FIRST launch of a build reads its descriptors out of the pinned staging slot (zero-copy) and its workgroup 0 leaves a copy of ALL levels' descriptors
+// in device memory for the launches behind it: no host-to-device copy command in front of the build (a 4.4 us blit kernel + 6.3 us of boundary per 64-frame
+// build in the round-6 trace, profiles/r06_pyramid.txt), and only the ~10^3 workgroups of one launch start with a read across the host link.
+__device__ __forceinline__ void pyr_mirror_descs(const PyrLevelDev* __restrict__ src, PyrLevelDev* __restrict__ mirror, const int count, const bool first_wg) {
+  static_assert(sizeof(PyrLevelDev) % 8 == 0, "descriptors are copied as 8-byte words");
+  if (!mirror || !first_wg) return;
+  const int words = count * (int)(sizeof(PyrLevelDev) / 8);
+  const unsigned long long* s = reinterpret_cast<const unsigned long long*>(src);
+  unsigned long long* d = reinterpret_cast<unsigned long long*>(mirror);
+  for (int i = threadIdx.x; i < words; i += blockDim.x) d[i] = s[i];
+}
+__global__ __launch_bounds__(kT) void k_pyr_level(const PyrLevelDev* __restrict__ descs, PyrLevelDev* __restrict__ mirror, const int mirror_count) {
+  pyr_mirror_descs(descs, mirror, mirror_count, (blockIdx.x | blockIdx.y | blockIdx.z) == 0);
   const PyrLevelDev& P = descs[blockIdx.z];
   const int W = P.W, H = P.H, OW = P.OW, OH = P.OH;
   const int x0 = blockIdx.x * kPyrTW, y0 = blockIdx.y * kPyrTH;
@@ -1176,7 +1188,9 @@ constexpr int kPyrStrip = 128;
 #define DFX_PYR_GRAD_AUX 2 // ... and of its gradient stores (nt: written once, not read by the build)
 #endif
 template <int NP>
-__global__ __launch_bounds__(512) void k_pyr_rows(const PyrLevelDev* __restrict__ descs, const int nstrips, const int nsegs, const int R) {
+__global__ __launch_bounds__(512) void k_pyr_rows(const PyrLevelDev* __restrict__ descs, const int nstrips, const int nsegs, const int R,
+                                                  PyrLevelDev* __restrict__ mirror, const int mirror_count) {
+  pyr_mirror_descs(descs, mirror, mirror_count, (blockIdx.x | blockIdx.y) == 0);   // (see k_pyr_level)
   const PyrLevelDev& P = descs[blockIdx.y];
   const int lane = threadIdx.x & 63;
   // a workgroup = the `wpg` strips side by side of one row segment (wpg = blockDim.x / 64 divides into nstrips groups): its waves walk down the same rows, so
@@ -1437,7 +1451,7 @@ hipError_t launch_pyr_tail(const PyrLevelDev* descs_dev, int n, int k0, int L, i
   return hipGetLastError();
 }
 
-hipError_t launch_pyr_level(const PyrLevelDev* descs_dev, int n, int W, int H, hipStream_t stream, bool rows_ok) {
+hipError_t launch_pyr_level(const PyrLevelDev* descs_dev, int n, int W, int H, hipStream_t stream, bool rows_ok, PyrLevelDev* mirror, int mirror_count) {
   if (rows_ok && (W & 1) == 0) {
     const int nstrips = (W + kPyrStrip - 1) / kPyrStrip;
     // rows per segment: ~4096 waves per launch (16 per CU) when there is that much work, segments of at least 4 rows (a segment re-reads 3 rows of its
@@ -1455,10 +1469,10 @@ hipError_t launch_pyr_level(const PyrLevelDev* descs_dev, int n, int W, int H, h
     int wpg = nstrips;
     if (wpg > 8) wpg = (nstrips + ((nstrips + 7) / 8) - 1) / ((nstrips + 7) / 8);
     const int gps = (nstrips + wpg - 1) / wpg;
-    hipLaunchKernelGGL(k_pyr_rows<1>, dim3(gps * nsegs, n), dim3(64 * wpg), 0, stream, descs_dev, nstrips, nsegs, R);
+    hipLaunchKernelGGL(k_pyr_rows<1>, dim3(gps * nsegs, n), dim3(64 * wpg), 0, stream, descs_dev, nstrips, nsegs, R, mirror, mirror_count);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(k_pyr_level, dim3((W + kPyrTW - 1) / kPyrTW, (H + kPyrTH - 1) / kPyrTH, n), dim3(kT), 0, stream, descs_dev);
+  hipLaunchKernelGGL(k_pyr_level, dim3((W + kPyrTW - 1) / kPyrTW, (H + kPyrTH - 1) / kPyrTH, n), dim3(kT), 0, stream, descs_dev, mirror, mirror_count);
   return hipGetLastError();
 }
 

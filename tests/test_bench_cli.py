@@ -58,3 +58,13 @@ def test_world_size_must_match_gpus(monkeypatch):
     with pytest.raises(SystemExit) as e:
         b.main()
     assert "WORLD_SIZE=4" in str(e.value.code)
+
+
+def test_help_prints(monkeypatch, capsys):
+    """argparse expands help strings with %: a bare percent sign in one of them made `bench.py --help` raise (round 6)."""
+    b = _bench()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--help"])
+    with pytest.raises(SystemExit) as e:
+        b.parse()
+    assert e.value.code == 0
+    assert "--workload" in capsys.readouterr().out

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Frame ingest: dfx_build_pyramid_batch_async over F frames of 640x480 (4 levels) -- event time per enqueue and roofline fraction (bytes: 4 read + 8 + 1 written
-per pixel and level), against the per-level operators frame by frame.  usage: pyramid_bench.py [frames=64]"""
+per pixel and level), against the per-level operators frame by frame.  usage: pyramid_bench.py [frames=64] [--build-only]"""
 import os
 import sys
 
@@ -10,7 +10,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 def main():
     import torch
     import deepfactors_amd as dfx
-    F = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    F = int(args[0]) if args else 64
     W, H, LV = 640, 480, 4
     dev = torch.device("cuda", 0)
     ctx = dfx.Context(0)
@@ -32,6 +33,9 @@ def main():
     us = timed(lambda: dfx.BuildPyramids(arr, ctx=ctx), 50, 200)
     byts = sum((W >> i) * (H >> i) * (12 + (1 if i + 1 < LV else 0)) for i in range(LV)) * F
     print(f"build_pyramid_batch {F} frames x {LV} levels: {us:.1f} us per enqueue = {byts / us / 1e3:.0f} GB/s = {byts / us / 1e3 / 8000:.3f} of 8 TB/s ({us / F:.2f} us per frame)")
+
+    if "--build-only" in sys.argv:
+        return
 
     # the yardstick: a device-to-device copy moving the volume of the level-0 launch (F x (4 B read + 8 + 1 B written) per pixel ~ half read, half written)
     vol = F * W * H * 13
