@@ -128,6 +128,10 @@ struct dfx_ctx {
   size_t stage_slot_bytes = 0;
   hipEvent_t stage_ev[kStageSlots] = {};
   hipEvent_t stage_rel_ev[kStageSlots] = {};   // stage_release's events: they only tell the HOST that the kernels / copies in front of them have read a slot -- no
+  std::vector<char> pyr_build, pyr_last;       // the descriptor block of the build being enqueued / of the one whose copy sits in pyr_dev
+  bool pyr_mirror_valid = false;
+  uint32_t pyr_seq = 0;                        // pyramid builds enqueued so far; build q's first kernel stores q into done_flag_host[kPyrStartWord] when it starts
+  uint32_t stage_pyr[kStageSlots] = {};        // != 0: the slot was last read by pyramid build stage_pyr[s] -- free once a LATER build is running (no event recorded)
   bool stage_rel[kStageSlots] = {};            // device-written data travels behind them, so they carry no system-scope fence (DFX_STAGE_EVENT_FLAGS); true = the slot's last guard
   bool stage_used[kStageSlots] = {};
   int stage_next = 0;
@@ -170,6 +174,9 @@ int ensure_device(dfx_ctx* c) {
 
 // Grows a device scratch buffer; callers drain the stream first when the old buffer may still be in use.
 // The clear is enqueued on the context's stream so that it is ordered before the kernels that use the buffer.
+#ifndef DFX_PYR_DESC_CACHE
+#define DFX_PYR_DESC_CACHE 1
+#endif
 #ifndef DFX_STAGE_EVENT_FLAGS
 #define DFX_STAGE_EVENT_FLAGS (hipEventDisableTiming | hipEventDisableSystemFence)
 #endif
@@ -260,12 +267,18 @@ int stage_reserve(dfx_ctx* c, size_t bytes) {
   for (int i = 0; i < kStageSlots; ++i) c->stage_used[i] = false;
   return DFX_OK;
 }
+constexpr int kPyrStartWord = 16;   // (its own cache line of the 128-byte flag area)
+int wait_pyr_started(dfx_ctx* c, uint32_t need);
 int stage_acquire(dfx_ctx* c, size_t bytes, int* slot, char** host) {
   int rc;
   if ((rc = stage_reserve(c, bytes))) return rc;
   const int s = c->stage_next;
   c->stage_next = (s + 1) % kStageSlots;
-  if (c->stage_used[s]) DFX_HIP(hipEventSynchronize(c->stage_rel[s] ? c->stage_rel_ev[s] : c->stage_ev[s]));
+  if (c->stage_used[s]) {
+    if (c->stage_pyr[s]) { if ((rc = wait_pyr_started(c, c->stage_pyr[s] + 1))) return rc; }
+    else DFX_HIP(hipEventSynchronize(c->stage_rel[s] ? c->stage_rel_ev[s] : c->stage_ev[s]));
+  }
+  c->stage_pyr[s] = 0;
   *slot = s;
   *host = c->stage_host + (size_t)s * c->stage_slot_bytes;
   return DFX_OK;
@@ -275,6 +288,7 @@ int stage_release(dfx_ctx* c, int slot) {
   DFX_HIP(hipEventRecord(c->stage_rel_ev[slot], c->stream));
   c->stage_used[slot] = true;
   c->stage_rel[slot] = true;
+  c->stage_pyr[slot] = 0;
   return DFX_OK;
 }
 
@@ -368,6 +382,27 @@ int poll_word(dfx_ctx* c, const uint32_t* f, uint32_t seq) {
     if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == seq) return DFX_OK;
     return fail(DFX_E_HIP, "the stream drained without the result flag (sequence %u)", seq);
   }
+}
+// A staging slot last read by pyramid build `need - 1` is free once build `need` (or a later one) has STARTED: its first workgroup stores the build's number into
+// the flag area (pyr_mirror_descs).  If no such build was enqueued, or it does not start within the polling bound, the stream is drained instead.  (The bound is
+// that of a host running a full ring -- kStageSlots - 1 builds -- ahead of the device: draining the stream there would idle the device once per ring.)
+constexpr long long kPyrStartSpinUs = 2000;
+int wait_pyr_started(dfx_ctx* c, uint32_t need) {
+  const uint32_t* f = c->done_flag_host + kPyrStartWord;
+  auto started = [&] { return (int32_t)(__atomic_load_n(f, __ATOMIC_ACQUIRE) - need) >= 0; };
+  if (started()) return DFX_OK;
+  if ((int32_t)(c->pyr_seq - need) >= 0) {
+    using clk = std::chrono::steady_clock;
+    const clk::time_point t0 = clk::now();
+    for (unsigned spins = 1;; ++spins) {
+      if (started()) return DFX_OK;
+      cpu_relax();
+      if ((spins & 0xff) == 0 && std::chrono::duration_cast<std::chrono::microseconds>(clk::now() - t0).count() >= kPyrStartSpinUs) break;
+    }
+  }
+  const hipError_t q = hipStreamSynchronize(c->stream);
+  if (q != hipSuccess) return fail(DFX_E_HIP, "stream failed while waiting for a staging slot: %s", hipGetErrorString(q));
+  return DFX_OK;
 }
 // The end of a blocking call that has no kernel of its own to signal (no result, or many last writers).  A word written by the command processor behind the
 // stream's work (hipStreamWriteValue32) and polled by the host was measured here too, interleaved with this in one process: the best case is 2.5 us sooner,
@@ -2175,10 +2210,9 @@ DFX_API int dfx_build_pyramid_batch_async(dfx_ctx* c, const dfx_pyramid* frames,
   if ((rc = ensure_device(c))) return rc;
   const int L = frames[0].levels;
   if (L < 1 || L > DFX_MAX_PYR_LEVELS) return fail(DFX_E_INVALID, "pyramid of %d levels (1 .. %d)", L, DFX_MAX_PYR_LEVELS);
-  int slot;
-  char* host;
-  if ((rc = stage_acquire(c, sizeof(dfx::PyrLevelDev) * (size_t)n * L, &slot, &host))) return rc;
-  dfx::PyrLevelDev* hd = reinterpret_cast<dfx::PyrLevelDev*>(host);
+  const size_t dbytes = sizeof(dfx::PyrLevelDev) * (size_t)n * L;
+  c->pyr_build.assign(dbytes, 0);   // (padding bytes zeroed: the block is compared with the previous build's)
+  dfx::PyrLevelDev* hd = reinterpret_cast<dfx::PyrLevelDev*>(c->pyr_build.data());
   bool rows_ok[DFX_MAX_PYR_LEVELS];
   for (int i = 0; i < DFX_MAX_PYR_LEVELS; ++i) rows_ok[i] = true;
   std::vector<const void*> written;
@@ -2214,7 +2248,17 @@ DFX_API int dfx_build_pyramid_batch_async(dfx_ctx* c, const dfx_pyramid* frames,
     if (rc) g_last_error = "frame " + std::to_string(k) + ": " + g_last_error;
   }
   if (!rc) rc = img_note_writes(c, written);
-  if (rc) { (void)stage_release(c, slot); return rc; }
+  if (rc) return rc;
+  // The same buffers as the previous build of this context (a camera's live frame, a ring of frames: UploadLiveFrame, deepfactors.cpp:616-630, fills the same
+  // pyramids frame after frame): the descriptors are still in device memory -- every launch reads them there, nothing is staged.
+  const bool cached = DFX_PYR_DESC_CACHE && L > 1 && c->pyr_dev && c->pyr_mirror_valid && c->pyr_last == c->pyr_build;
+  int slot = -1;
+  char* host = nullptr;
+  if (!cached) {
+    c->pyr_mirror_valid = false;
+    if ((rc = stage_acquire(c, dbytes, &slot, &host))) return rc;
+    std::memcpy(host, c->pyr_build.data(), dbytes);
+  }
   // Descriptors: no copy command in front of the build.  The FIRST launch reads the pinned staging slot itself (zero-copy) and its workgroup 0 mirrors the
   // descriptors of its own and all later levels into device memory, where the launches behind it read them (every one of the ~10^4 workgroups of a level
   // starts with its descriptor: levels 1-3 of a 64-frame build out of host memory measured 17.8 / 10.0 / 8.6 us against 15.8 / 8.4 / 6.3 out of device
@@ -2224,18 +2268,25 @@ DFX_API int dfx_build_pyramid_batch_async(dfx_ctx* c, const dfx_pyramid* frames,
   // the chain's launch latencies behind the 157 MB of gradient stores.  The blur-only kernel still takes 46 us of the combined kernel's 52 (a wave's walk is bound
   // by load latency per row, not by its bytes), and the cross-stream hand-over costs more than the chain: 88 -> 111 us per 64-frame build; profiles/r06_pyramid.txt.)
   void* hdev = nullptr;
-  const size_t dbytes = sizeof(dfx::PyrLevelDev) * (size_t)n * L;
-  {
+  if (!cached) {
     const hipError_t ge = hipHostGetDevicePointer(&hdev, host, 0);
     if (ge != hipSuccess) { (void)stage_release(c, slot); return fail(DFX_E_HIP, "hipHostGetDevicePointer failed: %s", hipGetErrorString(ge)); }
   }
-  if (L > 1) {
+  if (L > 1 && !cached) {
     if (c->pyr_bytes < dbytes) (void)hipStreamSynchronize(c->stream);
     if ((rc = grow_dev((void**)&c->pyr_dev, &c->pyr_bytes, dbytes, c->stream))) { (void)stage_release(c, slot); return rc; }
   }
   const dfx::PyrLevelDev* hostdev = reinterpret_cast<const dfx::PyrLevelDev*>(hdev);
   dfx::PyrLevelDev* mirror = L > 1 ? reinterpret_cast<dfx::PyrLevelDev*>(c->pyr_dev) : nullptr;
-  bool mirrored = false;   // a launch has left the descriptors in device memory
+  bool mirrored = cached;  // a launch has left the descriptors in device memory
+  if ((rc = ensure_done_flag(c))) { if (slot >= 0) (void)stage_release(c, slot); return rc; }
+  dfx::PyrStart start;     // the build's first launch reports that it is running (wait_pyr_started): the staging slot needs no event behind the build
+  start.word = c->done_flag_dev + kPyrStartWord;
+  if (!cached) {
+    start.seq = ++c->pyr_seq;
+    if (start.seq == 0) start.seq = ++c->pyr_seq;   // (0 = "slot not guarded by a build" in stage_pyr)
+  }
+  bool signalled = cached;   // (no slot to guard)
   // The small levels as ONE launch (k_pyr_tail: a few bands per frame, each workgroup with its rows of those levels in LDS): from the first level k0 >= 1 whose
   // image is at most kPyrTailMaxPixels (160 x 120 of a 640 x 480 build), when that is at least two levels: 6.0 + 4.4 us of launches and a boundary become one
   int k0 = L, tail_nb = 0, tail_rp = 0;
@@ -2254,15 +2305,21 @@ DFX_API int dfx_build_pyramid_batch_async(dfx_ctx* c, const dfx_pyramid* frames,
     if (!any) continue;
     const bool first = !mirrored && mirror;
     hipError_t e = dfx::launch_pyr_level((mirrored ? mirror : hostdev) + (size_t)i * n, n, (int)frames[0].img[i].w, (int)frames[0].img[i].h, c->stream, rows_ok[i],
-                                         first ? mirror + (size_t)i * n : nullptr, first ? (L - i) * n : 0);
-    if (e != hipSuccess) { (void)stage_release(c, slot); return fail(DFX_E_HIP, "k_pyr_level launch failed: %s", hipGetErrorString(e)); }
+                                         first ? mirror + (size_t)i * n : nullptr, first ? (L - i) * n : 0, signalled ? dfx::PyrStart{} : start);
+    if (e != hipSuccess) { c->pyr_mirror_valid = false; if (slot >= 0) (void)stage_release(c, slot); return fail(DFX_E_HIP, "k_pyr_level launch failed: %s", hipGetErrorString(e)); }
     mirrored = mirrored || first;
+    signalled = true;
   }
   if (k0 < L) {
     const hipError_t e = dfx::launch_pyr_tail(mirrored ? mirror : hostdev, n, k0, L, tail_nb, tail_rp, tail_lds, c->stream);   // (not mirrored: level 0 had nothing to do)
-    if (e != hipSuccess) { (void)stage_release(c, slot); return fail(DFX_E_HIP, "k_pyr_tail launch failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { c->pyr_mirror_valid = false; if (slot >= 0) (void)stage_release(c, slot); return fail(DFX_E_HIP, "k_pyr_tail launch failed: %s", hipGetErrorString(e)); }
   }
-  return stage_release(c, slot);
+  if (cached) return DFX_OK;
+  if (mirrored && mirror) { c->pyr_last.swap(c->pyr_build); c->pyr_mirror_valid = true; }   // (the mirror holds ALL levels only when the first launch was level 0's)
+  if (!signalled) return stage_release(c, slot);   // (nothing launched that reports: the event)
+  c->stage_used[slot] = true;
+  c->stage_pyr[slot] = start.seq;
+  return DFX_OK;
 }
 
 DFX_API int dfx_build_pyramid(dfx_ctx* c, const dfx_pyramid* frame) {

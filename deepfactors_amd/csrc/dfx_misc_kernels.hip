@@ -1033,16 +1033,28 @@ __device__ __forceinline__ void pyr_store(void* p, const T& v) {
 // The FIRST launch of a build reads its descriptors out of the pinned staging slot (zero-copy) and its workgroup 0 leaves a copy of ALL levels' descriptors
 // in device memory for the launches behind it: no host-to-device copy command in front of the build (a 4.4 us blit kernel + 6.3 us of boundary per 64-frame
 // build in the round-6 trace, profiles/r06_pyramid.txt), and only the ~10^3 workgroups of one launch start with a read across the host link.
-__device__ __forceinline__ void pyr_mirror_descs(const PyrLevelDev* __restrict__ src, PyrLevelDev* __restrict__ mirror, const int count, const bool first_wg) {
+// The same workgroup first stores the build's sequence number into a host-visible word: a kernel of build q running means everything in front of it on the stream
+// has completed, so the staging slots of the builds up to q - 1 are free again -- the host learns it without an event (a command-processor packet of ~3.5 us
+// behind every build, profiles/r06_pyramid.txt).
+__device__ __forceinline__ void pyr_mirror_descs(const PyrLevelDev* __restrict__ src, PyrLevelDev* __restrict__ mirror, const int count, const bool first_wg, const PyrStart st) {
   static_assert(sizeof(PyrLevelDev) % 8 == 0, "descriptors are copied as 8-byte words");
-  if (!mirror || !first_wg) return;
+  if (!first_wg) return;
+  if (st.word && threadIdx.x == 0) __hip_atomic_store(st.word, st.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (!mirror) return;
   const int words = count * (int)(sizeof(PyrLevelDev) / 8);
   const unsigned long long* s = reinterpret_cast<const unsigned long long*>(src);
   unsigned long long* d = reinterpret_cast<unsigned long long*>(mirror);
-  for (int i = threadIdx.x; i < words; i += blockDim.x) d[i] = s[i];
+  constexpr int NB = 8;   // every load of a batch is in flight before the first store: the source is across the host link (~2 us per round trip)
+  for (int base = 0; base < words; base += NB * (int)blockDim.x) {
+    unsigned long long v[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { const int i = base + j * (int)blockDim.x + (int)threadIdx.x; v[j] = i < words ? s[i] : 0ull; }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { const int i = base + j * (int)blockDim.x + (int)threadIdx.x; if (i < words) d[i] = v[j]; }
+  }
 }
-__global__ __launch_bounds__(kT) void k_pyr_level(const PyrLevelDev* __restrict__ descs, PyrLevelDev* __restrict__ mirror, const int mirror_count) {
-  pyr_mirror_descs(descs, mirror, mirror_count, (blockIdx.x | blockIdx.y | blockIdx.z) == 0);
+__global__ __launch_bounds__(kT) void k_pyr_level(const PyrLevelDev* __restrict__ descs, PyrLevelDev* __restrict__ mirror, const int mirror_count, const PyrStart st) {
+  pyr_mirror_descs(descs, mirror, mirror_count, (blockIdx.x | blockIdx.y | blockIdx.z) == 0, st);
   const PyrLevelDev& P = descs[blockIdx.z];
   const int W = P.W, H = P.H, OW = P.OW, OH = P.OH;
   const int x0 = blockIdx.x * kPyrTW, y0 = blockIdx.y * kPyrTH;
@@ -1188,10 +1200,18 @@ constexpr int kPyrStrip = 128;
 #define DFX_PYR_GRAD_AUX 2 // ... and of its gradient stores (nt: written once, not read by the build)
 #endif
 template <int NP>
+__device__ __forceinline__ void pyr_rows_body(const PyrLevelDev& P, const int nstrips, const int nsegs, const int R);
+template <int NP>
 __global__ __launch_bounds__(512) void k_pyr_rows(const PyrLevelDev* __restrict__ descs, const int nstrips, const int nsegs, const int R,
-                                                  PyrLevelDev* __restrict__ mirror, const int mirror_count) {
-  pyr_mirror_descs(descs, mirror, mirror_count, (blockIdx.x | blockIdx.y) == 0);   // (see k_pyr_level)
-  const PyrLevelDev& P = descs[blockIdx.y];
+                                                  PyrLevelDev* __restrict__ mirror, const int mirror_count, const PyrStart st) {
+  // (see k_pyr_level.  Measured and dropped: an extra workgroup column for the bookkeeping -- 64 more workgroups shift the whole grid's placement, level 0 45.8 -> 47.5 us;
+  // the level's descriptors by value in the kernel arguments for <= 64 frames -- no change: what level 0 gained over the 43.9 us it took behind the copy command is the
+  // tail of the previous build's write-backs, which the copy used to absorb.)
+  pyr_mirror_descs(descs, mirror, mirror_count, (blockIdx.x | blockIdx.y) == 0, st);   // (the short last row segment instead of workgroup 0: no difference)
+  pyr_rows_body<NP>(descs[blockIdx.y], nstrips, nsegs, R);
+}
+template <int NP>
+__device__ __forceinline__ void pyr_rows_body(const PyrLevelDev& P, const int nstrips, const int nsegs, const int R) {
   const int lane = threadIdx.x & 63;
   // a workgroup = the `wpg` strips side by side of one row segment (wpg = blockDim.x / 64 divides into nstrips groups): its waves walk down the same rows, so
   // the workgroup writes whole image rows (5 KB at 640 pixels) rather than 1-KB pieces of four different places
@@ -1451,7 +1471,7 @@ hipError_t launch_pyr_tail(const PyrLevelDev* descs_dev, int n, int k0, int L, i
   return hipGetLastError();
 }
 
-hipError_t launch_pyr_level(const PyrLevelDev* descs_dev, int n, int W, int H, hipStream_t stream, bool rows_ok, PyrLevelDev* mirror, int mirror_count) {
+hipError_t launch_pyr_level(const PyrLevelDev* descs_dev, int n, int W, int H, hipStream_t stream, bool rows_ok, PyrLevelDev* mirror, int mirror_count, PyrStart st) {
   if (rows_ok && (W & 1) == 0) {
     const int nstrips = (W + kPyrStrip - 1) / kPyrStrip;
     // rows per segment: ~4096 waves per launch (16 per CU) when there is that much work, segments of at least 4 rows (a segment re-reads 3 rows of its
@@ -1469,10 +1489,10 @@ hipError_t launch_pyr_level(const PyrLevelDev* descs_dev, int n, int W, int H, h
     int wpg = nstrips;
     if (wpg > 8) wpg = (nstrips + ((nstrips + 7) / 8) - 1) / ((nstrips + 7) / 8);
     const int gps = (nstrips + wpg - 1) / wpg;
-    hipLaunchKernelGGL(k_pyr_rows<1>, dim3(gps * nsegs, n), dim3(64 * wpg), 0, stream, descs_dev, nstrips, nsegs, R, mirror, mirror_count);
+    hipLaunchKernelGGL(k_pyr_rows<1>, dim3(gps * nsegs, n), dim3(64 * wpg), 0, stream, descs_dev, nstrips, nsegs, R, mirror, mirror_count, st);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(k_pyr_level, dim3((W + kPyrTW - 1) / kPyrTW, (H + kPyrTH - 1) / kPyrTH, n), dim3(kT), 0, stream, descs_dev, mirror, mirror_count);
+  hipLaunchKernelGGL(k_pyr_level, dim3((W + kPyrTW - 1) / kPyrTW, (H + kPyrTH - 1) / kPyrTH, n), dim3(kT), 0, stream, descs_dev, mirror, mirror_count, st);
   return hipGetLastError();
 }
 

@@ -137,3 +137,86 @@ def test_large_build_same_bits(dfx):
             g = torch.empty((h >> i, w >> i, 2), device="cuda")
             dfx.SobelGradients(ref, g)
             assert torch.equal(pyr_g[k][i], g), (k, i)
+
+
+def test_back_to_back_builds_over_rotating_buffer_sets_with_other_batched_work_between(dfx):
+    """The build's descriptors are read out of a ring of pinned staging slots by its first launch (which mirrors them to device memory for the later ones), and a
+    slot is handed out again once a LATER build has reported that it is running -- no event behind a build.  Forty enqueue-only builds over three rotating
+    buffer sets (so a slot that was reused too early, or a stale mirror, shows up as a pyramid built into / from the wrong buffers), with another batched operator
+    that stages through the same ring between them (event-guarded slots next to build-guarded ones), then a last build with nothing behind it."""
+    rng = np.random.default_rng(2026)
+    w, h, levels, nf, sets = 320, 240, 3, 5, 3
+    imgs = [[torch.from_numpy(rng.random((h, w), dtype=np.float32)).cuda() for _ in range(nf)] for _ in range(sets)]
+    pyr_i = [[_alloc(levels, w, h) for _ in range(nf)] for _ in range(sets)]
+    pyr_g = [[_alloc(levels, w, h, ch=2) for _ in range(nf)] for _ in range(sets)]
+    arrs = []
+    for s in range(sets):
+        for k in range(nf):
+            pyr_i[s][k][0].copy_(imgs[s][k])
+        arrs.append(dfx.make_pyramids(pyr_i[s], pyr_g[s]))
+    cs = 32
+    prx = [torch.rand((h, w), device="cuda") + 0.5 for _ in range(2)]
+    jac = [torch.rand((h, w * cs), device="cuda") * 0.01 for _ in range(2)]
+    dpt = [torch.empty((h, w), device="cuda") for _ in range(2)]
+    codes = rng.standard_normal((2, cs)).astype(np.float32)
+    for rep in range(40):
+        dfx.BuildPyramids(arrs[rep % sets])
+        if rep % 3 == 1:
+            dfx.UpdateDepthBatch(codes, prx, jac, 2.0, dpt)
+    dfx.BuildPyramids(arrs[0])
+    torch.cuda.synchronize()
+    for s in range(sets):
+        for k in range(nf):
+            ref = imgs[s][k]
+            for i in range(levels):
+                if i > 0:
+                    nxt = torch.empty((h >> i, w >> i), device="cuda")
+                    dfx.GaussianBlurDown(ref, nxt)
+                    ref = nxt
+                    assert torch.equal(pyr_i[s][k][i], ref), (s, k, i)
+                g = torch.empty((h >> i, w >> i, 2), device="cuda")
+                dfx.SobelGradients(ref, g)
+                assert torch.equal(pyr_g[s][k][i], g), (s, k, i)
+    one = torch.empty((h, w), device="cuda")
+    dfx.UpdateDepth(codes[0], prx[0], jac[0], 2.0, one)
+    assert torch.equal(dpt[0], one)
+
+
+def test_repeated_builds_into_the_same_buffers_follow_the_new_frame(dfx):
+    """A live frame's pyramid is rebuilt in place frame after frame (UploadLiveFrame, core/deepfactors.cpp:616-630): from the second build on the library finds the
+    previous build's descriptors still in device memory and stages nothing -- the result must follow the NEW level-0 image, a build over other buffers in between
+    must not be served from the remembered block, and neither must a build of fewer levels over the same buffers."""
+    rng = np.random.default_rng(77)
+    w, h, levels = 640, 480, 4
+    pi, pg = [_alloc(levels, w, h)], [_alloc(levels, w, h, ch=2)]
+    qi, qg = [_alloc(levels, w, h)], [_alloc(levels, w, h, ch=2)]
+    arr_p, arr_q = dfx.make_pyramids(pi, pg), dfx.make_pyramids(qi, qg)
+    arr_p3 = dfx.make_pyramids([pi[0][:3]], [pg[0][:3]])
+
+    def check(pyr_i, pyr_g, img, nl):
+        ref = img
+        for i in range(nl):
+            if i > 0:
+                nxt = torch.empty((h >> i, w >> i), device="cuda")
+                dfx.GaussianBlurDown(ref, nxt)
+                ref = nxt
+                assert torch.equal(pyr_i[i], ref), i
+            g = torch.empty((h >> i, w >> i, 2), device="cuda")
+            dfx.SobelGradients(ref, g)
+            assert torch.equal(pyr_g[i], g), i
+    for frame in range(6):
+        img = torch.from_numpy(rng.random((h, w), dtype=np.float32)).cuda()
+        pi[0][0].copy_(img)
+        if frame == 3:   # other buffers in between
+            qi[0][0].copy_(img * 0.5)
+            dfx.BuildPyramids(arr_q)
+        nl = 3 if frame == 4 else levels   # (frame 4: three levels of the same buffers; frame 5: four again)
+        if nl == 3:
+            pi[0][3].fill_(-7.0); pg[0][3].fill_(-7.0)
+        dfx.BuildPyramids(arr_p3 if nl == 3 else arr_p)
+        torch.cuda.synchronize()
+        check(pi[0], pg[0], img, nl)
+        if nl == 3:
+            assert bool((pi[0][3] == -7.0).all()) and bool((pg[0][3] == -7.0).all())
+        if frame == 3:
+            check(qi[0], qg[0], img * 0.5, levels)
