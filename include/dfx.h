@@ -192,8 +192,9 @@ DFX_API int dfx_last_schedule(dfx_ctx* ctx, int* dynamic);
 DFX_API int dfx_set_result_wait(dfx_ctx* ctx, int mode);
 /* Per-context switches that survived their A/B (value 0 / 1; an unknown option or value is an error).  Neither changes a result bit
  * (tests/test_gpu_desc_paths.py): they choose where a batched launch reads its descriptor array from.
- *  DFX_OPT_SIMPLE_DESC_ZEROCOPY (default 1)  batched SE3 step / EvaluateError / UpdateDepth / pyramid: the kernels read the descriptors straight
- *                                            out of the pinned, mapped staging slot instead of a device copy (-7 / -3.5 us per call of 128 pairs)
+ *  DFX_OPT_SIMPLE_DESC_ZEROCOPY (default 1)  batched SE3 step / EvaluateError / UpdateDepth: the kernels read the descriptors straight
+ *                                            out of the pinned, mapped staging slot instead of a device copy (-7 / -3.5 us per call of 128 pairs).
+ *                                            (The pyramid build always does for its first launch, which mirrors them to device memory for the later ones.)
  *  DFX_OPT_STEP_DESC_ZEROCOPY   (default 0)  the same for the batched SfM step: -8 us outside the kernel, +4 us inside it (3840 long-lived
  *                                            workgroups read 1.5 MB over PCIe); pays only when the tail runs on its own stream */
 #define DFX_OPT_SIMPLE_DESC_ZEROCOPY 1
