@@ -353,8 +353,9 @@ def small_operator_rooflines(dfx, synth, ctx, dev):
     one = event_time_us(torch, lambda: dfx.BuildPyramids(parr1, ctx=ctx), reps=100, warm=100)
     out["pyramid_build_64frames_4levels"] = dict(us=us, algorithmic_bytes=byts, algorithmic_gbs=byts / us / 1e3, frac=byts / us / 1e3 / HBM_PEAK_GBS, frames_per_s=F / (us * 1e-6),
                                                  single_frame_us=one, equals_per_level_operators=bool(torch.equal(pyr_i[0][1], ref1) and torch.equal(pyr_g[0][0], refg)),
-                                                 note="k_pyr_level x 4: image + gradient pyramids of 64 distinct 640x480 frames per enqueue (335 MB: beyond the Infinity Cache); us = the whole "
-                                                      "enqueue (four launches) in back-to-back calls; single_frame_us = one frame per enqueue (latency-bound: four dependent launches)")
+                                                 note="k_pyr_rows (levels 0, 1) + k_pyr_tail (levels 2-3): image + gradient pyramids of 64 distinct 640x480 frames per enqueue (339 MB: beyond the Infinity Cache); "
+                                                      "us = the whole enqueue (three launches, no copy command, no event) in back-to-back calls over the same buffers; single_frame_us = one frame per "
+                                                      "enqueue (latency-bound: three dependent launches)")
     del pyr_i, pyr_g, parr, parr1
     P = 128
     al, se3 = dfx.SfmAligner(code_size=CS, ctx=ctx), dfx.SE3Aligner(ctx=ctx)
