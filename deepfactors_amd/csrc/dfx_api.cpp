@@ -2305,7 +2305,7 @@ DFX_API int dfx_build_pyramid_batch_async(dfx_ctx* c, const dfx_pyramid* frames,
     if (!any) continue;
     const bool first = !mirrored && mirror;
     hipError_t e = dfx::launch_pyr_level((mirrored ? mirror : hostdev) + (size_t)i * n, n, (int)frames[0].img[i].w, (int)frames[0].img[i].h, c->stream, rows_ok[i],
-                                         first ? mirror + (size_t)i * n : nullptr, first ? (L - i) * n : 0, signalled ? dfx::PyrStart{} : start);
+                                         first ? mirror + (size_t)i * n : nullptr, first ? (L - i) * n : 0, signalled ? dfx::PyrStart{} : start, c->cu_count);
     if (e != hipSuccess) { c->pyr_mirror_valid = false; if (slot >= 0) (void)stage_release(c, slot); return fail(DFX_E_HIP, "k_pyr_level launch failed: %s", hipGetErrorString(e)); }
     mirrored = mirrored || first;
     signalled = true;

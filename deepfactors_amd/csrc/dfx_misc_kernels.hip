@@ -1471,24 +1471,49 @@ hipError_t launch_pyr_tail(const PyrLevelDev* descs_dev, int n, int k0, int L, i
   return hipGetLastError();
 }
 
-hipError_t launch_pyr_level(const PyrLevelDev* descs_dev, int n, int W, int H, hipStream_t stream, bool rows_ok, PyrLevelDev* mirror, int mirror_count, PyrStart st) {
+// Rows per segment of the row-streaming launch (`wpg` waves per workgroup, `gps` workgroups side by side per segment, n frames, `cus` compute units).
+// Every workgroup of such a launch lives about as long as the launch, so what matters first is that the compute units hold EQUAL numbers of them: level 0 of a
+// 64-frame 640x480 build with 13 segments per frame (832 workgroups = 3.25 per CU: the old "~4096 waves" rule) takes 46.2 us, with 12 segments (3 per CU) 41.1,
+// with 8 (2 per CU, 10 waves) 40.4, with 16 (4 per CU) 42.2, with 4 (1 per CU, 5 waves) 41.5; level 1 (three-wave workgroups) with 20 segments (5 per CU) 12.6, with
+// 12 (3 per CU, 9 waves) 12.4, with 24 (6 per CU) 13.1, with 8 (2 per CU, 6 waves) 13.7, with 10 (2.5 per CU) 13.5 -- same-box A/B, profiles/r06_pyramid.txt.
+// Rule: the fewest workgroups per CU k (the longest segments: the least halo re-reads) for which k * cus workgroups tile the frames exactly and a CU holds 8-16
+// waves; without such a k (few frames, odd counts) ~4096 waves per launch as before.  At least 4 rows per segment (a segment re-reads 3 rows of its neighbours).
+int pyr_rows_per_segment(int H, int nstrips, int wpg, int gps, int n, int cus) {
+  if (cus > 0) {
+    for (int k = 1; k <= 16; ++k) {
+      const int waves = k * wpg;
+      if (waves < 8) continue;
+      if (waves > 16) break;
+      const long long wgs = (long long)k * cus, per_seg = (long long)n * gps;
+      if (wgs % per_seg) continue;
+      const int nsegs = (int)(wgs / per_seg);
+      int R = (H + nsegs - 1) / nsegs;
+      R = (R + 1) & ~1;
+      if (R < 4) break;
+      if ((H + R - 1) / R != nsegs) continue;          // (the even R tiles the height into fewer segments)
+      const int rem = H % R;
+      if (rem && R - rem > R / 4) continue;             // (a last segment much shorter than the others is an unequal share again)
+      return R;
+    }
+  }
+  const long long total = (long long)H * nstrips * n;
+  int R = (int)((total + 4095) / 4096);
+  R = (R + 1) & ~1;
+  if (R < 4) R = 4;
+  if (R > 64) R = 64;
+  return R;
+}
+
+hipError_t launch_pyr_level(const PyrLevelDev* descs_dev, int n, int W, int H, hipStream_t stream, bool rows_ok, PyrLevelDev* mirror, int mirror_count, PyrStart st, int cus) {
   if (rows_ok && (W & 1) == 0) {
     const int nstrips = (W + kPyrStrip - 1) / kPyrStrip;
-    // rows per segment: ~4096 waves per launch (16 per CU) when there is that much work, segments of at least 4 rows (a segment re-reads 3 rows of its
-    // neighbours), at most 64
-    // rows per segment: ~4096 waves per launch (16 per CU) when there is that much work; at least 4 rows (a segment re-reads 3 rows of its neighbours), at most 64.
-    // Swept on MI355X (profiles/r06_pyramid.txt): 4096 / 8192 / 16384 waves and 2 / 4 / 8 rows in flight per wave all land level 0 of a 64-frame build at
-    // 51-56 us = 5.3 TB/s of reads + writes, the rate of a device-to-device copy of the same volume on this box: the memory system, not the launch shape
-    const long long total = (long long)H * nstrips * n;
-    int R = (int)((total + 4095) / 4096);
-    R = (R + 1) & ~1;
-    if (R < 4) R = 4;
-    if (R > 64) R = 64;
-    const int nsegs = (H + R - 1) / R;
     // a workgroup = the strips side by side of one row segment (at most 8 waves): whole image rows per workgroup (51.6 against 55.2 us with four-wave groups)
     int wpg = nstrips;
     if (wpg > 8) wpg = (nstrips + ((nstrips + 7) / 8) - 1) / ((nstrips + 7) / 8);
     const int gps = (nstrips + wpg - 1) / wpg;
+    const int R = pyr_rows_per_segment(H, nstrips, wpg, gps, n, cus);
+    const int nsegs = (H + R - 1) / R;
+    // (rows in flight per wave -- the template argument -- 2 / 4 / 8: no gain at any launch shape, profiles/r06_pyramid.txt)
     hipLaunchKernelGGL(k_pyr_rows<1>, dim3(gps * nsegs, n), dim3(64 * wpg), 0, stream, descs_dev, nstrips, nsegs, R, mirror, mirror_count, st);
     return hipGetLastError();
   }

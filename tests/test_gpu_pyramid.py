@@ -220,3 +220,42 @@ def test_repeated_builds_into_the_same_buffers_follow_the_new_frame(dfx):
             assert bool((pi[0][3] == -7.0).all()) and bool((pg[0][3] == -7.0).all())
         if frame == 3:
             check(qi[0], qg[0], img * 0.5, levels)
+
+
+@pytest.mark.parametrize("n", [64, 32, 16])
+def test_builds_whose_workgroups_tile_the_compute_units(dfx, n):
+    """Frame counts for which the row-streaming launches are shaped so that every compute unit holds the same number of workgroups (pyr_rows_per_segment:
+    64 frames of 640x480 -> segments of 60 rows at level 0 and 20 at level 1; 32 -> 30 / 10; 16 -> 10 / 6 or the ~4096-wave rule): other segment seams than
+    the small builds above walk over -- every level of the first, a middle and the last frame equals the per-level operators bit for bit, and every frame's
+    last level equals frame-by-frame builds (three frames per enqueue: the other rule)."""
+    rng = np.random.default_rng(1000 + n)
+    w, h, levels = 640, 480, 4
+    base = torch.from_numpy(rng.random((h + 64, w + 64), dtype=np.float32)).cuda()
+    pyr_i = [_alloc(levels, w, h) for _ in range(n)]
+    pyr_g = [_alloc(levels, w, h, ch=2) for _ in range(n)]
+    for k in range(n):
+        pyr_i[k][0].copy_(base[k % 61: k % 61 + h, (7 * k) % 59: (7 * k) % 59 + w])   # n distinct windows of one random field
+    dfx.BuildPyramids(pyr_i, pyr_g)
+    torch.cuda.synchronize()
+    for k in (0, n // 2 - 1, n - 1):
+        ref = pyr_i[k][0]
+        for i in range(levels):
+            if i > 0:
+                nxt = torch.empty((h >> i, w >> i), device="cuda")
+                dfx.GaussianBlurDown(ref, nxt)
+                ref = nxt
+                assert torch.equal(pyr_i[k][i], ref), (k, i)
+            g = torch.empty((h >> i, w >> i, 2), device="cuda")
+            dfx.SobelGradients(ref, g)
+            assert torch.equal(pyr_g[k][i], g), (k, i)
+    qi = [_alloc(levels, w, h) for _ in range(3)]
+    qg = [_alloc(levels, w, h, ch=2) for _ in range(3)]
+    for k0 in range(0, n - 2, 3):
+        for j in range(3):
+            qi[j][0].copy_(pyr_i[k0 + j][0])
+        dfx.BuildPyramids(qi, qg)
+        torch.cuda.synchronize()
+        for j in range(3):
+            for i in range(1, levels):
+                assert torch.equal(qi[j][i], pyr_i[k0 + j][i]) and torch.equal(qg[j][i], pyr_g[k0 + j][i]), (k0 + j, i)
+            assert torch.equal(qg[j][0], pyr_g[k0 + j][0]), (k0 + j, 0)
