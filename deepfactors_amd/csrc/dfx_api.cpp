@@ -1554,9 +1554,9 @@ int simple_launched(dfx_ctx* c, int slot) {
 // the row walk's items fall out of it (row_walk: waves per pair / bands -> row segments): 20 per CU = 40 workgroups per 640x480 pair of a
 // 128-pair batch = 16 segments of exactly 30 rows and 80 waves per CU = four full rounds of the SE3 step's 20 resident waves; 24 (rounds 3-4a)
 // gave 19 segments of 26 rows with a short last one (profiles/r04_launch_shape.txt: SE3 step 165 -> 160 us, EvaluateError 92 -> 88).
-int batch_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int n) {
+int batch_blocks(const dfx_ctx* c, uint32_t W, uint32_t H, int n, int wgs_per_cu = 20) {
   int b = simple_blocks(W, H);
-  const int cap = (20 * c->cu_count + n - 1) / n;
+  const int cap = (wgs_per_cu * c->cu_count + n - 1) / n;
   if (b > cap) b = cap;
   return b < 1 ? 1 : b;
 }
@@ -1582,7 +1582,9 @@ DFX_API int dfx_sfm_error_batch_async(dfx_ctx* c, const dfx_sfm_params* params, 
       return rc;
     }
   }
-  const int blocks = batch_blocks(c, W, H, n);
+  // EvaluateError: 15 per CU (30 workgroups = segments of exactly 16 rows per 640x480 pair of a 128-pair batch) against the SE3 step's 20: 82.0-82.5 against 84.4-85.1 us
+  // in same-box sweeps on two boxes (12: 88, 14: 82, 16: 86, 18: 83; the SE3 step is flat from 15 to 30; profiles/r06b_small_ops_shape.txt)
+  const int blocks = batch_blocks(c, W, H, n, 15);
   if ((rc = grow_partials(c, (size_t)n * blocks * dfx::kSimpleRow * sizeof(float)))) return rc;
   const dfx::SimplePairDev* dd;
   int slot;
