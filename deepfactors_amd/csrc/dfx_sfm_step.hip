@@ -1346,8 +1346,10 @@ __global__ __launch_bounds__(256) void k_sfm_finalize_b3_split(const float* __re
 // grid = pairs [+ nodes: workgroups that zero the blocks of nodes / pairs this rank holds no item of], 1024 threads.
 // Round 3, 128 pairs: k_sfm_finalize_b3 (768 workgroups, two rounds) 15.3 us + boundary + k_graph_assemble 6.5 us -> see DESIGN.md 3.7.
 
+// `tbeg` / `nt`: the workgroup's threads tbeg .. tbeg + nt - 1 do the node (a pair that completes BOTH its nodes gives each half of the workgroup one of them: the two
+// chains of dependent reads -- graph tables, then the incident pairs' items -- run side by side instead of one behind the other)
 template <int CS>
-__device__ __forceinline__ void tail_assemble_node(const TailGraphDev& tg, const char* __restrict__ items, size_t item_stride, int n) {
+__device__ __forceinline__ void tail_assemble_node(const TailGraphDev& tg, const char* __restrict__ items, size_t item_stride, int n, int tbeg, int nt) {
   constexpr int NP = 12 + CS, D = 6 + CS, NT = NP * (NP + 1) / 2;
   const GraphDev& G = tg.G;
   float* const Hd = tg.sys;
@@ -1361,7 +1363,8 @@ __device__ __forceinline__ void tail_assemble_node(const TailGraphDev& tg, const
   auto ld = [](const float* p) { return (double)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   const int k0 = G.kf_begin[n], k1 = G.kf_begin[n + 1];
   const int f0 = G.fr_begin[n], f1 = G.fr_begin[n + 1];
-  for (int e = threadIdx.x; e < D * D + D; e += blockDim.x) {
+  if ((int)threadIdx.x < tbeg || (int)threadIdx.x >= tbeg + nt) return;
+  for (int e = (int)threadIdx.x - tbeg; e < D * D + D; e += nt) {
     double acc = 0.0;
     if (e < D * D) {
       const int r = e / D, c = e - r * D;
@@ -1520,17 +1523,30 @@ __global__ __launch_bounds__(1024) void k_sfm_tail_b3(const float* __restrict__ 
   // order to the rest of the workgroup, and the items are read with device-scope loads.  ORD = false keeps the relaxed counter of rounds 3-4 for A/B
   // ran: same bits.
   if (ASM) {
-    __builtin_amdgcn_s_waitcnt(0);   // vmcnt = lgkmcnt = expcnt = 0: this wave's stores have completed
-    __syncthreads();
     const int gp = tg.first_pair + pair;
+    // (the nodes' local degrees -- three dependent reads of the constant graph tables -- in front of the wait for the stores: the two latencies overlap)
+    int need[2] = { 0, 0 }, node[2] = { 0, 0 };
     if (threadIdx.x < 64) {
-      const int lane = threadIdx.x;
-      int need[2], node[2];
 #pragma unroll
       for (int side = 0; side < 2; ++side) {
         node[side] = tg.pair_nodes[2 * gp + side];
         need[side] = tail_local_degree(tg, node[side]);
       }
+    }
+    __builtin_amdgcn_s_waitcnt(0);   // vmcnt = lgkmcnt = expcnt = 0: this wave's stores have completed
+    __syncthreads();
+    if (threadIdx.x >= 64) {   // off-diagonal block of this pair: single writer, from the item this workgroup has just written (device-scope loads of device-scope stores:
+      // complete since the barrier above); it waits for nobody's arrival, so the waves that do not count arrivals copy it WHILE wave 0 does
+      float* const Ho = tg.sys + (size_t)tg.G.n_nodes * D * D;
+      auto tri = [](int a, int b) { const int lo = a < b ? a : b, hi = a < b ? b : a; return lo * NP - lo * (lo - 1) / 2 + (hi - lo); };
+      for (int e = (int)threadIdx.x - 64; e < D * 6; e += 1024 - 64) {
+        const int r = e / 6, c = e - r * 6;
+        const int ia = r < 6 ? r : r + 6;
+        Ho[(size_t)gp * D * 6 + e] = __hip_atomic_load(&item[tri(ia, 6 + c)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x;
       if (lane == 0) {
         // ONE release fence in front of the two arrivals (fence-atomic synchronisation: the relaxed read-modify-writes behind it publish what the
         // barrier collected), ONE acquire fence behind them if either completed its node
@@ -1553,17 +1569,11 @@ __global__ __launch_bounds__(1024) void k_sfm_tail_b3(const float* __restrict__ 
 #ifdef DFX_TAIL_STOP
     if (DFX_TAIL_STOP == 4) return;
 #endif
-    {   // off-diagonal block of this pair: single writer, from the item this workgroup has just written (device-scope loads of device-scope stores)
-      float* const Ho = tg.sys + (size_t)tg.G.n_nodes * D * D;
-      auto tri = [](int a, int b) { const int lo = a < b ? a : b, hi = a < b ? b : a; return lo * NP - lo * (lo - 1) / 2 + (hi - lo); };
-      for (int e = threadIdx.x; e < D * 6; e += 1024) {
-        const int r = e / 6, c = e - r * 6;
-        const int ia = r < 6 ? r : r + 6;
-        Ho[(size_t)gp * D * 6 + e] = __hip_atomic_load(&item[tri(ia, 6 + c)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    if (todo[0] >= 0) tail_assemble_node<CS>(tg, items, item_stride, todo[0]);
-    if (todo[1] >= 0) tail_assemble_node<CS>(tg, items, item_stride, todo[1]);
+    if (todo[0] >= 0 && todo[1] >= 0) {
+      tail_assemble_node<CS>(tg, items, item_stride, todo[0], 0, 512);
+      tail_assemble_node<CS>(tg, items, item_stride, todo[1], 512, 512);
+    } else if (todo[0] >= 0) tail_assemble_node<CS>(tg, items, item_stride, todo[0], 0, 1024);
+    else if (todo[1] >= 0) tail_assemble_node<CS>(tg, items, item_stride, todo[1], 0, 1024);
   }
   // ---- the pair's valid0 shadow, when a wave of this launch changed the map (never in the steady state)
   rebuild_valid0_shadow(PD, W, H, launch_id, 0, 1, stamp);
