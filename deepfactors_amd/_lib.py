@@ -121,6 +121,7 @@ _PROTOS = {
     "dfx_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "dfx_profile_read_ex": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dfx_debug_read_partials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dfx_debug_pyramid_launch_shape": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dfx_img_alloc": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t, C.POINTER(Img)]),
     "dfx_img_free": (C.c_int, [C.c_void_p, C.POINTER(Img)]),
     "dfx_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),

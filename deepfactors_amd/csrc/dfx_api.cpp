@@ -2324,6 +2324,16 @@ DFX_API int dfx_build_pyramid_batch_async(dfx_ctx* c, const dfx_pyramid* frames,
   return DFX_OK;
 }
 
+DFX_API int dfx_debug_pyramid_launch_shape(int w, int h, int n, int cus, int* rows_per_segment, int* workgroups, int* waves_per_workgroup) {
+  if (w < 2 || (w & 1) || h < 1 || n < 1 || cus < 0) return fail(DFX_E_INVALID, "dfx_debug_pyramid_launch_shape: w even >= 2, h >= 1, n >= 1, cus >= 0");
+  int wpg, gps, R;
+  dfx::pyr_rows_shape(w, h, n, cus, &wpg, &gps, &R);
+  if (rows_per_segment) *rows_per_segment = R;
+  if (workgroups) *workgroups = gps * ((h + R - 1) / R) * n;
+  if (waves_per_workgroup) *waves_per_workgroup = wpg;
+  return DFX_OK;
+}
+
 DFX_API int dfx_build_pyramid(dfx_ctx* c, const dfx_pyramid* frame) {
   int rc;
   if ((rc = dfx_build_pyramid_batch_async(c, frame, 1))) return rc;

@@ -273,6 +273,8 @@ struct PyrStart { uint32_t* word = nullptr; uint32_t seq = 0; };
 hipError_t launch_pyr_level(const PyrLevelDev* descs_dev, int n, int W, int H, hipStream_t stream, bool rows_ok, PyrLevelDev* mirror = nullptr, int mirror_count = 0,
                             PyrStart st = PyrStart{}, int cus = 0);   // cus: compute units of the device (0: unknown), for the launch shape
 int pyr_rows_per_segment(int H, int nstrips, int wpg, int gps, int n, int cus);
+// the row-streaming launch of a level: waves per workgroup (the strips side by side, at most 8), workgroups per row segment, rows per segment
+void pyr_rows_shape(int W, int H, int n, int cus, int* wpg, int* gps, int* R);
 // levels k0 .. L-1 of every frame in one launch: `nb` bands (workgroups) per frame, each with its rows of those levels in LDS (descs: level-major [L][n]).
 // pyr_tail_plan: Hs / Ws = the levels' sizes, nl = L - k0; returns the bands per frame (0: does not qualify), the band height at the last level and the LDS bytes.
 constexpr size_t kPyrTailMaxLds = 144 * 1024;

@@ -1504,14 +1504,21 @@ int pyr_rows_per_segment(int H, int nstrips, int wpg, int gps, int n, int cus) {
   return R;
 }
 
+void pyr_rows_shape(int W, int H, int n, int cus, int* wpg_out, int* gps_out, int* R_out) {
+  const int nstrips = (W + kPyrStrip - 1) / kPyrStrip;
+  // a workgroup = the strips side by side of one row segment (at most 8 waves): whole image rows per workgroup (51.6 against 55.2 us with four-wave groups)
+  int wpg = nstrips;
+  if (wpg > 8) wpg = (nstrips + ((nstrips + 7) / 8) - 1) / ((nstrips + 7) / 8);
+  const int gps = (nstrips + wpg - 1) / wpg;
+  *wpg_out = wpg; *gps_out = gps;
+  *R_out = pyr_rows_per_segment(H, nstrips, wpg, gps, n, cus);
+}
+
 hipError_t launch_pyr_level(const PyrLevelDev* descs_dev, int n, int W, int H, hipStream_t stream, bool rows_ok, PyrLevelDev* mirror, int mirror_count, PyrStart st, int cus) {
   if (rows_ok && (W & 1) == 0) {
     const int nstrips = (W + kPyrStrip - 1) / kPyrStrip;
-    // a workgroup = the strips side by side of one row segment (at most 8 waves): whole image rows per workgroup (51.6 against 55.2 us with four-wave groups)
-    int wpg = nstrips;
-    if (wpg > 8) wpg = (nstrips + ((nstrips + 7) / 8) - 1) / ((nstrips + 7) / 8);
-    const int gps = (nstrips + wpg - 1) / wpg;
-    const int R = pyr_rows_per_segment(H, nstrips, wpg, gps, n, cus);
+    int wpg, gps, R;
+    pyr_rows_shape(W, H, n, cus, &wpg, &gps, &R);
     const int nsegs = (H + R - 1) / R;
     // (rows in flight per wave -- the template argument -- 2 / 4 / 8: no gain at any launch shape, profiles/r06_pyramid.txt)
     hipLaunchKernelGGL(k_pyr_rows<1>, dim3(gps * nsegs, n), dim3(64 * wpg), 0, stream, descs_dev, nstrips, nsegs, R, mirror, mirror_count, st);

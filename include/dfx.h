@@ -436,6 +436,10 @@ DFX_API int dfx_gaussian_blur_down(dfx_ctx* ctx, const dfx_img* in, const dfx_im
  * level's gradient (UploadLiveFrame leaves level 0 out, deepfactors.cpp:620-625).  All frames of a batch share the sizes of frame 0.
  * Same bits as the per-level calls dfx_gaussian_blur_down / dfx_sobel_gradients.  _async only enqueues; dfx_build_pyramid blocks like the
  * reference's calls. */
+/* Debug (host arithmetic only, no device needed): the shape dfx_build_pyramid_batch_async gives the row-streaming launch of a level of `n` frames of w x h on a
+ * device of `cus` compute units -- rows per segment and workgroups of the launch (tests/test_pyramid_shape.py: the segments tile the height, and where the frames
+ * allow it the workgroups tile the compute units exactly).  w must be even (the row-streaming kernel's precondition). */
+DFX_API int dfx_debug_pyramid_launch_shape(int w, int h, int n, int cus, int* rows_per_segment, int* workgroups, int* waves_per_workgroup);
 #define DFX_MAX_PYR_LEVELS 8
 typedef struct dfx_pyramid {
   int32_t levels;
