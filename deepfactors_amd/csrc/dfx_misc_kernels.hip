@@ -1476,25 +1476,26 @@ hipError_t launch_pyr_tail(const PyrLevelDev* descs_dev, int n, int k0, int L, i
 // 64-frame 640x480 build with 13 segments per frame (832 workgroups = 3.25 per CU: the old "~4096 waves" rule) takes 46.2 us, with 12 segments (3 per CU) 41.1,
 // with 8 (2 per CU, 10 waves) 40.4, with 16 (4 per CU) 42.2, with 4 (1 per CU, 5 waves) 41.5; level 1 (three-wave workgroups) with 20 segments (5 per CU) 12.6, with
 // 12 (3 per CU, 9 waves) 12.4, with 24 (6 per CU) 13.1, with 8 (2 per CU, 6 waves) 13.7, with 10 (2.5 per CU) 13.5 -- same-box A/B, profiles/r06_pyramid.txt.
-// Rule: the fewest workgroups per CU k (the longest segments: the least halo re-reads) for which k * cus workgroups tile the frames exactly and a CU holds 8-16
-// waves; without such a k (few frames, odd counts) ~4096 waves per launch as before.  At least 4 rows per segment (a segment re-reads 3 rows of its neighbours).
+// Rule: among the even segment heights whose busiest CU holds 8-16 waves, the one with the best product of (CU balance: workgroups / (workgroups of the busiest CU x
+// CUs)) x (segment balance: rows / (segments x segment height) -- a short last segment idles its share) x (1 - 1.5 / R: the 4 halo rows a segment re-reads, at the weight
+// the sweeps give them); exact tilings (64 frames: 8 segments of 60 rows, 2 workgroups per CU) score highest, frame counts that do not divide the CUs still get within a few
+// per cent of equal shares (60 frames: 480 workgroups on 256 CUs instead of 840).  Below a score of 0.8 -- few frames: fewer workgroups than CUs, or only tiny segments
+// balance -- ~4096 waves per launch as before.  At least 4 rows per segment (a segment re-reads 3 rows of its neighbours).
 int pyr_rows_per_segment(int H, int nstrips, int wpg, int gps, int n, int cus) {
   if (cus > 0) {
-    for (int k = 1; k <= 16; ++k) {
-      const int waves = k * wpg;
-      if (waves < 8) continue;
-      if (waves > 16) break;
-      const long long wgs = (long long)k * cus, per_seg = (long long)n * gps;
-      if (wgs % per_seg) continue;
-      const int nsegs = (int)(wgs / per_seg);
-      int R = (H + nsegs - 1) / nsegs;
-      R = (R + 1) & ~1;
-      if (R < 4) break;
-      if ((H + R - 1) / R != nsegs) continue;          // (the even R tiles the height into fewer segments)
-      const int rem = H % R;
-      if (rem && R - rem > R / 4) continue;             // (a last segment much shorter than the others is an unequal share again)
-      return R;
+    int best = 0;
+    double best_score = 0.8;
+    for (int R = 4; R <= ((H + 1) & ~1); R += 2) {
+      const int nsegs = (H + R - 1) / R;
+      const long long wgs = (long long)n * gps * nsegs;
+      if (wgs < cus) break;                                   // (fewer workgroups than CUs from here on)
+      const long long busiest = (wgs + cus - 1) / cus;
+      const long long waves = busiest * wpg;
+      if (waves < 8 || waves > 16) continue;
+      const double score = ((double)wgs / (double)(busiest * cus)) * ((double)H / ((double)nsegs * R)) * (1.0 - 1.5 / R);
+      if (score > best_score) { best_score = score; best = R; }
     }
+    if (best) return best;
   }
   const long long total = (long long)H * nstrips * n;
   int R = (int)((total + 4095) / 4096);

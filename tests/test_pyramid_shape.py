@@ -22,6 +22,20 @@ def test_the_measured_shapes(w, h, n, rows, wgs_per_cu):
     assert r == rows and g == wgs_per_cu * 256 and 8 <= wgs_per_cu * v <= 16
 
 
+@pytest.mark.parametrize("w,h,n,rows,wgs", [(640, 480, 60, 60, 480), (640, 480, 48, 30, 768), (320, 240, 48, 16, 720), (640, 480, 100, 96, 500)])
+def test_frame_counts_that_do_not_divide_the_cus_get_nearly_equal_shares(w, h, n, rows, wgs):
+    r, g, v = _shape(w, h, n)
+    assert (r, g) == (rows, wgs)
+    busiest = -(-g // 256)
+    assert g / (busiest * 256) >= 0.9 and 8 <= busiest * v <= 16
+
+
+def test_few_frames_keep_the_many_waves_rule():
+    for n in (1, 2, 3, 4, 9):
+        r, g, v = _shape(640, 480, n)
+        assert r == max(4, (-(-480 * 5 * n // 4096) + 1) & ~1)
+
+
 @pytest.mark.parametrize("cus", [0, 64, 256, 304])
 def test_segments_tile_the_height_for_every_size_and_count(cus):
     for w in (2, 64, 126, 130, 320, 640, 1024, 1280, 2048):
