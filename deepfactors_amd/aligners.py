@@ -181,7 +181,7 @@ class Context:
         elif stream is None:
             sh = None
         else:
-            sh = int(stream)
+            sh = int(stream.cuda_stream if isinstance(stream, torch.cuda.Stream) else stream)   # a torch.cuda.Stream or a raw hipStream_t, like set_stream
         check(L.dfx_ctx_create(self.device, C.c_void_p(sh) if sh else None, C.byref(self._h)))
 
     @property

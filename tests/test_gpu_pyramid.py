@@ -259,3 +259,40 @@ def test_builds_whose_workgroups_tile_the_compute_units(dfx, n):
             for i in range(1, levels):
                 assert torch.equal(qi[j][i], pyr_i[k0 + j][i]) and torch.equal(qg[j][i], pyr_g[k0 + j][i]), (k0 + j, i)
             assert torch.equal(qg[j][0], pyr_g[k0 + j][0]), (k0 + j, 0)
+
+
+def test_builds_on_a_side_stream_and_across_a_stream_switch(dfx):
+    """The staging-slot bookkeeping of the build (a slot is free once a later build has reported that it runs on the context's stream) on a non-default stream, and
+    across dfx_ctx_set_stream (which drains the old stream and forgets the ring's guards): 20 builds over two rotating buffer sets on a side stream, a switch to
+    another stream in the middle of the sequence, every result checked."""
+    rng = np.random.default_rng(31)
+    w, h, levels, nf = 256, 192, 3, 4
+    side, other = torch.cuda.Stream(), torch.cuda.Stream()
+    ctx = dfx.Context(0, stream=side)
+    imgs = [[torch.from_numpy(rng.random((h, w), dtype=np.float32)).cuda() for _ in range(nf)] for _ in range(2)]
+    pyr_i = [[_alloc(levels, w, h) for _ in range(nf)] for _ in range(2)]
+    pyr_g = [[_alloc(levels, w, h, ch=2) for _ in range(nf)] for _ in range(2)]
+    arrs = []
+    for s in range(2):
+        for k in range(nf):
+            pyr_i[s][k][0].copy_(imgs[s][k])
+        arrs.append(dfx.make_pyramids(pyr_i[s], pyr_g[s]))
+    torch.cuda.synchronize()
+    for rep in range(20):
+        if rep == 11:
+            ctx.set_stream(other)
+        dfx.BuildPyramids(arrs[rep % 2], ctx=ctx)
+    ctx.sync()
+    torch.cuda.synchronize()
+    for s in range(2):
+        for k in range(nf):
+            ref = imgs[s][k]
+            for i in range(levels):
+                if i > 0:
+                    nxt = torch.empty((h >> i, w >> i), device="cuda")
+                    dfx.GaussianBlurDown(ref, nxt)
+                    ref = nxt
+                    assert torch.equal(pyr_i[s][k][i], ref), (s, k, i)
+                g = torch.empty((h >> i, w >> i, 2), device="cuda")
+                dfx.SobelGradients(ref, g)
+                assert torch.equal(pyr_g[s][k][i], g), (s, k, i)
