@@ -18,6 +18,8 @@
 #   latency                  tests/cpp/latency_bench                                             -> latency_cpp.txt
 #   cpp                      tests/cpp/{shim,host,comm,ref_callers}_test                          -> cpp_tests.txt
 #   tracker                  tools/profile_tracker.py                                            -> tracker.json
+#   pyramid                  tools/pyr_call.sh (pyramid tests, events for 64 frames / 1 frame, kernel-trace timeline) -> pyr/*
+#   pyramid_traffic          tools/pyramid_traffic.sh (TCC_EA0 request counters of the build's launches)    -> pyr_traffic/pyramid_traffic.txt
 #   clocks                   tools/idle_gap_probe.py --idle-us 0 --seconds 3                     -> clock_power_steady.txt
 #   run:<command>            any command (timeout 600)                                           -> run_<n>.log
 set -u
@@ -94,6 +96,8 @@ PY
     gnround) { timeout 200 tests/cpp/gn_round_bench 16 7; timeout 300 tests/cpp/gn_round_bench 64 3 16; } > $OUT/gn_round_cpp$tag.txt 2>&1 < /dev/null; rc=$?; cat $OUT/gn_round_cpp$tag.txt;;
     latency) timeout 120 tests/cpp/latency_bench > $OUT/latency_cpp$tag.txt 2>&1 < /dev/null; rc=$?; tail -14 $OUT/latency_cpp$tag.txt;;
     cpp) rc=0; for t in shim_test host_test host_logic_test comm_test ref_callers_test; do [ -x tests/cpp/$t ] && { e=(); [ $t = comm_test ] && e=(DFX_RCCL_LIB=$PWD/tests/cpp/librccl_stub.so); env "${e[@]}" timeout 300 tests/cpp/$t 2>&1 | tail -2; r=${PIPESTATUS[0]}; [ $r -ne 0 ] && rc=$r; }; done > $OUT/cpp_tests$tag.txt 2>&1 < /dev/null; cat $OUT/cpp_tests$tag.txt;;
+    pyramid) timeout 600 tools/pyr_call.sh $OUT/pyr > $OUT/pyramid$tag.log 2>&1 < /dev/null; rc=$?; grep -E "build_pyramid|median|passed|failed" $OUT/pyramid$tag.log | cut -c1-150;;
+    pyramid_traffic) timeout 400 tools/pyramid_traffic.sh $OUT/pyr_traffic > $OUT/pyramid_traffic$tag.log 2>&1 < /dev/null; rc=$?; tail -4 $OUT/pyramid_traffic$tag.log | cut -c1-200;;
     tracker) timeout 120 python tools/profile_tracker.py > $OUT/tracker$tag.json 2>/dev/null < /dev/null; rc=$?; tail -2 $OUT/tracker$tag.json;;
     clocks) timeout 120 python tools/idle_gap_probe.py --idle-us 0 --seconds 3 > $OUT/clock_power_steady$tag.txt 2>&1 < /dev/null; rc=$?; grep "^idle" $OUT/clock_power_steady$tag.txt;;
     run) env "${envs[@]}" timeout 600 bash -c "$args" > $OUT/run_$n$tag.log 2>&1 < /dev/null; rc=$?; tail -20 $OUT/run_$n$tag.log;;
